@@ -1,0 +1,141 @@
+"""
+Generates the golden fixtures under tests/golden/ by IMPORTING THE REFERENCE (peleiden/rl-rubiks).
+
+Run only in the build container, where the reference is mounted read-only:
+
+    cd /tmp && PYTHONDONTWRITEBYTECODE=1 MPLBACKEND=Agg PYTHONPATH=/root/reference \
+        python /root/repo/tests/golden/make_golden.py [cube] [bfs] [agents]
+
+The fixtures are DATA (inputs + the reference's outputs).  No reference source travels with them.
+The GPU box never runs this script (it has no /root/reference); it only reads the committed files.
+"""
+import json
+import os
+import sys
+import warnings
+
+import numpy as np
+
+warnings.filterwarnings("ignore")
+OUT = os.path.dirname(os.path.abspath(__file__))
+
+
+def _reachable_states(cube, n, moves, seed):
+    """n states, each `moves` random moves away from solved (reference multi_rotate does the moving)."""
+    rng = np.random.RandomState(seed)
+    states = np.tile(cube.get_solved(), (n, 1))
+    for _ in range(moves):
+        states = cube.multi_rotate(states, rng.randint(0, 6, n), rng.randint(0, 2, n))
+    return states
+
+
+def make_cube():
+    from librubiks import cube
+    from librubiks.cube.cube import _Cube2024
+    assert cube.get_is2024()
+    fx = {}
+
+    # (1) move tables, (2) solved state
+    fx["maps"] = _Cube2024.maps.copy()
+    assert fx["maps"].shape == (2, 6, 2, 24) and fx["maps"].dtype == np.int8
+    with open("/root/reference/frontend/src/assets/maps.json") as f:
+        mj = json.load(f)
+    assert np.array_equal(np.array(mj["map_neg"]), fx["maps"][0])
+    assert np.array_equal(np.array(mj["map_pos"]), fx["maps"][1])
+    fx["solved"] = cube.get_solved()
+
+    # (3) scrambles: seeds {0, 42}, depths {20, 24}, first 16 games in call order
+    for seed in (0, 42):
+        for depth in (20, 24):
+            np.random.seed(seed)
+            S, Fs, Ds = [], [], []
+            for _ in range(16):
+                s, f, d = cube.scramble(depth, True)
+                S.append(s), Fs.append(f), Ds.append(d)
+            fx[f"scr_s{seed}_d{depth}_states"] = np.array(S)
+            fx[f"scr_s{seed}_d{depth}_faces"] = np.array(Fs)
+            fx[f"scr_s{seed}_d{depth}_dirs"] = np.array(Ds)
+
+    # (4) multi_rotate on 4096 reachable states, both directions; 12-child expansion of 256 states
+    rng = np.random.RandomState(1234)
+    states = _reachable_states(cube, 4096, 30, 7)
+    faces, dirs = rng.randint(0, 6, 4096), rng.randint(0, 2, 4096)
+    fx["mr_in"], fx["mr_faces"], fx["mr_dirs"] = states, faces.astype(np.uint8), dirs.astype(np.uint8)
+    fx["mr_out"] = cube.multi_rotate(states, faces, dirs)
+    assert fx["mr_out"].dtype == np.int8 and set(np.unique(dirs)) == {0, 1}
+    parents = states[:256]
+    fx["ex_parents"] = parents
+    fx["ex_children"] = cube.multi_rotate(np.repeat(parents, 12, axis=0), *cube.iter_actions(256))
+    # single-state rotate agrees row-wise (reference's own differential test, tests/test_cube.py:94-101)
+    for i in range(64):
+        assert np.array_equal(cube.rotate(states[i], faces[i], dirs[i]), fx["mr_out"][i])
+
+    # (5) multi_is_solved with solved rows at known positions
+    batch = _reachable_states(cube, 1000, 3, 11)   # depth 3: a few may be solved by chance
+    planted = np.array([0, 63, 64, 65, 127, 128, 511, 999])
+    batch[planted] = cube.get_solved()
+    fx["is_in"] = batch
+    fx["is_out"] = cube.multi_is_solved(batch)
+    assert fx["is_out"][planted].all()
+
+    # (6) as_oh: index form for 256 states + dense rows
+    oh = cube.as_oh(states[:256]).cpu().numpy()
+    assert oh.shape == (256, 480) and oh.dtype == np.float32 and (oh.sum(1) == 20).all()
+    fx["oh_in"] = states[:256]
+    fx["oh_cols"] = np.nonzero(oh)[1].reshape(256, 20).astype(np.int16)
+    fx["oh_dense_row0"] = oh[0]
+    fx["oh_single"] = cube.as_oh(states[5]).cpu().numpy()
+    assert fx["oh_single"].shape == (1, 480)
+
+    # (7) sequence_scrambler(8, 20, with_solved in {True, False}) after seed(0)
+    for ws in (True, False):
+        np.random.seed(0)
+        s, oh = cube.sequence_scrambler(8, 20, ws)
+        fx[f"seq_ws{int(ws)}_states"] = s
+        fx[f"seq_ws{int(ws)}_ohcols"] = np.nonzero(oh.cpu().numpy())[1].reshape(len(s), 20).astype(np.int16)
+
+    # (8) action helpers
+    fx["iter_actions_2"] = cube.iter_actions(2)
+    f12, d12 = cube.indices_to_actions(np.arange(12))
+    fx["i2a_faces"], fx["i2a_dirs"] = f12, d12
+    fx["rev_actions"] = cube.rev_actions(np.arange(12))
+    fx["rev_action_scalar"] = np.array([cube.rev_action(a) for a in range(12)])
+    fx["action_space"] = np.array(cube.action_space)
+
+    # (9) sticker nets of random states (as633) -- complements the literal nets in the reference's tests
+    fx["as633_in"] = states[:32]
+    fx["as633_out"] = np.array([cube.as633(s) for s in states[:32]])
+
+    np.savez_compressed(os.path.join(OUT, "cube_golden.npz"), **fx)
+    print("cube_golden.npz:", {k: v.shape for k, v in fx.items()})
+
+
+def make_bfs():
+    """BASELINE config #1: BFS on 10 depth-5 scrambles after set_seeds() (runeval.py defaults)."""
+    from librubiks import cube
+    from librubiks.utils import set_seeds
+    from librubiks.solving.agents import BFS
+    set_seeds()
+    agent = BFS()
+    states, lengths, seen, queues = [], [], [], []
+    for _ in range(10):
+        s, _, _ = cube.scramble(5, True)
+        ok = agent.search(s, None, 10_000_000)
+        assert ok
+        states.append(s), lengths.append(len(agent.action_queue)), seen.append(len(agent))
+        queues.append(list(agent.action_queue) + [-1] * (5 - len(agent.action_queue)))
+    print("BFS lengths", lengths, "states seen", seen)
+    np.savez_compressed(os.path.join(OUT, "bfs_golden.npz"), states=np.array(states),
+                        lengths=np.array(lengths), seen=np.array(seen), queues=np.array(queues))
+
+
+if __name__ == "__main__":
+    what = sys.argv[1:] or ["cube", "bfs", "agents"]
+    assert os.path.isdir("/root/reference"), "needs the mounted reference"
+    if "cube" in what:
+        make_cube()
+    if "bfs" in what:
+        make_bfs()
+    if "agents" in what:
+        from make_golden_agents import make_agents
+        make_agents()
