@@ -1,0 +1,32 @@
+"""
+librubiks -- MI355X-native drop-in for the hot path of peleiden/rl-rubiks.
+
+Same import surface as the reference package for that path (`from librubiks import cube, gpu`;
+`from librubiks.solving.agents import MCTS, AStar`; `from librubiks.model import Model, ModelConfig`),
+with the cube environment and the search loops running as hand-written HIP kernels for gfx950
+behind the C ABI declared in include/rubiks_hip.h.
+
+Mirrors reference librubiks/__init__.py:5-21 (`cpu`, `gpu`, `reset_cuda`, `no_grad`).
+There is NO CPU implementation of the cube environment in this package: without an MI355X and the
+built librubiks_hip.so every cube / agent call raises.
+"""
+import functools
+
+import torch
+
+cpu = torch.device("cpu")
+gpu = torch.device("cuda" if torch.cuda.is_available() else "cpu")
+
+
+def reset_cuda():
+    torch.cuda.empty_cache()
+    if torch.cuda.is_available():
+        torch.cuda.synchronize()
+
+
+def no_grad(fun):
+    @functools.wraps(fun)
+    def wrapper(*args, **kwargs):
+        with torch.no_grad():
+            return fun(*args, **kwargs)
+    return wrapper
