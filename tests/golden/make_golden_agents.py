@@ -1,0 +1,98 @@
+"""
+Search-agent traces recorded from the IMPORTED REFERENCE agents (librubiks/solving/agents.py MCTS,
+AStar) driven by tests/standin_net.StandInNet.  See make_golden.py for how to run.
+"""
+import os
+import sys
+
+import numpy as np
+import torch
+
+OUT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.dirname(OUT))
+from standin_net import StandInNet  # noqa: E402
+
+MCTS_CASES = [
+    # (name, scramble seed, depth, c, search_graph, max_states) -- seeds picked by scanning for
+    # cases the reference solves, incl. ones where the BFS shortening changes the action queue
+    ("d2_s3_graph", 3, 2, 0.6, True, 2000),
+    ("d3_s8_naive", 8, 3, 0.6, False, 2000),
+    ("d4_s17_c20_graph", 17, 4, 20.0, True, 2500),
+    ("d4_s17_c20_naive", 17, 4, 20.0, False, 2500),
+    ("d4_s24_c4_graph", 24, 4, 4.13, True, 2500),
+    ("d5_s1_c20_graph", 1, 5, 20.0, True, 2500),
+    ("d5_s7_c4_graph", 7, 5, 4.13, True, 2500),
+    ("d7_s25_c20_graph", 25, 7, 20.0, True, 2500),
+    ("d2_s1_unsolved", 1, 2, 0.6, True, 2000),
+    ("d20_graph", 6, 20, 0.6, True, 5000),
+    ("d20_naive_c4", 7, 20, 4.13, False, 2500),
+    ("d24_graph", 8, 24, 0.6, True, 1500),
+]
+ASTAR_CASES = [
+    # (name, scramble seed, depth, lambda, expansions, max_states)
+    ("d2_l0_n10", 11, 2, 0.0, 10, 3000),
+    ("d3_l05_n2", 12, 3, 0.5, 2, 3000),
+    ("d3_l1_n1", 13, 3, 1.0, 1, 3000),
+    ("d5_l02_n100", 14, 5, 0.2, 100, 6000),
+    ("d20_l02_n100", 15, 20, 0.2, 100, 8000),
+    ("d20_l016_n20", 16, 20, 0.16, 20, 4000),
+    ("d24_l02_n7", 17, 24, 0.2, 7, 2500),
+]
+
+
+def make_agents():
+    from librubiks import cube
+    from librubiks.solving.agents import MCTS, AStar
+    torch.set_num_threads(1)
+    net = StandInNet(seed=0)
+    fx = {f"net_{k}": v for k, v in net.numpy_weights().items()}
+    # reference outputs of the stand-in net on a few states, to pin the net itself
+    np.random.seed(99)
+    probe = np.array([cube.scramble(12)[0] for _ in range(32)])
+    with torch.no_grad():
+        p, v = net(cube.as_oh(probe))
+    fx["net_probe_states"], fx["net_probe_p"], fx["net_probe_v"] = probe, p.numpy(), v.numpy()
+
+    for name, seed, depth, c, graph, max_states in MCTS_CASES:
+        np.random.seed(seed)
+        state, _, _ = cube.scramble(depth, True)
+        agent = MCTS(net, c=c, search_graph=graph)
+        solved = agent.search(state, None, max_states)
+        n = len(agent)
+        assert sorted(agent.indices.values()) == list(range(1, n + 1))
+        pre = f"mcts_{name}_"
+        fx[pre + "state"] = state
+        fx[pre + "params"] = np.array([depth, c, int(graph), max_states, int(solved), n], dtype=np.float64)
+        fx[pre + "queue"] = np.array(list(agent.action_queue), dtype=np.int16)
+        fx[pre + "states"] = agent.states[:n + 1].copy()
+        fx[pre + "neighbors"] = agent.neighbors[:n + 1].astype(np.int32)
+        fx[pre + "leaves"] = agent.leaves[:n + 1].copy()
+        fx[pre + "N"] = agent.N[:n + 1].astype(np.int32)
+        fx[pre + "W"] = agent.W[:n + 1].copy()
+        fx[pre + "P"] = agent.P[:n + 1].astype(np.float32)
+        fx[pre + "V"] = agent.V[:n + 1].astype(np.float32)
+        assert np.array_equal(fx[pre + "P"][1:].astype(np.float64), agent.P[1:n + 1])   # values are f32-exact
+        fx[pre + "L"] = agent.L[:n + 1].astype(np.int32)
+        print(f"MCTS {name}: solved={solved} n={n} queue={list(agent.action_queue)[:12]}")
+
+    for name, seed, depth, lam, nexp, max_states in ASTAR_CASES:
+        np.random.seed(seed)
+        state, _, _ = cube.scramble(depth, True)
+        agent = AStar(net, lambda_=lam, expansions=nexp)
+        solved = agent.search(state, None, max_states)
+        n = len(agent)
+        pre = f"astar_{name}_"
+        fx[pre + "state"] = state
+        fx[pre + "params"] = np.array([depth, lam, nexp, max_states, int(solved), n], dtype=np.float64)
+        fx[pre + "queue"] = np.array(list(agent.action_queue), dtype=np.int16)
+        fx[pre + "states"] = agent.states[:n + 1].copy()
+        fx[pre + "G"] = agent.G[:n + 1].copy()
+        fx[pre + "parents"] = agent.parents[:n + 1].astype(np.int32)
+        fx[pre + "parent_actions"] = agent.parent_actions[:n + 1].astype(np.int8)
+        oq = sorted((float(c), int(i)) for c, i in agent.open_queue)
+        fx[pre + "open_cost"] = np.array([c for c, _ in oq])
+        fx[pre + "open_idx"] = np.array([i for _, i in oq], dtype=np.int32)
+        print(f"A* {name}: solved={solved} n={n} open={len(oq)} queue={list(agent.action_queue)[:12]}")
+
+    np.savez_compressed(os.path.join(OUT, "agents_golden.npz"), **fx)
+    print("agents_golden.npz", os.path.getsize(os.path.join(OUT, "agents_golden.npz")) // 1024, "KiB")

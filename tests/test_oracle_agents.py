@@ -1,0 +1,80 @@
+"""
+Pins oracle/agents.py (restated BFS / MCTS / A*) against traces recorded from the imported
+reference agents (tests/golden/agents_golden.npz, bfs_golden.npz).  CPU only, exact comparisons:
+same torch CPU arithmetic for the stand-in net on both sides, float64 bookkeeping as the reference.
+"""
+import numpy as np
+import pytest
+import torch
+
+from conftest import GOLDEN, golden_cases
+from oracle import agents as oa
+from oracle import cube as oc
+
+_G = np.load(f"{GOLDEN}/agents_golden.npz")
+
+
+def test_standin_net_pinned(agents_golden, standin_net):
+    with torch.no_grad():
+        p, v = standin_net(torch.from_numpy(oc.as_oh(agents_golden["net_probe_states"])))
+    assert np.array_equal(p.numpy(), agents_golden["net_probe_p"])
+    assert np.array_equal(v.numpy(), agents_golden["net_probe_v"])
+    from standin_net import StandInNet
+    regenerated = StandInNet(seed=0).numpy_weights()
+    for k, w in regenerated.items():
+        assert np.array_equal(w, agents_golden["net_" + k])
+
+
+def test_bfs_config1(bfs_golden):
+    """BASELINE config #1: 10 depth-5 scrambles, lengths and states-seen of the reference run."""
+    agent = oa.BFS()
+    for s, length, seen, queue in zip(bfs_golden["states"], bfs_golden["lengths"], bfs_golden["seen"],
+                                      bfs_golden["queues"]):
+        assert agent.search(s, 10_000_000)
+        assert len(agent.action_queue) == length and len(agent) == seen
+        assert list(agent.action_queue) == list(queue[:length])
+        for a in agent.action_queue:
+            s = oc.rotate(s, *oc.ACTION_SPACE[a])
+        assert oc.is_solved(s)
+
+
+@pytest.mark.parametrize("case", golden_cases(_G, "mcts_"))
+def test_mcts_trace(case, agents_golden, standin_net):
+    g = lambda k: agents_golden[f"mcts_{case}_{k}"]   # noqa: E731
+    depth, c, graph, max_states, solved, n = g("params")
+    agent = oa.MCTS(oa.TorchNet(standin_net), c=float(c), search_graph=bool(graph))
+    assert agent.search(g("state"), int(max_states)) == bool(solved)
+    n = int(n)
+    assert len(agent) == n
+    assert list(agent.action_queue) == list(g("queue"))
+    assert np.array_equal(agent.states[1:n + 1], g("states")[1:])
+    assert np.array_equal(agent.neighbors[:n + 1], g("neighbors"))
+    assert np.array_equal(agent.leaves[1:n + 1], g("leaves")[1:])
+    assert np.array_equal(agent.N[:n + 1], g("N"))
+    assert np.array_equal(agent.L[:n + 1], g("L"))
+    assert np.array_equal(agent.W[1:n + 1], g("W")[1:])
+    assert np.array_equal(agent.P[1:n + 1].astype(np.float32), g("P")[1:])
+    assert np.array_equal(agent.V[1:n + 1].astype(np.float32), g("V")[1:])
+    if solved:
+        s = g("state")
+        for a in agent.action_queue:
+            s = oc.rotate(s, *oc.ACTION_SPACE[a])
+        assert oc.is_solved(s)
+
+
+@pytest.mark.parametrize("case", golden_cases(_G, "astar_"))
+def test_astar_trace(case, agents_golden, standin_net):
+    g = lambda k: agents_golden[f"astar_{case}_{k}"]   # noqa: E731
+    depth, lam, nexp, max_states, solved, n = g("params")
+    agent = oa.AStar(oa.TorchNet(standin_net), lambda_=float(lam), expansions=int(nexp))
+    assert agent.search(g("state"), int(max_states)) == bool(solved)
+    n = int(n)
+    assert len(agent) == n
+    assert list(agent.action_queue) == list(g("queue"))
+    assert np.array_equal(agent.states[1:n + 1], g("states")[1:])
+    assert np.array_equal(agent.G[1:n + 1], g("G")[1:])
+    assert np.array_equal(agent.parents[2:n + 1], g("parents")[2:])
+    assert np.array_equal(agent.parent_actions[2:n + 1], g("parent_actions")[2:])
+    oq = sorted((float(c), int(i)) for c, i in agent.open_queue)
+    assert np.array_equal(np.array([i for _, i in oq]), g("open_idx"))
+    assert np.array_equal(np.array([c for c, _ in oq]), g("open_cost"))
