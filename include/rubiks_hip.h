@@ -109,6 +109,67 @@ int rc_apply_moves(int8_t *soa, const uint8_t *moves, size_t n, size_t stride, s
 int rc_sequence_states(const uint8_t *moves, int8_t *out_soa, size_t games, size_t depth,
                        int with_solved, size_t stride_out, rc_stream_t stream);
 
+/* ---- batched MCTS: one independent tree per scramble, lock-step iterations -------------------
+ *
+ * Replaces the per-tree Python loop of librubiks/solving/agents.py:415-645 (class MCTS) for B
+ * trees at once.  One iteration of every running tree =
+ *     rc_mcts_expand  ->  [network on the 12 B child rows]  ->  rc_mcts_backup  ->  rc_mcts_select
+ * Node indices are 1-based per tree, 0 = "no neighbour" (agents.py:419-421); node arrays are
+ * tree-major with capacity + 1 rows per tree.  All pointers are device pointers owned by the
+ * caller (zero-initialised before rc_mcts_init); the struct itself lives in host memory.
+ */
+#define RC_MCTS_RUNNING 0
+#define RC_MCTS_SOLVED 1        /* a child of the expanded leaf is the solved cube (agents.py:540-543) */
+#define RC_MCTS_EXHAUSTED 2     /* len + 12 > max_states (agents.py:476) or node capacity reached */
+#define RC_MCTS_PATH_OVERFLOW 3 /* PUCT descent longer than max_path (treated as unsolved) */
+#define RC_MCTS_ROOT_SOLVED 4   /* the scramble itself is solved (agents.py:468) */
+
+typedef struct rc_mcts {
+    uint32_t n_trees;    /* B */
+    uint32_t capacity;   /* largest node index per tree */
+    uint32_t hash_size;  /* slots per tree, power of two, >= 2 * (capacity + 1) */
+    uint32_t max_path;   /* descent buffer length per tree */
+    /* per node, [B][capacity + 1] (x12 where noted) */
+    void *keys;          /* uint32[4]: the 20 codes packed 5 bits each (6 codes per dword) */
+    int32_t *nbr;        /* x12  neighbors   (agents.py:421) */
+    float *P;            /* x12  policy      (agents.py:423); values are float32-exact in the reference too */
+    float *W;            /* x12  max value   (agents.py:426) */
+    int32_t *N;          /* x12  visit count (agents.py:425) */
+    uint16_t *L;         /* x12  virtual-loss COUNT; reference L = 100 * count (agents.py:427,433,589-591) */
+    float *V;            /*      value       (agents.py:424) */
+    uint8_t *leaf;       /*      is leaf     (agents.py:422) */
+    int32_t *hash;       /* [B][hash_size] open addressing, slot = node index or 0; full-key compare via keys */
+    /* per tree, [B] */
+    int32_t *n_nodes;    /* len(agent) (agents.py:644-645) */
+    int32_t *status;     /* RC_MCTS_* */
+    int32_t *solved_idx; /* node index of the solved child, solve_action = its action */
+    int32_t *solved_action;
+    int32_t *iterations;
+    int32_t *path_len;   /* number of nodes on the current descent path, root included */
+    int32_t *path_node;  /* [B][max_path] indices_visited (agents.py:581,592) */
+    uint8_t *path_act;   /* [B][max_path] actions_taken   (agents.py:582,593) */
+    /* per iteration staging */
+    int8_t *child_soa;   /* [20][child_stride]: child k of tree t at column 12 t + k (network input) */
+    size_t child_stride;
+    int32_t *child_idx;  /* [B][12] node index of every child of the expanded leaf */
+    uint32_t *new_mask;  /* [B] bit k set iff child k was not in the tree before */
+    uint8_t *expanded;   /* [B] 1 iff the tree expanded a leaf in the current iteration */
+} rc_mcts_t;
+
+/* Inserts the B root states (SoA) as node 1 of each tree; a solved root gets RC_MCTS_ROOT_SOLVED.
+ * Also writes the roots to child_soa columns 12 t so that the caller can evaluate them. */
+int rc_mcts_init(const rc_mcts_t *m, const int8_t *roots_soa, size_t stride, rc_stream_t stream);
+/* P[1], V[1] of every tree from row 12 t of probs[12 B][12] / values[12 B] (agents.py:470-473). */
+int rc_mcts_root_eval(const rc_mcts_t *m, const float *probs, const float *values, rc_stream_t stream);
+/* expand_leaf part 1 (agents.py:505-544): 12 children of the path's leaf, dedup against the tree,
+ * new indices in child order, links both ways, first solved child. */
+int rc_mcts_expand(const rc_mcts_t *m, uint32_t max_states, rc_stream_t stream);
+/* expand_leaf part 2 (agents.py:555-571): P, V of new children, W/N/L updates along the path.
+ * probs = softmax(policy logits) rows, values = value head, both for the 12 B child rows. */
+int rc_mcts_backup(const rc_mcts_t *m, const float *probs, const float *values, rc_stream_t stream);
+/* find_leaf (agents.py:575-595): PUCT descent with virtual loss, float64 arithmetic as NumPy's. */
+int rc_mcts_select(const rc_mcts_t *m, double c, rc_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,336 @@
+// Batched MCTS for MI355X (gfx950): B independent search trees advance in lock step, one
+// wavefront per tree per phase.  Restates the semantics of the reference's single-tree agent
+// (librubiks/solving/agents.py:415-645) so that every tree is node-for-node what the reference
+// would build for that scramble given the same network outputs.
+//
+// The work per tree per iteration is a dozen rows, so these kernels are latency-bound, not
+// bandwidth-bound: the design goal is few dependent memory round trips per phase, 12 lanes of the
+// wave doing the per-action work in parallel (ballots / DPP reductions instead of loops), and
+// no atomics across trees (each tree owns its node arrays and its hash table).
+#include "rubiks_common.h"
+
+namespace rubiks {
+
+constexpr int kA = kActions;   // 12
+
+// A node's state is stored packed: 20 codes of 5 bits, 6 per dword (cubies 0-5, 6-11, 12-17, 18-19).
+
+__device__ __forceinline__ bool key_eq(const uint4 &a, const uint4 &b) {
+    return a.x == b.x && a.y == b.y && a.z == b.z && a.w == b.w;
+}
+
+__device__ __forceinline__ u32 key_hash(const uint4 &k) {
+    u32 h = k.x * 0x9E3779B1u;
+    h ^= h >> 15;
+    h += k.y * 0x85EBCA77u;
+    h ^= h >> 13;
+    h += k.z * 0xC2B2AE3Du;
+    h ^= h >> 16;
+    h += k.w * 0x27D4EB2Fu;
+    h ^= h >> 15;
+    h *= 0x165667B1u;
+    h ^= h >> 16;
+    return h;
+}
+
+__device__ __forceinline__ u32 key_code(const uint4 &k, int j) {   // j compile-time after unrolling
+    const u32 w = (j < 6) ? k.x : (j < 12) ? k.y : (j < 18) ? k.z : k.w;
+    return (w >> (5 * (j % 6))) & 31u;
+}
+
+__device__ __forceinline__ void key_set(u32 (&w)[4], int j, u32 code) { w[j / 6] |= code << (5 * (j % 6)); }
+
+// Makes this wave's earlier global stores visible to its later loads (same CU, so L1/L2 in order
+// once the stores have left the wave).
+__device__ __forceinline__ void wave_store_fence() { 
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+    __builtin_amdgcn_s_waitcnt(0);
+ }
+
+// ---- init: root = node 1 ------------------------------------------------------------------------
+__global__ __launch_bounds__(kBlock) void k_mcts_init(rc_mcts_t m, const u8 *__restrict__ roots, size_t stride) {
+    const u32 t = blockIdx.x * kBlock + threadIdx.x;
+    if (t >= m.n_trees) return;
+    u32 w[4] = {0, 0, 0, 0};
+    bool solved = true;
+#pragma unroll
+    for (int j = 0; j < kPlanes; ++j) {
+        const u32 code = roots[(size_t)j * stride + t] & 31u;
+        key_set(w, j, code);
+        solved &= code == (u32)(u8)kTables.solved[j];
+        m.child_soa[(size_t)j * m.child_stride + (size_t)kA * t] = (int8_t)code;
+    }
+    const uint4 key = make_uint4(w[0], w[1], w[2], w[3]);
+    const size_t base = (size_t)t * (m.capacity + 1);
+    reinterpret_cast<uint4 *>(m.keys)[base + 1] = key;
+    m.hash[(size_t)t * m.hash_size + (key_hash(key) & (m.hash_size - 1))] = 1;
+    m.leaf[base + 1] = 1;
+    m.leaf[base] = 1;   // row 0 is never expanded; the reference's leaves[0] stays True as well
+    m.n_nodes[t] = 1;
+    m.status[t] = solved ? RC_MCTS_ROOT_SOLVED : RC_MCTS_RUNNING;
+    m.solved_idx[t] = solved ? 1 : -1;
+    m.solved_action[t] = -1;
+    m.iterations[t] = 0;
+    m.path_len[t] = 1;
+    m.path_node[(size_t)t * m.max_path] = 1;
+    m.expanded[t] = 0;
+    m.new_mask[t] = 0;
+}
+
+__global__ __launch_bounds__(kBlock) void k_mcts_root_eval(rc_mcts_t m, const float *__restrict__ probs,
+                                                          const float *__restrict__ values) {
+    const u32 i = blockIdx.x * kBlock + threadIdx.x;   // (tree, action)
+    if (i >= m.n_trees * kA) return;
+    const u32 t = i / kA, a = i - t * kA;
+    const size_t node = (size_t)t * (m.capacity + 1) + 1;
+    m.P[node * kA + a] = probs[(size_t)t * kA * kA + a];
+    if (a == 0) m.V[node] = values[(size_t)t * kA];
+}
+
+// ---- expand: one wave per tree, lane k < 12 owns child k ----------------------------------------
+__global__ __launch_bounds__(kWave) void k_mcts_expand(rc_mcts_t m, u32 max_states) {
+    __shared__ u32 s_lut[sizeof(kTables.lut) / 4];
+    stage_to_lds(s_lut, c_tables.lut, sizeof(kTables.lut));
+    __syncthreads();
+    const u8 *lut = reinterpret_cast<const u8 *>(s_lut);
+    const u32 t = blockIdx.x, lane = threadIdx.x;
+    if (lane == 0) m.expanded[t] = 0;
+    if (m.status[t] != RC_MCTS_RUNNING) return;
+    const int n = m.n_nodes[t];
+    if ((u32)n + kA > max_states || (u32)n + kA > m.capacity) {   // agents.py:476
+        if (lane == 0) m.status[t] = RC_MCTS_EXHAUSTED;
+        return;
+    }
+    const size_t base = (size_t)t * (m.capacity + 1);
+    uint4 *keys = reinterpret_cast<uint4 *>(m.keys) + base;
+    int *tab = m.hash + (size_t)t * m.hash_size;
+    const u32 mask = m.hash_size - 1;
+    const int plen = m.path_len[t];
+    const int leaf = m.path_node[(size_t)t * m.max_path + plen - 1];
+    const uint4 pk = keys[leaf];
+    const bool act = lane < kA;
+    const u32 a = lane & (kActionPad - 1);
+
+    // child k = action k on the leaf (agents.py:512-513)
+    u32 w[4] = {0, 0, 0, 0};
+    bool solved = act;
+#pragma unroll
+    for (int j = 0; j < kPlanes; ++j) {
+        const u32 code = lut[a * (2 * kCodePad) + (j >= kCorners ? kCodePad : 0) + key_code(pk, j)];
+        key_set(w, j, code);
+        solved &= code == (u32)(u8)kTables.solved[j];
+        if (act) m.child_soa[(size_t)j * m.child_stride + (size_t)kA * t + lane] = (int8_t)code;
+    }
+    const uint4 ck = make_uint4(w[0], w[1], w[2], w[3]);
+
+    // membership in this tree (agents.py:517-520): linear probing, full-key compare
+    u32 h = key_hash(ck) & mask;
+    int found = 0;
+    if (act) {
+        for (;;) {
+            const int s = tab[h];
+            if (s == 0) break;
+            if (key_eq(keys[s], ck)) { found = s; break; }
+            h = (h + 1) & mask;
+        }
+    }
+    // unseen children take the next indices in child order (agents.py:523)
+    const u64 newm = __ballot(act && found == 0);
+    const int rank = __popcll(newm & ((1ull << lane) - 1ull));
+    const int idx = found ? found : n + 1 + rank;
+    if (act && !found) {
+        keys[idx] = ck;
+        for (;;) {   // claim the first free slot from where the lookup stopped (siblings race here)
+            if (atomicCAS(&tab[h], 0, idx) == 0) break;
+            h = (h + 1) & mask;
+        }
+        m.leaf[base + idx] = 1;
+    }
+    if (act) {   // links both ways, for seen children too (agents.py:533-535)
+        m.nbr[(base + leaf) * kA + lane] = idx;
+        m.nbr[(base + idx) * kA + (lane ^ 1)] = leaf;
+        m.child_idx[(size_t)t * kA + lane] = idx;
+    }
+    const u64 solm = __ballot(solved);
+    if (lane == 0) {
+        m.leaf[base + leaf] = 0;
+        m.n_nodes[t] = n + __popcll(newm);
+        m.new_mask[t] = (u32)newm;
+        m.expanded[t] = 1;
+        m.iterations[t] += 1;
+    }
+    if (solm) {   // first solved child wins (agents.py:540-543)
+        const int first = __ffsll((unsigned long long)solm) - 1;
+        if ((int)lane == first) {
+            m.status[t] = RC_MCTS_SOLVED;
+            m.solved_idx[t] = idx;
+            m.solved_action[t] = first;
+        }
+    }
+}
+
+// ---- backup: P/V of the new children, W/N/L along the path (agents.py:555-571) ------------------
+__device__ __forceinline__ float wave_max12(float v, bool valid) {
+    float x = valid ? v : -INFINITY;
+#pragma unroll
+    for (int o = 8; o > 0; o >>= 1) x = fmaxf(x, __shfl_xor(x, o));   // lanes 0..15 only matter
+    return __shfl(x, 0);
+}
+
+__global__ __launch_bounds__(kWave) void k_mcts_backup(rc_mcts_t m, const float *__restrict__ probs,
+                                                      const float *__restrict__ values) {
+    const u32 t = blockIdx.x, lane = threadIdx.x;
+    if (!m.expanded[t]) return;
+    const size_t base = (size_t)t * (m.capacity + 1);
+    const int plen = m.path_len[t];
+    const int *pnode = m.path_node + (size_t)t * m.max_path;
+    const u8 *pact = m.path_act + (size_t)t * m.max_path;
+    const int leaf = pnode[plen - 1];
+    const bool act = lane < kA;
+    const u32 newm = m.new_mask[t];
+    const bool is_new = act && ((newm >> lane) & 1u);
+    const int idx = act ? m.child_idx[(size_t)t * kA + lane] : 0;
+    const size_t row = (size_t)t * kA + lane;   // this child's row in the network output
+
+    float v = 0.f;
+    if (is_new) {
+        v = values[row];
+        m.V[base + idx] = v;
+#pragma unroll
+        for (int a = 0; a < kA; ++a) {
+            m.P[(base + idx) * kA + a] = probs[row * kA + a];
+            m.W[(base + idx) * kA + a] = v;   // W[new] = v for all 12 actions (agents.py:561)
+        }
+    } else if (act) {
+        v = m.V[base + idx];
+    }
+    // best value among the new children (agents.py:559); with no new child the reference raises --
+    // defined here as the best existing neighbour value (oracle/agents.py docstring)
+    const float best = newm ? wave_max12(v, is_new) : wave_max12(v, act);
+    if (act) m.W[(base + leaf) * kA + lane] = v;   // W[leaf] = V[neighbors[leaf]] (agents.py:560)
+
+    // path updates.  NumPy's buffered `N[rows, cols] += 1` counts a (node, action) pair that occurs
+    // twice on the path only once; a mark bit reproduces that for any path length: first every
+    // path edge is marked, then whoever finds the mark replaces it by old + 1.
+    const int edges = plen - 1;
+    constexpr int kMark = 1 << 30;
+    for (int i = lane; i < edges; i += kWave) m.N[(base + pnode[i]) * kA + pact[i]] |= kMark;
+    wave_store_fence();
+    for (int i0 = 0; i0 < edges; i0 += kWave) {
+        const int i = i0 + lane;
+        if (i < edges) {
+            const size_t e = (base + pnode[i]) * kA + pact[i];
+            const int nv = m.N[e];
+            if (nv & kMark) m.N[e] = (nv & ~kMark) + 1;            // agents.py:568
+            m.W[e] = fmaxf(m.W[e], best);                           // agents.py:562
+            m.L[e] = 0;                                             // agents.py:569
+            m.L[(base + pnode[i + 1]) * kA + (pact[i] ^ 1)] = 0;    // agents.py:570
+        }
+        if (i0 + kWave < edges) wave_store_fence();
+    }
+}
+
+// ---- select: PUCT descent with virtual loss (agents.py:575-595) ---------------------------------
+__global__ __launch_bounds__(kWave) void k_mcts_select(rc_mcts_t m, double c) {
+    const u32 t = blockIdx.x, lane = threadIdx.x;
+    if (m.status[t] != RC_MCTS_RUNNING) return;
+    const size_t base = (size_t)t * (m.capacity + 1);
+    int *pnode = m.path_node + (size_t)t * m.max_path;
+    u8 *pact = m.path_act + (size_t)t * m.max_path;
+    const bool act = lane < kA;
+    const u32 la = act ? lane : 0;
+    int cur = 1, plen = 1;
+    while (!m.leaf[base + cur]) {
+        if (plen >= (int)m.max_path) {
+            if (lane == 0) m.status[t] = RC_MCTS_PATH_OVERFLOW;
+            break;
+        }
+        const size_t r = (base + cur) * kA + la;
+        const int n_a = m.N[r];
+        const double p_a = (double)m.P[r], w_a = (double)m.W[r], l_a = 100.0 * (double)m.L[r];
+        int sum_n = act ? n_a : 0;
+#pragma unroll
+        for (int o = 8; o > 0; o >>= 1) sum_n += __shfl_xor(sum_n, o);
+        sum_n = __shfl(sum_n, 0);
+        // NumPy evaluation order: ((c * P) * sqrt(sum N)) / (1 + N)  +  (W - L), all float64
+        const double u = ((c * p_a) * sqrt((double)sum_n)) / (double)(1 + n_a);
+        double score = u + (w_a - l_a);
+        // argmax, first maximum wins (agents.py:588)
+        int arg = (int)lane;
+        if (!act) { score = -INFINITY; arg = 64; }
+#pragma unroll
+        for (int o = 8; o > 0; o >>= 1) {
+            const double os = __shfl_xor(score, o);
+            const int oa = __shfl_xor(arg, o);
+            if (os > score || (os == score && oa < arg)) { score = os; arg = oa; }
+        }
+        arg = __shfl(arg, 0);
+        const int next = m.nbr[(base + cur) * kA + arg];
+        if (lane == 0) {
+            m.L[(base + cur) * kA + arg] += 1;            // L[cur, a] += nu     (agents.py:589)
+            m.L[(base + next) * kA + (arg ^ 1)] += 1;     // L[next, rev a] += nu (agents.py:591)
+            pact[plen - 1] = (u8)arg;
+            pnode[plen] = next;
+        }
+        wave_store_fence();   // the next level's L row must see these increments
+        cur = next;
+        ++plen;
+    }
+    if (lane == 0) m.path_len[t] = plen;
+}
+
+}  // namespace rubiks
+
+using namespace rubiks;
+
+static int check_mcts(const rc_mcts_t *m) {
+    RC_REQUIRE(m != nullptr, RC_ERR_NULL);
+    RC_REQUIRE(m->keys && m->nbr && m->P && m->W && m->N && m->L && m->V && m->leaf && m->hash && m->n_nodes &&
+                   m->status && m->solved_idx && m->solved_action && m->iterations && m->path_len && m->path_node &&
+                   m->path_act && m->child_soa && m->child_idx && m->new_mask && m->expanded,
+               RC_ERR_NULL);
+    RC_REQUIRE(m->n_trees > 0 && m->capacity >= 13 && m->max_path >= 2 && m->max_path <= 2048, RC_ERR_RANGE);
+    RC_REQUIRE((m->hash_size & (m->hash_size - 1)) == 0 && m->hash_size >= 2 * (m->capacity + 1), RC_ERR_RANGE);
+    RC_REQUIRE(aligned16(m->keys) && aligned16(m->child_soa) && (m->child_stride & 15u) == 0, RC_ERR_ALIGN);
+    RC_REQUIRE(m->child_stride >= round_up((size_t)m->n_trees * kActions, 16), RC_ERR_STRIDE);
+    return RC_OK;
+}
+
+extern "C" {
+
+int rc_mcts_init(const rc_mcts_t *m, const int8_t *roots_soa, size_t stride, rc_stream_t stream) {
+    if (int rc = check_mcts(m)) return rc;
+    RC_CHECK_SOA(roots_soa, m->n_trees, stride);
+    hipLaunchKernelGGL(k_mcts_init, dim3(grid_for(m->n_trees, kBlock, 1 << 30)), dim3(kBlock), 0, (hipStream_t)stream, *m,
+                       (const u8 *)roots_soa, stride);
+    return launch_status();
+}
+
+int rc_mcts_root_eval(const rc_mcts_t *m, const float *probs, const float *values, rc_stream_t stream) {
+    if (int rc = check_mcts(m)) return rc;
+    RC_REQUIRE(probs && values, RC_ERR_NULL);
+    hipLaunchKernelGGL(k_mcts_root_eval, dim3(grid_for((size_t)m->n_trees * kActions, kBlock, 1 << 30)), dim3(kBlock), 0,
+                       (hipStream_t)stream, *m, probs, values);
+    return launch_status();
+}
+
+int rc_mcts_expand(const rc_mcts_t *m, uint32_t max_states, rc_stream_t stream) {
+    if (int rc = check_mcts(m)) return rc;
+    hipLaunchKernelGGL(k_mcts_expand, dim3(m->n_trees), dim3(kWave), 0, (hipStream_t)stream, *m, max_states);
+    return launch_status();
+}
+
+int rc_mcts_backup(const rc_mcts_t *m, const float *probs, const float *values, rc_stream_t stream) {
+    if (int rc = check_mcts(m)) return rc;
+    RC_REQUIRE(probs && values, RC_ERR_NULL);
+    hipLaunchKernelGGL(k_mcts_backup, dim3(m->n_trees), dim3(kWave), 0, (hipStream_t)stream, *m, probs, values);
+    return launch_status();
+}
+
+int rc_mcts_select(const rc_mcts_t *m, double c, rc_stream_t stream) {
+    if (int rc = check_mcts(m)) return rc;
+    hipLaunchKernelGGL(k_mcts_select, dim3(m->n_trees), dim3(kWave), 0, (hipStream_t)stream, *m, c);
+    return launch_status();
+}
+
+}  // extern "C"

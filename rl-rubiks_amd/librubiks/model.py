@@ -1,0 +1,273 @@
+"""
+Policy/value network of the reference (librubiks/model.py:15-264) on PyTorch-ROCm.
+
+`ModelConfig` / `Model` keep the reference's constructor arguments, module layout and file layout
+(`model.pt` / `model-best.pt` state_dict + `config.json`), so checkpoints written by the reference
+load here and vice versa: the state_dict keys are the same (`shared_net.0.weight`,
+`shared_net.2.running_mean`, `policy_net.3.bias`, `shared_net.resblock0.layer1.weight`, ...).
+
+`InferenceNet` is what the batched search agents call: the eval-mode network with every
+BatchNorm folded into the following Linear, the two heads merged into shared GEMMs, weights in
+bf16 (MFMA through hipBLASLt) or fp32, fixed-shape buffers so that a whole search iteration can be
+captured into a HIP graph.  The forward is the only dense contraction on the hot path; everything
+else is integer work in csrc/.
+"""
+import json
+import os
+from copy import deepcopy
+from time import time
+
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from librubiks import gpu
+from librubiks.utils import NullLogger
+
+OH_WIDTH = 480
+N_ACTIONS = 12
+
+_ARCHS = {   # reference model.py:17-21
+    "fc_small": {"shared_sizes": [4096, 2048], "part_sizes": [512]},
+    "fc_big": {"shared_sizes": [8192, 4096, 2048], "part_sizes": [1024, 512]},
+    "res_small": {"shared_sizes": [4096, 1024], "part_sizes": [512], "res_blocks": 4, "res_size": 1024},
+    "res_big": {"shared_sizes": [8192, 4096, 2048], "part_sizes": [1024, 512], "res_blocks": 6, "res_size": 2048},
+}
+_ACTIVATIONS = {"elu": nn.ELU, "relu": nn.ReLU}
+
+
+class ModelConfig:
+    def __init__(self, activation_function=None, batchnorm=True, architecture="fc_small", init="glorot",
+                 is2024=True, **kwargs):   # unknown keys (e.g. `id`) are swallowed like the reference does (model.py:28)
+        self.activation_function = activation_function if activation_function is not None else nn.ELU()
+        self.batchnorm = batchnorm
+        self.architecture = architecture + "_small" if architecture in ("fc", "res") else architecture   # model.py:52-56
+        self.init = init
+        self.is2024 = is2024
+        self.id = hash(time())
+        if self.architecture == "conv":
+            raise NotImplementedError("the conv architecture needs the 6x8x6 representation (out of scope on MI355X)")
+        if self.architecture not in _ARCHS:
+            raise KeyError(f"Network architecture should be one of {sorted(_ARCHS)}, but '{architecture}' was given")
+        if not is2024:
+            raise NotImplementedError("only the 20x24 representation is implemented on MI355X")
+        arch = _ARCHS[self.architecture]
+        self.shared_sizes = list(arch["shared_sizes"])
+        self.part_sizes = list(arch["part_sizes"])
+        if self.architecture.startswith("res"):
+            self.res_blocks, self.res_size = arch["res_blocks"], arch["res_size"]
+
+    def as_json_dict(self):
+        name = [k for k, cls in _ACTIVATIONS.items() if isinstance(self.activation_function, cls)][0]
+        return {"activation_function": name, "batchnorm": self.batchnorm, "architecture": self.architecture,
+                "init": self.init, "is2024": self.is2024, "id": self.id}
+
+    @classmethod
+    def from_json_dict(cls, conf: dict):
+        conf = dict(conf)
+        conf["activation_function"] = _ACTIVATIONS[conf["activation_function"]]()
+        return cls(**conf)
+
+
+class NonConvResBlock(nn.Module):
+    """Two same-width Linear layers with a skip connection (reference model.py:221-247)."""
+
+    def __init__(self, width: int, activation: nn.Module, with_batchnorm: bool):
+        super().__init__()
+        self.layer1, self.layer2 = nn.Linear(width, width), nn.Linear(width, width)
+        self.activate = activation
+        self.with_batchnorm = with_batchnorm
+        if with_batchnorm:
+            self.batchnorm1, self.batchnorm2 = nn.BatchNorm1d(width), nn.BatchNorm1d(width)
+
+    def forward(self, x):
+        y = self.layer1(x)
+        if self.with_batchnorm:
+            y = self.batchnorm1(y)
+        y = self.layer2(self.activate(y))
+        if self.with_batchnorm:
+            y = self.batchnorm2(y)
+        return self.activate(y + x)
+
+
+class Model(nn.Module):
+    """Shared trunk 480 -> shared_sizes, then a policy head (12 logits) and a value head (1)."""
+
+    def __init__(self, config: ModelConfig, logger=NullLogger()):
+        super().__init__()
+        self.config, self.log = config, logger
+        trunk_out = config.shared_sizes[-1]
+        self.shared_net = nn.Sequential(*self._stack([OH_WIDTH, *config.shared_sizes], last_is_output=False))
+        if config.architecture.startswith("res"):
+            assert trunk_out == config.res_size
+            for i in range(config.res_blocks):
+                self.shared_net.add_module(f"resblock{i}",
+                                           NonConvResBlock(config.res_size, config.activation_function, config.batchnorm))
+        self.policy_net = nn.Sequential(*self._stack([trunk_out, *config.part_sizes, N_ACTIONS], last_is_output=True))
+        self.value_net = nn.Sequential(*self._stack([trunk_out, *config.part_sizes, 1], last_is_output=True))
+
+    @staticmethod
+    def create(config: ModelConfig, logger=NullLogger()):
+        return Model(config, logger).to(gpu)
+
+    def _stack(self, widths, last_is_output: bool):
+        """Linear -> activation -> BatchNorm1d per hidden layer (model.py:143-161); a bare Linear at an output."""
+        layers = []
+        for i, (fan_in, fan_out) in enumerate(zip(widths[:-1], widths[1:])):
+            lin = nn.Linear(fan_in, fan_out)
+            if self.config.init == "glorot":
+                nn.init.xavier_uniform_(lin.weight)
+            elif self.config.init == "he":
+                nn.init.kaiming_uniform_(lin.weight)
+            else:
+                nn.init.constant_(lin.weight, float(self.config.init))
+            layers.append(lin)
+            if not (last_is_output and i == len(widths) - 2):
+                layers.append(self.config.activation_function)
+                if self.config.batchnorm:
+                    layers.append(nn.BatchNorm1d(fan_out))
+        return layers
+
+    def forward(self, x, policy=True, value=True):
+        assert policy or value
+        x = self.shared_net(x)
+        out = []
+        if policy:
+            out.append(self.policy_net(x))
+        if value:
+            out.append(self.value_net(x))
+        return out if len(out) > 1 else out[0]
+
+    def clone(self):
+        twin = Model.create(self.config)
+        twin.load_state_dict({k: v.clone() for k, v in self.state_dict().items()})
+        return twin
+
+    def get_params(self):
+        return torch.cat([x.float().flatten() for x in self.state_dict().values()]).clone()
+
+    def save(self, save_dir: str, is_min=False):
+        os.makedirs(save_dir, exist_ok=True)
+        if is_min:
+            torch.save(self.state_dict(), os.path.join(save_dir, "model-best.pt"))
+            return
+        torch.save(self.state_dict(), os.path.join(save_dir, "model.pt"))
+        with open(os.path.join(save_dir, "config.json"), "w", encoding="utf-8") as f:
+            json.dump(self.config.as_json_dict(), f, indent=4)
+
+    @staticmethod
+    def load(load_dir: str, logger=NullLogger(), load_best=False):
+        with open(os.path.join(load_dir, "config.json"), encoding="utf-8") as f:
+            config = ModelConfig.from_json_dict(json.load(f))
+        path = os.path.join(load_dir, "model-best.pt" if load_best else "model.pt")
+        if not os.path.exists(path):   # fall back like the reference (model.py:202-206)
+            path = os.path.join(load_dir, "model.pt")
+        model = Model.create(config, logger)
+        model.load_state_dict(torch.load(path, map_location=gpu))
+        return model.to(gpu)
+
+
+# =================================================================================================
+# Inference engine for the search agents
+# =================================================================================================
+def _bn_affine(bn: nn.BatchNorm1d):
+    scale = bn.weight.double() / torch.sqrt(bn.running_var.double() + bn.eps)
+    return scale, bn.bias.double() - bn.running_mean.double() * scale
+
+
+def _fold_stack(seq: nn.Sequential, carry=None):
+    """
+    [(W, b, has_activation)] of a Linear/act/BN stack in eval mode with each BatchNorm folded into the
+    NEXT Linear; `carry` = (scale, shift) of a BatchNorm that precedes the stack.  Returns the list
+    and the trailing BatchNorm's affine (or None) for whoever consumes the stack's output.
+    """
+    out, mods, i = [], list(seq), 0
+    while i < len(mods):
+        lin = mods[i]
+        assert isinstance(lin, nn.Linear), f"cannot fold {type(lin).__name__}"
+        W, b = lin.weight.double(), lin.bias.double()
+        if carry is not None:
+            scale, shift = carry
+            b = b + W @ shift
+            W = W * scale[None, :]
+            carry = None
+        i += 1
+        has_act = i < len(mods) and isinstance(mods[i], (nn.ELU, nn.ReLU))
+        act = mods[i] if has_act else None
+        i += int(has_act)
+        if i < len(mods) and isinstance(mods[i], nn.BatchNorm1d):
+            carry = _bn_affine(mods[i])
+            i += 1
+        out.append((W, b, act))
+    return out, carry
+
+
+class InferenceNet:
+    """
+    Eval-mode forward of an fc_* `Model` as a chain of fused GEMMs:
+        x -> [Linear+act]* (trunk) -> [Linear+act] (both heads' first layers side by side) -> ... -> [13 outputs]
+    Returns (policy logits float32[n,12], values float32[n]).  Any other torch module (ResNet models,
+    test stand-ins) goes through `GenericNet`, which simply calls it.
+    """
+
+    def __init__(self, model: Model, dtype=torch.bfloat16, device=None):
+        assert isinstance(model, Model) and model.config.architecture.startswith("fc")
+        device = device or next(model.parameters()).device
+        was_training = model.training
+        model.eval()
+        with torch.no_grad():
+            trunk, carry = _fold_stack(model.shared_net)
+            pol, pc = _fold_stack(model.policy_net, carry)
+            val, vc = _fold_stack(model.value_net, carry)
+            assert pc is None and vc is None and len(pol) == len(val)
+            layers = list(trunk)
+            for d, ((Wp, bp, ap), (Wv, bv, av)) in enumerate(zip(pol, val)):
+                if d == 0:   # both heads read the trunk output: stack the rows
+                    W, b = torch.cat([Wp, Wv]), torch.cat([bp, bv])
+                else:        # afterwards the heads are independent: block diagonal
+                    W = torch.block_diag(Wp, Wv)
+                    b = torch.cat([bp, bv])
+                layers.append((W, b, ap))
+            self.layers = [(W.to(device=device, dtype=dtype).contiguous(), b.to(device=device, dtype=dtype), act)
+                           for W, b, act in layers]
+        model.train(was_training)
+        self.dtype, self.device = dtype, device
+        self.flops_per_state = 2 * sum(W.shape[0] * W.shape[1] for W, _, _ in self.layers)
+
+    @property
+    def input_dtype(self):
+        return self.dtype
+
+    @torch.no_grad()
+    def __call__(self, oh: torch.Tensor):
+        x = oh
+        for W, b, act in self.layers:
+            x = torch.addmm(b, x, W.t())
+            if act is not None:
+                x = F.relu_(x) if isinstance(act, nn.ReLU) else F.elu_(x, alpha=act.alpha)
+        out = x.float()
+        return out[:, :N_ACTIONS], out[:, N_ACTIONS]
+
+
+class GenericNet:
+    """Calls an arbitrary torch module with the reference's convention net(oh) -> [policy, value]."""
+
+    input_dtype = torch.float32
+
+    def __init__(self, module: nn.Module):
+        self.module = module
+        self.flops_per_state = None
+
+    @torch.no_grad()
+    def __call__(self, oh: torch.Tensor):
+        p, v = self.module(oh)
+        return p.float(), v.float().reshape(-1)
+
+
+def make_inference_net(net, dtype=torch.bfloat16):
+    """The fastest engine that preserves `net`'s eval-mode function."""
+    if isinstance(net, (InferenceNet, GenericNet)):
+        return net
+    if isinstance(net, Model) and net.config.architecture.startswith("fc"):
+        return InferenceNet(net, dtype=dtype)
+    return GenericNet(net)

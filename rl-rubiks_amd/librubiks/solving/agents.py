@@ -1,0 +1,228 @@
+"""
+Search agents of the hot path with the reference's API (librubiks/solving/agents.py):
+
+    MCTS(net, c, search_graph).search(state, time_limit=None, max_states=None) -> bool
+    .action_queue (deque of action indices), len(agent) (states explored), str(agent), .tt
+
+plus a batched entry point the reference lacks -- `search_batch(states, ...)` runs one tree per
+scramble in lock step on one MI355X; `search` is `search_batch` with a single tree.  The trees are
+built by the rc_mcts_* HIP kernels (csrc/rubiks_mcts.hip) with the reference's exact per-tree
+semantics; the network runs through librubiks.model.InferenceNet (bf16 MFMA by default,
+`net_dtype=torch.float32` for parity runs).
+"""
+from collections import deque
+
+import numpy as np
+import torch
+
+from librubiks import cube, gpu, no_grad
+from librubiks.cube.device import DeviceCubes
+from librubiks.model import Model
+from librubiks.solving import mcts_device as md
+from librubiks.utils import TickTock
+
+DEFAULT_NODE_CAP = 1 << 18   # per-tree node capacity when a search is bounded by time only
+
+
+class Agent:
+    _explored_states = 0
+
+    def __init__(self):
+        self.action_queue = deque()
+        self.tt = TickTock()
+
+    def reset(self, time_limit, max_states):
+        self._explored_states = 0
+        self.action_queue = deque()
+        self.tt.reset()
+        if hasattr(self, "net") and hasattr(self.net, "eval"):
+            self.net.eval()
+        assert time_limit or max_states   # reference agents.py:54
+        return time_limit or 1e10, max_states or int(1e10)
+
+    def __len__(self):
+        return self._explored_states
+
+
+class DeepAgent(Agent):
+    def __init__(self, net):
+        super().__init__()
+        self.net = net
+
+    @classmethod
+    def from_saved(cls, loc: str, use_best: bool, **kwargs):
+        return cls(Model.load(loc, load_best=use_best).to(gpu), **kwargs)
+
+
+class BatchResult:
+    """Per-scramble outcome of a batched search (shapes (B,)); `queues[t]` is tree t's action queue."""
+
+    def __init__(self, solved, lengths, nodes, queues, seconds, iterations, status):
+        self.solved, self.lengths, self.nodes, self.queues = solved, lengths, nodes, queues
+        self.seconds, self.iterations, self.status = seconds, iterations, status
+
+    @property
+    def states_per_sec(self) -> float:
+        return float(self.nodes.sum()) / max(self.seconds, 1e-12)
+
+
+class MCTS(DeepAgent):
+    """Batched PUCT graph search with virtual loss and max-backup (reference agents.py:415-645)."""
+
+    nu = 100
+
+    def __init__(self, net, c: float, search_graph: bool, net_dtype=torch.bfloat16, use_graph: bool = True,
+                 max_path: int = 1024, sync_every: int = 16):
+        super().__init__(net)
+        self.c, self.search_graph = float(c), bool(search_graph)
+        self.net_dtype, self.use_graph, self.max_path, self.sync_every = net_dtype, use_graph, max_path, sync_every
+        self.forest = None
+        self._tree = None      # host copy of tree 0, for the reference's inspectable attributes
+        self._engine = None
+
+    @classmethod
+    def from_saved(cls, loc: str, use_best: bool, c: float, search_graph: bool, **kwargs):
+        return cls(Model.load(loc, load_best=use_best).to(gpu), c=c, search_graph=search_graph, **kwargs)
+
+    def __str__(self):
+        return ("BFS" if self.search_graph else "Naive") + f" MCTS (c={self.c})"
+
+    def __len__(self):
+        return self._explored_states
+
+    # ---- batched search --------------------------------------------------------------------------
+    def _forest_for(self, n_trees: int, capacity: int) -> md.MCTSForest:
+        f = self.forest
+        if f is None or f.B != n_trees or f.C < capacity or f.C > 4 * capacity:
+            self.forest = None
+            torch.cuda.empty_cache()
+            f = self.forest = md.MCTSForest(n_trees, capacity, self.max_path)
+            f.set_net(self.net, self.net_dtype)
+        return f
+
+    @no_grad
+    def search_batch(self, states, time_limit: float = None, max_states: int = None,
+                     max_iterations: int = None) -> BatchResult:
+        """
+        One MCTS tree per row of `states` ((B,20) int8 NumPy array or DeviceCubes), all advanced in
+        lock step.  `max_states` is the reference's per-tree cap (stop when len + 12 > max_states);
+        `time_limit` bounds the wall time of the whole batch.
+        """
+        time_limit, max_states = self.reset(time_limit, max_states)
+        roots = states if isinstance(states, DeviceCubes) else DeviceCubes.from_numpy(np.asarray(states))
+        cap_states = int(max_states) if max_states < int(1e10) else DEFAULT_NODE_CAP
+        forest = self._forest_for(roots.n, max(cap_states, 16))
+        self.tt.tick()
+        forest.reset(roots)
+        it = 0
+        while True:
+            if max_iterations is not None and it >= max_iterations:
+                break
+            forest.step(self.c, cap_states, self.use_graph)
+            it += 1
+            if it % self.sync_every == 0 or (max_iterations is not None and it >= max_iterations):
+                if not forest.any_running() or self.tt.tock() >= time_limit:
+                    break
+        torch.cuda.synchronize()
+        seconds = self.tt.tock()
+        return self._collect(forest, seconds)
+
+    def _collect(self, forest: md.MCTSForest, seconds: float) -> BatchResult:
+        status = forest.status.cpu().numpy()
+        nodes = forest.n_nodes.cpu().numpy().astype(np.int64)
+        plen, pact = forest.paths()
+        sol_act = forest.solved_action.cpu().numpy()
+        sol_idx = forest.solved_idx.cpu().numpy()
+        solved = (status == md.SOLVED) | (status == md.ROOT_SOLVED)
+        queues = []
+        self._tree = None
+        for t in range(forest.B):
+            taken = [int(a) for a in pact[t, :plen[t] - 1]]
+            if status[t] == md.SOLVED:
+                q = taken + [int(sol_act[t])]                      # agents.py:483
+                if self.search_graph:
+                    q = self._shortened_queue(forest, t, int(sol_idx[t]), q)
+            elif status[t] == md.ROOT_SOLVED:
+                q = []
+            else:
+                q = taken                                          # best guess (agents.py:492)
+            queues.append(deque(q))
+        lengths = np.array([len(q) if s else -1 for q, s in zip(queues, solved)])
+        self._explored_states = int(nodes[0])
+        self.action_queue = queues[0]
+        return BatchResult(solved, lengths, nodes, queues, seconds, forest.iterations.cpu().numpy(), status)
+
+    # ---- solved-tree post-processing (agents.py:597-633) ----------------------------------------
+    def _shortened_queue(self, forest, t: int, solved_idx: int, fallback):
+        tree = self._completed_tree(forest, t)
+        if solved_idx == 1:
+            return fallback
+        nbr = tree["neighbors"]
+        n = tree["n"]
+        parent = np.zeros(n + 1, dtype=np.int64)
+        via = np.zeros(n + 1, dtype=np.int64)
+        seen = np.zeros(n + 1, dtype=bool)
+        seen[0] = seen[1] = True
+        frontier = np.array([1])
+        while len(frontier):
+            # scan order of the reference's FIFO BFS: frontier order, then action order
+            cand = nbr[frontier].ravel()
+            src = np.repeat(frontier, 12)
+            act = np.tile(np.arange(12), len(frontier))
+            keep = ~seen[cand]
+            cand, src, act = cand[keep], src[keep], act[keep]
+            uniq, first = np.unique(cand, return_index=True)
+            order = np.sort(first)
+            cand, src, act = cand[order], src[order], act[order]
+            parent[cand], via[cand], seen[cand] = src, act, True
+            if seen[solved_idx]:
+                q, v = [], solved_idx
+                while v != 1:
+                    q.append(int(via[v]))
+                    v = int(parent[v])
+                return q[::-1]
+            frontier = cand
+        return fallback
+
+    def _completed_tree(self, forest, t: int) -> dict:
+        """_complete_graph: link every leaf to those of its 12 children that exist in the tree."""
+        tree = forest.tree_arrays(t)
+        n = tree["n"]
+        leaves = np.flatnonzero(tree["leaves"][:n + 1])[1:]
+        if len(leaves):
+            kids = DeviceCubes.from_numpy(tree["states"][leaves]).expand12().numpy()
+            index = {s.tobytes(): i for i, s in enumerate(tree["states"][1:n + 1], start=1)}
+            kid_idx = np.array([index.get(k.tobytes(), 0) for k in kids])
+            rep = np.repeat(leaves, 12)
+            act = np.tile(np.arange(12), len(leaves))
+            tree["neighbors"][rep, act] = kid_idx
+            tree["neighbors"][kid_idx, act ^ 1] = rep
+            tree["neighbors"][0] = 0
+        if t == 0:
+            self._tree = tree
+        return tree
+
+    # ---- the reference's single-state API ----------------------------------------------------------
+    def search(self, state: np.ndarray, time_limit: float = None, max_states: int = None) -> bool:
+        res = self.search_batch(np.asarray(state)[None], time_limit, max_states)
+        return bool(res.solved[0])
+
+    def _host_tree(self):
+        if self._tree is None:
+            self._tree = self.forest.tree_arrays(0)
+        return self._tree
+
+    # inspectable attributes relied on by the reference's tests (tests/test_agents.py:54-92)
+    states = property(lambda self: self._host_tree()["states"])
+    neighbors = property(lambda self: self._host_tree()["neighbors"])
+    leaves = property(lambda self: self._host_tree()["leaves"])
+    P = property(lambda self: self._host_tree()["P"])
+    V = property(lambda self: self._host_tree()["V"])
+    W = property(lambda self: self._host_tree()["W"])
+    N = property(lambda self: self._host_tree()["N"])
+    L = property(lambda self: self._host_tree()["L"])
+
+    @property
+    def indices(self) -> dict:
+        tree = self._host_tree()
+        return {s.tobytes(): i for i, s in enumerate(tree["states"][1:tree["n"] + 1], start=1)}

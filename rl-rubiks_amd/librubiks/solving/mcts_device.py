@@ -1,0 +1,172 @@
+"""
+Device-resident forest of MCTS trees (one per scramble) and the lock-step iteration that drives
+the rc_mcts_* kernels of librubiks_hip.so.  Host code here only allocates HBM, sequences launches
+on torch's current stream and reads results back; no cube arithmetic happens on the host.
+
+Per node (tree-major, 1-based, row 0 = "no neighbour" sentinel like the reference's arrays,
+librubiks/solving/agents.py:417-459):  packed state 16 B, neighbors 12 x i32, P / W 12 x f32,
+N 12 x i32, virtual-loss count 12 x u16, V f32, leaf u8, plus 2 hash slots x i32  ->  ~270 B,
+so 1 024 trees x 175 000 nodes (the reference's default max_states) is ~48 GB of the 288 GB HBM3E.
+"""
+import ctypes
+from ctypes import POINTER, Structure, c_double, c_int, c_size_t, c_uint32, c_void_p
+
+import numpy as np
+import torch
+
+from librubiks import _hip
+from librubiks.cube.device import DeviceCubes
+from librubiks.model import make_inference_net
+
+RUNNING, SOLVED, EXHAUSTED, PATH_OVERFLOW, ROOT_SOLVED = 0, 1, 2, 3, 4
+N_ACT = 12
+
+
+class _McStruct(Structure):   # mirrors rc_mcts_t (include/rubiks_hip.h)
+    _fields_ = [("n_trees", c_uint32), ("capacity", c_uint32), ("hash_size", c_uint32), ("max_path", c_uint32)] + \
+               [(name, c_void_p) for name in ("keys", "nbr", "P", "W", "N", "L", "V", "leaf", "hash", "n_nodes", "status",
+                                              "solved_idx", "solved_action", "iterations", "path_len", "path_node",
+                                              "path_act", "child_soa")] + \
+               [("child_stride", c_size_t)] + \
+               [(name, c_void_p) for name in ("child_idx", "new_mask", "expanded")]
+
+
+_hip.register({
+    "rc_mcts_init": [POINTER(_McStruct), c_void_p, c_size_t, c_void_p],
+    "rc_mcts_root_eval": [POINTER(_McStruct), c_void_p, c_void_p, c_void_p],
+    "rc_mcts_expand": [POINTER(_McStruct), c_uint32, c_void_p],
+    "rc_mcts_backup": [POINTER(_McStruct), c_void_p, c_void_p, c_void_p],
+    "rc_mcts_select": [POINTER(_McStruct), c_double, c_void_p],
+})
+
+
+def unpack_keys(keys: np.ndarray) -> np.ndarray:
+    """(n,4) uint32 packed states -> (n,20) int8 codes (6 codes of 5 bits per dword)."""
+    keys = keys.astype(np.uint32).reshape(-1, 4)
+    out = np.empty((len(keys), 20), dtype=np.int8)
+    for j in range(20):
+        out[:, j] = (keys[:, j // 6] >> np.uint32(5 * (j % 6))) & np.uint32(31)
+    return out
+
+
+class MCTSForest:
+    def __init__(self, n_trees: int, capacity: int, max_path: int = 1024, device=None):
+        self.lib = _hip.lib()
+        dev = device or torch.device("cuda", torch.cuda.current_device())
+        B, C = int(n_trees), int(capacity)
+        assert B > 0 and C >= 13 and 2 <= max_path <= 2048
+        self.B, self.C, self.max_path, self.device = B, C, max_path, dev
+        self.hash_size = 1 << int(np.ceil(np.log2(2 * (C + 1))))
+        z = lambda shape, dt: torch.zeros(shape, dtype=dt, device=dev)   # noqa: E731
+        rows = B * (C + 1)
+        self.keys = z((rows, 4), torch.int32)
+        self.nbr = z((rows, N_ACT), torch.int32)
+        self.P = z((rows, N_ACT), torch.float32)
+        self.W = z((rows, N_ACT), torch.float32)
+        self.N = z((rows, N_ACT), torch.int32)
+        self.L = z((rows, N_ACT), torch.int16)
+        self.V = z((rows,), torch.float32)
+        self.leaf = z((rows,), torch.uint8)
+        self.hash = z((B, self.hash_size), torch.int32)
+        self.n_nodes, self.status = z((B,), torch.int32), z((B,), torch.int32)
+        self.solved_idx, self.solved_action = z((B,), torch.int32), z((B,), torch.int32)
+        self.iterations, self.path_len = z((B,), torch.int32), z((B,), torch.int32)
+        self.path_node = z((B, max_path), torch.int32)
+        self.path_act = z((B, max_path), torch.uint8)
+        self.children = DeviceCubes.empty(N_ACT * B, dev)
+        self.child_idx = z((B, N_ACT), torch.int32)
+        self.new_mask = z((B,), torch.int32)
+        self.expanded = z((B,), torch.uint8)
+        self.probs = z((N_ACT * B, N_ACT), torch.float32)     # static network outputs (graph capture)
+        self.values = z((N_ACT * B,), torch.float32)
+        s = _McStruct()
+        s.n_trees, s.capacity, s.hash_size, s.max_path = B, C, self.hash_size, max_path
+        for name in ("keys", "nbr", "P", "W", "N", "L", "V", "leaf", "hash", "n_nodes", "status", "solved_idx",
+                     "solved_action", "iterations", "path_len", "path_node", "path_act", "child_idx", "new_mask",
+                     "expanded"):
+            setattr(s, name, getattr(self, name).data_ptr())
+        s.child_soa, s.child_stride = self.children.soa.data_ptr(), self.children.stride
+        self.struct = s
+        self.engine = None
+        self._oh = None
+        self._graph = None
+        self._graph_key = None
+
+    def bytes_allocated(self) -> int:
+        return sum(t.numel() * t.element_size() for t in (self.keys, self.nbr, self.P, self.W, self.N, self.L, self.V,
+                                                           self.leaf, self.hash, self.path_node, self.path_act))
+
+    # ---- network ---------------------------------------------------------------------------------
+    def set_net(self, net, dtype=torch.bfloat16):
+        self.engine = make_inference_net(net, dtype)
+        self._oh = torch.empty((N_ACT * self.B, 480), dtype=self.engine.input_dtype, device=self.device)
+        self._graph = None
+
+    def _evaluate_children(self):
+        """child_soa -> one-hot (HIP kernel) -> network -> softmax -> static probs / values buffers."""
+        self.children.as_oh(out=self._oh)
+        logits, values = self.engine(self._oh)
+        torch.softmax(logits, dim=1, out=self.probs)   # agents.py:552 (`p.softmax(dim=1)`)
+        self.values.copy_(values)
+
+    # ---- search phases ---------------------------------------------------------------------------
+    def reset(self, roots: DeviceCubes):
+        """Empties every tree and plants root t = roots[t] as node 1; evaluates the roots (agents.py:466-473)."""
+        assert roots.n == self.B and self.engine is not None
+        for t in (self.nbr, self.N, self.L, self.hash, self.leaf):
+            t.zero_()
+        st = _hip.stream_ptr()
+        _hip.check(self.lib.rc_mcts_init(ctypes.byref(self.struct), roots.soa.data_ptr(), roots.stride, st), "rc_mcts_init")
+        self._evaluate_children()   # row 12 t holds root t (the other 11 rows are ignored)
+        _hip.check(self.lib.rc_mcts_root_eval(ctypes.byref(self.struct), self.probs.data_ptr(), self.values.data_ptr(), st),
+                   "rc_mcts_root_eval")
+
+    def _iteration(self, c: float, max_states: int):
+        st = _hip.stream_ptr()
+        m = ctypes.byref(self.struct)
+        _hip.check(self.lib.rc_mcts_expand(m, max_states, st), "rc_mcts_expand")
+        self._evaluate_children()
+        _hip.check(self.lib.rc_mcts_backup(m, self.probs.data_ptr(), self.values.data_ptr(), st), "rc_mcts_backup")
+        _hip.check(self.lib.rc_mcts_select(m, c, st), "rc_mcts_select")
+
+    def step(self, c: float, max_states: int, use_graph: bool = True):
+        """One lock-step iteration of every running tree: expand -> network -> backup -> select."""
+        if not use_graph:
+            return self._iteration(c, max_states)
+        key = (float(c), int(max_states))
+        if self._graph is None or self._graph_key != key:
+            # this call's iteration runs eagerly (hipBLASLt picks its kernels, the allocator settles);
+            # the capture that follows only records launches, it does not advance the search
+            self._iteration(c, max_states)
+            torch.cuda.synchronize()
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g):
+                self._iteration(c, max_states)
+            self._graph, self._graph_key = g, key
+            return
+        self._graph.replay()
+
+    def any_running(self) -> bool:
+        return bool((self.status == RUNNING).any().item())
+
+    # ---- results ---------------------------------------------------------------------------------
+    def tree_arrays(self, t: int) -> dict:
+        """Host copies of tree t's node arrays, shaped like the reference agent's attributes."""
+        n = int(self.n_nodes[t].item())
+        lo, hi = t * (self.C + 1), t * (self.C + 1) + n + 1
+        keys = self.keys[lo:hi].cpu().numpy().view(np.uint32)
+        states = unpack_keys(keys)
+        return {
+            "n": n, "states": states,
+            "neighbors": self.nbr[lo:hi].cpu().numpy().astype(np.int64),
+            "P": self.P[lo:hi].cpu().numpy().astype(np.float64),
+            "V": self.V[lo:hi].cpu().numpy().astype(np.float64),
+            "W": self.W[lo:hi].cpu().numpy().astype(np.float64),
+            "N": self.N[lo:hi].cpu().numpy().astype(np.int64),
+            "L": self.L[lo:hi].cpu().numpy().astype(np.float64) * 100.0,
+            "leaves": self.leaf[lo:hi].cpu().numpy().astype(bool),
+        }
+
+    def paths(self):
+        """(path_len[B], path_act[B,max_path]) on the host."""
+        return self.path_len.cpu().numpy(), self.path_act.cpu().numpy()

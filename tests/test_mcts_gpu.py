@@ -1,0 +1,167 @@
+"""
+GPU parity tests of the batched MCTS (rc_mcts_* kernels behind librubiks.solving.agents.MCTS).
+
+1. Golden traces: every tree recorded from the REFERENCE agent (tests/golden/agents_golden.npz) is
+   rebuilt node-for-node by the HIP path (fp32 stand-in network whose outputs are exact integers/16).
+2. Batched vs oracle: B independent scrambles in one lock-step batch, each compared with the
+   restated single-tree agent (oracle/agents.py) fed by the same network on the same device.
+3. The reference's own structural invariants (tests/test_agents.py:38-94) restated, with the real
+   fc_small network on the bf16 engine.
+"""
+import numpy as np
+import pytest
+import torch
+
+from conftest import GOLDEN, golden_cases
+
+pytestmark = pytest.mark.gpu
+
+from oracle import agents as oa  # noqa: E402  (checker only)
+from oracle import cube as oc  # noqa: E402
+
+_G = np.load(f"{GOLDEN}/agents_golden.npz")
+
+
+@pytest.fixture(scope="module")
+def net_gpu(standin_net):
+    return standin_net.cuda()
+
+
+def _compare_tree(tree: dict, ref: dict, n: int, exact_p: bool):
+    assert tree["n"] == n
+    assert np.array_equal(tree["states"][1:n + 1], ref["states"][1:n + 1])
+    assert np.array_equal(tree["neighbors"][:n + 1], ref["neighbors"][:n + 1])
+    assert np.array_equal(tree["leaves"][1:n + 1], ref["leaves"][1:n + 1])
+    assert np.array_equal(tree["N"][:n + 1], ref["N"][:n + 1])
+    assert np.array_equal(tree["L"][:n + 1], ref["L"][:n + 1])
+    assert np.array_equal(tree["V"][1:n + 1], np.asarray(ref["V"][1:n + 1], dtype=np.float64))   # integers / 16: exact
+    assert np.array_equal(tree["W"][1:n + 1], ref["W"][1:n + 1])
+    if exact_p:
+        assert np.array_equal(tree["P"][1:n + 1], np.asarray(ref["P"][1:n + 1], dtype=np.float64))
+    else:   # softmax evaluated by torch on another device: float32 rounding only
+        assert np.allclose(tree["P"][1:n + 1], ref["P"][1:n + 1], rtol=0, atol=1e-6)
+
+
+@pytest.mark.parametrize("case", golden_cases(_G, "mcts_"))
+@pytest.mark.parametrize("use_graph", [False, True])
+def test_reference_trace(case, use_graph, agents_golden, net_gpu):
+    from librubiks.solving.agents import MCTS
+    g = lambda k: agents_golden[f"mcts_{case}_{k}"]   # noqa: E731
+    depth, c, graph, max_states, solved, n = g("params")
+    agent = MCTS(net_gpu, c=float(c), search_graph=bool(graph), net_dtype=torch.float32, use_graph=use_graph)
+    assert agent.search(g("state"), None, int(max_states)) == bool(solved)
+    assert len(agent) == int(n)
+    assert list(agent.action_queue) == list(g("queue"))
+    ref = {k: g(k) for k in ("states", "neighbors", "leaves", "N", "L", "V", "W", "P")}
+    tree = agent._host_tree()
+    _compare_tree(tree, ref, int(n), exact_p=False)
+    assert agent.indices[g("state").tobytes()] == 1 and len(agent.indices) == int(n)
+
+
+def test_batch_vs_oracle(net_gpu):
+    """96 scrambles of depth 1..8 in one lock-step batch; every tree equals the oracle's single-tree run."""
+    from librubiks.solving.agents import MCTS
+    np.random.seed(5)
+    states = np.array([oc.scramble(1 + i % 8, True)[0] for i in range(96)])
+    states[17] = oc.get_solved()          # a solved root in the middle of the batch
+    max_states = 700
+    for c, graph in ((0.6, True), (4.13, False)):
+        agent = MCTS(net_gpu, c=c, search_graph=graph, net_dtype=torch.float32)
+        res = agent.search_batch(states, None, max_states)
+        onet = oa.TorchNet(net_gpu, device="cuda")
+        n_solved = 0
+        for t, s in enumerate(states):
+            ref = oa.MCTS(onet, c=c, search_graph=graph)
+            ok = ref.search(s, max_states)
+            assert bool(res.solved[t]) == ok, f"tree {t}"
+            assert res.nodes[t] == len(ref), f"tree {t}"
+            assert list(res.queues[t]) == list(ref.action_queue), f"tree {t}"
+            assert res.lengths[t] == (len(ref.action_queue) if ok else -1)
+            if t % 8 == 3 and not oc.is_solved(s):
+                tree = agent.forest.tree_arrays(t)
+                if graph and ok:   # the oracle completed its graph in place; do the same on the copy
+                    tree = agent._completed_tree(agent.forest, t)
+                refd = {k: getattr(ref, k) for k in ("states", "neighbors", "leaves", "N", "L", "V", "W", "P")}
+                _compare_tree(tree, refd, len(ref), exact_p=True)
+            if ok:
+                n_solved += 1
+                x = s
+                for a in res.queues[t]:
+                    x = oc.rotate(x, *oc.ACTION_SPACE[a])
+                assert oc.is_solved(x)
+        assert n_solved >= 20
+        assert res.solved[17] and res.lengths[17] == 0 and res.nodes[17] == 1
+
+
+def test_max_iterations_and_budget(net_gpu):
+    """Unsolved trees stop exactly where the reference's `len + 12 <= max_states` loop stops."""
+    from librubiks.solving.agents import MCTS
+    np.random.seed(9)
+    states = np.array([oc.scramble(20, True)[0] for _ in range(40)])
+    agent = MCTS(net_gpu, c=0.6, search_graph=True, net_dtype=torch.float32, sync_every=7)
+    res = agent.search_batch(states, None, 333)
+    onet = oa.TorchNet(net_gpu, device="cuda")
+    for t in (0, 7, 39):
+        ref = oa.MCTS(onet, c=0.6, search_graph=True)
+        assert not ref.search(states[t], 333)
+        assert res.nodes[t] == len(ref) and res.iterations[t] == ref.iterations
+        assert list(res.queues[t]) == list(ref.action_queue)
+    assert (res.nodes <= 333).all() and (res.nodes + 12 > 333).all()
+    assert not res.solved.any() and (res.lengths == -1).all()
+
+
+def test_structural_invariants_real_net():
+    """tests/test_agents.py:38-94 of the reference, on fc_small with the bf16 inference engine."""
+    from librubiks import cube
+    from librubiks.model import Model, ModelConfig
+    from librubiks.solving.agents import MCTS
+    torch.manual_seed(0)
+    np.random.seed(0)
+    net = Model.create(ModelConfig()).eval()
+    for depth, graph in ((50, False), (3, False), (3, True)):
+        state, _, _ = cube.scramble(depth)
+        agent = MCTS(net, c=1, search_graph=graph)
+        solved = agent.search(state, None, 1500)
+        idx = agent.indices
+        assert idx[state.tobytes()] == 1
+        vals = sorted(idx.values())
+        assert vals[0] == 1 and np.all(np.diff(vals) == 1) and len(vals) == len(agent)
+        used = np.array(vals)
+        states = agent.states
+        for s, i in idx.items():
+            assert states[i].tobytes() == s
+        assert np.array_equal(states[1], state)
+        if not graph:
+            kids = oc.expand12(states[used]).reshape(len(used), 12, 20)
+            nb = agent.neighbors[used]
+            assert ((nb == 0) | (nb <= len(agent))).all()
+            for r, c_ in zip(*np.nonzero(nb)):
+                assert np.array_equal(states[nb[r, c_]], kids[r, c_])
+            assert np.all(agent.neighbors[used].all(axis=1) != agent.leaves[used])
+        # P and V are the network's outputs on the stored states; bf16 weights/activations vs the fp32
+        # module: tolerance 3e-2 absolute (values are O(1) for a glorot-initialised net)
+        with torch.no_grad():
+            p, v = net(cube.as_oh(states[used]))
+        p, v = p.softmax(dim=1).cpu().numpy(), v.squeeze().cpu().numpy()
+        assert np.allclose(agent.P[used], p, atol=3e-2)
+        assert np.allclose(agent.V[used], v, atol=3e-2)
+        assert agent.W[used].all()
+        x = state
+        assert all(0 <= a < 12 for a in agent.action_queue)
+        for a in agent.action_queue:
+            x = cube.rotate(x, *cube.action_space[a])
+        assert cube.is_solved(x) == solved
+
+
+def test_time_limit_only():
+    """A search bounded by wall time alone stops, reports unsolved trees and a best-guess queue."""
+    from librubiks.model import Model, ModelConfig
+    from librubiks.solving.agents import MCTS
+    torch.manual_seed(0)
+    np.random.seed(1)
+    net = Model.create(ModelConfig()).eval()
+    states = np.array([oc.scramble(20, True)[0] for _ in range(8)])
+    agent = MCTS(net, c=0.6, search_graph=True)
+    res = agent.search_batch(states, time_limit=0.5, max_states=20000)
+    assert res.seconds < 30 and (res.nodes > 12).all()
+    assert str(agent) == "BFS MCTS (c=0.6)"

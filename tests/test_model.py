@@ -1,0 +1,79 @@
+"""Network plumbing that runs without a GPU: checkpoint layout and BatchNorm folding of InferenceNet."""
+import numpy as np
+import torch
+
+from librubiks.model import InferenceNet, Model, ModelConfig, make_inference_net, GenericNet
+
+
+def _randomise_bn(model, seed=0):
+    g = torch.Generator().manual_seed(seed)
+    for mod in model.modules():
+        if isinstance(mod, torch.nn.BatchNorm1d):
+            mod.running_mean.copy_(torch.randn(mod.num_features, generator=g) * 0.3)
+            mod.running_var.copy_(torch.rand(mod.num_features, generator=g) + 0.5)
+            mod.weight.data.copy_(torch.rand(mod.num_features, generator=g) + 0.5)
+            mod.bias.data.copy_(torch.randn(mod.num_features, generator=g) * 0.2)
+
+
+def _one_hot(n, seed=0):
+    rng = np.random.RandomState(seed)
+    oh = np.zeros((n, 480), dtype=np.float32)
+    oh[np.repeat(np.arange(n), 20), (24 * np.arange(20) + rng.randint(0, 24, (n, 20))).ravel()] = 1
+    return torch.from_numpy(oh)
+
+
+def test_state_dict_layout_matches_reference_names():
+    torch.manual_seed(0)
+    m = Model(ModelConfig())
+    keys = list(m.state_dict().keys())
+    # the reference's fc_small: Linear(0) ELU(1) BN(2) Linear(3) ELU(4) BN(5) | heads Linear(0) ELU BN(2) Linear(3)
+    for k in ("shared_net.0.weight", "shared_net.2.running_mean", "shared_net.3.bias", "shared_net.5.num_batches_tracked",
+              "policy_net.0.weight", "policy_net.2.weight", "policy_net.3.bias", "value_net.3.weight"):
+        assert k in keys
+    assert sum(p.numel() for p in m.parameters()) == 12_480_013
+    assert m.shared_net[0].weight.shape == (4096, 480) and m.value_net[3].weight.shape == (1, 512)
+    r = Model(ModelConfig(architecture="res_small"))
+    assert "shared_net.resblock3.batchnorm2.running_var" in r.state_dict()
+    assert ModelConfig(architecture="fc").architecture == "fc_small"   # legacy names (model.py:52-56)
+
+
+def test_save_load_round_trip(tmp_path):
+    torch.manual_seed(1)
+    m = Model(ModelConfig(activation_function=torch.nn.ReLU(), batchnorm=True))
+    _randomise_bn(m)
+    m.save(str(tmp_path))
+    m.save(str(tmp_path), is_min=True)
+    m2 = Model.load(str(tmp_path), load_best=True)
+    assert isinstance(m2.config.activation_function, torch.nn.ReLU)
+    x = _one_hot(5)
+    m.eval(), m2.eval()
+    with torch.no_grad():
+        for a, b in zip(m(x), m2(x)):
+            assert torch.equal(a, b)
+
+
+def test_inference_net_folding_fp32():
+    """BN folding + head merging must be the same function as Model.eval() (fp32, tolerance 1e-4 relative)."""
+    for act in (torch.nn.ELU(), torch.nn.ReLU()):
+        for bn in (True, False):
+            torch.manual_seed(2)
+            m = Model(ModelConfig(activation_function=act, batchnorm=bn))
+            _randomise_bn(m)
+            m.eval()
+            x = _one_hot(64, seed=3)
+            with torch.no_grad():
+                p_ref, v_ref = m(x)
+            eng = InferenceNet(m, dtype=torch.float32)
+            p, v = eng(x)
+            assert p.shape == (64, 12) and v.shape == (64,)
+            assert torch.allclose(p, p_ref, rtol=1e-4, atol=1e-4)
+            assert torch.allclose(v, v_ref.reshape(-1), rtol=1e-4, atol=1e-4)
+            assert eng.flops_per_state >= 2 * (480 * 4096 + 4096 * 2048 + 2 * 2048 * 512 + 512 * 13)
+            assert m.training is False
+
+
+def test_make_inference_net_dispatch():
+    from standin_net import StandInNet
+    assert isinstance(make_inference_net(StandInNet(0)), GenericNet)
+    assert isinstance(make_inference_net(Model(ModelConfig()), torch.float32), InferenceNet)
+    assert isinstance(make_inference_net(Model(ModelConfig(architecture="res_small"))), GenericNet)
