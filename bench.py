@@ -1,0 +1,268 @@
+"""
+bench.py -- MCTS node expansions/sec on depth-20 scrambles (BASELINE.json metric), one process per GPU.
+
+    python bench.py --gpus 1 --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
+
+Workload (BASELINE.json configs[1]): 1 024 depth-20 scrambles per GPU (np.random.seed(0), the
+reference's scramble stream), MCTS c = 0.6 with graph search, fc_small policy/value net with
+glorot weights from torch.manual_seed(0) (no trained weights exist offline), bf16 inference engine.
+A "step" is one lock-step MCTS iteration of every tree on the rank: expand 12 children per leaf
+(HIP), one-hot (HIP), network forward (PyTorch-ROCm / hipBLASLt MFMA), backup + PUCT descent (HIP),
+replayed as one HIP graph.  value = unique states inserted into the trees by all ranks during the K
+timed steps / max-over-ranks wall time (inputs resident in HBM before the timed region).
+Ranks own disjoint scramble slices (weak scaling); the only collectives are the barrier, the
+max/sum reductions of the result and one all_gather of per-tree node counts.
+
+Also printed on the same JSON line:
+  roofline      dominant kernel group of the timed step = the network's GEMMs (MFMA bound)
+  roofline_env  the hand-written environment kernels in isolation at 2^24 states (HBM bound;
+                multi_rotate is the north_star's roofline target)
+  phases        per-phase milliseconds of one MCTS step (HIP events, eager replay of the same step)
+  cpu_baseline  the restated reference agent (oracle/, NumPy + torch CPU) on this box's host cores
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path[:0] = [ROOT, os.path.join(ROOT, "rl-rubiks_amd")]
+
+HBM_PEAK_GBPS = 8000.0      # MI355X_MICROARCH.md: HBM3E peak
+MFMA_BF16_PEAK_TFLOPS = 2500.0   # dense bf16
+MFMA_F32_PEAK_TFLOPS = 157.3
+
+
+def event_ms(fn, reps, warm=2):
+    for _ in range(warm):
+        fn()
+    evs = [torch.cuda.Event(enable_timing=True) for _ in range(reps + 1)]
+    evs[0].record()
+    for i in range(reps):
+        fn()
+        evs[i + 1].record()
+    torch.cuda.synchronize()
+    ts = [evs[i].elapsed_time(evs[i + 1]) for i in range(reps)]
+    return float(np.mean(ts)), float(np.min(ts))
+
+
+def env_roofline(log2n=24):
+    """Environment kernels alone, HBM-resident inputs, HIP events on the launch stream."""
+    from librubiks.cube import DeviceCubes
+    n = 1 << log2n
+    g = torch.Generator(device="cuda").manual_seed(0)
+    cubes = DeviceCubes.solved(n)
+    for _ in range(30):   # states 30 random moves from solved
+        cubes = cubes.multi_rotate(torch.randint(0, 12, (n,), dtype=torch.uint8, device="cuda", generator=g))
+    act = torch.randint(0, 12, (n,), dtype=torch.uint8, device="cuda", generator=g)
+    out = DeviceCubes.empty(n)
+    res = []
+
+    def add(kernel, unit, unit_bytes, units, fn, reps=20):
+        mean, best = event_ms(fn, reps)
+        gbps = unit_bytes * units / (mean * 1e-3) / 1e9
+        res.append({"kernel": kernel, "bound": "hbm", "units": units, "unit": unit, "bytes_per_unit": unit_bytes,
+                    "ms": round(mean, 4), "achieved": round(gbps, 1), "peak": HBM_PEAK_GBPS, "unit_rate": "GB/s",
+                    "frac": round(gbps / HBM_PEAK_GBPS, 4), "Munits_per_s": round(units / (mean * 1e-3) / 1e6, 1)})
+
+    add("multi_rotate", "state", 41, n, lambda: cubes.multi_rotate(act, out=out))
+    npar = n // 4
+    parents = DeviceCubes(cubes.soa[:, :npar].contiguous(), npar)
+    kids = DeviceCubes.empty(12 * npar)
+    add("expand12", "parent", 260, npar, lambda: parents.expand12(out=kids))
+    del kids
+    flags = torch.empty(n, dtype=torch.uint8, device="cuda")
+    from librubiks import _hip
+    lib = _hip.lib()
+    add("is_solved(flags)", "state", 21, n,
+        lambda: _hip.check(lib.rc_is_solved(cubes.soa.data_ptr(), flags.data_ptr(), None, None, n, cubes.stride,
+                                            _hip.stream_ptr())))
+    mask = torch.zeros(n // 64 + 2, dtype=torch.int64, device="cuda")
+    add("is_solved(mask)", "state", 20.125, n,
+        lambda: _hip.check(lib.rc_is_solved(cubes.soa.data_ptr(), None, mask.data_ptr(), None, n, cubes.stride,
+                                            _hip.stream_ptr())))
+    noh = n // 16
+    small = DeviceCubes(cubes.soa[:, :noh].contiguous(), noh)
+    oh = torch.empty((noh, 480), dtype=torch.float32, device="cuda")
+    add("as_oh(f32)", "state", 1940, noh, lambda: small.as_oh(out=oh))
+    oh = torch.empty((noh, 480), dtype=torch.bfloat16, device="cuda")
+    add("as_oh(bf16)", "state", 980, noh, lambda: small.as_oh(out=oh))
+    return res
+
+
+def phase_times(forest, c, max_states, reps):
+    """Per-phase HIP-event timing of the eager step (same launches the captured graph replays)."""
+    import ctypes
+    from librubiks import _hip
+    lib, m = forest.lib, ctypes.byref(forest.struct)
+    names = ["expand", "as_oh", "net_forward", "softmax+copy", "backup", "select"]
+    acc = {k: 0.0 for k in names}
+    for _ in range(reps):
+        ev = [torch.cuda.Event(enable_timing=True) for _ in range(len(names) + 1)]
+        st = _hip.stream_ptr()
+        ev[0].record()
+        _hip.check(lib.rc_mcts_expand(m, max_states, st))
+        ev[1].record()
+        forest.children.as_oh(out=forest._oh)
+        ev[2].record()
+        logits, values = forest.engine(forest._oh)
+        ev[3].record()
+        torch.softmax(logits, dim=1, out=forest.probs)
+        forest.values.copy_(values)
+        ev[4].record()
+        _hip.check(lib.rc_mcts_backup(m, forest.probs.data_ptr(), forest.values.data_ptr(), st))
+        ev[5].record()
+        _hip.check(lib.rc_mcts_select(m, c, st))
+        ev[6].record()
+        torch.cuda.synchronize()
+        for i, k in enumerate(names):
+            acc[k] += ev[i].elapsed_time(ev[i + 1])
+    return {k: round(v / reps, 4) for k, v in acc.items()}
+
+
+def cpu_baseline(model, depth, budget_s=15.0, max_states=5000):
+    """Restated reference MCTS (oracle/) with the same weights on the host cores, bounded sample."""
+    import copy
+    from oracle import agents as oa
+    from oracle import cube as oc
+    cpu_model = copy.deepcopy(model).cpu().float().eval()
+    net = oa.TorchNet(cpu_model, device="cpu")
+    np.random.seed(0)
+    nodes, t0, games = 0, time.perf_counter(), 0
+    while time.perf_counter() - t0 < budget_s:
+        s, _, _ = oc.scramble(depth, True)
+        agent = oa.MCTS(net, c=0.6, search_graph=True)
+        agent.search(s, max_states)
+        nodes += len(agent)
+        games += 1
+    dt = time.perf_counter() - t0
+    return {"value": round(nodes / dt, 1), "unit": "node expansions/s", "cores": torch.get_num_threads(),
+            "host_cpus": os.cpu_count(), "kind": "port",
+            "sample": f"{games} depth-{depth} scrambles x max_states={max_states}, single-tree MCTS c=0.6 "
+                      f"(oracle/agents.py on NumPy + torch CPU fp32), {dt:.1f} s"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--trees", type=int, default=1024, help="MCTS trees (scrambles) per GPU")
+    ap.add_argument("--depth", type=int, default=20)
+    ap.add_argument("--dtype", default="bf16", choices=["bf16", "f32"])
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-env-roofline", action="store_true")
+    ap.add_argument("--phase-reps", type=int, default=20)
+    args = ap.parse_args()
+
+    rank, world = int(os.environ.get("RANK", 0)), int(os.environ.get("WORLD_SIZE", 1))
+    local_rank = int(os.environ.get("LOCAL_RANK", 0))
+    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))   # nccl == RCCL on ROCm
+
+    from librubiks import cube
+    from librubiks.cube import DeviceCubes
+    from librubiks.model import Model, ModelConfig
+    from librubiks.solving.agents import MCTS
+    from librubiks.solving.sharding import gather_results, shard_range
+
+    # ---- synthetic inputs: the reference's scramble stream, sliced by rank ------------------------
+    np.random.seed(0)
+    total = args.trees * world
+    all_cubes, _, _ = cube.scramble_batch(total, args.depth, True)
+    lo, hi = shard_range(total, rank, world)
+    roots = DeviceCubes.empty(hi - lo)
+    roots.soa[:, :hi - lo] = all_cubes.soa[:, lo:hi]
+    del all_cubes
+
+    torch.manual_seed(0)
+    model = Model.create(ModelConfig()).eval()
+    net_dtype = torch.bfloat16 if args.dtype == "bf16" else torch.float32
+    c = 0.6
+    capacity = 12 * (args.warmup + args.steps + args.phase_reps + 8) + 64
+    agent = MCTS(model, c=c, search_graph=True, net_dtype=net_dtype)
+    forest = agent._forest_for(roots.n, capacity)
+    max_states = forest.C
+    forest.reset(roots)
+
+    # ---- warm-up (first step runs eagerly and captures the HIP graph), then the timed region ------
+    for _ in range(max(args.warmup, 1)):
+        forest.step(c, max_states, use_graph=True)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    nodes0 = int(forest.n_nodes.sum().item())
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        forest.step(c, max_states, use_graph=True)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    seconds = time.perf_counter() - t0
+    nodes = int(forest.n_nodes.sum().item()) - nodes0
+
+    stats = torch.tensor([seconds, float(nodes)], dtype=torch.float64, device="cuda")
+    if world > 1:
+        tmax = stats[:1].clone()
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        nsum = stats[1:].clone()
+        dist.all_reduce(nsum, op=dist.ReduceOp.SUM)
+        seconds, nodes = float(tmax.item()), int(nsum.item())
+    # final aggregation of per-tree results (the one data collective of a real evaluation run)
+    status = forest.status.cpu().numpy()
+    gathered = gather_results({"nodes": forest.n_nodes.cpu().numpy(), "solved": status == 1,
+                               "lengths": np.full(hi - lo, -1)}, total, device="cuda")
+
+    if rank != 0:
+        if world > 1:
+            dist.barrier()
+            dist.destroy_process_group()
+        return
+
+    rows = 12 * roots.n
+    phases = phase_times(forest, c, max_states, args.phase_reps) if args.phase_reps else {}
+    flops = forest.engine.flops_per_state * rows
+    peak = MFMA_BF16_PEAK_TFLOPS if args.dtype == "bf16" else MFMA_F32_PEAK_TFLOPS
+    roofline = None
+    if phases:
+        tf = flops / (phases["net_forward"] * 1e-3) / 1e12
+        roofline = {"kernel": f"policy/value net forward on {rows} child rows ({len(forest.engine.layers)} hipBLASLt "
+                              "GEMMs + bias + ELU, BatchNorm folded)",
+                    "bound": "mfma", "achieved": round(tf, 1), "peak": peak, "unit": "TFLOP/s",
+                    "frac": round(tf / peak, 4), "traffic": None,
+                    "flops_per_launch": flops, "ms_per_launch": phases["net_forward"]}
+    result = {
+        "metric": "MCTS node expansions/sec, depth-20 scrambles", "value": round(nodes / seconds, 1),
+        "unit": "node expansions/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": round(seconds / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak",
+        "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
+        "config": {"workload": f"{args.trees} depth-{args.depth} scrambles per GPU, MCTS agent (c=0.6, graph search), "
+                               "fc_small net, random-init weights", "trees_per_gpu": args.trees,
+                   "scramble_depth": args.depth, "net_rows_per_step": rows, "parallelism": f"scramble-sharded x{world}"},
+        "nodes_expanded": nodes, "solve_rate": float(np.mean(gathered["solved"])),
+        "roofline": roofline, "phases_ms": phases,
+    }
+    if not args.no_env_roofline and world == 1:
+        del forest, agent
+        torch.cuda.empty_cache()
+        result["roofline_env"] = env_roofline()
+    if not args.no_cpu_baseline and world == 1:
+        result["cpu_baseline"] = cpu_baseline(model, args.depth)
+    print(json.dumps(result))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,52 @@
+"""N > 1 path on CPU: two gloo ranks shard the games, gather per-game results, agree on the summary."""
+import os
+import socket
+
+import numpy as np
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from librubiks.solving.sharding import gather_results, shard_range, summarize
+
+
+def test_shard_range_covers_everything():
+    for n in (0, 1, 7, 1024, 65536, 1001):
+        for world in (1, 2, 3, 8):
+            spans = [shard_range(n, r, world) for r in range(world)]
+            assert spans[0][0] == 0 and spans[-1][1] == n
+            assert all(a[1] == b[0] for a, b in zip(spans, spans[1:]))
+            assert max(hi - lo for lo, hi in spans) - min(hi - lo for lo, hi in spans) <= 1
+
+
+def _worker(rank, world, port, n_games, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    lo, hi = shard_range(n_games, rank, world)
+    g = np.arange(lo, hi)
+    local = {"solved": (g % 3 == 0), "lengths": np.where(g % 3 == 0, g % 11, -1), "nodes": 100 + g}
+    full = gather_results(local, n_games)
+    q.put((rank, {k: v.tolist() for k, v in full.items()}, summarize(full, 2.0)))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_rank_gather_uneven():
+    n_games, world = 37, 2
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, n_games, q)) for r in range(world)]
+    [p.start() for p in procs]
+    got = sorted(q.get(timeout=120) for _ in range(world))
+    [p.join(60) for p in procs]
+    assert all(p.exitcode == 0 for p in procs)
+    g = np.arange(n_games)
+    for rank, full, summary in got:
+        assert full["nodes"] == (100 + g).tolist()
+        assert full["solved"] == (g % 3 == 0).tolist()
+        assert full["lengths"] == np.where(g % 3 == 0, g % 11, -1).tolist()
+        assert summary["games"] == n_games and summary["nodes"] == int((100 + g).sum())
+        assert abs(summary["nodes_per_sec"] - (100 + g).sum() / 2.0) < 1e-6
+    assert got[0][2] == got[1][2]
