@@ -170,6 +170,69 @@ int rc_mcts_backup(const rc_mcts_t *m, const float *probs, const float *values, 
 /* find_leaf (agents.py:575-595): PUCT descent with virtual loss, float64 arithmetic as NumPy's. */
 int rc_mcts_select(const rc_mcts_t *m, double c, rc_stream_t stream);
 
+/* ---- batched weighted A*: B independent problems, N expansions each per iteration --------------
+ *
+ * Replaces the per-problem Python loop of librubiks/solving/agents.py:171-413 (class AStar).
+ * One iteration of every running problem =
+ *     rc_astar_pop_expand -> [prefix sum of new_count on the caller's side] -> rc_astar_gather_new
+ *     -> [value network on the compacted new states] -> rc_astar_push_relax
+ * Node indices are 1-based per problem (index 0 unused, agents.py:189); arrays are problem-major
+ * with capacity + 1 rows.  Device pointers, zero-initialised by the caller except `claim`, which
+ * must be filled with INT32_MAX.
+ */
+#define RC_ASTAR_RUNNING 0
+#define RC_ASTAR_SOLVED 1        /* a NEW state of the batch is the solved cube (agents.py:321-323) */
+#define RC_ASTAR_EXHAUSTED 2     /* len + 12 N > max_states (agents.py:236) or capacity reached */
+#define RC_ASTAR_OPEN_EMPTY 3    /* open list ran dry (the reference would spin; defined as unsolved) */
+#define RC_ASTAR_ROOT_SOLVED 4   /* agents.py:230 */
+
+typedef struct rc_astar {
+    uint32_t n_problems; /* B */
+    uint32_t capacity;   /* largest node index per problem */
+    uint32_t hash_size;  /* slots per problem, power of two, >= 2 * (capacity + 1) */
+    uint32_t expansions; /* N (agents.py:218) */
+    /* per node, [B][capacity + 1] */
+    void *keys;              /* uint32[4] packed state (as rc_mcts) */
+    int32_t *G;              /* path cost; integer valued in the reference's float array (agents.py:203,311) */
+    int32_t *parents;        /* agents.py:204 */
+    uint8_t *parent_actions; /* agents.py:205 */
+    int32_t *claim;          /* scratch for first-/last-occurrence election, INT32_MAX when idle */
+    int32_t *hash;           /* [B][hash_size]: > 0 node index, < 0 pending child row -(row+1), 0 empty */
+    /* open list: binary min-heap on (cost, index), [B][capacity + 1] */
+    double *heap_cost;
+    int32_t *heap_idx;
+    /* per problem, [B] */
+    int32_t *heap_size;
+    int32_t *n_nodes;        /* len(agent) (agents.py:409-410) */
+    int32_t *status;         /* RC_ASTAR_* */
+    int32_t *solved_idx;
+    int32_t *iterations;
+    int32_t *n_popped;       /* parents expanded in the current iteration */
+    int32_t *new_count;      /* states added in the current iteration */
+    /* per iteration staging, [B][N] and [B][12 N] */
+    int32_t *popped;         /* node indices in pop order (agents.py:238-239) */
+    void *child_keys;        /* uint32[4] per child row 12 p + k */
+    int32_t *child_node;     /* node index of a seen child / hash slot of an unseen one */
+    int32_t *row_tmp;        /* scratch per row (relaxation values) */
+    uint8_t *row_flags;      /* bit0 first occurrence & unseen (new state), bit1 first occurrence & seen */
+} rc_astar_t;
+
+/* Root = node 1 with G = 0 and cost 0 on the open list (agents.py:233-234). */
+int rc_astar_init(const rc_astar_t *a, const int8_t *roots_soa, size_t stride, rc_stream_t stream);
+/* Pops min(len(open), N) lowest (cost, index) nodes, expands their 12 N children, dedups against
+ * the problem's states and inside the batch (first occurrence in row order, agents.py:286-295),
+ * appends the new states with G, parent, parent_action (agents.py:299-313).  Sets new_count. */
+int rc_astar_pop_expand(const rc_astar_t *a, uint32_t max_states, rc_stream_t stream);
+/* Writes the new states of every problem into out_soa at columns new_offset[b] .. (exclusive prefix
+ * sum of new_count, B + 1 entries) -- the compacted network input of this iteration. */
+int rc_astar_gather_new(const rc_astar_t *a, const int32_t *new_offset, int8_t *out_soa, size_t stride,
+                        rc_stream_t stream);
+/* cost = lambda * G - value (float64, agents.py:383), push on the open list (agents.py:315-317),
+ * win check on the new states (agents.py:321-323), else relaxation of the first-seen children
+ * (agents.py:326-328,333-367).  values[new_offset[b] + i] belongs to new state i of problem b. */
+int rc_astar_push_relax(const rc_astar_t *a, const int32_t *new_offset, const float *values, double lambda,
+                        rc_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -60,4 +60,39 @@ __device__ __forceinline__ void stage_to_lds(u32 *dst, const void *src, int byte
 // 5-bit code of byte b of a packed dword (state codes are 0..23; masking keeps table reads in range).
 __device__ __forceinline__ u32 code_of(u32 packed, int b) { return (packed >> (8 * b)) & 31u; }
 
+// ---- packed node states shared by the search kernels ---------------------------------------------
+// A node's state is stored packed: 20 codes of 5 bits, 6 per dword (cubies 0-5, 6-11, 12-17, 18-19).
+
+__device__ __forceinline__ bool key_eq(const uint4 &a, const uint4 &b) {
+    return a.x == b.x && a.y == b.y && a.z == b.z && a.w == b.w;
+}
+
+__device__ __forceinline__ u32 key_hash(const uint4 &k) {
+    u32 h = k.x * 0x9E3779B1u;
+    h ^= h >> 15;
+    h += k.y * 0x85EBCA77u;
+    h ^= h >> 13;
+    h += k.z * 0xC2B2AE3Du;
+    h ^= h >> 16;
+    h += k.w * 0x27D4EB2Fu;
+    h ^= h >> 15;
+    h *= 0x165667B1u;
+    h ^= h >> 16;
+    return h;
+}
+
+__device__ __forceinline__ u32 key_code(const uint4 &k, int j) {   // j compile-time after unrolling
+    const u32 w = (j < 6) ? k.x : (j < 12) ? k.y : (j < 18) ? k.z : k.w;
+    return (w >> (5 * (j % 6))) & 31u;
+}
+
+__device__ __forceinline__ void key_set(u32 (&w)[4], int j, u32 code) { w[j / 6] |= code << (5 * (j % 6)); }
+
+// Makes this wave's earlier global stores visible to its later loads (same CU, so L1/L2 in order
+// once the stores have left the wave).
+__device__ __forceinline__ void wave_store_fence() { 
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+    __builtin_amdgcn_s_waitcnt(0);
+ }
+
 }  // namespace rubiks

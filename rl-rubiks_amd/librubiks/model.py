@@ -228,8 +228,10 @@ class InferenceNet:
                     W = torch.block_diag(Wp, Wv)
                     b = torch.cat([bp, bv])
                 layers.append((W, b, ap))
-            self.layers = [(W.to(device=device, dtype=dtype).contiguous(), b.to(device=device, dtype=dtype), act)
-                           for W, b, act in layers]
+            cast = lambda ls: [(W.to(device=device, dtype=dtype).contiguous(), b.to(device=device, dtype=dtype), act)  # noqa: E731
+                               for W, b, act in ls]
+            self.layers = cast(layers)
+            self.value_layers = cast(list(trunk) + list(val))   # A* needs the value head only (agents.py:380)
         model.train(was_training)
         self.dtype, self.device = dtype, device
         self.flops_per_state = 2 * sum(W.shape[0] * W.shape[1] for W, _, _ in self.layers)
@@ -248,6 +250,19 @@ class InferenceNet:
         out = x.float()
         return out[:, :N_ACTIONS], out[:, N_ACTIONS]
 
+    @staticmethod
+    def _run(layers, x):
+        for W, b, act in layers:
+            x = torch.addmm(b, x, W.t())
+            if act is not None:
+                x = F.relu_(x) if isinstance(act, nn.ReLU) else F.elu_(x, alpha=act.alpha)
+        return x
+
+    @torch.no_grad()
+    def value(self, oh: torch.Tensor) -> torch.Tensor:
+        """Value head only, float32[n]."""
+        return self._run(self.value_layers, oh).float().reshape(-1)
+
 
 class GenericNet:
     """Calls an arbitrary torch module with the reference's convention net(oh) -> [policy, value]."""
@@ -262,6 +277,10 @@ class GenericNet:
     def __call__(self, oh: torch.Tensor):
         p, v = self.module(oh)
         return p.float(), v.float().reshape(-1)
+
+    @torch.no_grad()
+    def value(self, oh: torch.Tensor) -> torch.Tensor:
+        return self.module(oh, policy=False, value=True).float().reshape(-1)
 
 
 def make_inference_net(net, dtype=torch.bfloat16):

@@ -18,6 +18,7 @@ import torch
 from librubiks import cube, gpu, no_grad
 from librubiks.cube.device import DeviceCubes
 from librubiks.model import Model
+from librubiks.solving import astar_device as ad
 from librubiks.solving import mcts_device as md
 from librubiks.utils import TickTock
 
@@ -226,3 +227,104 @@ class MCTS(DeepAgent):
     def indices(self) -> dict:
         tree = self._host_tree()
         return {s.tobytes(): i for i, s in enumerate(tree["states"][1:tree["n"] + 1], start=1)}
+
+
+class AStar(DeepAgent):
+    """
+    Batch weighted A* (DeepCubeA style; reference agents.py:171-413): every iteration expands the
+    `expansions` open nodes of lowest cost  lambda * G(node) - value_net(node).
+    `search_batch` runs one such search per scramble, all on one GPU; `search` is the batch of one.
+    """
+
+    def __init__(self, net, lambda_: float, expansions: int, net_dtype=torch.bfloat16):
+        super().__init__(net)
+        self.lambda_, self.expansions, self.net_dtype = float(lambda_), int(expansions), net_dtype
+        self.batch = None
+        self._arrays = None
+
+    @classmethod
+    def from_saved(cls, loc: str, use_best: bool, lambda_: float, expansions: int, **kwargs):
+        return cls(Model.load(loc, load_best=use_best).to(gpu), lambda_=lambda_, expansions=expansions, **kwargs)
+
+    def __str__(self):
+        return f"AStar (lambda={self.lambda_}, N={self.expansions})"
+
+    def __len__(self):
+        return self._explored_states
+
+    def _batch_for(self, n_problems: int, capacity: int):
+        b = self.batch
+        if b is None or b.B != n_problems or b.N != self.expansions or b.C < capacity or b.C > 4 * capacity:
+            self.batch = None
+            torch.cuda.empty_cache()
+            b = self.batch = ad.AStarBatch(n_problems, capacity, self.expansions)
+            b.set_net(self.net, self.net_dtype)
+        return b
+
+    @no_grad
+    def search_batch(self, states, time_limit: float = None, max_states: int = None,
+                     max_iterations: int = None) -> BatchResult:
+        time_limit, max_states = self.reset(time_limit, max_states)
+        roots = states if isinstance(states, DeviceCubes) else DeviceCubes.from_numpy(np.asarray(states))
+        cap_states = int(max_states) if max_states < int(1e10) else DEFAULT_NODE_CAP
+        batch = self._batch_for(roots.n, max(cap_states, 12 * self.expansions + 1))
+        self.tt.tick()
+        batch.reset(roots)
+        it = 0
+        while max_iterations is None or it < max_iterations:
+            batch.iteration(self.lambda_, cap_states)
+            it += 1
+            if not batch.any_running() or self.tt.tock() >= time_limit:
+                break
+        torch.cuda.synchronize()
+        seconds = self.tt.tock()
+        status = batch.status.cpu().numpy()
+        nodes = batch.n_nodes.cpu().numpy().astype(np.int64)
+        solved = (status == ad.SOLVED) | (status == ad.ROOT_SOLVED)
+        sol_idx = batch.solved_idx.cpu().numpy()
+        queues = []
+        for b in range(batch.B):
+            q = deque()
+            if status[b] == ad.SOLVED:   # walk the parent pointers back to the root (agents.py:244-251)
+                lo = b * (batch.C + 1)
+                par = batch.parents[lo:lo + nodes[b] + 1].cpu().numpy()
+                pact = batch.parent_actions[lo:lo + nodes[b] + 1].cpu().numpy()
+                i = int(sol_idx[b])
+                while i != 1:
+                    q.appendleft(int(pact[i]))
+                    i = int(par[i])
+            queues.append(q)
+        lengths = np.array([len(q) if s else -1 for q, s in zip(queues, solved)])
+        self._explored_states = int(nodes[0])
+        self.action_queue = queues[0]
+        self._arrays = None
+        return BatchResult(solved, lengths, nodes, queues, seconds, batch.iterations.cpu().numpy(), status)
+
+    def search(self, state: np.ndarray, time_limit: float = None, max_states: int = None) -> bool:
+        return bool(self.search_batch(np.asarray(state)[None], time_limit, max_states).solved[0])
+
+    # ---- inspectable attributes relied on by the reference's tests (tests/test_agents.py:110-145) ----
+    def _host(self):
+        if self._arrays is None:
+            self._arrays = self.batch.problem_arrays(0)
+        return self._arrays
+
+    states = property(lambda self: self._host()["states"])
+    G = property(lambda self: self._host()["G"])
+    parents = property(lambda self: self._host()["parents"])
+    parent_actions = property(lambda self: self._host()["parent_actions"])
+    open_queue = property(lambda self: self._host()["open_queue"])
+
+    @property
+    def indices(self) -> dict:
+        h = self._host()
+        return {s.tobytes(): i for i, s in enumerate(h["states"][1:h["n"] + 1], start=1)}
+
+    @no_grad
+    def cost(self, states: np.ndarray, indeces: np.ndarray) -> np.ndarray:
+        """lambda * G[indeces] - value_net(states) (agents.py:369-383), evaluated on the device net."""
+        from librubiks.model import make_inference_net
+        eng = self.batch.engine if self.batch is not None else make_inference_net(self.net, self.net_dtype)
+        oh = DeviceCubes.from_numpy(np.asarray(states)).as_oh(eng.input_dtype)
+        h = -eng.value(oh).cpu().numpy().astype(np.float64)
+        return self.lambda_ * np.asarray(self.G)[indeces] + h

@@ -1,0 +1,125 @@
+"""
+GPU parity tests of the batched weighted A* (rc_astar_* kernels behind librubiks.solving.agents.AStar).
+
+1. Golden traces recorded from the REFERENCE agent are reproduced exactly: node count, action queue,
+   every state, G, parent, parent action, and the open list as a sorted (cost, index) sequence.
+2. Batches of independent problems equal the oracle's single-problem runs problem by problem.
+3. The reference's own A* tests (tests/test_agents.py:96-145) restated.
+"""
+import numpy as np
+import pytest
+import torch
+
+from conftest import GOLDEN, golden_cases
+
+pytestmark = pytest.mark.gpu
+
+from oracle import agents as oa  # noqa: E402  (checker only)
+from oracle import cube as oc  # noqa: E402
+
+_G = np.load(f"{GOLDEN}/agents_golden.npz")
+
+
+@pytest.fixture(scope="module")
+def net_gpu(standin_net):
+    return standin_net.cuda()
+
+
+def _compare_problem(host: dict, ref, n: int):
+    assert host["n"] == n
+    assert np.array_equal(host["states"][1:n + 1], ref["states"][1:n + 1])
+    assert np.array_equal(host["G"][1:n + 1], ref["G"][1:n + 1])
+    assert np.array_equal(host["parents"][2:n + 1], ref["parents"][2:n + 1])
+    assert np.array_equal(host["parent_actions"][2:n + 1], ref["parent_actions"][2:n + 1])
+    got = sorted((float(c), int(i)) for c, i in host["open_queue"])
+    assert [i for _, i in got] == list(ref["open_idx"])
+    assert np.array_equal(np.array([c for c, _ in got]), np.asarray(ref["open_cost"], dtype=np.float64))
+
+
+@pytest.mark.parametrize("case", golden_cases(_G, "astar_"))
+def test_reference_trace(case, agents_golden, net_gpu):
+    from librubiks.solving.agents import AStar
+    g = lambda k: agents_golden[f"astar_{case}_{k}"]   # noqa: E731
+    depth, lam, nexp, max_states, solved, n = g("params")
+    agent = AStar(net_gpu, lambda_=float(lam), expansions=int(nexp), net_dtype=torch.float32)
+    assert agent.search(g("state"), None, int(max_states)) == bool(solved)
+    assert len(agent) == int(n)
+    assert list(agent.action_queue) == list(g("queue"))
+    ref = {k: g(k) for k in ("states", "G", "parents", "parent_actions", "open_idx", "open_cost")}
+    _compare_problem(agent._host(), ref, int(n))
+    assert str(agent) == f"AStar (lambda={float(lam)}, N={int(nexp)})"
+
+
+def test_batch_vs_oracle(net_gpu):
+    from librubiks.solving.agents import AStar
+    np.random.seed(21)
+    states = np.array([oc.scramble(1 + i % 7, True)[0] for i in range(70)])
+    states[9] = oc.get_solved()
+    onet = oa.TorchNet(net_gpu, device="cuda")
+    for lam, nexp, max_states in ((0.2, 16, 1500), (0.0, 5, 400), (1.0, 1, 300)):
+        agent = AStar(net_gpu, lambda_=lam, expansions=nexp, net_dtype=torch.float32)
+        res = agent.search_batch(states, None, max_states)
+        n_solved = 0
+        for b, s in enumerate(states):
+            ref = oa.AStar(onet, lambda_=lam, expansions=nexp)
+            ok = ref.search(s, max_states)
+            assert bool(res.solved[b]) == ok, f"problem {b}"
+            assert res.nodes[b] == len(ref), f"problem {b}"
+            assert list(res.queues[b]) == list(ref.action_queue), f"problem {b}"
+            if b % 6 == 1:
+                oq = sorted((float(c), int(i)) for c, i in ref.open_queue)
+                refd = {"states": ref.states, "G": ref.G, "parents": ref.parents, "parent_actions": ref.parent_actions,
+                        "open_idx": [i for _, i in oq], "open_cost": [c for c, _ in oq]}
+                _compare_problem(agent.batch.problem_arrays(b), refd, len(ref))
+            if ok:
+                n_solved += 1
+                x = s
+                for a in res.queues[b]:
+                    x = oc.rotate(x, *oc.ACTION_SPACE[a])
+                assert oc.is_solved(x)
+        assert n_solved >= 15
+        assert res.solved[9] and res.lengths[9] == 0 and res.nodes[9] == 0
+
+
+def test_reference_agent_tests_restated():
+    """tests/test_agents.py:96-145: easy games are won and replayable; root G = 0, its 12 children have G = 1."""
+    from librubiks import cube
+    from librubiks.model import Model, ModelConfig
+    from librubiks.solving.agents import AStar
+    torch.manual_seed(0)
+    np.random.seed(0)
+    net = Model.create(ModelConfig()).eval()
+    for lam, nexp in ((0, 10), (0.5, 2), (1, 1)):
+        agent = AStar(net, lam, nexp)
+        state, _, _ = cube.scramble(2, force_not_solved=True)
+        if agent.search(state, time_limit=1, max_states=20000):
+            for a in agent.action_queue:
+                state = cube.rotate(state, *cube.action_space[a])
+            assert cube.is_solved(state)
+    init_state, _, _ = cube.scramble(3)
+    agent = AStar(net, lambda_=0.1, expansions=5)
+    agent.search(init_state, time_limit=1, max_states=20000)
+    idx = agent.indices
+    assert idx[init_state.tobytes()] == 1 and agent.G[1] == 0
+    for action in cube.action_space:
+        child = cube.rotate(init_state, *action)
+        i = idx[child.tobytes()]
+        assert agent.G[i] == 1 and agent.parents[i] == 1
+    states, _ = cube.sequence_scrambler(5, 1, True)
+    assert agent.cost(states, np.ones(5, dtype=int)).shape == (5,)
+
+
+def test_large_batch_throughput_sanity():
+    """512 depth-20 problems x N=100 for a few iterations: every problem adds states, budgets hold."""
+    from librubiks import cube
+    from librubiks.model import Model, ModelConfig
+    from librubiks.solving.agents import AStar
+    torch.manual_seed(0)
+    np.random.seed(2)
+    net = Model.create(ModelConfig()).eval()
+    cubes, _, _ = cube.scramble_batch(512, 20, True)
+    agent = AStar(net, lambda_=0.2, expansions=100)
+    res = agent.search_batch(cubes, None, 6000, max_iterations=4)
+    assert (res.iterations == 4).all()
+    assert (res.nodes > 1000).all() and (res.nodes <= 6000).all()
+    assert res.states_per_sec > 1e5
