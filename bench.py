@@ -107,7 +107,7 @@ def phase_times(forest, c, max_states, reps):
     import ctypes
     from librubiks import _hip
     lib, m = forest.lib, ctypes.byref(forest.struct)
-    names = ["expand", "as_oh", "net_forward", "softmax+copy", "backup", "select"]
+    names = ["expand", "input_layer", "net_forward", "softmax+copy", "backup", "select"]
     acc = {k: 0.0 for k in names}
     for _ in range(reps):
         ev = [torch.cuda.Event(enable_timing=True) for _ in range(len(names) + 1)]
@@ -115,9 +115,16 @@ def phase_times(forest, c, max_states, reps):
         ev[0].record()
         _hip.check(lib.rc_mcts_expand(m, max_states, st))
         ev[1].record()
-        forest.children.as_oh(out=forest._oh)
+        if forest._fused:
+            x1 = forest.engine.first_layer(forest.children, forest._x1)
+        else:
+            forest.children.as_oh(out=forest._oh)
         ev[2].record()
-        logits, values = forest.engine(forest._oh)
+        if forest._fused:
+            out = forest.engine._run(forest.engine.layers[1:], x1).float()
+            logits, values = out[:, :12], out[:, 12]
+        else:
+            logits, values = forest.engine(forest._oh)
         ev[3].record()
         torch.softmax(logits, dim=1, out=forest.probs)
         forest.values.copy_(values)
@@ -255,16 +262,28 @@ def main():
 
     rows = 12 * roots.n
     phases = phase_times(forest, c, max_states, args.phase_reps) if args.phase_reps else {}
-    flops = forest.engine.flops_per_state * rows
+    eng = forest.engine
     peak = MFMA_BF16_PEAK_TFLOPS if args.dtype == "bf16" else MFMA_F32_PEAK_TFLOPS
-    roofline = None
+    roofline = roofline_input = None
     if phases:
+        # GEMM group actually executed on MFMA: every layer when the input is a one-hot matrix, layers 2..
+        # when the input layer is the fused gather-sum kernel (which is HBM/LDS work, reported separately)
+        gemm_layers = eng.layers[1:] if forest._fused else eng.layers
+        flops = 2 * sum(W.shape[0] * W.shape[1] for W, _, _ in gemm_layers) * rows
         tf = flops / (phases["net_forward"] * 1e-3) / 1e12
-        roofline = {"kernel": f"policy/value net forward on {rows} child rows ({len(forest.engine.layers)} hipBLASLt "
-                              "GEMMs + bias + ELU, BatchNorm folded)",
+        roofline = {"kernel": f"policy/value net GEMMs on {rows} child rows ({len(gemm_layers)} hipBLASLt GEMMs + bias + "
+                              "ELU passes, BatchNorm folded, heads merged)",
                     "bound": "mfma", "achieved": round(tf, 1), "peak": peak, "unit": "TFLOP/s",
                     "frac": round(tf / peak, 4), "traffic": None,
                     "flops_per_launch": flops, "ms_per_launch": phases["net_forward"]}
+        if forest._fused:
+            H = eng._fused_first[4]
+            nbytes = (20 + 2 * H) * rows
+            gbps = nbytes / (phases["input_layer"] * 1e-3) / 1e9
+            roofline_input = {"kernel": "rc_first_layer_bf16 (one-hot x W1 as 20-row gather-sum from LDS + bias + ELU)",
+                              "bound": "hbm", "achieved": round(gbps, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                              "frac": round(gbps / HBM_PEAK_GBPS, 4), "algorithmic_bytes": nbytes,
+                              "bytes_per_unit": 20 + 2 * H, "traffic": None, "ms_per_launch": phases["input_layer"]}
     result = {
         "metric": "MCTS node expansions/sec, depth-20 scrambles", "value": round(nodes / seconds, 1),
         "unit": "node expansions/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -274,7 +293,7 @@ def main():
                                "fc_small net, random-init weights", "trees_per_gpu": args.trees,
                    "scramble_depth": args.depth, "net_rows_per_step": rows, "parallelism": f"scramble-sharded x{world}"},
         "nodes_expanded": nodes, "solve_rate": float(np.mean(gathered["solved"])),
-        "roofline": roofline, "phases_ms": phases,
+        "roofline": roofline, "roofline_input_layer": roofline_input, "phases_ms": phases,
     }
     if not args.no_env_roofline and world == 1:
         del forest, agent

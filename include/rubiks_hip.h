@@ -109,6 +109,20 @@ int rc_apply_moves(int8_t *soa, const uint8_t *moves, size_t n, size_t stride, s
 int rc_sequence_states(const uint8_t *moves, int8_t *out_soa, size_t games, size_t depth,
                        int with_solved, size_t stride_out, rc_stream_t stream);
 
+/* ---- network input layer fused with the one-hot encoding ------------------------------------------
+ * out[i][c] = act( bias[c] + sum_j w1t[24 j + s[i][j]][c] )   (bf16 out, fp32 accumulation)
+ * = activation(Linear(480, H)(as_oh(states))) of the reference (librubiks/cube/cube.py:265-277 feeding
+ * the first nn.Linear of librubiks/model.py:123-127,150-157) without materialising the one-hot
+ * matrix: a one-hot row has exactly 20 ones, so the product is a 20-row gather-sum of W1^T.
+ *   w1t : bf16 [480][H] row-major (the Linear weight transposed), bias: float[H], out: bf16 [n][H]
+ *   H   : multiple of 128;  activation: 0 = none, 1 = ReLU, 2 = ELU(alpha)
+ * Algorithmic HBM bytes per state: 20 in + 2 H out (W1^T is 0.96 H KB, L2-resident). */
+#define RC_ACT_NONE 0
+#define RC_ACT_RELU 1
+#define RC_ACT_ELU 2
+int rc_first_layer_bf16(const int8_t *soa, size_t n, size_t stride, const uint16_t *w1t, const float *bias,
+                        uint16_t *out, size_t H, int activation, float alpha, rc_stream_t stream);
+
 /* ---- batched MCTS: one independent tree per scramble, lock-step iterations -------------------
  *
  * Replaces the per-tree Python loop of librubiks/solving/agents.py:415-645 (class MCTS) for B

@@ -1,0 +1,137 @@
+// Network-side kernels that touch cube states: the input layer of the policy/value MLP fused with
+// the one-hot encoding.  as_oh(states) @ W1^T is a 20-row gather-sum because a one-hot row has
+// exactly 20 ones; doing it from an LDS-resident slice of W1^T removes the (n x 480) one-hot matrix,
+// the K = 480 GEMM and the separate bias + activation pass.
+#include "rubiks_common.h"
+
+namespace rubiks {
+
+typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;
+
+constexpr int kFLCols = 128;                  // output columns per workgroup: one LDS bank row (256 B) of bf16
+constexpr int kFLThreads = 512;               // 8 waves = 2 per SIMD; 32 row slots x 16 column chunks of 8
+constexpr int kFLRowSlots = kFLThreads / 16;  // rows produced per pass
+constexpr int kFLChunkRows = 512;             // rows whose table indices are staged at a time
+constexpr int kOH = 480;
+
+__device__ __forceinline__ float act_apply(float x, int act, float alpha) {
+    if (act == RC_ACT_RELU) return fmaxf(x, 0.f);
+    if (act == RC_ACT_ELU) return x > 0.f ? x : alpha * (__expf(x) - 1.f);
+    return x;
+}
+
+__device__ __forceinline__ u32 pack_bf16(float lo, float hi) {
+    typedef __attribute__((ext_vector_type(2))) float float2_;
+    typedef __attribute__((ext_vector_type(2))) __bf16 bf2;
+    float2_ v = {lo, hi};
+    bf2 r = __builtin_convertvector(v, bf2);   // v_cvt_pk_bf16_f32, round to nearest even
+    return __builtin_bit_cast(u32, r);
+}
+
+template <int ACT>
+__global__ __launch_bounds__(kFLThreads) void k_first_layer(const u8 *__restrict__ soa, size_t n, size_t stride,
+                                                            const uint4 *__restrict__ w1t, const float *__restrict__ bias,
+                                                            uint4 *__restrict__ out, u32 H, u32 rows_per_block, float alpha) {
+    extern __shared__ __attribute__((aligned(256))) unsigned char lds[];
+    uint4 *wslice = reinterpret_cast<uint4 *>(lds);                                    // [480][16] x 16 B
+    unsigned short *sidx = reinterpret_cast<unsigned short *>(lds + kOH * kFLCols * 2);   // [kFLChunkRows][20]
+    const u32 tid = threadIdx.x;
+    const u32 col_tiles = H / kFLCols;
+    const u32 ct = blockIdx.x % col_tiles, rg = blockIdx.x / col_tiles;
+    const size_t row_lo = (size_t)rg * rows_per_block;
+    if (row_lo >= n) return;
+    const size_t row_hi = (row_lo + rows_per_block < n) ? row_lo + rows_per_block : n;
+
+    // W1^T[:, 128 ct .. 128 ct + 127] -> LDS: row k is one 256-byte bank row, so a ds_read_b128 of
+    // chunk c of ANY row hits bank quad c: 16 lanes reading the 16 chunks of a row never conflict.
+    const u32 h16 = H / 8;   // 16-byte chunks per global row
+    for (u32 i = tid; i < kOH * 16; i += kFLThreads) wslice[i] = w1t[(size_t)(i >> 4) * h16 + ct * 16 + (i & 15)];
+
+    const u32 slot = tid >> 4, chunk = tid & 15;
+    float b[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) b[e] = bias[ct * kFLCols + chunk * 8 + e];
+    const bf16x2 sel_lo = __builtin_bit_cast(bf16x2, 0x00003f80u);   // (1, 0): picks the low bf16 of a pair
+    const bf16x2 sel_hi = __builtin_bit_cast(bf16x2, 0x3f800000u);   // (0, 1)
+
+    for (size_t c0 = row_lo; c0 < row_hi; c0 += kFLChunkRows) {
+        const u32 crow = (u32)((row_hi - c0 < (size_t)kFLChunkRows) ? row_hi - c0 : kFLChunkRows);
+        __syncthreads();   // previous chunk's readers are done (and wslice is complete on the first pass)
+        for (u32 i = tid; i < kPlanes * kFLChunkRows; i += kFLThreads) {   // plane-major: coalesced byte loads
+            const u32 j = i / kFLChunkRows, rr = i % kFLChunkRows;
+            if (rr < crow) {
+                u32 idx = 24u * j + (soa[(size_t)j * stride + c0 + rr] & 31u);
+                sidx[rr * kPlanes + j] = (unsigned short)(idx < (u32)kOH ? idx : kOH - 1);
+            }
+        }
+        __syncthreads();
+        for (u32 r = slot; r < crow; r += kFLRowSlots) {
+            const u32 *ridx = reinterpret_cast<const u32 *>(sidx + r * kPlanes);   // 20 u16 = 10 dwords (row stride 40 B)
+            float acc[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) acc[e] = b[e];
+#pragma unroll
+            for (int jj = 0; jj < kPlanes / 2; ++jj) {
+                const u32 two = ridx[jj];
+#pragma unroll
+                for (int h = 0; h < 2; ++h) {
+                    const u32 k = h ? (two >> 16) : (two & 0xffffu);
+                    const uint4 w = wslice[k * 16 + chunk];
+                    const u32 ww[4] = {w.x, w.y, w.z, w.w};
+#pragma unroll
+                    for (int d = 0; d < 4; ++d) {
+                        const bf16x2 pair = __builtin_bit_cast(bf16x2, ww[d]);
+                        acc[2 * d] = __builtin_amdgcn_fdot2_f32_bf16(pair, sel_lo, acc[2 * d], false);
+                        acc[2 * d + 1] = __builtin_amdgcn_fdot2_f32_bf16(pair, sel_hi, acc[2 * d + 1], false);
+                    }
+                }
+            }
+#pragma unroll
+            for (int e = 0; e < 8; ++e) acc[e] = act_apply(acc[e], ACT, alpha);
+            out[(c0 + r) * h16 + ct * 16 + chunk] =
+                make_uint4(pack_bf16(acc[0], acc[1]), pack_bf16(acc[2], acc[3]), pack_bf16(acc[4], acc[5]), pack_bf16(acc[6], acc[7]));
+        }
+    }
+}
+
+}  // namespace rubiks
+
+using namespace rubiks;
+
+extern "C" int rc_first_layer_bf16(const int8_t *soa, size_t n, size_t stride, const uint16_t *w1t, const float *bias,
+                                   uint16_t *out, size_t H, int activation, float alpha, rc_stream_t stream) {
+    if (n == 0) return RC_OK;
+    RC_CHECK_SOA(soa, n, stride);
+    RC_REQUIRE(w1t && bias && out, RC_ERR_NULL);
+    RC_REQUIRE(aligned16(w1t) && aligned16(out), RC_ERR_ALIGN);
+    RC_REQUIRE(H >= kFLCols && H % kFLCols == 0 && activation >= RC_ACT_NONE && activation <= RC_ACT_ELU, RC_ERR_RANGE);
+    const u32 col_tiles = (u32)(H / kFLCols);
+    // LDS (120 KiB slice + 20 KiB indices) allows one workgroup per CU: aim at ~2 x 256 workgroups in total
+    u32 row_groups = (512 + col_tiles - 1) / col_tiles;
+    u32 rows_per_block = (u32)round_up(ceil_div(n, row_groups), kFLRowSlots);
+    if (rows_per_block < 64) rows_per_block = 64;
+    row_groups = (u32)ceil_div(n, rows_per_block);
+    const size_t lds_bytes = (size_t)kOH * kFLCols * 2 + (size_t)kFLChunkRows * kPlanes * 2;
+    const dim3 grid(col_tiles * row_groups), block(kFLThreads);
+    hipStream_t s = (hipStream_t)stream;
+    const u8 *in = (const u8 *)soa;
+    const uint4 *w = (const uint4 *)w1t;
+    uint4 *o = (uint4 *)out;
+#define RC_LAUNCH_FL(ACT)                                                                                          \
+    do {                                                                                                           \
+        static bool attr_set = false;                                                                              \
+        if (!attr_set) {                                                                                           \
+            hipError_t e = hipFuncSetAttribute((const void *)k_first_layer<ACT>,                                    \
+                                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);        \
+            if (e != hipSuccess) return hip_rc(e);                                                                 \
+            attr_set = true;                                                                                       \
+        }                                                                                                          \
+        hipLaunchKernelGGL(k_first_layer<ACT>, grid, block, lds_bytes, s, in, n, stride, w, bias, o, (u32)H,        \
+                           rows_per_block, alpha);                                                                 \
+    } while (0)
+    if (activation == RC_ACT_ELU) RC_LAUNCH_FL(RC_ACT_ELU);
+    else if (activation == RC_ACT_RELU) RC_LAUNCH_FL(RC_ACT_RELU);
+    else RC_LAUNCH_FL(RC_ACT_NONE);
+#undef RC_LAUNCH_FL
+    return launch_status();
+}

@@ -235,6 +235,13 @@ class InferenceNet:
         model.train(was_training)
         self.dtype, self.device = dtype, device
         self.flops_per_state = 2 * sum(W.shape[0] * W.shape[1] for W, _, _ in self.layers)
+        # Input layer fused with the one-hot encoding (csrc/rubiks_net.hip): needs bf16 and H % 128 == 0
+        W1, b1, act1 = self.layers[0]
+        self._fused_first = None
+        if dtype == torch.bfloat16 and W1.is_cuda and W1.shape[0] % 128 == 0 and W1.shape[1] == OH_WIDTH:
+            code = 0 if act1 is None else 1 if isinstance(act1, nn.ReLU) else 2
+            self._fused_first = (W1.t().contiguous(), b1.float().contiguous(), code,
+                                 float(getattr(act1, "alpha", 1.0)), W1.shape[0])
 
     @property
     def input_dtype(self):
@@ -249,6 +256,32 @@ class InferenceNet:
                 x = F.relu_(x) if isinstance(act, nn.ReLU) else F.elu_(x, alpha=act.alpha)
         out = x.float()
         return out[:, :N_ACTIONS], out[:, N_ACTIONS]
+
+    @property
+    def supports_cubes(self) -> bool:
+        return self._fused_first is not None
+
+    @torch.no_grad()
+    def first_layer(self, cubes, out: torch.Tensor = None) -> torch.Tensor:
+        """act(Linear(as_oh(cubes))) as one HIP kernel: bf16 [n, H] without a one-hot matrix."""
+        from librubiks import _hip
+        w1t, b1, code, alpha, H = self._fused_first
+        if out is None:
+            out = torch.empty((cubes.n, H), dtype=torch.bfloat16, device=w1t.device)
+        _hip.check(_hip.lib().rc_first_layer_bf16(cubes.soa.data_ptr(), cubes.n, cubes.stride, w1t.data_ptr(),
+                                                  b1.data_ptr(), out.data_ptr(), H, code, alpha, _hip.stream_ptr()),
+                   "rc_first_layer_bf16")
+        return out
+
+    @torch.no_grad()
+    def forward_cubes(self, cubes, x1: torch.Tensor = None):
+        """(policy logits, values) straight from device-resident cube states."""
+        out = self._run(self.layers[1:], self.first_layer(cubes, x1)).float()
+        return out[:, :N_ACTIONS], out[:, N_ACTIONS]
+
+    @torch.no_grad()
+    def value_cubes(self, cubes, x1: torch.Tensor = None) -> torch.Tensor:
+        return self._run(self.value_layers[1:], self.first_layer(cubes, x1)).float().reshape(-1)
 
     @staticmethod
     def _run(layers, x):

@@ -99,13 +99,21 @@ class MCTSForest:
     # ---- network ---------------------------------------------------------------------------------
     def set_net(self, net, dtype=torch.bfloat16):
         self.engine = make_inference_net(net, dtype)
-        self._oh = torch.empty((N_ACT * self.B, 480), dtype=self.engine.input_dtype, device=self.device)
+        self._fused = bool(getattr(self.engine, "supports_cubes", False))
+        if self._fused:   # the input layer reads the child SoA directly: no one-hot matrix
+            self._oh = None
+            self._x1 = torch.empty((N_ACT * self.B, self.engine._fused_first[4]), dtype=torch.bfloat16, device=self.device)
+        else:
+            self._oh = torch.empty((N_ACT * self.B, 480), dtype=self.engine.input_dtype, device=self.device)
         self._graph = None
 
     def _evaluate_children(self):
         """child_soa -> one-hot (HIP kernel) -> network -> softmax -> static probs / values buffers."""
-        self.children.as_oh(out=self._oh)
-        logits, values = self.engine(self._oh)
+        if self._fused:
+            logits, values = self.engine.forward_cubes(self.children, self._x1)
+        else:
+            self.children.as_oh(out=self._oh)
+            logits, values = self.engine(self._oh)
         torch.softmax(logits, dim=1, out=self.probs)   # agents.py:552 (`p.softmax(dim=1)`)
         self.values.copy_(values)
 
