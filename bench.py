@@ -190,6 +190,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-env-roofline", action="store_true")
     ap.add_argument("--phase-reps", type=int, default=20)
+    ap.add_argument("--first-layer-table", default="auto", choices=["auto", "f16", "bf16", "onehot"],
+                    help="input layer: fused gather-sum with an f16 / bf16 table, or the one-hot GEMM")
     args = ap.parse_args()
 
     rank, world = int(os.environ.get("RANK", 0)), int(os.environ.get("WORLD_SIZE", 1))
@@ -219,7 +221,9 @@ def main():
     net_dtype = torch.bfloat16 if args.dtype == "bf16" else torch.float32
     c = 0.6
     capacity = 12 * (args.warmup + args.steps + args.phase_reps + 8) + 64
-    agent = MCTS(model, c=c, search_graph=True, net_dtype=net_dtype)
+    from librubiks.model import InferenceNet
+    engine = InferenceNet(model, dtype=net_dtype, first_layer_table=args.first_layer_table)
+    agent = MCTS(engine, c=c, search_graph=True, net_dtype=net_dtype)
     forest = agent._forest_for(roots.n, capacity)
     max_states = forest.C
     forest.reset(roots)

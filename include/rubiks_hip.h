@@ -114,14 +114,15 @@ int rc_sequence_states(const uint8_t *moves, int8_t *out_soa, size_t games, size
  * = activation(Linear(480, H)(as_oh(states))) of the reference (librubiks/cube/cube.py:265-277 feeding
  * the first nn.Linear of librubiks/model.py:123-127,150-157) without materialising the one-hot
  * matrix: a one-hot row has exactly 20 ones, so the product is a 20-row gather-sum of W1^T.
- *   w1t : bf16 [480][H] row-major (the Linear weight transposed), bias: float[H], out: bf16 [n][H]
- *   H   : multiple of 128;  activation: 0 = none, 1 = ReLU, 2 = ELU(alpha)
+ *   w1t : [480][H] row-major 16-bit table (the Linear weight transposed): bf16, or IEEE f16 when
+ *         table_is_f16 != 0 (11 mantissa bits instead of 8; one v_fma_mix_f32 converts and adds)
+ *   bias: float[H], out: bf16 [n][H];  H: multiple of 128;  activation: 0 = none, 1 = ReLU, 2 = ELU(alpha)
  * Algorithmic HBM bytes per state: 20 in + 2 H out (W1^T is 0.96 H KB, L2-resident). */
 #define RC_ACT_NONE 0
 #define RC_ACT_RELU 1
 #define RC_ACT_ELU 2
 int rc_first_layer_bf16(const int8_t *soa, size_t n, size_t stride, const uint16_t *w1t, const float *bias,
-                        uint16_t *out, size_t H, int activation, float alpha, rc_stream_t stream);
+                        uint16_t *out, size_t H, int activation, float alpha, int table_is_f16, rc_stream_t stream);
 
 /* ---- batched MCTS: one independent tree per scramble, lock-step iterations -------------------
  *

@@ -6,10 +6,8 @@
 
 namespace rubiks {
 
-typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;
-
 constexpr int kFLCols = 128;                  // output columns per workgroup: one LDS bank row (256 B) of bf16
-constexpr int kFLThreads = 512;               // 8 waves = 2 per SIMD; 32 row slots x 16 column chunks of 8
+constexpr int kFLThreads = 1024;              // 16 waves = 4 per SIMD (LDS allows one workgroup per CU); 64 row slots x 16 chunks of 8 columns
 constexpr int kFLRowSlots = kFLThreads / 16;  // rows produced per pass
 constexpr int kFLChunkRows = 512;             // rows whose table indices are staged at a time
 constexpr int kOH = 480;
@@ -28,8 +26,8 @@ __device__ __forceinline__ u32 pack_bf16(float lo, float hi) {
     return __builtin_bit_cast(u32, r);
 }
 
-template <int ACT>
-__global__ __launch_bounds__(kFLThreads) void k_first_layer(const u8 *__restrict__ soa, size_t n, size_t stride,
+template <int ACT, bool F16>
+__global__ __launch_bounds__(kFLThreads) __attribute__((amdgpu_waves_per_eu(4, 4))) void k_first_layer(const u8 *__restrict__ soa, size_t n, size_t stride,
                                                             const uint4 *__restrict__ w1t, const float *__restrict__ bias,
                                                             uint4 *__restrict__ out, u32 H, u32 rows_per_block, float alpha) {
     extern __shared__ __attribute__((aligned(256))) unsigned char lds[];
@@ -48,47 +46,74 @@ __global__ __launch_bounds__(kFLThreads) void k_first_layer(const u8 *__restrict
     for (u32 i = tid; i < kOH * 16; i += kFLThreads) wslice[i] = w1t[(size_t)(i >> 4) * h16 + ct * 16 + (i & 15)];
 
     const u32 slot = tid >> 4, chunk = tid & 15;
-    float b[8];
-#pragma unroll
-    for (int e = 0; e < 8; ++e) b[e] = bias[ct * kFLCols + chunk * 8 + e];
-    const bf16x2 sel_lo = __builtin_bit_cast(bf16x2, 0x00003f80u);   // (1, 0): picks the low bf16 of a pair
-    const bf16x2 sel_hi = __builtin_bit_cast(bf16x2, 0x3f800000u);   // (0, 1)
+    float *sbias = reinterpret_cast<float *>(lds + kOH * kFLCols * 2 + kFLChunkRows * kPlanes * 2);   // [128]
+    if (tid < kFLCols) sbias[tid] = bias[ct * kFLCols + tid];
 
     for (size_t c0 = row_lo; c0 < row_hi; c0 += kFLChunkRows) {
         const u32 crow = (u32)((row_hi - c0 < (size_t)kFLChunkRows) ? row_hi - c0 : kFLChunkRows);
         __syncthreads();   // previous chunk's readers are done (and wslice is complete on the first pass)
-        for (u32 i = tid; i < kPlanes * kFLChunkRows; i += kFLThreads) {   // plane-major: coalesced byte loads
-            const u32 j = i / kFLChunkRows, rr = i % kFLChunkRows;
-            if (rr < crow) {
-                u32 idx = 24u * j + (soa[(size_t)j * stride + c0 + rr] & 31u);
+        {   // stage the chunk's table indices: all of a thread's byte loads are issued before the first is used
+            constexpr int kPer = kPlanes * kFLChunkRows / kFLThreads;   // 10 planes per thread
+            const u32 rr = tid % kFLChunkRows, j0 = tid / kFLChunkRows;
+            u32 code[kPer];
+#pragma unroll
+            for (int t = 0; t < kPer; ++t) {
+                const u32 j = j0 + t * (kFLThreads / kFLChunkRows);
+                code[t] = (rr < crow) ? soa[(size_t)j * stride + c0 + rr] : 0;
+            }
+#pragma unroll
+            for (int t = 0; t < kPer; ++t) {
+                const u32 j = j0 + t * (kFLThreads / kFLChunkRows);
+                const u32 idx = 24u * j + (code[t] & 31u);
                 sidx[rr * kPlanes + j] = (unsigned short)(idx < (u32)kOH ? idx : kOH - 1);
             }
         }
         __syncthreads();
+        uint4 *out_c = out + c0 * h16;
+#pragma unroll 1
         for (u32 r = slot; r < crow; r += kFLRowSlots) {
             const u32 *ridx = reinterpret_cast<const u32 *>(sidx + r * kPlanes);   // 20 u16 = 10 dwords (row stride 40 B)
+            // table rows are requested kFLBatch at a time before any is consumed: the LDS latency is paid
+            // 20 / kFLBatch times per output chunk instead of 20 times
             float acc[8];
-#pragma unroll
-            for (int e = 0; e < 8; ++e) acc[e] = b[e];
+            {
+                const float4 b0 = reinterpret_cast<const float4 *>(sbias)[2 * chunk], b1 = reinterpret_cast<const float4 *>(sbias)[2 * chunk + 1];
+                acc[0] = b0.x; acc[1] = b0.y; acc[2] = b0.z; acc[3] = b0.w;
+                acc[4] = b1.x; acc[5] = b1.y; acc[6] = b1.z; acc[7] = b1.w;
+            }
+            u32 kk[kPlanes];
 #pragma unroll
             for (int jj = 0; jj < kPlanes / 2; ++jj) {
                 const u32 two = ridx[jj];
+                kk[2 * jj] = (two & 0xffffu) * 16 + chunk;
+                kk[2 * jj + 1] = (two >> 16) * 16 + chunk;
+            }
+            constexpr int kFLBatch = F16 ? 10 : 5;   // table rows requested from LDS before any is consumed (register budget)
 #pragma unroll
-                for (int h = 0; h < 2; ++h) {
-                    const u32 k = h ? (two >> 16) : (two & 0xffffu);
-                    const uint4 w = wslice[k * 16 + chunk];
-                    const u32 ww[4] = {w.x, w.y, w.z, w.w};
+            for (int q = 0; q < kPlanes / kFLBatch; ++q) {
+                uint4 w[kFLBatch];
+#pragma unroll
+                for (int j = 0; j < kFLBatch; ++j) w[j] = wslice[kk[q * kFLBatch + j]];
+                __builtin_amdgcn_sched_barrier(0);   // keep the batch's loads ahead of its adds, and the batches apart
+#pragma unroll
+                for (int j = 0; j < kFLBatch; ++j) {
+                    const u32 ww[4] = {w[j].x, w[j].y, w[j].z, w[j].w};
 #pragma unroll
                     for (int d = 0; d < 4; ++d) {
-                        const bf16x2 pair = __builtin_bit_cast(bf16x2, ww[d]);
-                        acc[2 * d] = __builtin_amdgcn_fdot2_f32_bf16(pair, sel_lo, acc[2 * d], false);
-                        acc[2 * d + 1] = __builtin_amdgcn_fdot2_f32_bf16(pair, sel_hi, acc[2 * d + 1], false);
+                        if (F16) {   // f16 table: v_fma_mix_f32 converts a half and adds it in ONE instruction (h * 1.0 + acc, exact)
+                            asm volatile("v_fma_mix_f32 %0, %1, 1.0, %0 op_sel:[0,0,0] op_sel_hi:[1,0,0]" : "+v"(acc[2 * d]) : "v"(ww[d]));
+                            asm volatile("v_fma_mix_f32 %0, %1, 1.0, %0 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "+v"(acc[2 * d + 1]) : "v"(ww[d]));
+                        } else {     // bf16 table: bf16 -> f32 is a 16-bit shift / mask, then a plain f32 add
+                            acc[2 * d] += __uint_as_float(ww[d] << 16);
+                            acc[2 * d + 1] += __uint_as_float(ww[d] & 0xffff0000u);
+                        }
                     }
                 }
+                __builtin_amdgcn_sched_barrier(0);
             }
 #pragma unroll
             for (int e = 0; e < 8; ++e) acc[e] = act_apply(acc[e], ACT, alpha);
-            out[(c0 + r) * h16 + ct * 16 + chunk] =
+            out_c[r * h16 + ct * 16 + chunk] =
                 make_uint4(pack_bf16(acc[0], acc[1]), pack_bf16(acc[2], acc[3]), pack_bf16(acc[4], acc[5]), pack_bf16(acc[6], acc[7]));
         }
     }
@@ -99,39 +124,46 @@ __global__ __launch_bounds__(kFLThreads) void k_first_layer(const u8 *__restrict
 using namespace rubiks;
 
 extern "C" int rc_first_layer_bf16(const int8_t *soa, size_t n, size_t stride, const uint16_t *w1t, const float *bias,
-                                   uint16_t *out, size_t H, int activation, float alpha, rc_stream_t stream) {
+                                   uint16_t *out, size_t H, int activation, float alpha, int table_is_f16, rc_stream_t stream) {
     if (n == 0) return RC_OK;
     RC_CHECK_SOA(soa, n, stride);
     RC_REQUIRE(w1t && bias && out, RC_ERR_NULL);
     RC_REQUIRE(aligned16(w1t) && aligned16(out), RC_ERR_ALIGN);
     RC_REQUIRE(H >= kFLCols && H % kFLCols == 0 && activation >= RC_ACT_NONE && activation <= RC_ACT_ELU, RC_ERR_RANGE);
     const u32 col_tiles = (u32)(H / kFLCols);
-    // LDS (120 KiB slice + 20 KiB indices) allows one workgroup per CU: aim at ~2 x 256 workgroups in total
-    u32 row_groups = (512 + col_tiles - 1) / col_tiles;
+    // LDS (120 KiB slice + 20 KiB indices) allows one workgroup per CU: one wave of 256 workgroups, so
+    // that every W1 slice is staged once per row group
+    u32 row_groups = (256 + col_tiles - 1) / col_tiles;
     u32 rows_per_block = (u32)round_up(ceil_div(n, row_groups), kFLRowSlots);
     if (rows_per_block < 64) rows_per_block = 64;
     row_groups = (u32)ceil_div(n, rows_per_block);
-    const size_t lds_bytes = (size_t)kOH * kFLCols * 2 + (size_t)kFLChunkRows * kPlanes * 2;
+    const size_t lds_bytes = (size_t)kOH * kFLCols * 2 + (size_t)kFLChunkRows * kPlanes * 2 + kFLCols * sizeof(float);
     const dim3 grid(col_tiles * row_groups), block(kFLThreads);
     hipStream_t s = (hipStream_t)stream;
     const u8 *in = (const u8 *)soa;
     const uint4 *w = (const uint4 *)w1t;
     uint4 *o = (uint4 *)out;
-#define RC_LAUNCH_FL(ACT)                                                                                          \
+#define RC_LAUNCH_FL(ACT, F16)                                                                                     \
     do {                                                                                                           \
         static bool attr_set = false;                                                                              \
         if (!attr_set) {                                                                                           \
-            hipError_t e = hipFuncSetAttribute((const void *)k_first_layer<ACT>,                                    \
+            hipError_t e = hipFuncSetAttribute((const void *)k_first_layer<ACT, F16>,                               \
                                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);        \
             if (e != hipSuccess) return hip_rc(e);                                                                 \
             attr_set = true;                                                                                       \
         }                                                                                                          \
-        hipLaunchKernelGGL(k_first_layer<ACT>, grid, block, lds_bytes, s, in, n, stride, w, bias, o, (u32)H,        \
+        hipLaunchKernelGGL((k_first_layer<ACT, F16>), grid, block, lds_bytes, s, in, n, stride, w, bias, o, (u32)H, \
                            rows_per_block, alpha);                                                                 \
     } while (0)
-    if (activation == RC_ACT_ELU) RC_LAUNCH_FL(RC_ACT_ELU);
-    else if (activation == RC_ACT_RELU) RC_LAUNCH_FL(RC_ACT_RELU);
-    else RC_LAUNCH_FL(RC_ACT_NONE);
+#define RC_LAUNCH_FL_ACT(F16)                                       \
+    do {                                                            \
+        if (activation == RC_ACT_ELU) RC_LAUNCH_FL(RC_ACT_ELU, F16); \
+        else if (activation == RC_ACT_RELU) RC_LAUNCH_FL(RC_ACT_RELU, F16); \
+        else RC_LAUNCH_FL(RC_ACT_NONE, F16);                        \
+    } while (0)
+    if (table_is_f16) RC_LAUNCH_FL_ACT(true);
+    else RC_LAUNCH_FL_ACT(false);
+#undef RC_LAUNCH_FL_ACT
 #undef RC_LAUNCH_FL
     return launch_status();
 }

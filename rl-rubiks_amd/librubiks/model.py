@@ -210,7 +210,7 @@ class InferenceNet:
     test stand-ins) goes through `GenericNet`, which simply calls it.
     """
 
-    def __init__(self, model: Model, dtype=torch.bfloat16, device=None):
+    def __init__(self, model: Model, dtype=torch.bfloat16, device=None, first_layer_table: str = "auto"):
         assert isinstance(model, Model) and model.config.architecture.startswith("fc")
         device = device or next(model.parameters()).device
         was_training = model.training
@@ -238,10 +238,18 @@ class InferenceNet:
         # Input layer fused with the one-hot encoding (csrc/rubiks_net.hip): needs bf16 and H % 128 == 0
         W1, b1, act1 = self.layers[0]
         self._fused_first = None
-        if dtype == torch.bfloat16 and W1.is_cuda and W1.shape[0] % 128 == 0 and W1.shape[1] == OH_WIDTH:
+        if dtype == torch.bfloat16 and W1.is_cuda and W1.shape[0] % 128 == 0 and W1.shape[1] == OH_WIDTH \
+                and first_layer_table != "onehot":
             code = 0 if act1 is None else 1 if isinstance(act1, nn.ReLU) else 2
-            self._fused_first = (W1.t().contiguous(), b1.float().contiguous(), code,
-                                 float(getattr(act1, "alpha", 1.0)), W1.shape[0])
+            # 16-bit table for the gather-sum, built from the fp32 folded weights: IEEE f16 when every
+            # weight fits its range (11 mantissa bits, i.e. closer to fp32 than bf16, and the kernel
+            # converts + adds in one v_fma_mix_f32), bf16 otherwise
+            W1_full = layers[0][0].to(device)
+            use_f16 = first_layer_table in ("auto", "f16") and bool(torch.isfinite(W1_full).all()) \
+                and float(W1_full.abs().max()) < 6.0e4
+            table = W1_full.t().to(torch.float16 if use_f16 else torch.bfloat16).contiguous()
+            self._fused_first = (table, layers[0][1].to(device).float().contiguous(), code,
+                                 float(getattr(act1, "alpha", 1.0)), W1.shape[0], int(use_f16))
 
     @property
     def input_dtype(self):
@@ -265,12 +273,12 @@ class InferenceNet:
     def first_layer(self, cubes, out: torch.Tensor = None) -> torch.Tensor:
         """act(Linear(as_oh(cubes))) as one HIP kernel: bf16 [n, H] without a one-hot matrix."""
         from librubiks import _hip
-        w1t, b1, code, alpha, H = self._fused_first
+        w1t, b1, code, alpha, H, is_f16 = self._fused_first
         if out is None:
             out = torch.empty((cubes.n, H), dtype=torch.bfloat16, device=w1t.device)
         _hip.check(_hip.lib().rc_first_layer_bf16(cubes.soa.data_ptr(), cubes.n, cubes.stride, w1t.data_ptr(),
-                                                  b1.data_ptr(), out.data_ptr(), H, code, alpha, _hip.stream_ptr()),
-                   "rc_first_layer_bf16")
+                                                  b1.data_ptr(), out.data_ptr(), H, code, alpha, is_f16,
+                                                  _hip.stream_ptr()), "rc_first_layer_bf16")
         return out
 
     @torch.no_grad()

@@ -33,7 +33,8 @@ def _model(act=None, seed=0):
 
 @pytest.mark.parametrize("n", [1, 17, 512, 513, 4099, 12288])
 @pytest.mark.parametrize("act", ["elu", "relu"])
-def test_first_layer_matches_onehot_gemm(n, act):
+@pytest.mark.parametrize("table", ["bf16", "f16"])
+def test_first_layer_matches_onehot_gemm(n, act, table):
     """
     rc_first_layer_bf16 == act(as_oh(s) @ W1^T + b1) computed in fp32 from the SAME bf16 weights,
     then rounded to bf16.  The sums have 20 terms in a different order: tolerance = 1 bf16 ulp
@@ -42,14 +43,14 @@ def test_first_layer_matches_onehot_gemm(n, act):
     from librubiks.cube import DeviceCubes
     from librubiks.model import InferenceNet
     m = _model(torch.nn.ELU() if act == "elu" else torch.nn.ReLU())
-    eng = InferenceNet(m, dtype=torch.bfloat16)
-    assert eng.supports_cubes
+    eng = InferenceNet(m, dtype=torch.bfloat16, first_layer_table=table)
+    assert eng.supports_cubes and eng._fused_first[5] == int(table == "f16")
     s = _states(n, seed=n)
     cubes = DeviceCubes.from_numpy(s)
     got = eng.first_layer(cubes).float()
-    W1, b1, a1 = eng.layers[0]
     oh = torch.from_numpy(oc.as_oh(s)).cuda()
-    ref = oh @ W1.float().t() + b1.float()
+    # reference: the SAME 16-bit table and fp32 bias, accumulated in fp32 by a dense product
+    ref = oh @ eng._fused_first[0].float() + eng._fused_first[1]
     ref = torch.nn.functional.elu(ref) if act == "elu" else torch.relu(ref)
     ref = ref.to(torch.bfloat16).float()
     assert got.shape == (n, 4096)
@@ -88,6 +89,7 @@ def test_first_layer_argument_errors():
     b = torch.zeros(128, device="cuda")
     out = torch.zeros(256 * 128, dtype=torch.bfloat16, device="cuda")
     args = (soa.data_ptr(), 100, 256, w.data_ptr(), b.data_ptr(), out.data_ptr())
-    assert lib.rc_first_layer_bf16(*args, 100, 2, 1.0, None) == -4    # H not a multiple of 128
-    assert lib.rc_first_layer_bf16(*args, 128, 7, 1.0, None) == -4    # unknown activation
-    assert lib.rc_first_layer_bf16(*args, 128, 2, 1.0, None) == 0
+    assert lib.rc_first_layer_bf16(*args, 100, 2, 1.0, 0, None) == -4    # H not a multiple of 128
+    assert lib.rc_first_layer_bf16(*args, 128, 7, 1.0, 0, None) == -4    # unknown activation
+    assert lib.rc_first_layer_bf16(*args, 128, 2, 1.0, 0, None) == 0
+    assert lib.rc_first_layer_bf16(*args, 128, 1, 1.0, 1, None) == 0
