@@ -245,6 +245,7 @@ def main():
     torch.cuda.synchronize()
     seconds = time.perf_counter() - t0
     nodes = int(forest.n_nodes.sum().item()) - nodes0
+    mean_path = float(forest.path_len.float().mean().item())
 
     stats = torch.tensor([seconds, float(nodes)], dtype=torch.float64, device="cuda")
     if world > 1:
@@ -296,7 +297,7 @@ def main():
         "config": {"workload": f"{args.trees} depth-{args.depth} scrambles per GPU, MCTS agent (c=0.6, graph search), "
                                "fc_small net, random-init weights", "trees_per_gpu": args.trees,
                    "scramble_depth": args.depth, "net_rows_per_step": rows, "parallelism": f"scramble-sharded x{world}"},
-        "nodes_expanded": nodes, "solve_rate": float(np.mean(gathered["solved"])),
+        "nodes_expanded": nodes, "mean_descent_depth": round(mean_path, 2), "solve_rate": float(np.mean(gathered["solved"])),
         "roofline": roofline, "roofline_input_layer": roofline_input, "phases_ms": phases,
     }
     if not args.no_env_roofline and world == 1:

@@ -95,4 +95,52 @@ __device__ __forceinline__ void wave_store_fence() {
     __builtin_amdgcn_s_waitcnt(0);
  }
 
+// ---- reductions over a 16-lane row with DPP (VALU-speed cross-lane moves, no LDS crossbar) --------------
+// The four steps (swap neighbours, swap pairs, mirror within 8, mirror within 16) pair every lane with
+// partners that together cover the row, so after them EVERY lane of the row holds the row's result.
+constexpr int kDppXor1 = 0xB1;         // quad_perm:[1,0,3,2]
+constexpr int kDppXor2 = 0x4E;         // quad_perm:[2,3,0,1]
+constexpr int kDppHalfMirror = 0x141;  // row_half_mirror
+constexpr int kDppMirror = 0x140;      // row_mirror
+
+template <int CTRL> __device__ __forceinline__ int dpp_int(int v) {
+    return __builtin_amdgcn_update_dpp(v, v, CTRL, 0xf, 0xf, false);
+}
+template <int CTRL> __device__ __forceinline__ float dpp_float(float v) {
+    return __int_as_float(dpp_int<CTRL>(__float_as_int(v)));
+}
+template <int CTRL> __device__ __forceinline__ double dpp_double(double v) {
+    const long long b = __double_as_longlong(v);
+    const int lo = dpp_int<CTRL>((int)(b & 0xffffffffll)), hi = dpp_int<CTRL>((int)(b >> 32));
+    return __longlong_as_double(((long long)hi << 32) | (unsigned int)lo);
+}
+
+__device__ __forceinline__ int row16_sum(int v) {
+    v += dpp_int<kDppXor1>(v);
+    v += dpp_int<kDppXor2>(v);
+    v += dpp_int<kDppHalfMirror>(v);
+    v += dpp_int<kDppMirror>(v);
+    return v;
+}
+__device__ __forceinline__ float row16_max(float v) {
+    v = fmaxf(v, dpp_float<kDppXor1>(v));
+    v = fmaxf(v, dpp_float<kDppXor2>(v));
+    v = fmaxf(v, dpp_float<kDppHalfMirror>(v));
+    v = fmaxf(v, dpp_float<kDppMirror>(v));
+    return v;
+}
+// argmax with "first maximum wins": the larger score, and on equal scores the smaller index
+template <int CTRL> __device__ __forceinline__ void argmax_step(double &score, int &arg) {
+    const double os = dpp_double<CTRL>(score);
+    const int oa = dpp_int<CTRL>(arg);
+    if (os > score || (os == score && oa < arg)) { score = os; arg = oa; }
+}
+__device__ __forceinline__ int row16_argmax_first(double score, int arg) {
+    argmax_step<kDppXor1>(score, arg);
+    argmax_step<kDppXor2>(score, arg);
+    argmax_step<kDppHalfMirror>(score, arg);
+    argmax_step<kDppMirror>(score, arg);
+    return arg;
+}
+
 }  // namespace rubiks

@@ -136,11 +136,8 @@ __global__ __launch_bounds__(kWave) void k_mcts_expand(rc_mcts_t m, u32 max_stat
 }
 
 // ---- backup: P/V of the new children, W/N/L along the path (agents.py:555-571) ------------------
-__device__ __forceinline__ float wave_max12(float v, bool valid) {
-    float x = valid ? v : -INFINITY;
-#pragma unroll
-    for (int o = 8; o > 0; o >>= 1) x = fmaxf(x, __shfl_xor(x, o));   // lanes 0..15 only matter
-    return __shfl(x, 0);
+__device__ __forceinline__ float wave_max12(float v, bool valid) {   // lanes 0..15 only matter
+    return __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(row16_max(valid ? v : -INFINITY))));
 }
 
 __global__ __launch_bounds__(kWave) void k_mcts_backup(rc_mcts_t m, const float *__restrict__ probs,
@@ -197,6 +194,11 @@ __global__ __launch_bounds__(kWave) void k_mcts_backup(rc_mcts_t m, const float 
 }
 
 // ---- select: PUCT descent with virtual loss (agents.py:575-595) ---------------------------------
+// One dependent memory round trip per tree level: the leaf flag and the five 12-wide rows of the
+// current node are requested together (a leaf's rows exist too, they are just not used), the chosen
+// neighbour comes out of a lane shuffle, and the virtual-loss counts are updated from registers
+// (lane `arg` stores L[cur][arg] + 1; the increment of L[next][arg ^ 1] is carried into the next
+// level, where lane arg ^ 1 adds it to the row it has just loaded and stores it back).
 __global__ __launch_bounds__(kWave) void k_mcts_select(rc_mcts_t m, double c) {
     const u32 t = blockIdx.x, lane = threadIdx.x;
     if (m.status[t] != RC_MCTS_RUNNING) return;
@@ -206,39 +208,41 @@ __global__ __launch_bounds__(kWave) void k_mcts_select(rc_mcts_t m, double c) {
     const bool act = lane < kA;
     const u32 la = act ? lane : 0;
     int cur = 1, plen = 1;
-    while (!m.leaf[base + cur]) {
+    int carried = -1;   // action slot of `cur` whose L count still has to take the +1 of the incoming edge
+    for (;;) {
+        const size_t r = (base + cur) * kA + la;
+        const u8 is_leaf = m.leaf[base + cur];
+        const int n_a = m.N[r];
+        const float p_f = m.P[r], w_f = m.W[r];
+        // L is the one array this descent both stores and may re-read (the graph has cycles): its loads
+        // bypass the CU's L1 (agent-scope, served by L2), so they observe this wave's earlier write-through
+        // stores without a per-level fence; vmcnt retires loads and stores in issue order, and every level
+        // waits for its loads, hence for all older stores.
+        u32 l_cnt = __hip_atomic_load(&m.L[r], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const int nb = m.nbr[r];
+        if ((int)lane == carried) {   // L[cur, rev(a_prev)] += nu (agents.py:591), also when cur is a leaf
+            l_cnt += 1;
+            m.L[r] = (u16)l_cnt;
+        }
+        if (is_leaf) break;
         if (plen >= (int)m.max_path) {
             if (lane == 0) m.status[t] = RC_MCTS_PATH_OVERFLOW;
             break;
         }
-        const size_t r = (base + cur) * kA + la;
-        const int n_a = m.N[r];
-        const double p_a = (double)m.P[r], w_a = (double)m.W[r], l_a = 100.0 * (double)m.L[r];
-        int sum_n = act ? n_a : 0;
-#pragma unroll
-        for (int o = 8; o > 0; o >>= 1) sum_n += __shfl_xor(sum_n, o);
-        sum_n = __shfl(sum_n, 0);
+        // lanes 0..15 form one DPP row; lanes 12..15 carry neutral elements
+        const int sum_n = __builtin_amdgcn_readfirstlane(row16_sum(act ? n_a : 0));
         // NumPy evaluation order: ((c * P) * sqrt(sum N)) / (1 + N)  +  (W - L), all float64
-        const double u = ((c * p_a) * sqrt((double)sum_n)) / (double)(1 + n_a);
-        double score = u + (w_a - l_a);
+        const double u = ((c * (double)p_f) * sqrt((double)sum_n)) / (double)(1 + n_a);
+        const double score = act ? u + ((double)w_f - 100.0 * (double)l_cnt) : -INFINITY;
         // argmax, first maximum wins (agents.py:588)
-        int arg = (int)lane;
-        if (!act) { score = -INFINITY; arg = 64; }
-#pragma unroll
-        for (int o = 8; o > 0; o >>= 1) {
-            const double os = __shfl_xor(score, o);
-            const int oa = __shfl_xor(arg, o);
-            if (os > score || (os == score && oa < arg)) { score = os; arg = oa; }
-        }
-        arg = __shfl(arg, 0);
-        const int next = m.nbr[(base + cur) * kA + arg];
+        const int arg = __builtin_amdgcn_readfirstlane(row16_argmax_first(score, act ? (int)lane : 64));
+        const int next = __builtin_amdgcn_readlane(nb, arg);
+        if ((int)lane == arg) m.L[r] = (u16)(l_cnt + 1);   // L[cur, a] += nu (agents.py:589)
         if (lane == 0) {
-            m.L[(base + cur) * kA + arg] += 1;            // L[cur, a] += nu     (agents.py:589)
-            m.L[(base + next) * kA + (arg ^ 1)] += 1;     // L[next, rev a] += nu (agents.py:591)
             pact[plen - 1] = (u8)arg;
             pnode[plen] = next;
         }
-        wave_store_fence();   // the next level's L row must see these increments
+        carried = arg ^ 1;
         cur = next;
         ++plen;
     }
