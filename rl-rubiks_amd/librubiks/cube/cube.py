@@ -184,40 +184,57 @@ def _moves_tensor(actions_dn: np.ndarray, stride: int) -> torch.Tensor:
     return torch.from_numpy(buf).cuda()
 
 
-def scramble_batch(games: int, depth: int, force_not_solved: bool = False):
+def scramble_batch(games: int, depth, force_not_solved: bool = False):
     """
-    `games` scrambles of `depth` random moves, bit-identical to calling the reference's
-    scramble(depth, force_not_solved) `games` times in a row: the draws come from the legacy global
-    np.random stream in the reference's order (per game: faces, then directions; a scramble that
-    comes out solved is redrawn before the next game draws, cube.py:213-214), while all moves are
-    applied by one rc_apply_moves launch.
-    Returns (DeviceCubes, faces int[games, depth], dirs int[games, depth]).
+    `games` scrambles, bit-identical to calling the reference's scramble(depth, force_not_solved)
+    `games` times in a row: the draws come from the legacy global np.random stream in the reference's
+    order (per game: faces, then directions; a scramble that comes out solved is redrawn before the
+    next game draws, cube.py:213-214), while all moves are applied by one rc_apply_moves launch.
+    `depth` is an int, or a callable drawing one game's depth from np.random right before that game's
+    moves are drawn (the Evaluator's deep mode, evaluation.py:73-74).
+    Returns (DeviceCubes, faces int[games, max depth], dirs int[games, max depth]); with per-game
+    depths the unused tail of a row is -1 (faces) / 0 (dirs).
     """
     _hip.lib()
-    faces = np.empty((games, depth), dtype=np.int64)
-    dirs = np.empty((games, depth), dtype=np.int64)
+    sampler = depth if callable(depth) else None
+    depths = np.zeros(games, dtype=np.int64) if sampler else np.full(games, int(depth), dtype=np.int64)
+    width = 999 if sampler else int(depth)
+    faces = np.full((games, width), -1 if sampler else 0, dtype=np.int64)
+    dirs = np.zeros((games, width), dtype=np.int64)
     cubes = DeviceCubes.solved(games)
-    if games == 0 or depth == 0:
+    if games == 0 or width == 0:
         return cubes, faces, dirs
-    start = 0
+    start, redraw = 0, False
     while start < games:
         stop = min(games, start + _SCRAMBLE_PASS)
         after_draw = []   # RNG state right after game g's draws, needed only if g must be redrawn
         for g in range(start, stop):
-            faces[g] = np.random.randint(6, size=(depth,))
-            dirs[g] = np.random.randint(2, size=(depth,))
+            if sampler and not (redraw and g == start):   # a redrawn game keeps its depth (the recursion is inside scramble)
+                depths[g] = sampler()
+            d = depths[g]
+            faces[g, :d] = np.random.randint(6, size=(d,))
+            dirs[g, :d] = np.random.randint(2, size=(d,))
             if force_not_solved:
                 after_draw.append(np.random.get_state())
+        # moves beyond a game's own depth are action 12: identity padding of the kernels' move table
+        acts = np.where(np.arange(width)[None, :] < depths[start:stop, None],
+                        _actions_of(np.maximum(faces[start:stop], 0), dirs[start:stop]), 12).astype(np.uint8)
+        acts = acts[:, :max(1, int(depths[start:stop].max()))]
         part = DeviceCubes.solved(stop - start)
-        part.apply_moves(_moves_tensor(_actions_of(faces[start:stop], dirs[start:stop]).T, part.stride))
-        solved = part.is_solved().cpu().numpy() if force_not_solved else np.zeros(stop - start, dtype=bool)
+        part.apply_moves(_moves_tensor(acts.T, part.stride))
+        solved = part.is_solved().cpu().numpy() & (depths[start:stop] != 0) if force_not_solved \
+            else np.zeros(stop - start, dtype=bool)
         first = int(np.argmax(solved)) if solved.any() else stop - start
         cubes.soa[:, start:start + first] = part.soa[:, :first]
-        if first < stop - start:
+        redraw = first < stop - start
+        if redraw:
             # game start+first came out solved: the reference redraws it from the stream position
             # right after its first draw, and every later game follows that (cube.py:213-214)
             np.random.set_state(after_draw[first])
         start += first
+    if sampler:
+        w = max(1, int(depths.max()))
+        faces, dirs = faces[:, :w], dirs[:, :w]
     return cubes, faces, dirs
 
 

@@ -1,0 +1,98 @@
+"""
+Batched Evaluator with the reference's interface and result shapes (librubiks/solving/evaluation.py:15-125,
+result files as librubiks/jobs.py:283-300,313-322) -- plots excluded.
+
+    res, states, times = Evaluator(n_games, scrambling_depths, max_time, max_states).eval(agent)
+
+The reference plays the games one after another; here all `n_games` scrambles of a depth are searched
+at once through `agent.search_batch` (one tree / one A* problem per scramble on the GPU).  The
+scrambles are the reference's own (same np.random stream, `cube.scramble(depth, True)` per game), so
+`res` / `states` are comparable game by game with a reference run on the same seed for agents that
+do not draw random numbers themselves (MCTS, AStar).  `max_time` bounds every game's wall time as in
+the reference, but the games of a depth run concurrently.  `times[d, g]` is the batch wall time
+divided by the number of games (a throughput-equivalent per-game time).
+"""
+import json
+import os
+
+import numpy as np
+
+from librubiks import cube
+from librubiks.utils import NullLogger, TickTock, bernoulli_error
+
+
+class Evaluator:
+    def __init__(self, n_games, scrambling_depths, max_time=None, max_states=None, logger=NullLogger()):
+        self.n_games, self.max_time, self.max_states = n_games, max_time, max_states
+        self.tt = TickTock()
+        self.log = logger
+        # range(0) means "deep": every game draws its own depth uniformly in [100, 999] (evaluation.py:30,73-74)
+        self.scrambling_depths = np.array(scrambling_depths) if scrambling_depths != range(0) else np.array([0])
+
+    def _isdeep(self):
+        return self.scrambling_depths.size == 1 and self.scrambling_depths[0] == 0
+
+    def approximate_time(self):
+        return self.max_time * len(self.scrambling_depths)   # games of a depth run concurrently
+
+    def eval(self, agent):
+        """(res, states, times), each (len(scrambling_depths), n_games); res = solution length or -1."""
+        res, states, times = [], [], []
+        for d in self.scrambling_depths:
+            depth = (lambda: np.random.randint(100, 1000)) if self._isdeep() else int(d)
+            if hasattr(agent, "search_batch"):
+                cubes, _, _ = cube.scramble_batch(self.n_games, depth, True)
+                self.tt.profile(f"Evaluation of {agent}. Depth {'100 - 999' if self._isdeep() else d}")
+                out = agent.search_batch(cubes, self.max_time, self.max_states)
+                dt = self.tt.end_profile()
+                res.append(out.lengths)
+                states.append(out.nodes)
+                times.append(np.full(self.n_games, dt / self.n_games))
+            else:   # agents without a batched search: the reference's game-by-game loop
+                r, s, t = [], [], []
+                for _ in range(self.n_games):
+                    dd = depth() if callable(depth) else depth
+                    state, _, _ = cube.scramble(dd, True)
+                    self.tt.profile(f"Evaluation of {agent}. Depth {d}")
+                    found = agent.search(state, self.max_time, self.max_states)
+                    t.append(self.tt.end_profile())
+                    r.append(len(agent.action_queue) if found else -1)
+                    s.append(len(agent))
+                res.append(r), states.append(s), times.append(t)
+        res, states, times = np.array(res, dtype=np.int64), np.array(states, dtype=np.int64), np.array(times, dtype=float)
+        for i, d in enumerate(self.scrambling_depths):
+            self.log_this_depth(res[i], states[i], times[i], d)
+        return res, states, times
+
+    def log_this_depth(self, res, states, times, depth) -> dict:
+        """Summary statistics of one depth (evaluation.py:96-125); logged and returned."""
+        won = res[res != -1]
+        share = len(won) / len(res)
+        ok = times != 0
+        sps = states[ok] / times[ok]
+        summary = {
+            "depth": int(depth), "share_completed": share, "ci95": float(bernoulli_error(share, len(res), 0.05)),
+            "mean_turns": float(won.mean()) if won.size else None,
+            "median_turns": float(np.median(won)) if won.size else None,
+            "states_per_game": float(states.mean()), "states_per_sec": float(sps.mean()) if sps.size else 0.0,
+            "time_per_game": float(times.mean()),
+        }
+        self.log(f"Scrambling depth {depth if depth else 'deep'}\n"
+                 f"\tShare completed: {share * 100:.2f} % {bernoulli_error(share, len(res), 0.05, stringify=True)} (approx. 95 % CI)\n"
+                 + (f"\tTurns to win: {won.mean():.2f} +/- {won.std():.1f} (std.), Median: {np.median(won):.0f}\n" if won.size else "")
+                 + f"\tStates seen: Pr. game: {states.mean():.2f} +/- {states.std():.0f} (std.), Pr. sec.: {summary['states_per_sec']:.2f}\n"
+                 f"\tTime:  {times.mean():.4f} +/- {times.std():.4f} (std.)")
+        return summary
+
+    def save(self, location: str, name: str, res, states, times) -> list:
+        """The reference's result files: <name>_results.npy, _states_seen.npy, _playtimes.npy + eval_settings.json."""
+        sub = os.path.join(location, "evaluation_results")
+        os.makedirs(sub, exist_ok=True)
+        paths = [os.path.join(sub, f"{name}_{kind}.npy") for kind in ("results", "states_seen", "playtimes")]
+        for p, arr in zip(paths, (res, states, times)):
+            np.save(p, arr)
+        settings = {name: {"n_games": self.n_games, "max_time": self.max_time, "max_states": self.max_states,
+                           "scrambling_depths": self.scrambling_depths.tolist()}}
+        with open(os.path.join(location, "eval_settings.json"), "w", encoding="utf-8") as f:
+            json.dump(settings, f, indent=4)
+        return paths

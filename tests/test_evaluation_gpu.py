@@ -1,0 +1,62 @@
+"""Batched Evaluator vs the reference's game-by-game protocol restated on the oracle (same RNG stream)."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from oracle import agents as oa  # noqa: E402  (checker only)
+from oracle import cube as oc  # noqa: E402
+
+
+def _sequential_reference(make_agent, depths, n_games, max_states):
+    res, states = [], []
+    for d in depths:
+        for _ in range(n_games):
+            s, _, _ = oc.scramble(int(d), True)
+            agent = make_agent()
+            ok = agent.search(s, max_states)
+            res.append(len(agent.action_queue) if ok else -1)
+            states.append(len(agent))
+    return np.reshape(res, (len(depths), n_games)), np.reshape(states, (len(depths), n_games))
+
+
+def test_evaluator_matches_sequential_protocol(standin_net, tmp_path):
+    from librubiks.solving.agents import MCTS, AStar
+    from librubiks.solving.evaluation import Evaluator
+    net = standin_net.cuda()
+    onet = oa.TorchNet(net, device="cuda")
+    depths, n_games, max_states = range(1, 6), 12, 400
+    for make_prod, make_ref in (
+        (lambda: MCTS(net, c=0.6, search_graph=True, net_dtype=torch.float32), lambda: oa.MCTS(onet, 0.6, True)),
+        (lambda: AStar(net, lambda_=0.2, expansions=8, net_dtype=torch.float32), lambda: oa.AStar(onet, 0.2, 8)),
+    ):
+        np.random.seed(123)
+        ev = Evaluator(n_games, depths, max_time=None, max_states=max_states)
+        res, states, times = ev.eval(make_prod())
+        np.random.seed(123)
+        ref_res, ref_states = _sequential_reference(make_ref, depths, n_games, max_states)
+        assert res.shape == states.shape == times.shape == (5, n_games)
+        assert np.array_equal(res, ref_res)
+        assert np.array_equal(states, ref_states)
+        assert (res[0] == 1).all()   # depth-1 scrambles are always solved in one move
+        summary = ev.log_this_depth(res[0], states[0], times[0], 1)
+        assert summary["share_completed"] == 1.0 and summary["ci95"] == 0.0 and summary["mean_turns"] == 1.0
+        paths = ev.save(str(tmp_path), "agent", res, states, times)
+        assert np.array_equal(np.load(paths[0]), res) and np.load(paths[2]).shape == (5, n_games)
+
+
+def test_deep_mode_scrambles_follow_reference_stream():
+    """Deep evaluation: every game draws its depth in [100, 999] right before its moves (evaluation.py:73-74)."""
+    from librubiks import cube
+    np.random.seed(7)
+    expect = []
+    for _ in range(10):
+        d = np.random.randint(100, 1000)
+        expect.append(oc.scramble(d, True)[0])
+    end = np.random.get_state()[1].copy()
+    np.random.seed(7)
+    cubes, faces, dirs = cube.scramble_batch(10, lambda: np.random.randint(100, 1000), True)
+    assert np.array_equal(np.random.get_state()[1], end)
+    assert np.array_equal(cubes.numpy(), np.array(expect))
+    assert faces.shape[1] == int((faces >= 0).sum(1).max())
