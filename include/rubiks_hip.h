@@ -124,6 +124,17 @@ int rc_sequence_states(const uint8_t *moves, int8_t *out_soa, size_t games, size
 int rc_first_layer_bf16(const int8_t *soa, size_t n, size_t stride, const uint16_t *w1t, const float *bias,
                         uint16_t *out, size_t H, int activation, float alpha, int table_is_f16, rc_stream_t stream);
 
+/* ---- Autodidactic-iteration targets (librubiks/train.py:292-325) ----------------------------------
+ * For state i with children 12 i .. 12 i + 11 (rc_expand12 order):
+ *   q[k]   = values[12 i + k] + (child_solved[12 i + k] ? win_reward : -1)
+ *   policy_target[i] = first argmax_k q[k];   value_target[i] = q[policy_target[i]]
+ *   fix_mode 1 ("lapanfix")  : value_target[i] = 0 where state_solved[i]
+ *   fix_mode 2 ("schultzfix"): value_target[i] = 0 where i % depth == 0
+ * values: float[12 n]; child_solved: uint8[12 n]; state_solved: uint8[n] (may be NULL unless fix_mode 1). */
+int rc_adi_targets(const float *values, const uint8_t *child_solved, const uint8_t *state_solved, size_t n,
+                   size_t depth, float win_reward, int fix_mode, int64_t *policy_target, float *value_target,
+                   rc_stream_t stream);
+
 /* ---- batched MCTS: one independent tree per scramble, lock-step iterations -------------------
  *
  * Replaces the per-tree Python loop of librubiks/solving/agents.py:415-645 (class MCTS) for B

@@ -119,9 +119,42 @@ __global__ __launch_bounds__(kFLThreads) __attribute__((amdgpu_waves_per_eu(4, 4
     }
 }
 
+// ADI targets: 12-way segmented argmax of value + reward, with the goal-state fixes (train.py:292-325).
+__global__ __launch_bounds__(kBlock) void k_adi_targets(const float *__restrict__ values, const u8 *__restrict__ child_solved,
+                                                        const u8 *__restrict__ state_solved, size_t n, size_t depth,
+                                                        float win_reward, int fix_mode, long long *__restrict__ policy,
+                                                        float *__restrict__ value) {
+    for (size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += (size_t)gridDim.x * kBlock) {
+        float best = 0.f;
+        int arg = 0;
+#pragma unroll
+        for (int k = 0; k < kActions; ++k) {
+            const float q = values[i * kActions + k] + (child_solved[i * kActions + k] ? win_reward : -1.f);
+            if (k == 0 || q > best) { best = q; arg = k; }   // first maximum
+        }
+        if (fix_mode == 1 && state_solved[i]) best = 0.f;
+        if (fix_mode == 2 && i % depth == 0) best = 0.f;
+        policy[i] = arg;
+        value[i] = best;
+    }
+}
+
 }  // namespace rubiks
 
 using namespace rubiks;
+
+extern "C" int rc_adi_targets(const float *values, const uint8_t *child_solved, const uint8_t *state_solved, size_t n,
+                              size_t depth, float win_reward, int fix_mode, int64_t *policy_target, float *value_target,
+                              rc_stream_t stream) {
+    if (n == 0) return RC_OK;
+    RC_REQUIRE(values && child_solved && policy_target && value_target, RC_ERR_NULL);
+    RC_REQUIRE(fix_mode >= 0 && fix_mode <= 2 && depth > 0, RC_ERR_RANGE);
+    RC_REQUIRE(fix_mode != 1 || state_solved != nullptr, RC_ERR_NULL);
+    hipLaunchKernelGGL(k_adi_targets, dim3(grid_for(n)), dim3(kBlock), 0, (hipStream_t)stream, values, child_solved,
+                       state_solved, n, depth, win_reward, fix_mode, (long long *)policy_target, value_target);
+    return launch_status();
+}
+
 
 extern "C" int rc_first_layer_bf16(const int8_t *soa, size_t n, size_t stride, const uint16_t *w1t, const float *bias,
                                    uint16_t *out, size_t H, int activation, float alpha, int table_is_f16, rc_stream_t stream) {

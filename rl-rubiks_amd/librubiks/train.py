@@ -1,0 +1,169 @@
+"""
+Autodidactic-iteration training with the reference's `Train` interface (librubiks/train.py:18-412),
+with the whole data-generation path resident on the GPU:
+
+    sequence_scrambler (HIP) -> expand12 (HIP) -> is_solved (HIP) -> value net -> rc_adi_targets (HIP)
+
+so the rollout's (games * depth * 12) substates never exist on the host (the reference builds them
+in NumPy and ships a 377 MB one-hot matrix to the GPU every rollout at BASELINE config #4).
+The optimisation loop is stock PyTorch, like the reference's.  Plots and TrainAnalysis are out of
+scope.  Data-parallel training over several GPUs: every rank generates games / world_size games of
+each rollout and gradients are averaged with one all_reduce per step (`average_gradients`).
+"""
+import numpy as np
+import torch
+import torch.distributed as dist
+
+from librubiks import _hip, cube, gpu, no_grad
+from librubiks.cube.device import DeviceCubes
+from librubiks.model import InferenceNet, Model
+from librubiks.utils import NullLogger, TickTock
+
+_FIX = {"paper": 0, "reward0": 0, "lapanfix": 1, "schultzfix": 2}
+
+
+def average_gradients(net: torch.nn.Module):
+    """Mean of the gradients over all ranks in one flat all_reduce (RCCL on GPUs); no-op for a single process."""
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+        return
+    grads = [p.grad for p in net.parameters() if p.grad is not None]
+    flat = torch.cat([g.reshape(-1) for g in grads])
+    dist.all_reduce(flat, op=dist.ReduceOp.SUM)
+    flat /= dist.get_world_size()
+    offset = 0
+    for g in grads:
+        g.copy_(flat[offset:offset + g.numel()].view_as(g))
+        offset += g.numel()
+
+
+class Train:
+    def __init__(self, rollouts: int, batch_size: int, rollout_games: int, rollout_depth: int, optim_fn,
+                 alpha_update: float, lr: float, gamma: float, update_interval: int, agent, evaluator,
+                 evaluation_interval: int, with_analysis: bool = False, tau: float = 1, reward_method: str = "lapanfix",
+                 policy_criterion=torch.nn.CrossEntropyLoss, value_criterion=torch.nn.MSELoss, logger=NullLogger(),
+                 adi_net_dtype=torch.float32):
+        assert reward_method in _FIX, f"reward_method must be one of {sorted(_FIX)}"
+        assert not with_analysis, "TrainAnalysis is out of scope of the MI355X build"
+        self.rollouts, self.rollout_games, self.rollout_depth = rollouts, rollout_games, rollout_depth
+        self.states_per_rollout = rollout_depth * rollout_games
+        self.batch_size = batch_size or self.states_per_rollout
+        self.reward_method, self.tau = reward_method, tau
+        self.alpha_update, self.lr, self.gamma, self.update_interval = alpha_update, lr, gamma, update_interval
+        self.optim = optim_fn
+        self.policy_criterion = policy_criterion(reduction="none")
+        self.value_criterion = value_criterion(reduction="none")
+        self.agent, self.evaluator, self.log = agent, evaluator, logger
+        self.adi_net_dtype = adi_net_dtype
+        # evaluation schedule of the reference (train.py:63-73)
+        if evaluation_interval:
+            ev = np.arange(0, rollouts, evaluation_interval) - 1
+            ev = ev[1:] if evaluation_interval == 1 else np.concatenate([[0], ev[1:]])
+            if len(ev) == 0 or ev[-1] != rollouts - 1:
+                ev = np.append(ev, rollouts - 1)
+            self.evaluation_rollouts = ev
+        else:
+            self.evaluation_rollouts = np.array([])
+        self.tt = TickTock()
+        self.adi_chunk = 1 << 19   # substates per value-network call
+
+    # ---- data generation (train.py:257-339), device resident -------------------------------------
+    @no_grad
+    def ADI_traindata(self, net, alpha: float):
+        """
+        (one-hot states float32[G*D, 480], policy targets int64[G*D], value targets float32[G*D],
+        loss weights float32[G*D]), all on the GPU.
+        """
+        lib, st = _hip.lib(), _hip.stream_ptr()
+        net.eval()
+        G, D = self.rollout_games, self.rollout_depth
+        states = cube.sequence_scrambler_device(G, D, with_solved=self.reward_method == "lapanfix")
+        n = states.n
+        kids = states.expand12()
+        kid_solved = kids.is_solved().view(torch.uint8)
+        state_solved = states.is_solved().view(torch.uint8)
+        values = torch.empty(12 * n, dtype=torch.float32, device=states.soa.device)
+        engine = InferenceNet(net, self.adi_net_dtype) if isinstance(net, Model) and \
+            net.config.architecture.startswith("fc") and self.adi_net_dtype != torch.float32 else None
+        for lo in range(0, 12 * n, self.adi_chunk):   # chunked like the reference's adi_ff_batches (train.py:301-310)
+            m = min(self.adi_chunk, 12 * n - lo)
+            part = DeviceCubes(kids.soa[:, lo:lo + ((m + 15) // 16) * 16].contiguous(), m) if (lo or m < 12 * n) else kids
+            if engine is not None and engine.supports_cubes:
+                values[lo:lo + m] = engine.value_cubes(part)
+            else:
+                values[lo:lo + m] = net(part.as_oh(torch.float32), policy=False, value=True).float().reshape(-1)
+        policy_targets = torch.empty(n, dtype=torch.int64, device=values.device)
+        value_targets = torch.empty(n, dtype=torch.float32, device=values.device)
+        _hip.check(lib.rc_adi_targets(values.data_ptr(), kid_solved.data_ptr(), state_solved.data_ptr(), n, D,
+                                      0.0 if self.reward_method == "reward0" else 1.0, _FIX[self.reward_method],
+                                      policy_targets.data_ptr(), value_targets.data_ptr(), st), "rc_adi_targets")
+        # loss weights (train.py:330-333): host arithmetic on a (G*D,) vector, independent of the states
+        weighted = np.tile(1 / np.arange(1, D + 1), G)
+        ws, us = weighted.sum(), len(weighted)
+        loss_weights = ((1 - alpha) * weighted / ws + alpha * np.ones_like(weighted) / us) * (ws + us)
+        return states.as_oh(torch.float32), policy_targets, value_targets, \
+            torch.from_numpy(loss_weights).float().to(values.device)
+
+    # ---- training loop (train.py:111-255) ----------------------------------------------------------
+    def train(self, net: Model):
+        self.tt.reset()
+        self.tt.tick()
+        best_solve, best_net = 0, net.clone()
+        self.agent.net = net
+        generator_net = net.clone()
+        alpha = 1 if self.alpha_update == 1 else 0
+        optimizer = self.optim(net.parameters(), lr=self.lr)
+        scheduler = torch.optim.lr_scheduler.StepLR(optimizer, 1, self.gamma)
+        self.policy_losses, self.value_losses = np.zeros(self.rollouts), np.zeros(self.rollouts)
+        self.train_losses, self.sol_percents = np.empty(self.rollouts), []
+        for rollout in range(self.rollouts):
+            generator_net = self._update_gen_net(generator_net, net) if self.tau != 1 else net
+            self.tt.profile("ADI training data")
+            data, policy_targets, value_targets, loss_weights = self.ADI_traindata(generator_net, alpha)
+            self.tt.end_profile("ADI training data")
+            self.tt.profile("Training loop")
+            net.train()
+            batches = self._get_batches(len(data), self.batch_size)
+            for batch in batches:
+                optimizer.zero_grad()
+                policy_pred, value_pred = net(data[batch], policy=True, value=True)
+                policy_loss = self.policy_criterion(policy_pred, policy_targets[batch]) * loss_weights[batch]
+                value_loss = self.value_criterion(value_pred.squeeze(1), value_targets[batch]) * loss_weights[batch]
+                torch.mean(policy_loss + value_loss).backward()
+                average_gradients(net)
+                optimizer.step()
+                self.policy_losses[rollout] += float(policy_loss.detach().mean()) / len(batches)
+                self.value_losses[rollout] += float(value_loss.detach().mean()) / len(batches)
+            self.train_losses[rollout] = self.policy_losses[rollout] + self.value_losses[rollout]
+            self.tt.end_profile("Training loop")
+            if rollout and self.update_interval and rollout % self.update_interval == 0:   # train.py:190-200
+                if self.gamma != 1:
+                    scheduler.step()
+                if self.alpha_update and (alpha + self.alpha_update <= 1 or np.isclose(alpha + self.alpha_update, 1)):
+                    alpha += self.alpha_update
+                elif self.alpha_update and alpha < 1 and alpha + self.alpha_update > 1:
+                    alpha = 1
+            if rollout in self.evaluation_rollouts and self.evaluator is not None:
+                net.eval()
+                self.agent.net = net
+                results, _, _ = self.evaluator.eval(self.agent)
+                reward = float((results != -1).mean())
+                self.sol_percents.append(reward)
+                if reward > best_solve:
+                    best_solve, best_net = reward, net.clone()
+        return net, best_net
+
+    def _update_gen_net(self, generator_net: Model, net: Model):
+        """generator <- tau * net + (1 - tau) * generator, over the whole state_dict (train.py:341-353)."""
+        gen, new = generator_net.state_dict(), net.state_dict()
+        for name, p in new.items():
+            if gen[name].dtype.is_floating_point:
+                gen[name].copy_(self.tau * p + (1 - self.tau) * gen[name])
+            else:   # integer buffers (num_batches_tracked): same formula, truncated like the reference's copy_
+                gen[name].copy_((self.tau * p + (1 - self.tau) * gen[name]).to(gen[name].dtype))
+        return generator_net.to(gpu)
+
+    @staticmethod
+    def _get_batches(size: int, bsize: int):
+        """Contiguous slices; the reference shuffles an index array it then never uses (train.py:400-410)."""
+        n = int(np.ceil(size / bsize))
+        return [slice(b * bsize, min(size, (b + 1) * bsize)) for b in range(n)]

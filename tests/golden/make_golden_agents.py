@@ -96,3 +96,26 @@ def make_agents():
 
     np.savez_compressed(os.path.join(OUT, "agents_golden.npz"), **fx)
     print("agents_golden.npz", os.path.getsize(os.path.join(OUT, "agents_golden.npz")) // 1024, "KiB")
+
+
+def make_adi():
+    """ADI training targets of the reference's Train.ADI_traindata (librubiks/train.py:257-339)."""
+    from librubiks.train import Train
+    from librubiks.solving.agents import PolicySearch
+    net = StandInNet(seed=0)
+    fx = {}
+    for method in ("paper", "lapanfix", "schultzfix", "reward0"):
+        for games, depth, alpha in ((6, 10, 0.0), (5, 7, 0.4)):
+            tr = Train(rollouts=1, batch_size=10, rollout_games=games, rollout_depth=depth, optim_fn=torch.optim.Adam,
+                       alpha_update=0, lr=1e-3, gamma=1, update_interval=0, agent=PolicySearch(None), evaluator=None,
+                       evaluation_interval=0, with_analysis=False, tau=1, reward_method=method)
+            np.random.seed(31)
+            oh, ptar, vtar, w = tr.ADI_traindata(net, alpha)
+            pre = f"adi_{method}_{games}x{depth}_"
+            fx[pre + "ohcols"] = np.nonzero(oh.cpu().numpy())[1].reshape(games * depth, 20).astype(np.int16)
+            fx[pre + "policy"] = ptar.numpy()
+            fx[pre + "value"] = vtar.numpy()
+            fx[pre + "weights"] = w.numpy()
+            fx[pre + "alpha"] = np.array([alpha])
+            print(pre, ptar[:8].tolist(), vtar[:4].tolist())
+    np.savez_compressed(os.path.join(OUT, "adi_golden.npz"), **fx)

@@ -78,3 +78,19 @@ def test_astar_trace(case, agents_golden, standin_net):
     oq = sorted((float(c), int(i)) for c, i in agent.open_queue)
     assert np.array_equal(np.array([i for _, i in oq]), g("open_idx"))
     assert np.array_equal(np.array([c for c, _ in oq]), g("open_cost"))
+
+
+@pytest.mark.parametrize("method", ["paper", "lapanfix", "schultzfix", "reward0"])
+def test_adi_targets(method, standin_net):
+    """oracle/train.py against Train.ADI_traindata of the reference (tests/golden/adi_golden.npz)."""
+    from oracle import train as ot
+    g = np.load(f"{GOLDEN}/adi_golden.npz")
+    net = oa.TorchNet(standin_net)
+    for games, depth in ((6, 10), (5, 7)):
+        pre = f"adi_{method}_{games}x{depth}_"
+        np.random.seed(31)
+        states, pol, val, w = ot.adi_traindata(net.value, games, depth, method, float(g[pre + "alpha"][0]))
+        assert np.array_equal(oc.oh_indices(states), g[pre + "ohcols"])
+        assert np.array_equal(pol, g[pre + "policy"])
+        assert np.array_equal(val, g[pre + "value"])
+        assert np.array_equal(w, g[pre + "weights"])

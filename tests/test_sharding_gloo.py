@@ -50,3 +50,39 @@ def test_two_rank_gather_uneven():
         assert summary["games"] == n_games and summary["nodes"] == int((100 + g).sum())
         assert abs(summary["nodes_per_sec"] - (100 + g).sum() / 2.0) < 1e-6
     assert got[0][2] == got[1][2]
+
+
+def _grad_worker(rank, world, port, q):
+    import torch
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from librubiks.train import average_gradients
+    torch.manual_seed(0)
+    net = torch.nn.Sequential(torch.nn.Linear(6, 4), torch.nn.ReLU(), torch.nn.Linear(4, 2))
+    x = torch.full((3, 6), float(rank + 1))
+    net(x).sum().backward()
+    local = [p.grad.clone() for p in net.parameters()]
+    average_gradients(net)
+    q.put((rank, [g.tolist() for g in local], [p.grad.tolist() for p in net.parameters()]))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_data_parallel_gradient_average():
+    """Config #4's only collective: the mean of per-rank gradients in one flat all_reduce."""
+    world = 2
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_grad_worker, args=(r, world, port, q)) for r in range(world)]
+    [p.start() for p in procs]
+    got = sorted(q.get(timeout=120) for _ in range(world))
+    [p.join(60) for p in procs]
+    assert all(p.exitcode == 0 for p in procs)
+    mean = [np.mean([np.array(got[r][1][i]) for r in range(world)], axis=0) for i in range(len(got[0][1]))]
+    for r in range(world):
+        for i, m in enumerate(mean):
+            assert np.allclose(np.array(got[r][2][i]), m, atol=1e-6)
+    assert not np.allclose(np.array(got[0][1][0]), np.array(got[1][1][0]))   # local gradients did differ

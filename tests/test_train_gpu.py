@@ -1,0 +1,92 @@
+"""
+Device-resident ADI (librubiks.train.Train) against the reference's recorded targets and the oracle,
+plus a short end-to-end training run.  Integer outputs exact; value targets exact as well because the
+stand-in net's outputs are exact in fp32.
+"""
+import numpy as np
+import pytest
+import torch
+
+from conftest import GOLDEN
+
+pytestmark = pytest.mark.gpu
+
+from oracle import agents as oa  # noqa: E402  (checker only)
+from oracle import cube as oc  # noqa: E402
+from oracle import train as ot  # noqa: E402
+
+
+def _trainer(games, depth, method, **kw):
+    from librubiks.train import Train
+    args = dict(rollouts=1, batch_size=10, rollout_games=games, rollout_depth=depth, optim_fn=torch.optim.Adam,
+                alpha_update=0, lr=1e-3, gamma=1, update_interval=0, agent=None, evaluator=None, evaluation_interval=0,
+                with_analysis=False, tau=1, reward_method=method)
+    args.update(kw)
+    return Train(**args)
+
+
+@pytest.mark.parametrize("method", ["paper", "lapanfix", "schultzfix", "reward0"])
+def test_adi_targets_golden(method, standin_net):
+    g = np.load(f"{GOLDEN}/adi_golden.npz")
+    net = standin_net.cuda()
+    for games, depth in ((6, 10), (5, 7)):
+        pre = f"adi_{method}_{games}x{depth}_"
+        np.random.seed(31)
+        oh, pol, val, w = _trainer(games, depth, method).ADI_traindata(net, float(g[pre + "alpha"][0]))
+        assert oh.is_cuda and oh.dtype == torch.float32 and oh.shape == (games * depth, 480)
+        assert np.array_equal(np.nonzero(oh.cpu().numpy())[1].reshape(-1, 20), g[pre + "ohcols"])
+        assert pol.dtype == torch.int64 and np.array_equal(pol.cpu().numpy(), g[pre + "policy"])
+        assert np.array_equal(val.cpu().numpy(), g[pre + "value"])
+        assert np.array_equal(w.cpu().numpy(), g[pre + "weights"])
+
+
+@pytest.mark.parametrize("method", ["paper", "lapanfix", "schultzfix", "reward0"])
+def test_adi_targets_vs_oracle_large(method, standin_net):
+    """BASELINE config #4 shape per GPU: 2 048 states x 12 substates, chunked value calls."""
+    net = standin_net.cuda()
+    tr = _trainer(64, 32, method)
+    tr.adi_chunk = 4096   # force several chunks
+    np.random.seed(5)
+    oh, pol, val, w = tr.ADI_traindata(net, 0.3)
+    np.random.seed(5)
+    states, rpol, rval, rw = ot.adi_traindata(oa.TorchNet(net, device="cuda").value, 64, 32, method, 0.3)
+    assert np.array_equal(np.nonzero(oh.cpu().numpy())[1].reshape(-1, 20), oc.oh_indices(states))
+    assert np.array_equal(pol.cpu().numpy(), rpol)
+    assert np.array_equal(val.cpu().numpy(), rval)
+    assert np.allclose(w.cpu().numpy(), rw, rtol=1e-6)
+
+
+def test_adi_bf16_engine_close_to_fp32():
+    """Value targets from the bf16 inference engine stay within 5e-2 of the fp32 module's (values are O(1))."""
+    from librubiks.model import Model, ModelConfig
+    torch.manual_seed(0)
+    net = Model.create(ModelConfig()).eval()
+    np.random.seed(1)
+    _, p32, v32, _ = _trainer(32, 20, "lapanfix").ADI_traindata(net, 0.0)
+    np.random.seed(1)
+    _, p16, v16, _ = _trainer(32, 20, "lapanfix", adi_net_dtype=torch.bfloat16).ADI_traindata(net, 0.0)
+    assert torch.allclose(v32, v16, atol=5e-2)
+    assert float((p32 == p16).float().mean()) > 0.9   # near-ties may flip the argmax
+
+
+def test_short_training_run():
+    """Three rollouts of the full loop (ADI -> minibatch SGD -> evaluation) on fc_small."""
+    from librubiks.model import Model, ModelConfig
+    from librubiks.solving.agents import MCTS
+    from librubiks.solving.evaluation import Evaluator
+    from librubiks.train import Train
+    torch.manual_seed(0)
+    np.random.seed(0)
+    net = Model.create(ModelConfig())
+    before = net.get_params().clone()
+    agent = MCTS(net, c=0.6, search_graph=False)
+    ev = Evaluator(n_games=16, scrambling_depths=range(1, 3), max_time=None, max_states=200)
+    tr = Train(rollouts=3, batch_size=256, rollout_games=64, rollout_depth=12, optim_fn=torch.optim.Adam, alpha_update=0.5,
+               lr=1e-4, gamma=0.5, update_interval=1, agent=agent, evaluator=ev, evaluation_interval=2,
+               tau=0.3, reward_method="lapanfix")
+    net, best = tr.train(net)
+    assert np.isfinite(tr.train_losses).all() and (tr.train_losses > 0).all()
+    assert not torch.equal(before, net.get_params())
+    assert list(tr.evaluation_rollouts) == [0, 2] and len(tr.sol_percents) == 2
+    assert all(0 <= s <= 1 for s in tr.sol_percents)
+    assert isinstance(best, Model)
