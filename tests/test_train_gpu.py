@@ -87,6 +87,7 @@ def test_short_training_run():
     net, best = tr.train(net)
     assert np.isfinite(tr.train_losses).all() and (tr.train_losses > 0).all()
     assert not torch.equal(before, net.get_params())
-    assert list(tr.evaluation_rollouts) == [0, 2] and len(tr.sol_percents) == 2
+    # schedule of the reference (train.py:63-73): arange(0, 3, 2) - 1 -> [0, 1], plus the last rollout
+    assert list(tr.evaluation_rollouts) == [0, 1, 2] and len(tr.sol_percents) == 3
     assert all(0 <= s <= 1 for s in tr.sol_percents)
     assert isinstance(best, Model)
