@@ -50,6 +50,15 @@ class TorchNet:
             p, v = self.module(oh)
             return p.softmax(dim=1).cpu().numpy(), v.cpu().numpy().reshape(-1)
 
+    def logits(self, states: np.ndarray):
+        """Raw policy-head outputs (EGVM takes the argmax of these, agents.py:700-701)."""
+        torch = self.torch
+        with torch.no_grad():
+            if len(states) == 0:
+                return np.zeros((0, N_ACT), dtype=np.float32)
+            oh = torch.from_numpy(cube.as_oh(states)).to(self.device)
+            return self.module(oh, policy=True, value=False).cpu().numpy()
+
     def value(self, states: np.ndarray):
         torch = self.torch
         with torch.no_grad():
@@ -369,3 +378,112 @@ class AStar:
     def cost(self, states: np.ndarray, idx: np.ndarray) -> np.ndarray:
         h = -self.net.value(states)
         return self.lambda_ * self.G[idx] + h
+
+
+# =================================================================================================
+# One-step-lookahead agents and EGVM  (agents.py:14-169, 649-726)
+# =================================================================================================
+# The reference's Agent.search loop is `while tock() < time_limit and len(self) < max_states`, but
+# len(self) is only updated when the loop ends (agents.py:30-38), so these agents are bounded by
+# wall time alone.  For deterministic tests the restatement bounds the number of steps by
+# `max_states` instead (same as the MI355X build); on solved games both agree with the reference.
+class _StepAgent:
+    def __init__(self):
+        self.action_queue = deque()
+        self._explored = 0
+
+    def __len__(self):
+        return self._explored
+
+    def search(self, state: np.ndarray, max_states: int) -> bool:
+        self.action_queue = deque()
+        self._explored = 0
+        if cube.is_solved(state):
+            return True
+        found = False
+        while len(self.action_queue) < max_states:
+            action, state, found = self._step(state)
+            self.action_queue.append(action)
+            if found:
+                break
+        self._explored = len(self.action_queue)
+        return found
+
+
+class PolicySearch(_StepAgent):
+    """Greedy policy (agents.py:132-151, sample_policy=False)."""
+
+    def __init__(self, net):
+        super().__init__()
+        self.net = net
+
+    def _step(self, state):
+        p, _ = self.net(state[None])
+        action = int(p[0].argmax())
+        state = cube.rotate(state, *cube.ACTION_SPACE[action])
+        return action, state, cube.is_solved(state)
+
+
+class ValueSearch(_StepAgent):
+    """Greedy value with a one-move solution check (agents.py:154-169)."""
+
+    def __init__(self, net):
+        super().__init__()
+        self.net = net
+
+    def _step(self, state):
+        children = cube.expand12(state[None])
+        hit = np.flatnonzero(cube.multi_is_solved(children))
+        if hit.size:
+            return int(hit[0]), children[hit[0]], True
+        action = int(np.argmax(self.net.value(children)))
+        return action, children[action], False
+
+
+class EGVM:
+    """Epsilon-greedy value maximisation (agents.py:649-726); draws from the global np.random stream."""
+
+    def __init__(self, net, epsilon: float, workers: int, depth: int):
+        self.net, self.epsilon, self.workers, self.depth = net, epsilon, workers, depth
+        self.action_queue = deque()
+        self._explored = 0
+
+    def __len__(self):
+        return self._explored
+
+    def search(self, state: np.ndarray, max_states: int) -> bool:
+        self.action_queue = deque()
+        self._explored = 0
+        if cube.is_solved(state):
+            return True
+        while len(self) + self.workers * self.depth <= max_states:
+            paths, states, solved = self._expand(state)
+            if solved is not None:
+                w, d = solved
+                self.action_queue += deque(int(a) for a in paths[w, :d])
+                return True
+            best = int(np.argmax(self.net.value(states)))   # rows are worker-major: row w * depth + d (agents.py:681-682,714)
+            state = states[best]
+            worker, depth = best // self.depth, best % self.depth
+            self.action_queue += deque(int(a) for a in paths[worker, :depth + 1])
+        return False
+
+    def _expand(self, state):
+        states = cube.repeat_state(state, self.workers)
+        paths = np.empty((self.workers, self.depth), dtype=int)
+        visited = np.empty((self.workers * self.depth, 20), dtype=np.int8)
+        for d in range(self.depth):
+            use_random = np.random.choice(2, self.workers, p=[1 - self.epsilon, self.epsilon]).astype(bool)
+            actions = np.empty(self.workers, dtype=int)
+            actions[use_random] = np.random.randint(0, N_ACT, use_random.sum())
+            if (~use_random).any():
+                actions[~use_random] = self.net.logits(states[~use_random]).argmax(axis=1)
+            paths[:, d] = actions
+            states = cube.multi_rotate_actions(states, actions)
+            hit = np.flatnonzero(cube.multi_is_solved(states))
+            if hit.size:
+                self._explored += (d + 1) * self.workers
+                return paths, None, (int(hit[0]), d + 1)
+            visited[np.arange(self.workers) * self.depth + d] = states   # agents.py:681-682,714
+        self._explored += len(visited)
+        return paths, visited, None

@@ -328,3 +328,215 @@ class AStar(DeepAgent):
         oh = DeviceCubes.from_numpy(np.asarray(states)).as_oh(eng.input_dtype)
         h = -eng.value(oh).cpu().numpy().astype(np.float64)
         return self.lambda_ * np.asarray(self.G)[indeces] + h
+
+
+# =================================================================================================
+# Rollout agents (reference agents.py:82-90, 132-169, 649-726), batched over games on the device
+# =================================================================================================
+DEFAULT_STEP_CAP = 1000   # steps per game when a rollout search is bounded by time only
+
+
+def _evaluate(engine, cubes: DeviceCubes):
+    """(policy logits float32[n,12], values float32[n]) of device-resident states."""
+    if getattr(engine, "supports_cubes", False):
+        return engine.forward_cubes(cubes)
+    return engine(cubes.as_oh(engine.input_dtype))
+
+
+def _values(engine, cubes: DeviceCubes):
+    if getattr(engine, "supports_cubes", False):
+        return engine.value_cubes(cubes)
+    return engine.value(cubes.as_oh(engine.input_dtype))
+
+
+class _StepAgent(Agent):
+    """
+    Agents that take one move per step.  The reference bounds them by wall time only (its
+    `len(self) < max_states` test reads a counter that is updated after the loop, agents.py:30-38);
+    here `max_states` additionally caps the number of moves per game, which keeps runs deterministic.
+    All games of a batch step together; a finished game idles on the identity action.
+    """
+
+    def _actions(self, cubes: DeviceCubes, running: torch.Tensor):
+        """-> (uint8 actions [n_padded], bool solved_after [n]) for the current states."""
+        raise NotImplementedError
+
+    @no_grad
+    def search_batch(self, states, time_limit: float = None, max_states: int = None) -> BatchResult:
+        time_limit, max_states = self.reset(time_limit, max_states)
+        cubes = states if isinstance(states, DeviceCubes) else DeviceCubes.from_numpy(np.asarray(states))
+        cubes = DeviceCubes(cubes.soa.clone(), cubes.n)
+        B = cubes.n
+        cap = int(max_states) if max_states < int(1e10) else DEFAULT_STEP_CAP
+        self.tt.tick()
+        solved = cubes.is_solved().clone()
+        root_solved = solved.clone()
+        running = ~solved
+        history = []
+        steps = torch.zeros(B, dtype=torch.int64, device=solved.device)
+        while len(history) < cap and bool(running.any()) and self.tt.tock() < time_limit:
+            actions = self._actions(cubes, running)
+            actions[:B][~running] = 12                        # identity padding of the move table
+            cubes.multi_rotate(actions, out=cubes)
+            history.append(actions[:B].clone())
+            steps += running
+            now = cubes.is_solved()
+            solved |= now & running
+            running &= ~now
+        torch.cuda.synchronize()
+        seconds = self.tt.tock()
+        hist = torch.stack(history, 1).cpu().numpy() if history else np.zeros((B, 0), dtype=np.uint8)
+        steps, solved_h = steps.cpu().numpy(), solved.cpu().numpy()
+        queues = [deque(int(a) for a in hist[g, :steps[g]]) for g in range(B)]
+        lengths = np.where(solved_h, steps, -1)
+        self._explored_states = int(steps[0])
+        self.action_queue = queues[0]
+        status = np.where(root_solved.cpu().numpy(), 4, np.where(solved_h, 1, 2))
+        return BatchResult(solved_h, lengths, steps.astype(np.int64), queues, seconds, steps, status)
+
+    def search(self, state: np.ndarray, time_limit: float = None, max_states: int = None) -> bool:
+        return bool(self.search_batch(np.asarray(state)[None], time_limit, max_states).solved[0])
+
+
+def _pad16(t: torch.Tensor) -> torch.Tensor:
+    n = t.numel()
+    out = torch.zeros((n + 15) // 16 * 16, dtype=torch.uint8, device=t.device)
+    out[:n] = t
+    return out
+
+
+class RandomSearch(_StepAgent):
+    """Uniformly random moves from np.random (reference agents.py:82-90); one draw per running game per step."""
+
+    def _actions(self, cubes, running):
+        a = torch.from_numpy(np.random.randint(12, size=cubes.n).astype(np.uint8)).to(cubes.soa.device)
+        return _pad16(a)
+
+    def __str__(self):
+        return "Random depth-first search"
+
+
+class PolicySearch(_StepAgent, DeepAgent):
+    """Follows the policy head: greedy argmax of softmax(policy), or samples it (reference agents.py:132-151)."""
+
+    def __init__(self, net, sample_policy=False, net_dtype=torch.bfloat16):
+        DeepAgent.__init__(self, net)
+        self.sample_policy, self.net_dtype, self._engine = sample_policy, net_dtype, None
+
+    @classmethod
+    def from_saved(cls, loc: str, use_best: bool, sample_policy=False, **kw):
+        return cls(Model.load(loc, load_best=use_best).to(gpu), sample_policy, **kw)
+
+    def reset(self, time_limit, max_states):
+        from librubiks.model import make_inference_net
+        out = super().reset(time_limit, max_states)
+        self._engine = make_inference_net(self.net, self.net_dtype)   # rebuilt per search: weights may have been trained
+        return out
+
+    def _actions(self, cubes, running):
+        logits, _ = _evaluate(self._engine, cubes)
+        p = torch.softmax(logits, dim=1)
+        if self.sample_policy:   # np.random.choice per game, in game order (agents.py:140)
+            pn = p.double().cpu().numpy()
+            a = np.array([np.random.choice(12, p=row / row.sum()) for row in pn], dtype=np.uint8)
+            return _pad16(torch.from_numpy(a).to(p.device))
+        return _pad16(p.argmax(dim=1).to(torch.uint8))
+
+    def __str__(self):
+        return f"{'Sampled' if self.sample_policy else 'Greedy'} policy"
+
+
+class ValueSearch(_StepAgent, DeepAgent):
+    """Moves to the child of highest value; a solved child is taken at once (reference agents.py:154-169)."""
+
+    def __init__(self, net, net_dtype=torch.bfloat16):
+        DeepAgent.__init__(self, net)
+        self.net_dtype, self._engine = net_dtype, None
+
+    reset = PolicySearch.reset
+
+    def _actions(self, cubes, running):
+        kids = cubes.expand12()
+        solved = kids.is_solved().view(cubes.n, 12)
+        v = _values(self._engine, kids).view(cubes.n, 12)
+        best = v.argmax(dim=1)
+        first_solved = solved.to(torch.uint8).argmax(dim=1)   # first True (argmax returns the first maximum)
+        return _pad16(torch.where(solved.any(dim=1), first_solved, best).to(torch.uint8))
+
+    def __str__(self):
+        return "Greedy value"
+
+
+class EGVM(DeepAgent):
+    """
+    Epsilon-greedy value maximisation (reference agents.py:649-726): `workers` epsilon-greedy policy
+    rollouts of `depth` moves from the current state, then jump to the visited state of highest value.
+    The random draws follow the reference's np.random call order, so a game is reproducible against
+    it; the workers of a game run in parallel on the device, games run one after another.
+    """
+
+    def __init__(self, net, epsilon: float, workers: int, depth: int, net_dtype=torch.bfloat16):
+        super().__init__(net)
+        self.epsilon, self.workers, self.depth, self.net_dtype = epsilon, workers, depth, net_dtype
+
+    @classmethod
+    def from_saved(cls, loc: str, use_best: bool, epsilon: float, workers: int, depth: int, **kw):
+        return cls(Model.load(loc, load_best=use_best).to(gpu), epsilon, workers, depth, **kw)
+
+    def __str__(self):
+        return f"EGVM (e={self.epsilon}, w={self.workers}, d={self.depth})"
+
+    @no_grad
+    def search(self, state: np.ndarray, time_limit: float = None, max_states: int = None) -> bool:
+        from librubiks.model import make_inference_net
+        time_limit, max_states = self.reset(time_limit, max_states)
+        engine = make_inference_net(self.net, self.net_dtype)
+        self.tt.tick()
+        cur = DeviceCubes.from_numpy(np.asarray(state)[None])
+        if bool(cur.is_solved()[0]):
+            return True
+        W, D = self.workers, self.depth
+        while self.tt.tock() < time_limit and len(self) + W * D <= max_states:
+            cubes = DeviceCubes.empty(W)
+            cubes.soa[:, :W] = cur.soa[:, :1]
+            paths = np.empty((W, D), dtype=int)
+            visited = DeviceCubes.empty(W * D)
+            hit = None
+            for d in range(D):
+                use_random = np.random.choice(2, W, p=[1 - self.epsilon, self.epsilon]).astype(bool)
+                actions = np.empty(W, dtype=int)
+                actions[use_random] = np.random.randint(0, 12, use_random.sum())
+                if (~use_random).any():
+                    logits, _ = _evaluate(engine, cubes)
+                    actions[~use_random] = logits.argmax(dim=1).cpu().numpy()[~use_random]
+                paths[:, d] = actions
+                cubes.multi_rotate(_pad16(torch.from_numpy(actions.astype(np.uint8)).cuda()), out=cubes)
+                solved = cubes.is_solved().cpu().numpy()
+                if solved.any():
+                    self._explored_states += (d + 1) * W
+                    hit = (int(np.flatnonzero(solved)[0]), d + 1)
+                    break
+                visited.soa[:, d:W * D:D] = cubes.soa[:, :W]     # row w * depth + d (agents.py:681-682,714)
+            if hit is not None:
+                self.action_queue += deque(int(a) for a in paths[hit[0], :hit[1]])
+                return True
+            self._explored_states += W * D
+            best = int(_values(engine, visited).argmax())
+            cur = DeviceCubes.empty(1)
+            cur.soa[:, :1] = visited.soa[:, best:best + 1]
+            worker, depth = best // D, best % D
+            self.action_queue += deque(int(a) for a in paths[worker, :depth + 1])
+        return False
+
+    def search_batch(self, states, time_limit: float = None, max_states: int = None) -> BatchResult:
+        states = states.numpy() if isinstance(states, DeviceCubes) else np.asarray(states)
+        solved, lengths, nodes, queues = [], [], [], []
+        tt = TickTock()
+        tt.tick()
+        for s in states:
+            ok = self.search(s, time_limit, max_states)
+            solved.append(ok), lengths.append(len(self.action_queue) if ok else -1)
+            nodes.append(len(self)), queues.append(self.action_queue)
+        solved = np.array(solved)
+        return BatchResult(solved, np.array(lengths), np.array(nodes, dtype=np.int64), queues, tt.tock(),
+                           np.zeros(len(states), dtype=int), np.where(solved, 1, 2))

@@ -130,7 +130,7 @@ def make_bfs():
 
 
 if __name__ == "__main__":
-    what = sys.argv[1:] or ["cube", "bfs", "agents", "adi"]
+    what = sys.argv[1:] or ["cube", "bfs", "agents", "adi", "simple"]
     assert os.path.isdir("/root/reference"), "needs the mounted reference"
     if "cube" in what:
         make_cube()
@@ -139,6 +139,9 @@ if __name__ == "__main__":
     if "agents" in what:
         from make_golden_agents import make_agents
         make_agents()
+    if "simple" in what:
+        from make_golden_agents import make_simple_agents
+        make_simple_agents()
     if "adi" in what:
         from make_golden_agents import make_adi
         make_adi()

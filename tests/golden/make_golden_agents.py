@@ -119,3 +119,40 @@ def make_adi():
             fx[pre + "alpha"] = np.array([alpha])
             print(pre, ptar[:8].tolist(), vtar[:4].tolist())
     np.savez_compressed(os.path.join(OUT, "adi_golden.npz"), **fx)
+
+
+def make_simple_agents():
+    """ValueSearch / PolicySearch (solved games only: they are wall-time bounded) and EGVM (max_states bounded)."""
+    from librubiks import cube
+    from librubiks.solving.agents import ValueSearch, PolicySearch, EGVM
+    torch.set_num_threads(1)
+    net = StandInNet(seed=0)
+    fx = {}
+    for name, cls in (("value", ValueSearch), ("policy", PolicySearch)):
+        states, queues = [], []
+        for depth in (1, 2, 3, 4, 5):
+            for seed in range(40):
+                np.random.seed(1000 * depth + seed)
+                s, _, _ = cube.scramble(depth, True)
+                agent = cls(net)
+                if agent.search(s, time_limit=0.15) and len(agent.action_queue) <= 64:
+                    states.append(s)
+                    queues.append(list(agent.action_queue) + [-1] * (64 - len(agent.action_queue)))
+        fx[f"{name}_states"], fx[f"{name}_queues"] = np.array(states), np.array(queues, dtype=np.int16)
+        print(name, "solved cases:", len(states), "max len", max((sum(a >= 0 for a in q) for q in queues), default=0))
+    cases = []
+    for i, (eps, workers, depth, sdepth, max_states) in enumerate(
+            [(0.1, 4, 12, 3, 600), (0.3, 10, 5, 4, 1000), (0.0, 6, 8, 2, 480), (0.5, 16, 3, 5, 960), (0.2, 8, 10, 20, 800),
+             (0.9, 32, 4, 1, 1280), (1.0, 64, 3, 2, 1920)]):
+        for seed in (1, 2, 3):
+            np.random.seed(100 * i + seed)
+            s, _, _ = cube.scramble(sdepth, True)
+            agent = EGVM(net, eps, workers, depth)
+            ok = agent.search(s, None, max_states)
+            pre = f"egvm_{i}_{seed}_"
+            fx[pre + "state"] = s
+            fx[pre + "params"] = np.array([eps, workers, depth, max_states, int(ok), len(agent), 100 * i + seed])
+            fx[pre + "queue"] = np.array(list(agent.action_queue), dtype=np.int16)
+            cases.append((ok, len(agent), len(agent.action_queue)))
+    print("EGVM cases (solved, len, queue):", cases)
+    np.savez_compressed(os.path.join(OUT, "simple_agents_golden.npz"), **fx)

@@ -94,3 +94,27 @@ def test_adi_targets(method, standin_net):
         assert np.array_equal(pol, g[pre + "policy"])
         assert np.array_equal(val, g[pre + "value"])
         assert np.array_equal(w, g[pre + "weights"])
+
+
+def test_value_search_and_egvm_traces(standin_net):
+    """oracle ValueSearch / EGVM against traces of the reference agents (simple_agents_golden.npz)."""
+    g = np.load(f"{GOLDEN}/simple_agents_golden.npz")
+    net = oa.TorchNet(standin_net)
+    assert len(g["value_states"]) > 50
+    for s, q in zip(g["value_states"], g["value_queues"]):
+        agent = oa.ValueSearch(net)
+        assert agent.search(s, 64)
+        assert list(agent.action_queue) == list(q[q >= 0])
+    cases = sorted(k[:-len("params")] for k in g.files if k.startswith("egvm_") and k.endswith("params"))
+    n_solved = 0
+    for pre in cases:
+        eps, workers, depth, max_states, solved, n, seed = g[pre + "params"]
+        np.random.seed(int(seed))
+        state, _, _ = oc.scramble({0: 3, 1: 4, 2: 2, 3: 5, 4: 20, 5: 1, 6: 2}[int(pre.split("_")[1])], True)
+        assert np.array_equal(state, g[pre + "state"])
+        agent = oa.EGVM(net, float(eps), int(workers), int(depth))
+        assert agent.search(state, int(max_states)) == bool(solved)
+        assert len(agent) == int(n)
+        assert list(agent.action_queue) == list(g[pre + "queue"])
+        n_solved += int(solved)
+    assert n_solved >= 2
