@@ -416,22 +416,28 @@ class RandomSearch(_StepAgent):
         return "Random depth-first search"
 
 
-class PolicySearch(_StepAgent, DeepAgent):
+class _DeepStepAgent(_StepAgent, DeepAgent):
+    def __init__(self, net, net_dtype=torch.bfloat16):
+        DeepAgent.__init__(self, net)
+        self.net_dtype, self._engine = net_dtype, None
+
+    def reset(self, time_limit, max_states):
+        from librubiks.model import make_inference_net
+        out = Agent.reset(self, time_limit, max_states)
+        self._engine = make_inference_net(self.net, self.net_dtype)   # rebuilt per search: weights may have been trained
+        return out
+
+
+class PolicySearch(_DeepStepAgent):
     """Follows the policy head: greedy argmax of softmax(policy), or samples it (reference agents.py:132-151)."""
 
     def __init__(self, net, sample_policy=False, net_dtype=torch.bfloat16):
-        DeepAgent.__init__(self, net)
-        self.sample_policy, self.net_dtype, self._engine = sample_policy, net_dtype, None
+        super().__init__(net, net_dtype)
+        self.sample_policy = sample_policy
 
     @classmethod
     def from_saved(cls, loc: str, use_best: bool, sample_policy=False, **kw):
         return cls(Model.load(loc, load_best=use_best).to(gpu), sample_policy, **kw)
-
-    def reset(self, time_limit, max_states):
-        from librubiks.model import make_inference_net
-        out = super().reset(time_limit, max_states)
-        self._engine = make_inference_net(self.net, self.net_dtype)   # rebuilt per search: weights may have been trained
-        return out
 
     def _actions(self, cubes, running):
         logits, _ = _evaluate(self._engine, cubes)
@@ -446,14 +452,8 @@ class PolicySearch(_StepAgent, DeepAgent):
         return f"{'Sampled' if self.sample_policy else 'Greedy'} policy"
 
 
-class ValueSearch(_StepAgent, DeepAgent):
+class ValueSearch(_DeepStepAgent):
     """Moves to the child of highest value; a solved child is taken at once (reference agents.py:154-169)."""
-
-    def __init__(self, net, net_dtype=torch.bfloat16):
-        DeepAgent.__init__(self, net)
-        self.net_dtype, self._engine = net_dtype, None
-
-    reset = PolicySearch.reset
 
     def _actions(self, cubes, running):
         kids = cubes.expand12()
