@@ -190,6 +190,11 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-env-roofline", action="store_true")
     ap.add_argument("--phase-reps", type=int, default=20)
+    ap.add_argument("--weights", default=os.path.join(ROOT, "weights", "fc_small_r1"),
+                    help="checkpoint directory (model.pt + config.json); random-init weights if it does not exist")
+    ap.add_argument("--solve-max-states", type=int, default=50000,
+                    help="after the timed steps, search the same scrambles to completion with this per-tree cap and "
+                         "report the solve rate (0 = skip)")
     ap.add_argument("--first-layer-table", default="auto", choices=["auto", "f16", "bf16", "onehot"],
                     help="input layer: fused gather-sum with an f16 / bf16 table, or the one-hot GEMM")
     args = ap.parse_args()
@@ -217,7 +222,12 @@ def main():
     del all_cubes
 
     torch.manual_seed(0)
-    model = Model.create(ModelConfig()).eval()
+    if os.path.isdir(args.weights):
+        model = Model.load(args.weights).eval()
+        weights_note = f"{os.path.relpath(args.weights, ROOT)} (ADI-trained on one MI355X by tools/train_eval.py; see weights/README.md)"
+    else:
+        model = Model.create(ModelConfig()).eval()
+        weights_note = "random-init (glorot, torch.manual_seed(0))"
     net_dtype = torch.bfloat16 if args.dtype == "bf16" else torch.float32
     c = 0.6
     capacity = 12 * (args.warmup + args.steps + args.phase_reps + 8) + 64
@@ -254,10 +264,22 @@ def main():
         nsum = stats[1:].clone()
         dist.all_reduce(nsum, op=dist.ReduceOp.SUM)
         seconds, nodes = float(tmax.item()), int(nsum.item())
-    # final aggregation of per-tree results (the one data collective of a real evaluation run)
-    status = forest.status.cpu().numpy()
-    gathered = gather_results({"nodes": forest.n_nodes.cpu().numpy(), "solved": status == 1,
-                               "lengths": np.full(hi - lo, -1)}, total, device="cuda")
+    # ---- solve rate: the same scrambles searched to completion (untimed for `value`) -----------------------
+    if args.solve_max_states:
+        phases_early = phase_times(forest, c, max_states, args.phase_reps) if (args.phase_reps and rank == 0) else {}
+        rows_early, eng_early, fused_early = 12 * roots.n, forest.engine, forest._fused
+        del forest
+        agent.forest = None
+        torch.cuda.empty_cache()
+        t_solve = time.perf_counter()
+        full = agent.search_batch(roots, None, args.solve_max_states)
+        solve_seconds = time.perf_counter() - t_solve
+        local = {"nodes": full.nodes, "solved": full.solved, "lengths": full.lengths}
+    else:
+        status = forest.status.cpu().numpy()
+        local = {"nodes": forest.n_nodes.cpu().numpy(), "solved": status == 1, "lengths": np.full(hi - lo, -1)}
+    # final aggregation of per-tree results: the one data collective of an evaluation run (RCCL all_gather)
+    gathered = gather_results(local, total, device="cuda")
 
     if rank != 0:
         if world > 1:
@@ -265,15 +287,18 @@ def main():
             dist.destroy_process_group()
         return
 
-    rows = 12 * roots.n
-    phases = phase_times(forest, c, max_states, args.phase_reps) if args.phase_reps else {}
-    eng = forest.engine
+    if args.solve_max_states:
+        rows, phases, eng, fused = rows_early, phases_early, eng_early, fused_early
+    else:
+        rows = 12 * roots.n
+        phases = phase_times(forest, c, max_states, args.phase_reps) if args.phase_reps else {}
+        eng, fused = forest.engine, forest._fused
     peak = MFMA_BF16_PEAK_TFLOPS if args.dtype == "bf16" else MFMA_F32_PEAK_TFLOPS
     roofline = roofline_input = None
     if phases:
         # GEMM group actually executed on MFMA: every layer when the input is a one-hot matrix, layers 2..
         # when the input layer is the fused gather-sum kernel (which is HBM/LDS work, reported separately)
-        gemm_layers = eng.layers[1:] if forest._fused else eng.layers
+        gemm_layers = eng.layers[1:] if fused else eng.layers
         flops = 2 * sum(W.shape[0] * W.shape[1] for W, _, _ in gemm_layers) * rows
         tf = flops / (phases["net_forward"] * 1e-3) / 1e12
         roofline = {"kernel": f"policy/value net GEMMs on {rows} child rows ({len(gemm_layers)} hipBLASLt GEMMs + bias + "
@@ -281,7 +306,7 @@ def main():
                     "bound": "mfma", "achieved": round(tf, 1), "peak": peak, "unit": "TFLOP/s",
                     "frac": round(tf / peak, 4), "traffic": None,
                     "flops_per_launch": flops, "ms_per_launch": phases["net_forward"]}
-        if forest._fused:
+        if fused:
             H = eng._fused_first[4]
             nbytes = (20 + 2 * H) * rows
             gbps = nbytes / (phases["input_layer"] * 1e-3) / 1e9
@@ -295,13 +320,20 @@ def main():
         "ms_per_step": round(seconds / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak",
         "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
         "config": {"workload": f"{args.trees} depth-{args.depth} scrambles per GPU, MCTS agent (c=0.6, graph search), "
-                               "fc_small net, random-init weights", "trees_per_gpu": args.trees,
+                               f"fc_small net, weights: {weights_note}", "trees_per_gpu": args.trees,
                    "scramble_depth": args.depth, "net_rows_per_step": rows, "parallelism": f"scramble-sharded x{world}"},
         "nodes_expanded": nodes, "mean_descent_depth": round(mean_path, 2), "solve_rate": float(np.mean(gathered["solved"])),
+        "solve_run": ({"max_states_per_tree": args.solve_max_states, "games": int(total),
+                       "ci95": float(1.959963984540054 * np.sqrt(np.mean(gathered["solved"]) * (1 - np.mean(gathered["solved"])) / total)),
+                       "mean_solution_length": float(np.mean(gathered["lengths"][gathered["solved"].astype(bool)]))
+                       if np.any(gathered["solved"]) else None,
+                       "nodes": int(np.sum(gathered["nodes"])), "seconds_rank0": round(solve_seconds, 2),
+                       "note": "same scrambles searched to completion after the timed steps; not part of `value`"}
+                      if args.solve_max_states else None),
         "roofline": roofline, "roofline_input_layer": roofline_input, "phases_ms": phases,
     }
     if not args.no_env_roofline and world == 1:
-        del forest, agent
+        agent.forest = None
         torch.cuda.empty_cache()
         result["roofline_env"] = env_roofline()
     if not args.no_cpu_baseline and world == 1:

@@ -195,6 +195,9 @@ int rc_mcts_expand(const rc_mcts_t *m, uint32_t max_states, rc_stream_t stream);
 int rc_mcts_backup(const rc_mcts_t *m, const float *probs, const float *values, rc_stream_t stream);
 /* find_leaf (agents.py:575-595): PUCT descent with virtual loss, float64 arithmetic as NumPy's. */
 int rc_mcts_select(const rc_mcts_t *m, double c, rc_stream_t stream);
+/* _complete_graph (agents.py:597-611) for every tree with status RC_MCTS_SOLVED: each leaf is linked, both
+ * ways, to those of its 12 children that already exist in the tree (looked up in the tree's hash table). */
+int rc_mcts_complete_graph(const rc_mcts_t *m, rc_stream_t stream);
 
 /* ---- batched weighted A*: B independent problems, N expansions each per iteration --------------
  *

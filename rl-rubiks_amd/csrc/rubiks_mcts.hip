@@ -249,6 +249,41 @@ __global__ __launch_bounds__(kWave) void k_mcts_select(rc_mcts_t m, double c) {
     if (lane == 0) m.path_len[t] = plen;
 }
 
+// ---- _complete_graph (agents.py:597-611): one workgroup per solved tree, one thread per (leaf, action) ----
+__global__ __launch_bounds__(kBlock) void k_mcts_complete_graph(rc_mcts_t m) {
+    __shared__ u32 s_lut[sizeof(kTables.lut) / 4];
+    stage_to_lds(s_lut, c_tables.lut, sizeof(kTables.lut));
+    __syncthreads();
+    const u8 *lut = reinterpret_cast<const u8 *>(s_lut);
+    const u32 t = blockIdx.x;
+    if (m.status[t] != RC_MCTS_SOLVED) return;
+    const size_t base = (size_t)t * (m.capacity + 1);
+    const uint4 *keys = reinterpret_cast<const uint4 *>(m.keys) + base;
+    const int *tab = m.hash + (size_t)t * m.hash_size;
+    const u32 mask = m.hash_size - 1;
+    const u32 n = (u32)m.n_nodes[t];
+    for (u32 w = threadIdx.x; w < n * kA; w += kBlock) {
+        const u32 node = 1 + w / kA, a = w % kA;
+        if (!m.leaf[base + node]) continue;
+        const uint4 pk = keys[node];
+        u32 kw[4] = {0, 0, 0, 0};
+#pragma unroll
+        for (int j = 0; j < kPlanes; ++j)
+            key_set(kw, j, lut[a * (2 * kCodePad) + (j >= kCorners ? kCodePad : 0) + key_code(pk, j)]);
+        const uint4 ck = make_uint4(kw[0], kw[1], kw[2], kw[3]);
+        u32 h = key_hash(ck) & mask;
+        int found = 0;
+        for (;;) {
+            const int s = tab[h];
+            if (s == 0) break;
+            if (key_eq(keys[s], ck)) { found = s; break; }
+            h = (h + 1) & mask;
+        }
+        m.nbr[(base + node) * kA + a] = found;                        // 0 when the child is not in the tree
+        if (found) m.nbr[(base + found) * kA + (a ^ 1)] = (int)node;  // the only node whose action a^1 leads here
+    }
+}
+
 }  // namespace rubiks
 
 using namespace rubiks;
@@ -294,6 +329,12 @@ int rc_mcts_backup(const rc_mcts_t *m, const float *probs, const float *values, 
     if (int rc = check_mcts(m)) return rc;
     RC_REQUIRE(probs && values, RC_ERR_NULL);
     hipLaunchKernelGGL(k_mcts_backup, dim3(m->n_trees), dim3(kWave), 0, (hipStream_t)stream, *m, probs, values);
+    return launch_status();
+}
+
+int rc_mcts_complete_graph(const rc_mcts_t *m, rc_stream_t stream) {
+    if (int rc = check_mcts(m)) return rc;
+    hipLaunchKernelGGL(k_mcts_complete_graph, dim3(m->n_trees), dim3(kBlock), 0, (hipStream_t)stream, *m);
     return launch_status();
 }
 

@@ -137,12 +137,14 @@ class MCTS(DeepAgent):
         solved = (status == md.SOLVED) | (status == md.ROOT_SOLVED)
         queues = []
         self._tree = None
+        if self.search_graph and (status == md.SOLVED).any():
+            forest.complete_graphs()   # _complete_graph of all solved trees in one launch
         for t in range(forest.B):
             taken = [int(a) for a in pact[t, :plen[t] - 1]]
             if status[t] == md.SOLVED:
                 q = taken + [int(sol_act[t])]                      # agents.py:483
                 if self.search_graph:
-                    q = self._shortened_queue(forest, t, int(sol_idx[t]), q)
+                    q = self._shortened_queue(forest.neighbors_of(t, int(nodes[t])), int(sol_idx[t]), q)
             elif status[t] == md.ROOT_SOLVED:
                 q = []
             else:
@@ -154,25 +156,25 @@ class MCTS(DeepAgent):
         return BatchResult(solved, lengths, nodes, queues, seconds, forest.iterations.cpu().numpy(), status)
 
     # ---- solved-tree post-processing (agents.py:597-633) ----------------------------------------
-    def _shortened_queue(self, forest, t: int, solved_idx: int, fallback):
-        tree = self._completed_tree(forest, t)
+    @staticmethod
+    def _shortened_queue(nbr: np.ndarray, solved_idx: int, fallback):
+        """_shorten_action_queue (agents.py:613-633): BFS over the completed graph from the root to the
+        solved node, level-synchronous but in the scan order of the reference's FIFO queue."""
         if solved_idx == 1:
             return fallback
-        nbr = tree["neighbors"]
-        n = tree["n"]
+        n = len(nbr) - 1
         parent = np.zeros(n + 1, dtype=np.int64)
         via = np.zeros(n + 1, dtype=np.int64)
         seen = np.zeros(n + 1, dtype=bool)
         seen[0] = seen[1] = True
         frontier = np.array([1])
         while len(frontier):
-            # scan order of the reference's FIFO BFS: frontier order, then action order
-            cand = nbr[frontier].ravel()
+            cand = nbr[frontier].ravel()                       # frontier order, then action order
             src = np.repeat(frontier, 12)
             act = np.tile(np.arange(12), len(frontier))
             keep = ~seen[cand]
             cand, src, act = cand[keep], src[keep], act[keep]
-            uniq, first = np.unique(cand, return_index=True)
+            _, first = np.unique(cand, return_index=True)      # the first discoverer becomes the parent
             order = np.sort(first)
             cand, src, act = cand[order], src[order], act[order]
             parent[cand], via[cand], seen[cand] = src, act, True
@@ -185,31 +187,13 @@ class MCTS(DeepAgent):
             frontier = cand
         return fallback
 
-    def _completed_tree(self, forest, t: int) -> dict:
-        """_complete_graph: link every leaf to those of its 12 children that exist in the tree."""
-        tree = forest.tree_arrays(t)
-        n = tree["n"]
-        leaves = np.flatnonzero(tree["leaves"][:n + 1])[1:]
-        if len(leaves):
-            kids = DeviceCubes.from_numpy(tree["states"][leaves]).expand12().numpy()
-            index = {s.tobytes(): i for i, s in enumerate(tree["states"][1:n + 1], start=1)}
-            kid_idx = np.array([index.get(k.tobytes(), 0) for k in kids])
-            rep = np.repeat(leaves, 12)
-            act = np.tile(np.arange(12), len(leaves))
-            tree["neighbors"][rep, act] = kid_idx
-            tree["neighbors"][kid_idx, act ^ 1] = rep
-            tree["neighbors"][0] = 0
-        if t == 0:
-            self._tree = tree
-        return tree
-
     # ---- the reference's single-state API ----------------------------------------------------------
     def search(self, state: np.ndarray, time_limit: float = None, max_states: int = None) -> bool:
         res = self.search_batch(np.asarray(state)[None], time_limit, max_states)
         return bool(res.solved[0])
 
     def _host_tree(self):
-        if self._tree is None:
+        if self._tree is None:   # after a solved graph search the device arrays already hold the completed graph
             self._tree = self.forest.tree_arrays(0)
         return self._tree
 

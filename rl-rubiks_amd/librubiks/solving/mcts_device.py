@@ -37,6 +37,7 @@ _hip.register({
     "rc_mcts_expand": [POINTER(_McStruct), c_uint32, c_void_p],
     "rc_mcts_backup": [POINTER(_McStruct), c_void_p, c_void_p, c_void_p],
     "rc_mcts_select": [POINTER(_McStruct), c_double, c_void_p],
+    "rc_mcts_complete_graph": [POINTER(_McStruct), c_void_p],
 })
 
 
@@ -174,6 +175,14 @@ class MCTSForest:
             "L": self.L[lo:hi].cpu().numpy().astype(np.float64) * 100.0,
             "leaves": self.leaf[lo:hi].cpu().numpy().astype(bool),
         }
+
+    def complete_graphs(self):
+        """_complete_graph of every solved tree, on the device (agents.py:597-611)."""
+        _hip.check(self.lib.rc_mcts_complete_graph(ctypes.byref(self.struct), _hip.stream_ptr()), "rc_mcts_complete_graph")
+
+    def neighbors_of(self, t: int, n: int) -> np.ndarray:
+        lo = t * (self.C + 1)
+        return self.nbr[lo:lo + n + 1].cpu().numpy().astype(np.int64)
 
     def paths(self):
         """(path_len[B], path_act[B,max_path]) on the host."""
