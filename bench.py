@@ -131,7 +131,7 @@ def phase_times(forest, c, max_states, reps):
         ev[4].record()
         _hip.check(lib.rc_mcts_backup(m, forest.probs.data_ptr(), forest.values.data_ptr(), st))
         ev[5].record()
-        _hip.check(lib.rc_mcts_select(m, c, st))
+        _hip.check(lib.rc_mcts_select(m, c, forest.level_budget, st))
         ev[6].record()
         torch.cuda.synchronize()
         for i, k in enumerate(names):
@@ -195,6 +195,8 @@ def main():
     ap.add_argument("--solve-max-states", type=int, default=50000,
                     help="after the timed steps, search the same scrambles to completion with this per-tree cap and "
                          "report the solve rate (0 = skip)")
+    ap.add_argument("--level-budget", type=int, default=0,
+                    help="new tree levels a PUCT descent may walk per step before it is suspended (0 = strict lock step)")
     ap.add_argument("--first-layer-table", default="auto", choices=["auto", "f16", "bf16", "onehot"],
                     help="input layer: fused gather-sum with an f16 / bf16 table, or the one-hot GEMM")
     args = ap.parse_args()
@@ -233,7 +235,7 @@ def main():
     capacity = 12 * (args.warmup + args.steps + args.phase_reps + 8) + 64
     from librubiks.model import InferenceNet
     engine = InferenceNet(model, dtype=net_dtype, first_layer_table=args.first_layer_table)
-    agent = MCTS(engine, c=c, search_graph=True, net_dtype=net_dtype)
+    agent = MCTS(engine, c=c, search_graph=True, net_dtype=net_dtype, level_budget=args.level_budget)
     forest = agent._forest_for(roots.n, capacity)
     max_states = forest.C
     forest.reset(roots)
@@ -320,7 +322,7 @@ def main():
         "ms_per_step": round(seconds / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak",
         "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
         "config": {"workload": f"{args.trees} depth-{args.depth} scrambles per GPU, MCTS agent (c=0.6, graph search), "
-                               f"fc_small net, weights: {weights_note}", "trees_per_gpu": args.trees,
+                               f"fc_small net, weights: {weights_note}", "trees_per_gpu": args.trees, "select_level_budget": args.level_budget,
                    "scramble_depth": args.depth, "net_rows_per_step": rows, "parallelism": f"scramble-sharded x{world}"},
         "nodes_expanded": nodes, "mean_descent_depth": round(mean_path, 2), "solve_rate": float(np.mean(gathered["solved"])),
         "solve_run": ({"max_states_per_tree": args.solve_max_states, "games": int(total),

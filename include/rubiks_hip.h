@@ -164,6 +164,7 @@ typedef struct rc_mcts {
     uint16_t *L;         /* x12  virtual-loss COUNT; reference L = 100 * count (agents.py:427,433,589-591) */
     float *V;            /*      value       (agents.py:424) */
     uint8_t *leaf;       /*      is leaf     (agents.py:422) */
+    int32_t *stamp;      /*      scratch of rc_mcts_select: (iteration, first level) a node was seen on the path */
     int32_t *hash;       /* [B][hash_size] open addressing, slot = node index or 0; full-key compare via keys */
     /* per tree, [B] */
     int32_t *n_nodes;    /* len(agent) (agents.py:644-645) */
@@ -172,6 +173,7 @@ typedef struct rc_mcts {
     int32_t *solved_action;
     int32_t *iterations;
     int32_t *path_len;   /* number of nodes on the current descent path, root included */
+    int32_t *pending;    /* 0, or (carried action + 2) of a descent that rc_mcts_select suspended at its level budget */
     int32_t *path_node;  /* [B][max_path] indices_visited (agents.py:581,592) */
     uint8_t *path_act;   /* [B][max_path] actions_taken   (agents.py:582,593) */
     /* per iteration staging */
@@ -193,8 +195,13 @@ int rc_mcts_expand(const rc_mcts_t *m, uint32_t max_states, rc_stream_t stream);
 /* expand_leaf part 2 (agents.py:555-571): P, V of new children, W/N/L updates along the path.
  * probs = softmax(policy logits) rows, values = value head, both for the 12 B child rows. */
 int rc_mcts_backup(const rc_mcts_t *m, const float *probs, const float *values, rc_stream_t stream);
-/* find_leaf (agents.py:575-595): PUCT descent with virtual loss, float64 arithmetic as NumPy's. */
-int rc_mcts_select(const rc_mcts_t *m, double c, rc_stream_t stream);
+/* find_leaf (agents.py:575-595): PUCT descent with virtual loss, float64 arithmetic as NumPy's.
+ * level_budget = 0: every running tree descends to its leaf (strict lock step).
+ * level_budget > 0: a tree walks at most that many NEW levels per call; if it has not reached a leaf it is
+ * suspended (pending) and resumes in the next call, and rc_mcts_expand / rc_mcts_backup skip it meanwhile.
+ * Each tree still performs exactly the reference's sequence of iterations; only their timing changes, so the
+ * slowest descent of the batch no longer sets the pace of every iteration. */
+int rc_mcts_select(const rc_mcts_t *m, double c, uint32_t level_budget, rc_stream_t stream);
 /* _complete_graph (agents.py:597-611) for every tree with status RC_MCTS_SOLVED: each leaf is linked, both
  * ways, to those of its 12 children that already exist in the tree (looked up in the tree's hash table). */
 int rc_mcts_complete_graph(const rc_mcts_t *m, rc_stream_t stream);

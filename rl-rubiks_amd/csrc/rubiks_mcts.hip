@@ -38,6 +38,7 @@ __global__ __launch_bounds__(kBlock) void k_mcts_init(rc_mcts_t m, const u8 *__r
     m.solved_action[t] = -1;
     m.iterations[t] = 0;
     m.path_len[t] = 1;
+    m.pending[t] = 0;
     m.path_node[(size_t)t * m.max_path] = 1;
     m.expanded[t] = 0;
     m.new_mask[t] = 0;
@@ -61,7 +62,7 @@ __global__ __launch_bounds__(kWave) void k_mcts_expand(rc_mcts_t m, u32 max_stat
     const u8 *lut = reinterpret_cast<const u8 *>(s_lut);
     const u32 t = blockIdx.x, lane = threadIdx.x;
     if (lane == 0) m.expanded[t] = 0;
-    if (m.status[t] != RC_MCTS_RUNNING) return;
+    if (m.status[t] != RC_MCTS_RUNNING || m.pending[t]) return;   // a suspended descent has no leaf yet
     const int n = m.n_nodes[t];
     if ((u32)n + kA > max_states || (u32)n + kA > m.capacity) {   // agents.py:476
         if (lane == 0) m.status[t] = RC_MCTS_EXHAUSTED;
@@ -194,29 +195,98 @@ __global__ __launch_bounds__(kWave) void k_mcts_backup(rc_mcts_t m, const float 
 }
 
 // ---- select: PUCT descent with virtual loss (agents.py:575-595) ---------------------------------
-// One dependent memory round trip per tree level: the leaf flag and the five 12-wide rows of the
-// current node are requested together (a leaf's rows exist too, they are just not used), the chosen
-// neighbour comes out of a lane shuffle, and the virtual-loss counts are updated from registers
-// (lane `arg` stores L[cur][arg] + 1; the increment of L[next][arg ^ 1] is carried into the next
-// level, where lane arg ^ 1 adds it to the row it has just loaded and stores it back).
-__global__ __launch_bounds__(kWave) void k_mcts_select(rc_mcts_t m, double c) {
-    const u32 t = blockIdx.x, lane = threadIdx.x;
+// Scores of one node, NumPy's evaluation order in float64: ((c * P) * sqrt(sum N)) / (1 + N) + (W - L).
+// Runs on a 16-lane DPP row (lanes 12..15 carry neutral elements); every lane of the row gets the result.
+__device__ __forceinline__ int puct_argmax(double c, int n_a, float p_f, float w_f, u32 l_cnt, bool act, int lane_in_row) {
+    const int sum_n = row16_sum(act ? n_a : 0);
+    const double u = ((c * (double)p_f) * sqrt((double)sum_n)) / (double)(1 + n_a);
+    const double score = act ? u + ((double)w_f - 100.0 * (double)l_cnt) : -INFINITY;
+    return row16_argmax_first(score, act ? lane_in_row : 64);   // first maximum wins (agents.py:588)
+}
+
+// L holds 16-bit counts; two of them share a dword, which is what the atomic unit adds to.
+__device__ __forceinline__ void l_count_add(u16 *L, size_t e) {
+    atomicAdd(reinterpret_cast<u32 *>(L) + (e >> 1), 1u << (16 * (e & 1)));
+}
+
+// One 256-thread workgroup per tree.
+//
+// The descent restarts at the root every iteration (that is the algorithm), but consecutive descents
+// share long prefixes: only the nodes of the previous path changed (N + 1, max-backup of W).  So the
+// levels of the PREVIOUS path are re-validated in parallel, 16 levels per pass (one 16-lane row per
+// level): level k keeps its action iff the argmax at its node is unchanged.  This is exact as long as
+// no node occurs twice in the prefix, because then the only virtual loss a level can see is the one
+// of its own arrival edge; the first level that changes its action, repeats a node, or is the old
+// leaf becomes the start of the ordinary sequential descent (one memory round trip per level).
+__global__ __launch_bounds__(kBlock) void k_mcts_select(rc_mcts_t m, double c, u32 level_budget) {
+    __shared__ int s_first;   // first level that has to be walked sequentially
+    const u32 t = blockIdx.x, tid = threadIdx.x;
     if (m.status[t] != RC_MCTS_RUNNING) return;
     const size_t base = (size_t)t * (m.capacity + 1);
     int *pnode = m.path_node + (size_t)t * m.max_path;
     u8 *pact = m.path_act + (size_t)t * m.max_path;
+    const int plen_old = m.path_len[t];
+    const int epoch = m.iterations[t];
+    const u32 row = tid >> 4, rl = tid & 15;
+    const bool ract = rl < kA;
+    const u32 rla = ract ? rl : 0;
+    const int resume = m.pending[t];   // uniform over the workgroup
+    if (!resume) {
+    if (tid == 0) s_first = plen_old - 1;   // the old leaf has just been expanded: always re-evaluated
+    // first level at which every node of the old path occurs: larger key = later iteration, then earlier level
+    for (int k = tid; k < plen_old; k += kBlock) atomicMax(&m.stamp[base + pnode[k]], epoch * 2048 + 2047 - k);
+    // __syncthreads() alone does not wait for no-return atomics: drain them before the barrier publishes them
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    for (int k0 = 0; k0 < plen_old - 1; k0 += 16) {
+        __syncthreads();
+        const int first = s_first;
+        __syncthreads();
+        if (k0 > first) break;
+        const int k = k0 + (int)row;
+        if (k < plen_old - 1) {
+            const int node = pnode[k], a_old = pact[k];
+            const int arrive = k > 0 ? (pact[k - 1] ^ 1) : -1;
+            const int seen = __hip_atomic_load(&m.stamp[base + node], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const bool repeat = 2047 - (seen & 2047) < k;
+            const size_t r = (base + node) * kA + rla;
+            const int b = puct_argmax(c, m.N[r], m.P[r], m.W[r], (int)rl == arrive ? 1u : 0u, ract, (int)rl);
+            if (rl == 0 && (repeat || b != a_old)) atomicMin(&s_first, k);
+        }
+    }
+    __syncthreads();
+    const int first = s_first;
+    // the kept prefix takes its virtual losses: L[n_k, a_k] += nu and L[n_k+1, rev a_k] += nu (agents.py:589-591)
+    for (int k = tid; k < first; k += kBlock) {
+        const int a = pact[k];
+        l_count_add(m.L, (base + pnode[k]) * kA + a);
+        l_count_add(m.L, (base + pnode[k + 1]) * kA + (a ^ 1));
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the adds must have reached L2 before wave 0 reads L
+    } else if (tid == 0) {
+        s_first = plen_old - 1;   // a suspended descent continues where it stopped
+    }
+    __syncthreads();
+    if (tid >= kWave) return;
+
+    // sequential descent from level `first`, one wave, one dependent memory round trip per level: the
+    // leaf flag and the five 12-wide rows of the node are requested together, the neighbour comes out of
+    // a lane read, and the virtual-loss counts are updated from registers.
+    const u32 lane = tid;
     const bool act = lane < kA;
     const u32 la = act ? lane : 0;
-    int cur = 1, plen = 1;
-    int carried = -1;   // action slot of `cur` whose L count still has to take the +1 of the incoming edge
+    const int start = s_first;
+    int cur = pnode[start], plen = start + 1;
+    int carried = resume ? resume - 2 : -1;   // action slot of `cur` whose L count still has to take the +1 of the incoming edge
+    u32 walked = 0;
+    int suspended = 0;
     for (;;) {
         const size_t r = (base + cur) * kA + la;
         const u8 is_leaf = m.leaf[base + cur];
         const int n_a = m.N[r];
         const float p_f = m.P[r], w_f = m.W[r];
         // L is the one array this descent both stores and may re-read (the graph has cycles): its loads
-        // bypass the CU's L1 (agent-scope, served by L2), so they observe this wave's earlier write-through
-        // stores without a per-level fence; vmcnt retires loads and stores in issue order, and every level
+        // bypass the CU's L1 (agent scope, served by L2), so they observe this wave's earlier write-through
+        // stores and the atomics above; vmcnt retires loads and stores in issue order, and every level
         // waits for its loads, hence for all older stores.
         u32 l_cnt = __hip_atomic_load(&m.L[r], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         const int nb = m.nbr[r];
@@ -229,13 +299,12 @@ __global__ __launch_bounds__(kWave) void k_mcts_select(rc_mcts_t m, double c) {
             if (lane == 0) m.status[t] = RC_MCTS_PATH_OVERFLOW;
             break;
         }
-        // lanes 0..15 form one DPP row; lanes 12..15 carry neutral elements
-        const int sum_n = __builtin_amdgcn_readfirstlane(row16_sum(act ? n_a : 0));
-        // NumPy evaluation order: ((c * P) * sqrt(sum N)) / (1 + N)  +  (W - L), all float64
-        const double u = ((c * (double)p_f) * sqrt((double)sum_n)) / (double)(1 + n_a);
-        const double score = act ? u + ((double)w_f - 100.0 * (double)l_cnt) : -INFINITY;
-        // argmax, first maximum wins (agents.py:588)
-        const int arg = __builtin_amdgcn_readfirstlane(row16_argmax_first(score, act ? (int)lane : 64));
+        if (level_budget && walked >= level_budget) {   // out of budget at a non-leaf: resume here next call
+            suspended = 1;                              // (cur's arrival loss is stored already: carried = none)
+            break;
+        }
+        ++walked;
+        const int arg = __builtin_amdgcn_readfirstlane(puct_argmax(c, n_a, p_f, w_f, l_cnt, act, (int)lane));
         const int next = __builtin_amdgcn_readlane(nb, arg);
         if ((int)lane == arg) m.L[r] = (u16)(l_cnt + 1);   // L[cur, a] += nu (agents.py:589)
         if (lane == 0) {
@@ -246,7 +315,10 @@ __global__ __launch_bounds__(kWave) void k_mcts_select(rc_mcts_t m, double c) {
         cur = next;
         ++plen;
     }
-    if (lane == 0) m.path_len[t] = plen;
+    if (lane == 0) {
+        m.path_len[t] = plen;
+        m.pending[t] = suspended;   // 1 = resume at path_len - 1 with no carried loss (encoding: carried + 2)
+    }
 }
 
 // ---- _complete_graph (agents.py:597-611): one workgroup per solved tree, one thread per (leaf, action) ----
@@ -290,9 +362,9 @@ using namespace rubiks;
 
 static int check_mcts(const rc_mcts_t *m) {
     RC_REQUIRE(m != nullptr, RC_ERR_NULL);
-    RC_REQUIRE(m->keys && m->nbr && m->P && m->W && m->N && m->L && m->V && m->leaf && m->hash && m->n_nodes &&
+    RC_REQUIRE(m->keys && m->nbr && m->P && m->W && m->N && m->L && m->V && m->leaf && m->stamp && m->hash && m->n_nodes &&
                    m->status && m->solved_idx && m->solved_action && m->iterations && m->path_len && m->path_node &&
-                   m->path_act && m->child_soa && m->child_idx && m->new_mask && m->expanded,
+                   m->pending && m->path_act && m->child_soa && m->child_idx && m->new_mask && m->expanded,
                RC_ERR_NULL);
     RC_REQUIRE(m->n_trees > 0 && m->capacity >= 13 && m->max_path >= 2 && m->max_path <= 2048, RC_ERR_RANGE);
     RC_REQUIRE((m->hash_size & (m->hash_size - 1)) == 0 && m->hash_size >= 2 * (m->capacity + 1), RC_ERR_RANGE);
@@ -338,9 +410,9 @@ int rc_mcts_complete_graph(const rc_mcts_t *m, rc_stream_t stream) {
     return launch_status();
 }
 
-int rc_mcts_select(const rc_mcts_t *m, double c, rc_stream_t stream) {
+int rc_mcts_select(const rc_mcts_t *m, double c, uint32_t level_budget, rc_stream_t stream) {
     if (int rc = check_mcts(m)) return rc;
-    hipLaunchKernelGGL(k_mcts_select, dim3(m->n_trees), dim3(kWave), 0, (hipStream_t)stream, *m, c);
+    hipLaunchKernelGGL(k_mcts_select, dim3(m->n_trees), dim3(kBlock), 0, (hipStream_t)stream, *m, c, level_budget);
     return launch_status();
 }
 

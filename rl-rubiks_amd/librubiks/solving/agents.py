@@ -73,8 +73,17 @@ class MCTS(DeepAgent):
     nu = 100
 
     def __init__(self, net, c: float, search_graph: bool, net_dtype=torch.bfloat16, use_graph: bool = True,
-                 max_path: int = 1024, sync_every: int = 16):
+                 max_path: int = 1024, sync_every: int = 16, level_budget="auto"):
+        """
+        level_budget: how many NEW tree levels a PUCT descent may walk per lock-step iteration before it is
+        suspended until the next one (0 = unlimited).  Every tree still performs exactly the reference's
+        sequence of iterations; a budget only stops the deepest descent of the batch from pacing all trees.
+        Measured on 1 024 depth-20 trees with trained weights it does not pay (suspended trees waste network
+        rows: 21.9 M nodes/s at 0, 21.2 M at 48, 17.7 M at 16), so "auto" means 0; it is a knob for
+        oversubscribed set-ups (more trees than leaf slots).
+        """
         super().__init__(net)
+        self.level_budget = level_budget
         self.c, self.search_graph = float(c), bool(search_graph)
         self.net_dtype, self.use_graph, self.max_path, self.sync_every = net_dtype, use_graph, max_path, sync_every
         self.forest = None
@@ -99,6 +108,7 @@ class MCTS(DeepAgent):
             torch.cuda.empty_cache()
             f = self.forest = md.MCTSForest(n_trees, capacity, self.max_path)
             f.set_net(self.net, self.net_dtype)
+        f.level_budget = 0 if self.level_budget == "auto" else int(self.level_budget)
         return f
 
     @no_grad

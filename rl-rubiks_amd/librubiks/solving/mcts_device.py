@@ -24,9 +24,9 @@ N_ACT = 12
 
 class _McStruct(Structure):   # mirrors rc_mcts_t (include/rubiks_hip.h)
     _fields_ = [("n_trees", c_uint32), ("capacity", c_uint32), ("hash_size", c_uint32), ("max_path", c_uint32)] + \
-               [(name, c_void_p) for name in ("keys", "nbr", "P", "W", "N", "L", "V", "leaf", "hash", "n_nodes", "status",
-                                              "solved_idx", "solved_action", "iterations", "path_len", "path_node",
-                                              "path_act", "child_soa")] + \
+               [(name, c_void_p) for name in ("keys", "nbr", "P", "W", "N", "L", "V", "leaf", "stamp", "hash", "n_nodes",
+                                              "status", "solved_idx", "solved_action", "iterations", "path_len", "pending",
+                                              "path_node", "path_act", "child_soa")] + \
                [("child_stride", c_size_t)] + \
                [(name, c_void_p) for name in ("child_idx", "new_mask", "expanded")]
 
@@ -36,7 +36,7 @@ _hip.register({
     "rc_mcts_root_eval": [POINTER(_McStruct), c_void_p, c_void_p, c_void_p],
     "rc_mcts_expand": [POINTER(_McStruct), c_uint32, c_void_p],
     "rc_mcts_backup": [POINTER(_McStruct), c_void_p, c_void_p, c_void_p],
-    "rc_mcts_select": [POINTER(_McStruct), c_double, c_void_p],
+    "rc_mcts_select": [POINTER(_McStruct), c_double, c_uint32, c_void_p],
     "rc_mcts_complete_graph": [POINTER(_McStruct), c_void_p],
 })
 
@@ -68,10 +68,12 @@ class MCTSForest:
         self.L = z((rows, N_ACT), torch.int16)
         self.V = z((rows,), torch.float32)
         self.leaf = z((rows,), torch.uint8)
+        self.stamp = z((rows,), torch.int32)
         self.hash = z((B, self.hash_size), torch.int32)
         self.n_nodes, self.status = z((B,), torch.int32), z((B,), torch.int32)
         self.solved_idx, self.solved_action = z((B,), torch.int32), z((B,), torch.int32)
         self.iterations, self.path_len = z((B,), torch.int32), z((B,), torch.int32)
+        self.pending = z((B,), torch.int32)
         self.path_node = z((B, max_path), torch.int32)
         self.path_act = z((B, max_path), torch.uint8)
         self.children = DeviceCubes.empty(N_ACT * B, dev)
@@ -82,8 +84,8 @@ class MCTSForest:
         self.values = z((N_ACT * B,), torch.float32)
         s = _McStruct()
         s.n_trees, s.capacity, s.hash_size, s.max_path = B, C, self.hash_size, max_path
-        for name in ("keys", "nbr", "P", "W", "N", "L", "V", "leaf", "hash", "n_nodes", "status", "solved_idx",
-                     "solved_action", "iterations", "path_len", "path_node", "path_act", "child_idx", "new_mask",
+        for name in ("keys", "nbr", "P", "W", "N", "L", "V", "leaf", "stamp", "hash", "n_nodes", "status", "solved_idx",
+                     "solved_action", "iterations", "path_len", "pending", "path_node", "path_act", "child_idx", "new_mask",
                      "expanded"):
             setattr(s, name, getattr(self, name).data_ptr())
         s.child_soa, s.child_stride = self.children.soa.data_ptr(), self.children.stride
@@ -122,7 +124,7 @@ class MCTSForest:
     def reset(self, roots: DeviceCubes):
         """Empties every tree and plants root t = roots[t] as node 1; evaluates the roots (agents.py:466-473)."""
         assert roots.n == self.B and self.engine is not None
-        for t in (self.nbr, self.N, self.L, self.hash, self.leaf):
+        for t in (self.nbr, self.N, self.L, self.hash, self.leaf, self.stamp):
             t.zero_()
         st = _hip.stream_ptr()
         _hip.check(self.lib.rc_mcts_init(ctypes.byref(self.struct), roots.soa.data_ptr(), roots.stride, st), "rc_mcts_init")
@@ -130,19 +132,21 @@ class MCTSForest:
         _hip.check(self.lib.rc_mcts_root_eval(ctypes.byref(self.struct), self.probs.data_ptr(), self.values.data_ptr(), st),
                    "rc_mcts_root_eval")
 
+    level_budget = 0   # new levels a tree may descend per iteration (0 = unlimited, strict lock step)
+
     def _iteration(self, c: float, max_states: int):
         st = _hip.stream_ptr()
         m = ctypes.byref(self.struct)
         _hip.check(self.lib.rc_mcts_expand(m, max_states, st), "rc_mcts_expand")
         self._evaluate_children()
         _hip.check(self.lib.rc_mcts_backup(m, self.probs.data_ptr(), self.values.data_ptr(), st), "rc_mcts_backup")
-        _hip.check(self.lib.rc_mcts_select(m, c, st), "rc_mcts_select")
+        _hip.check(self.lib.rc_mcts_select(m, c, self.level_budget, st), "rc_mcts_select")
 
     def step(self, c: float, max_states: int, use_graph: bool = True):
         """One lock-step iteration of every running tree: expand -> network -> backup -> select."""
         if not use_graph:
             return self._iteration(c, max_states)
-        key = (float(c), int(max_states))
+        key = (float(c), int(max_states), int(self.level_budget))
         if self._graph is None or self._graph_key != key:
             # this call's iteration runs eagerly (hipBLASLt picks its kernels, the allocator settles);
             # the capture that follows only records launches, it does not advance the search

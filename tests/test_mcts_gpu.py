@@ -91,6 +91,27 @@ def test_batch_vs_oracle(net_gpu):
         assert res.solved[17] and res.lengths[17] == 0 and res.nodes[17] == 1
 
 
+@pytest.mark.parametrize("budget", [1, 3, 48])
+def test_level_budget_does_not_change_trees(budget, net_gpu):
+    """Suspended descents (rc_mcts_select level budget) only re-time iterations: every tree is still the oracle's."""
+    from librubiks.solving.agents import MCTS
+    np.random.seed(11)
+    states = np.array([oc.scramble(2 + i % 9, True)[0] for i in range(72)])
+    agent = MCTS(net_gpu, c=4.13, search_graph=True, net_dtype=torch.float32, level_budget=budget)
+    res = agent.search_batch(states, None, 900)
+    assert agent.forest.level_budget == budget
+    onet = oa.TorchNet(net_gpu, device="cuda")
+    for t, s in enumerate(states):
+        ref = oa.MCTS(onet, c=4.13, search_graph=True)
+        ok = ref.search(s, 900)
+        assert bool(res.solved[t]) == ok and res.nodes[t] == len(ref), f"tree {t}"
+        assert list(res.queues[t]) == list(ref.action_queue), f"tree {t}"
+        assert res.iterations[t] == ref.iterations, f"tree {t}"
+        if t % 9 == 4:
+            refd = {k: getattr(ref, k) for k in ("states", "neighbors", "leaves", "N", "L", "V", "W", "P")}
+            _compare_tree(agent.forest.tree_arrays(t), refd, len(ref), exact_p=True)
+
+
 def test_max_iterations_and_budget(net_gpu):
     """Unsolved trees stop exactly where the reference's `len + 12 <= max_states` loop stops."""
     from librubiks.solving.agents import MCTS
