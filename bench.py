@@ -121,15 +121,18 @@ def phase_times(forest, c, max_states, reps):
             forest.children.as_oh(out=forest._oh)
         ev[2].record()
         if forest._fused:
-            out = forest.engine._run(forest.engine.layers[1:], x1).float()
-            logits, values = out[:, :12], out[:, 12]
+            head = forest.engine._run(forest.engine.layers[1:], x1)
         else:
             logits, values = forest.engine(forest._oh)
         ev[3].record()
-        torch.softmax(logits, dim=1, out=forest.probs)
-        forest.values.copy_(values)
+        if not forest._fused:
+            torch.softmax(logits, dim=1, out=forest.probs)
+            forest.values.copy_(values)
         ev[4].record()
-        _hip.check(lib.rc_mcts_backup(m, forest.probs.data_ptr(), forest.values.data_ptr(), st))
+        if forest._fused:   # softmax + value extraction happen inside the backup kernel
+            _hip.check(lib.rc_mcts_backup_head(m, head.data_ptr(), head.stride(0), int(head.dtype == torch.bfloat16), st))
+        else:
+            _hip.check(lib.rc_mcts_backup(m, forest.probs.data_ptr(), forest.values.data_ptr(), st))
         ev[5].record()
         _hip.check(lib.rc_mcts_select(m, c, forest.level_budget, st))
         ev[6].record()

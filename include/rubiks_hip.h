@@ -195,6 +195,11 @@ int rc_mcts_expand(const rc_mcts_t *m, uint32_t max_states, rc_stream_t stream);
 /* expand_leaf part 2 (agents.py:555-571): P, V of new children, W/N/L updates along the path.
  * probs = softmax(policy logits) rows, values = value head, both for the 12 B child rows. */
 int rc_mcts_backup(const rc_mcts_t *m, const float *probs, const float *values, rc_stream_t stream);
+/* Same as rc_mcts_backup, but straight from the network's head output: row r of `head` (bf16 when
+ * head_is_bf16 != 0, else float; `ld` elements per row) holds the 12 policy logits followed by the value.
+ * P = softmax(logits) is evaluated in float32 inside the kernel (max-subtracted, expf), which removes the
+ * separate cast / slice / softmax / copy launches of the generic path. */
+int rc_mcts_backup_head(const rc_mcts_t *m, const void *head, size_t ld, int head_is_bf16, rc_stream_t stream);
 /* find_leaf (agents.py:575-595): PUCT descent with virtual loss, float64 arithmetic as NumPy's.
  * level_budget = 0: every running tree descends to its leaf (strict lock step).
  * level_budget > 0: a tree walks at most that many NEW levels per call; if it has not reached a leaf it is

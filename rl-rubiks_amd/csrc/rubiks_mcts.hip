@@ -141,8 +141,17 @@ __device__ __forceinline__ float wave_max12(float v, bool valid) {   // lanes 0.
     return __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(row16_max(valid ? v : -INFINITY))));
 }
 
-__global__ __launch_bounds__(kWave) void k_mcts_backup(rc_mcts_t m, const float *__restrict__ probs,
-                                                      const float *__restrict__ values) {
+__device__ __forceinline__ float head_elem(const void *head, size_t i, bool bf16) {
+    return bf16 ? __uint_as_float((u32) reinterpret_cast<const u16 *>(head)[i] << 16) : reinterpret_cast<const float *>(head)[i];
+}
+
+// HEAD = false: probs / values are separate float arrays (generic path, softmax done by the caller).
+// HEAD = true : `probs` is the head GEMM's output (12 logits + value per row, bf16 or float) and the softmax
+//               happens here.
+template <bool HEAD>
+__global__ __launch_bounds__(kWave) void k_mcts_backup(rc_mcts_t m, const void *__restrict__ probs_or_head,
+                                                      const float *__restrict__ values, size_t ld, bool head_bf16) {
+    const float *probs = reinterpret_cast<const float *>(probs_or_head);
     const u32 t = blockIdx.x, lane = threadIdx.x;
     if (!m.expanded[t]) return;
     const size_t base = (size_t)t * (m.capacity + 1);
@@ -158,11 +167,25 @@ __global__ __launch_bounds__(kWave) void k_mcts_backup(rc_mcts_t m, const float 
 
     float v = 0.f;
     if (is_new) {
-        v = values[row];
+        float p[kA];
+        if (HEAD) {
+            float mx = -INFINITY, sum = 0.f;
+#pragma unroll
+            for (int a = 0; a < kA; ++a) { p[a] = head_elem(probs_or_head, row * ld + a, head_bf16); mx = fmaxf(mx, p[a]); }
+#pragma unroll
+            for (int a = 0; a < kA; ++a) { p[a] = expf(p[a] - mx); sum += p[a]; }
+#pragma unroll
+            for (int a = 0; a < kA; ++a) p[a] /= sum;   // agents.py:552 softmax(dim=1)
+            v = head_elem(probs_or_head, row * ld + kA, head_bf16);
+        } else {
+#pragma unroll
+            for (int a = 0; a < kA; ++a) p[a] = probs[row * kA + a];
+            v = values[row];
+        }
         m.V[base + idx] = v;
 #pragma unroll
         for (int a = 0; a < kA; ++a) {
-            m.P[(base + idx) * kA + a] = probs[row * kA + a];
+            m.P[(base + idx) * kA + a] = p[a];
             m.W[(base + idx) * kA + a] = v;   // W[new] = v for all 12 actions (agents.py:561)
         }
     } else if (act) {
@@ -400,7 +423,17 @@ int rc_mcts_expand(const rc_mcts_t *m, uint32_t max_states, rc_stream_t stream) 
 int rc_mcts_backup(const rc_mcts_t *m, const float *probs, const float *values, rc_stream_t stream) {
     if (int rc = check_mcts(m)) return rc;
     RC_REQUIRE(probs && values, RC_ERR_NULL);
-    hipLaunchKernelGGL(k_mcts_backup, dim3(m->n_trees), dim3(kWave), 0, (hipStream_t)stream, *m, probs, values);
+    hipLaunchKernelGGL(k_mcts_backup<false>, dim3(m->n_trees), dim3(kWave), 0, (hipStream_t)stream, *m, (const void *)probs,
+                       values, (size_t)0, false);
+    return launch_status();
+}
+
+int rc_mcts_backup_head(const rc_mcts_t *m, const void *head, size_t ld, int head_is_bf16, rc_stream_t stream) {
+    if (int rc = check_mcts(m)) return rc;
+    RC_REQUIRE(head != nullptr, RC_ERR_NULL);
+    RC_REQUIRE(ld >= (size_t)kActions + 1, RC_ERR_RANGE);
+    hipLaunchKernelGGL(k_mcts_backup<true>, dim3(m->n_trees), dim3(kWave), 0, (hipStream_t)stream, *m, head,
+                       (const float *)nullptr, ld, head_is_bf16 != 0);
     return launch_status();
 }
 

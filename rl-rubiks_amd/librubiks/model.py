@@ -282,6 +282,11 @@ class InferenceNet:
         return out
 
     @torch.no_grad()
+    def head_cubes(self, cubes, x1: torch.Tensor = None) -> torch.Tensor:
+        """Raw output of the merged head GEMM, [n, 13] in the engine's dtype: 12 policy logits, then the value."""
+        return self._run(self.layers[1:], self.first_layer(cubes, x1))
+
+    @torch.no_grad()
     def forward_cubes(self, cubes, x1: torch.Tensor = None):
         """(policy logits, values) straight from device-resident cube states."""
         out = self._run(self.layers[1:], self.first_layer(cubes, x1)).float()

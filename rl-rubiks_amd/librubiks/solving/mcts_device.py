@@ -36,6 +36,7 @@ _hip.register({
     "rc_mcts_root_eval": [POINTER(_McStruct), c_void_p, c_void_p, c_void_p],
     "rc_mcts_expand": [POINTER(_McStruct), c_uint32, c_void_p],
     "rc_mcts_backup": [POINTER(_McStruct), c_void_p, c_void_p, c_void_p],
+    "rc_mcts_backup_head": [POINTER(_McStruct), c_void_p, c_size_t, c_int, c_void_p],
     "rc_mcts_select": [POINTER(_McStruct), c_double, c_uint32, c_void_p],
     "rc_mcts_complete_graph": [POINTER(_McStruct), c_void_p],
 })
@@ -138,8 +139,13 @@ class MCTSForest:
         st = _hip.stream_ptr()
         m = ctypes.byref(self.struct)
         _hip.check(self.lib.rc_mcts_expand(m, max_states, st), "rc_mcts_expand")
-        self._evaluate_children()
-        _hip.check(self.lib.rc_mcts_backup(m, self.probs.data_ptr(), self.values.data_ptr(), st), "rc_mcts_backup")
+        if self._fused:   # head GEMM output (12 logits + value per row) goes straight into the backup kernel
+            head = self.engine.head_cubes(self.children, self._x1)
+            _hip.check(self.lib.rc_mcts_backup_head(m, head.data_ptr(), head.stride(0), int(head.dtype == torch.bfloat16), st),
+                       "rc_mcts_backup_head")
+        else:
+            self._evaluate_children()
+            _hip.check(self.lib.rc_mcts_backup(m, self.probs.data_ptr(), self.values.data_ptr(), st), "rc_mcts_backup")
         _hip.check(self.lib.rc_mcts_select(m, c, self.level_budget, st), "rc_mcts_select")
 
     def step(self, c: float, max_states: int, use_graph: bool = True):

@@ -184,3 +184,35 @@ def test_time_limit_only():
     res = agent.search_batch(states, time_limit=0.5, max_states=20000)
     assert res.seconds < 30 and (res.nodes > 12).all()
     assert str(agent) == "BFS MCTS (c=0.6)"
+
+
+def test_fused_head_backup_matches_generic_path():
+    """
+    rc_mcts_backup_head (softmax inside the kernel, bf16 head output) vs the generic path (torch softmax):
+    after ONE iteration from the same roots the stored P agree to 1e-6 and V / W / N exactly.
+    """
+    import ctypes
+    from librubiks import _hip, cube
+    from librubiks.model import InferenceNet, Model, ModelConfig
+    from librubiks.solving.mcts_device import MCTSForest
+    torch.manual_seed(0)
+    np.random.seed(3)
+    net = Model.create(ModelConfig()).eval()
+    cubes, _, _ = cube.scramble_batch(256, 12, True)
+    eng = InferenceNet(net, torch.bfloat16)
+    a, b = MCTSForest(256, 64), MCTSForest(256, 64)
+    for f in (a, b):
+        f.set_net(eng)
+        f.reset(cubes)
+    a._iteration(0.6, 64)                      # fused: head -> backup_head
+    st, m = _hip.stream_ptr(), ctypes.byref(b.struct)
+    _hip.check(b.lib.rc_mcts_expand(m, 64, st))
+    head = eng.head_cubes(b.children, b._x1).float()
+    probs, values = torch.softmax(head[:, :12], dim=1).contiguous(), head[:, 12].contiguous()
+    _hip.check(b.lib.rc_mcts_backup(m, probs.data_ptr(), values.data_ptr(), st))
+    _hip.check(b.lib.rc_mcts_select(m, 0.6, 0, st))
+    torch.cuda.synchronize()
+    assert torch.equal(a.n_nodes, b.n_nodes) and torch.equal(a.nbr, b.nbr)
+    assert torch.equal(a.V, b.V) and torch.equal(a.W, b.W) and torch.equal(a.N, b.N)
+    assert torch.allclose(a.P, b.P, rtol=0, atol=1e-6)
+    assert torch.equal(a.path_len, b.path_len)
