@@ -123,6 +123,12 @@ int rc_sequence_states(const uint8_t *moves, int8_t *out_soa, size_t games, size
 #define RC_ACT_ELU 2
 int rc_first_layer_bf16(const int8_t *soa, size_t n, size_t stride, const uint16_t *w1t, const float *bias,
                         uint16_t *out, size_t H, int activation, float alpha, int table_is_f16, rc_stream_t stream);
+/* The same layer on the matrix cores: out = act(as_oh(s) @ W1^T + bias) with the one-hot A-fragments of
+ * v_mfma_f32_32x32x16_bf16 generated in registers from the cube codes (the one-hot matrix never exists in
+ * memory) and a 128-column slice of W1 resident in LDS as the B operand.
+ *   w1: bf16 [H][480] row-major = the nn.Linear weight as stored; other arguments as above. */
+int rc_first_layer_mfma_bf16(const int8_t *soa, size_t n, size_t stride, const uint16_t *w1, const float *bias,
+                             uint16_t *out, size_t H, int activation, float alpha, rc_stream_t stream);
 
 /* ---- Autodidactic-iteration targets (librubiks/train.py:292-325) ----------------------------------
  * For state i with children 12 i .. 12 i + 11 (rc_expand12 order):

@@ -119,6 +119,102 @@ __global__ __launch_bounds__(kFLThreads) __attribute__((amdgpu_waves_per_eu(4, 4
     }
 }
 
+// =================================================================================================
+// Input layer on the matrix cores.
+//   out[32 states x 128 cols] per wave = OneHot[32 x 480] * W1slice^T[480 x 128], 30 k-steps of
+//   v_mfma_f32_32x32x16_bf16 per 32-column tile.
+//   A (32 x 16 per k-step): lane l (r = l & 31, h = l >> 5) holds A[state r][k = 16 ks + 8 h + j], j = 0..7.
+//     8 | 24, so those eight one-hot positions lie inside ONE cubie's 24-wide block: cubie (2 ks + h) / 3,
+//     offset 8 * ((2 ks + h) % 3).  The fragment is "1.0 at position code - offset if that is in 0..7".
+//   B (16 x 32): lane holds B[k = 16 ks + 8 h + j][col r] = W1[col][k..k+7]: one 16-byte LDS read from the
+//     slice stored column-major-in-k with a 976-byte pitch (61 x 16 B, odd -> the 16 lanes of a ds_read_b128
+//     group hit 16 different bank quads).
+//   D: lane holds column l & 31 of states (reg & 3) + 8 (reg >> 2) + 4 h.
+// Epilogue: + bias, activation, bf16, transposed through a per-wave LDS tile so that global stores are 16 B
+// per lane along the output rows.
+// =================================================================================================
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+
+constexpr int kMfCols = 128;                        // output columns per workgroup
+constexpr int kMfPitch = 976;                       // bytes per column of the LDS slice: 480 bf16 + 16 B pad
+constexpr int kMfWaves = 4;                         // one per SIMD
+constexpr int kMfTile = 32;                         // states per wave tile
+constexpr int kMfStage = kMfTile * kMfCols * 2;     // 8 KiB transposition tile per wave
+
+template <int ACT>
+__global__ __launch_bounds__(kMfWaves * kWave) void k_first_layer_mfma(const u8 *__restrict__ soa, size_t n, size_t stride,
+                                                                     const uint4 *__restrict__ w1, const float *__restrict__ bias,
+                                                                     uint4 *__restrict__ out, u32 H, u32 rows_per_block,
+                                                                     float alpha) {
+    extern __shared__ __attribute__((aligned(256))) unsigned char lds[];
+    unsigned char *wslice = lds;                                                   // [128 cols][976 B]
+    const u32 tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    unsigned char *stage = lds + kMfCols * kMfPitch + wave * kMfStage;             // [32 states][128 cols] bf16
+    const u32 col_tiles = H / kMfCols;
+    const u32 ct = blockIdx.x % col_tiles, rg = blockIdx.x / col_tiles;
+    const size_t row_lo = (size_t)rg * rows_per_block;
+    if (row_lo >= n) return;
+    const size_t row_hi = (row_lo + rows_per_block < n) ? row_lo + rows_per_block : n;
+
+    // W1[128 ct .. +127][0..479] -> LDS, 60 chunks of 16 B per column
+    for (u32 i = tid; i < kMfCols * 60; i += kMfWaves * kWave) {
+        const u32 col = i / 60, q = i % 60;
+        *reinterpret_cast<uint4 *>(wslice + col * kMfPitch + q * 16) = w1[(size_t)(ct * kMfCols + col) * 60 + q];
+    }
+    const u32 r = lane & 31, h = lane >> 5;
+    float b[4];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) b[c] = bias[ct * kMfCols + c * 32 + r];
+    __syncthreads();
+
+    for (size_t t0 = row_lo + (size_t)wave * kMfTile; t0 < row_hi; t0 += (size_t)kMfWaves * kMfTile) {
+        const size_t row = t0 + r;
+        u32 code[kPlanes];
+#pragma unroll
+        for (int j = 0; j < kPlanes; ++j) code[j] = (row < n) ? (soa[(size_t)j * stride + row] & 31u) : 31u;   // 31 matches no position
+        f32x16 acc[4];
+#pragma unroll
+        for (int c = 0; c < 4; ++c)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) acc[c][i] = 0.f;
+#pragma unroll
+        for (int ks = 0; ks < 30; ++ks) {
+            // this lane's eight k positions: cubie (2 ks + h) / 3 at offset 8 * ((2 ks + h) % 3)
+            const u32 cj = h ? code[(2 * ks + 1) / 3] : code[(2 * ks) / 3];
+            const u32 off = h ? 8u * ((2 * ks + 1) % 3) : 8u * ((2 * ks) % 3);
+            const u32 pos = cj - off;                                   // 0..7 iff the 1 falls into this fragment
+            const u32 one = (pos & 1u) ? 0x3f800000u : 0x00003f80u;     // bf16 1.0 in the high / low half
+            const u32 d = pos >> 1;
+            const uint4 a4 = make_uint4(d == 0 ? one : 0u, d == 1 ? one : 0u, d == 2 ? one : 0u, d == 3 ? one : 0u);
+            const bf16x8 a = __builtin_bit_cast(bf16x8, a4);
+            const unsigned char *bk = wslice + (16 * ks + 8 * h) * 2;
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                const uint4 b4 = *reinterpret_cast<const uint4 *>(bk + (c * 32 + r) * kMfPitch);
+                acc[c] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, __builtin_bit_cast(bf16x8, b4), acc[c], 0, 0, 0);
+            }
+        }
+        // epilogue: bias + activation -> bf16 -> per-wave LDS tile [state][col] -> coalesced 16-byte stores
+#pragma unroll
+        for (int c = 0; c < 4; ++c)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                const u32 st = (i & 3) + 8 * (i >> 2) + 4 * h;
+                const float v = act_apply(acc[c][i] + b[c], ACT, alpha);
+                *reinterpret_cast<u16 *>(stage + st * (kMfCols * 2) + (c * 32 + r) * 2) = (u16)(pack_bf16(v, 0.f) & 0xffffu);
+            }
+        // (a wave only ever touches its own tile, and LDS operations of one wave complete in order)
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            const u32 chunk = q * 64 + lane;            // 16-byte chunk of the 32 x 256-byte tile
+            const u32 st = chunk >> 4, cc = chunk & 15;
+            const uint4 v = *reinterpret_cast<const uint4 *>(stage + st * (kMfCols * 2) + cc * 16);
+            if (t0 + st < n) out[(t0 + st) * (H / 8) + ct * 16 + cc] = v;
+        }
+    }
+}
+
 // ADI targets: 12-way segmented argmax of value + reward, with the goal-state fixes (train.py:292-325).
 __global__ __launch_bounds__(kBlock) void k_adi_targets(const float *__restrict__ values, const u8 *__restrict__ child_solved,
                                                         const u8 *__restrict__ state_solved, size_t n, size_t depth,
@@ -142,6 +238,39 @@ __global__ __launch_bounds__(kBlock) void k_adi_targets(const float *__restrict_
 }  // namespace rubiks
 
 using namespace rubiks;
+
+extern "C" int rc_first_layer_mfma_bf16(const int8_t *soa, size_t n, size_t stride, const uint16_t *w1, const float *bias,
+                                        uint16_t *out, size_t H, int activation, float alpha, rc_stream_t stream) {
+    if (n == 0) return RC_OK;
+    RC_CHECK_SOA(soa, n, stride);
+    RC_REQUIRE(w1 && bias && out, RC_ERR_NULL);
+    RC_REQUIRE(aligned16(w1) && aligned16(out), RC_ERR_ALIGN);
+    RC_REQUIRE(H >= kMfCols && H % kMfCols == 0 && activation >= RC_ACT_NONE && activation <= RC_ACT_ELU, RC_ERR_RANGE);
+    const u32 col_tiles = (u32)(H / kMfCols);
+    u32 row_groups = (256 + col_tiles - 1) / col_tiles;   // one workgroup per CU (LDS), every W1 slice staged once per row group
+    u32 rows_per_block = (u32)round_up(ceil_div(n, row_groups), kMfWaves * kMfTile);
+    row_groups = (u32)ceil_div(n, rows_per_block);
+    const size_t lds_bytes = (size_t)kMfCols * kMfPitch + (size_t)kMfWaves * kMfStage;
+    const dim3 grid(col_tiles * row_groups), block(kMfWaves * kWave);
+    hipStream_t s = (hipStream_t)stream;
+#define RC_LAUNCH_MF(ACT)                                                                                          \
+    do {                                                                                                           \
+        static bool attr_set = false;                                                                              \
+        if (!attr_set) {                                                                                           \
+            hipError_t e = hipFuncSetAttribute((const void *)k_first_layer_mfma<ACT>,                               \
+                                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);        \
+            if (e != hipSuccess) return hip_rc(e);                                                                 \
+            attr_set = true;                                                                                       \
+        }                                                                                                          \
+        hipLaunchKernelGGL(k_first_layer_mfma<ACT>, grid, block, lds_bytes, s, (const u8 *)soa, n, stride,          \
+                           (const uint4 *)w1, bias, (uint4 *)out, (u32)H, rows_per_block, alpha);                  \
+    } while (0)
+    if (activation == RC_ACT_ELU) RC_LAUNCH_MF(RC_ACT_ELU);
+    else if (activation == RC_ACT_RELU) RC_LAUNCH_MF(RC_ACT_RELU);
+    else RC_LAUNCH_MF(RC_ACT_NONE);
+#undef RC_LAUNCH_MF
+    return launch_status();
+}
 
 extern "C" int rc_adi_targets(const float *values, const uint8_t *child_solved, const uint8_t *state_solved, size_t n,
                               size_t depth, float win_reward, int fix_mode, int64_t *policy_target, float *value_target,

@@ -34,6 +34,7 @@ SIGNATURES = {
     "rc_sequence_states": [P, P, SZ, SZ, I, SZ, P],
     "rc_adi_targets": [P, P, P, SZ, SZ, ctypes.c_float, I, P, P, P],
     "rc_first_layer_bf16": [P, SZ, SZ, P, P, P, SZ, I, ctypes.c_float, I, P],
+    "rc_first_layer_mfma_bf16": [P, SZ, SZ, P, P, P, SZ, I, ctypes.c_float, P],
 }
 _RESTYPES = {"rc_error_string": c_char_p}
 
