@@ -148,62 +148,119 @@ __global__ __launch_bounds__(kMfWaves * kWave) void k_first_layer_mfma(const u8 
                                                                      uint4 *__restrict__ out, u32 H, u32 rows_per_block,
                                                                      float alpha) {
     extern __shared__ __attribute__((aligned(256))) unsigned char lds[];
-    unsigned char *wslice = lds;                                                   // [128 cols][976 B]
+    unsigned char *wslice = lds;                                                   // [128 slots][976 B]
     const u32 tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     unsigned char *stage = lds + kMfCols * kMfPitch + wave * kMfStage;             // [32 states][128 cols] bf16
+    uint4 *onehot = reinterpret_cast<uint4 *>(lds + kMfCols * kMfPitch + kMfWaves * kMfStage);   // [9] A fragments
     const u32 col_tiles = H / kMfCols;
     const u32 ct = blockIdx.x % col_tiles, rg = blockIdx.x / col_tiles;
     const size_t row_lo = (size_t)rg * rows_per_block;
     if (row_lo >= n) return;
     const size_t row_hi = (row_lo + rows_per_block < n) ? row_lo + rows_per_block : n;
 
-    // W1[128 ct .. +127][0..479] -> LDS, 60 chunks of 16 B per column
-    for (u32 i = tid; i < kMfCols * 60; i += kMfWaves * kWave) {
-        const u32 col = i / 60, q = i % 60;
-        *reinterpret_cast<uint4 *>(wslice + col * kMfPitch + q * 16) = w1[(size_t)(ct * kMfCols + col) * 60 + q];
-    }
-    const u32 r = lane & 31, h = lane >> 5;
-    float b[4];
+    // W1[128 ct .. +127][0..479] -> LDS, 60 chunks of 16 B per column.  Column g of the slice goes to slot
+    // (g % 4) * 32 + g / 4: MFMA column tile c, lane r then owns column 4 r + c, i.e. a lane's four accumulators
+    // are four ADJACENT output columns (one 8-byte store per state in the epilogue), while the B reads of a
+    // tile still walk 32 consecutive slots (conflict-free with the odd 16-byte pitch).
+    {   // 7 680 chunks / 256 threads = 30 per thread, requested ten at a time before the first LDS write
+        constexpr int kPer = kMfCols * 60 / (kMfWaves * kWave), kBatch = 10;
 #pragma unroll
-    for (int c = 0; c < 4; ++c) b[c] = bias[ct * kMfCols + c * 32 + r];
-    __syncthreads();
-
-    for (size_t t0 = row_lo + (size_t)wave * kMfTile; t0 < row_hi; t0 += (size_t)kMfWaves * kMfTile) {
-        const size_t row = t0 + r;
-        u32 code[kPlanes];
+        for (int b0 = 0; b0 < kPer; b0 += kBatch) {
+            uint4 tmp[kBatch];
 #pragma unroll
-        for (int j = 0; j < kPlanes; ++j) code[j] = (row < n) ? (soa[(size_t)j * stride + row] & 31u) : 31u;   // 31 matches no position
-        f32x16 acc[4];
+            for (int t = 0; t < kBatch; ++t) {
+                const u32 i = tid + (b0 + t) * (kMfWaves * kWave);
+                tmp[t] = w1[(size_t)(ct * kMfCols + i / 60) * 60 + i % 60];
+            }
 #pragma unroll
-        for (int c = 0; c < 4; ++c)
-#pragma unroll
-            for (int i = 0; i < 16; ++i) acc[c][i] = 0.f;
-#pragma unroll
-        for (int ks = 0; ks < 30; ++ks) {
-            // this lane's eight k positions: cubie (2 ks + h) / 3 at offset 8 * ((2 ks + h) % 3)
-            const u32 cj = h ? code[(2 * ks + 1) / 3] : code[(2 * ks) / 3];
-            const u32 off = h ? 8u * ((2 * ks + 1) % 3) : 8u * ((2 * ks) % 3);
-            const u32 pos = cj - off;                                   // 0..7 iff the 1 falls into this fragment
-            const u32 one = (pos & 1u) ? 0x3f800000u : 0x00003f80u;     // bf16 1.0 in the high / low half
-            const u32 d = pos >> 1;
-            const uint4 a4 = make_uint4(d == 0 ? one : 0u, d == 1 ? one : 0u, d == 2 ? one : 0u, d == 3 ? one : 0u);
-            const bf16x8 a = __builtin_bit_cast(bf16x8, a4);
-            const unsigned char *bk = wslice + (16 * ks + 8 * h) * 2;
-#pragma unroll
-            for (int c = 0; c < 4; ++c) {
-                const uint4 b4 = *reinterpret_cast<const uint4 *>(bk + (c * 32 + r) * kMfPitch);
-                acc[c] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, __builtin_bit_cast(bf16x8, b4), acc[c], 0, 0, 0);
+            for (int t = 0; t < kBatch; ++t) {
+                const u32 i = tid + (b0 + t) * (kMfWaves * kWave);
+                const u32 g = i / 60, slot = (g & 3) * 32 + (g >> 2);
+                *reinterpret_cast<uint4 *>(wslice + slot * kMfPitch + (i % 60) * 16) = tmp[t];
             }
         }
-        // epilogue: bias + activation -> bf16 -> per-wave LDS tile [state][col] -> coalesced 16-byte stores
+    }
+    if (tid < 9) {   // A fragment "bf16 1.0 at position p" for p = 0..7, all zero for p = 8
+        u32 w[4] = {0, 0, 0, 0};
+        if (tid < 8) w[tid >> 1] = (tid & 1) ? 0x3f800000u : 0x00003f80u;
+        onehot[tid] = make_uint4(w[0], w[1], w[2], w[3]);
+    }
+    const u32 r = lane & 31, h = lane >> 5;
+    float b[4];   // bias of this lane's four columns 4 r + c
+#pragma unroll
+    for (int c = 0; c < 4; ++c) b[c] = bias[ct * kMfCols + 4 * r + c];
+    __syncthreads();
+
+    // The next tile's cube codes travel while the current tile computes.  Rows past the end are clamped to the
+    // last state (their results are never stored), which keeps the 20 loads free of branches.
+    u32 code_next[kPlanes];
+    {
+        const size_t row = row_lo + (size_t)wave * kMfTile + r;
+        const u8 *p = soa + (row < n ? row : n - 1);
+#pragma unroll
+        for (int j = 0; j < kPlanes; ++j) code_next[j] = p[(size_t)j * stride];
+    }
+    const u32 off_a = h ? 8u : 0u, off_c = h ? 16u : 8u;   // this lane half's offsets in k-steps 3m and 3m + 2
+    for (size_t t0 = row_lo + (size_t)wave * kMfTile; t0 < row_hi; t0 += (size_t)kMfWaves * kMfTile) {
+        u32 code[kPlanes];
+#pragma unroll
+        for (int j = 0; j < kPlanes; ++j) code[j] = code_next[j] & 31u;
+        {
+            const size_t row = t0 + (size_t)kMfWaves * kMfTile + r;
+            const u8 *p = soa + (row < n ? row : n - 1);
+#pragma unroll
+            for (int j = 0; j < kPlanes; ++j) code_next[j] = p[(size_t)j * stride];
+        }
+        // Three k-steps (48 one-hot positions) cover two cubies.  Lane half h = 0 sees (cubie 2m, offset 0),
+        // (2m, 16), (2m+1, 8); half h = 1 sees (2m, 8), (2m+1, 0), (2m+1, 16): only the middle step depends on
+        // the half in WHICH cubie it reads, so that select is done once per cubie pair.
+        u32 mid[kPlanes / 2];
+#pragma unroll
+        for (int m2 = 0; m2 < kPlanes / 2; ++m2) mid[m2] = h ? code[2 * m2 + 1] : code[2 * m2] - 16u;
+        f32x16 acc[4];   // start from the bias: the epilogue needs no add
 #pragma unroll
         for (int c = 0; c < 4; ++c)
 #pragma unroll
-            for (int i = 0; i < 16; ++i) {
-                const u32 st = (i & 3) + 8 * (i >> 2) + 4 * h;
-                const float v = act_apply(acc[c][i] + b[c], ACT, alpha);
-                *reinterpret_cast<u16 *>(stage + st * (kMfCols * 2) + (c * 32 + r) * 2) = (u16)(pack_bf16(v, 0.f) & 0xffffu);
+            for (int i = 0; i < 16; ++i) acc[c][i] = b[c];
+        // Software pipeline over the 30 k-steps: while the four MFMAs of step ks run, the B fragments of step
+        // ks + 1 are already on their way from LDS and so is its one-hot A fragment, so no MFMA waits for an
+        // LDS round trip or sits behind the hazard slots of a freshly written operand.
+        auto a_frag = [&](int ks) -> uint4 {
+            const int m2 = ks / 3, ph = ks % 3;
+            const u32 pos = ph == 0 ? code[2 * m2] - off_a : ph == 1 ? mid[m2] : code[2 * m2 + 1] - off_c;
+            return onehot[min(pos, 8u)];                    // pos in 0..7 iff the 1 falls into this fragment
+        };
+        const unsigned char *bbase = wslice + r * kMfPitch + 16 * h;   // + c * 32 * pitch + 32 * ks
+        uint4 a_cur = a_frag(0), b_cur[4];
+#pragma unroll
+        for (int c = 0; c < 4; ++c) b_cur[c] = *reinterpret_cast<const uint4 *>(bbase + c * 32 * kMfPitch);
+#pragma unroll
+        for (int ks = 0; ks < 30; ++ks) {
+            uint4 a_nxt = a_cur, b_nxt[4] = {b_cur[0], b_cur[1], b_cur[2], b_cur[3]};
+            if (ks + 1 < 30) {
+#pragma unroll
+                for (int c = 0; c < 4; ++c) b_nxt[c] = *reinterpret_cast<const uint4 *>(bbase + c * 32 * kMfPitch + 32 * (ks + 1));
+                a_nxt = a_frag(ks + 1);
             }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int c = 0; c < 4; ++c)
+                acc[c] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a_cur),
+                                                                 __builtin_bit_cast(bf16x8, b_cur[c]), acc[c], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+            a_cur = a_nxt;
+#pragma unroll
+            for (int c = 0; c < 4; ++c) b_cur[c] = b_nxt[c];
+        }
+        // epilogue: activation -> bf16; the lane's columns 4 r .. 4 r + 3 of one state are one 8-byte LDS write into
+        // the per-wave tile [state][col]; the tile is then read back along rows for 16-byte coalesced global stores
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            const u32 st = (i & 3) + 8 * (i >> 2) + 4 * h;
+            const uint2 v = make_uint2(pack_bf16(act_apply(acc[0][i], ACT, alpha), act_apply(acc[1][i], ACT, alpha)),
+                                       pack_bf16(act_apply(acc[2][i], ACT, alpha), act_apply(acc[3][i], ACT, alpha)));
+            *reinterpret_cast<uint2 *>(stage + st * (kMfCols * 2) + r * 8) = v;
+        }
         // (a wave only ever touches its own tile, and LDS operations of one wave complete in order)
 #pragma unroll
         for (int q = 0; q < 8; ++q) {
@@ -250,7 +307,7 @@ extern "C" int rc_first_layer_mfma_bf16(const int8_t *soa, size_t n, size_t stri
     u32 row_groups = (256 + col_tiles - 1) / col_tiles;   // one workgroup per CU (LDS), every W1 slice staged once per row group
     u32 rows_per_block = (u32)round_up(ceil_div(n, row_groups), kMfWaves * kMfTile);
     row_groups = (u32)ceil_div(n, rows_per_block);
-    const size_t lds_bytes = (size_t)kMfCols * kMfPitch + (size_t)kMfWaves * kMfStage;
+    const size_t lds_bytes = (size_t)kMfCols * kMfPitch + (size_t)kMfWaves * kMfStage + 9 * 16;
     const dim3 grid(col_tiles * row_groups), block(kMfWaves * kWave);
     hipStream_t s = (hipStream_t)stream;
 #define RC_LAUNCH_MF(ACT)                                                                                          \
