@@ -207,9 +207,16 @@ def main():
     rank, world = int(os.environ.get("RANK", 0)), int(os.environ.get("WORLD_SIZE", 1))
     local_rank = int(os.environ.get("LOCAL_RANK", 0))
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
-    torch.cuda.set_device(local_rank)
+    # one process per GPU; RUBIKS_DIST_BACKEND=gloo lets several ranks share one GPU to rehearse the N > 1 code path
+    backend = os.environ.get("RUBIKS_DIST_BACKEND", "nccl")   # nccl == RCCL on ROCm
+    device_index = local_rank % torch.cuda.device_count()
+    torch.cuda.set_device(device_index)
+    coll_device = "cuda" if backend == "nccl" else "cpu"
     if world > 1:
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))   # nccl == RCCL on ROCm
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", device_index))
+        else:
+            dist.init_process_group(backend)
 
     from librubiks import cube
     from librubiks.cube import DeviceCubes
@@ -262,7 +269,7 @@ def main():
     nodes = int(forest.n_nodes.sum().item()) - nodes0
     mean_path = float(forest.path_len.float().mean().item())
 
-    stats = torch.tensor([seconds, float(nodes)], dtype=torch.float64, device="cuda")
+    stats = torch.tensor([seconds, float(nodes)], dtype=torch.float64, device=coll_device)
     if world > 1:
         tmax = stats[:1].clone()
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
@@ -284,7 +291,7 @@ def main():
         status = forest.status.cpu().numpy()
         local = {"nodes": forest.n_nodes.cpu().numpy(), "solved": status == 1, "lengths": np.full(hi - lo, -1)}
     # final aggregation of per-tree results: the one data collective of an evaluation run (RCCL all_gather)
-    gathered = gather_results(local, total, device="cuda")
+    gathered = gather_results(local, total, device=coll_device)
 
     if rank != 0:
         if world > 1:
