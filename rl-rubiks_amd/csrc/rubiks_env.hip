@@ -12,6 +12,26 @@ namespace rubiks {
 // multi_rotate: out[j][i] = lut[act[i]][kind(j)][in[j][i]]        (librubiks/cube/cube.py:256-263)
 // Each lane owns 4*W consecutive cubes: one W-dword load per plane (W=4 -> 16 B/lane, 1 KiB/wave).
 // =================================================================================================
+// Streaming accesses of the large-batch variants are non-temporal (`nt`): every byte is touched once, so
+// keeping it out of the caches' replacement state is worth ~15 % of HBM bandwidth (5.15 -> 5.9 TB/s on multi_rotate).
+typedef unsigned v4u __attribute__((ext_vector_type(4)));
+template <bool NT> __device__ __forceinline__ uint4 ld16(const uint4 *p) {
+    if (NT) {
+        const v4u t = __builtin_nontemporal_load(reinterpret_cast<const v4u *>(p));
+        return make_uint4(t[0], t[1], t[2], t[3]);
+    }
+    return *p;
+}
+template <bool NT> __device__ __forceinline__ void st16(uint4 *p, const uint4 &v) {
+    if (NT) {
+        v4u t = {v.x, v.y, v.z, v.w};
+        __builtin_nontemporal_store(t, reinterpret_cast<v4u *>(p));
+    } else {
+        *p = v;
+    }
+}
+template <bool NT> __device__ __forceinline__ u32 ld4(const u32 *p) { return NT ? __builtin_nontemporal_load(p) : *p; }
+
 template <int W> struct DW;
 template <> struct DW<1> { using T = u32; };
 template <> struct DW<2> { using T = uint2; };
@@ -26,7 +46,7 @@ template <> __device__ __forceinline__ u32 pack<1>(const u32 (&w)[1]) { return w
 template <> __device__ __forceinline__ uint2 pack<2>(const u32 (&w)[2]) { return make_uint2(w[0], w[1]); }
 template <> __device__ __forceinline__ uint4 pack<4>(const u32 (&w)[4]) { return make_uint4(w[0], w[1], w[2], w[3]); }
 
-template <int W>
+template <int W, int NT = 0>
 __global__ __launch_bounds__(kBlock) void k_multi_rotate(const typename DW<W>::T *__restrict__ in,
                                                          const typename DW<W>::T *__restrict__ act,
                                                          typename DW<W>::T *__restrict__ out, size_t n_vec,
@@ -46,7 +66,12 @@ __global__ __launch_bounds__(kBlock) void k_multi_rotate(const typename DW<W>::T
         for (int j = 0; j < kPlanes; ++j) {
             const int kofs = (j >= kCorners) ? kCodePad : 0;
             u32 v[W], r[W];
-            unpack<W>(in[(size_t)j * sin_vec + g], v);
+            if (NT & 2) {
+                typedef unsigned nvec __attribute__((ext_vector_type(W)));
+                const nvec t = __builtin_nontemporal_load(reinterpret_cast<const nvec *>(&in[(size_t)j * sin_vec + g]));
+#pragma unroll
+                for (int w = 0; w < W; ++w) v[w] = t[w];
+            } else unpack<W>(in[(size_t)j * sin_vec + g], v);
 #pragma unroll
             for (int w = 0; w < W; ++w) {
                 u32 acc = 0;
@@ -54,7 +79,13 @@ __global__ __launch_bounds__(kBlock) void k_multi_rotate(const typename DW<W>::T
                 for (int b = 0; b < 4; ++b) acc |= (u32)lut[abase[4 * w + b] + kofs + code_of(v[w], b)] << (8 * b);
                 r[w] = acc;
             }
-            out[(size_t)j * sout_vec + g] = pack<W>(r);
+            if (NT & 1) {
+                typedef unsigned nvec __attribute__((ext_vector_type(W)));
+                nvec t;
+#pragma unroll
+                for (int w = 0; w < W; ++w) t[w] = r[w];
+                __builtin_nontemporal_store(t, reinterpret_cast<nvec *>(&out[(size_t)j * sout_vec + g]));
+            } else out[(size_t)j * sout_vec + g] = pack<W>(r);
         }
     }
 }
@@ -67,7 +98,7 @@ __global__ __launch_bounds__(kBlock) void k_multi_rotate(const typename DW<W>::T
 // a single 4-byte read of the action-minor table lut4[kind][code][4m..4m+3].  Stores are 16 B per
 // lane, fully coalesced.
 // =================================================================================================
-template <int BLOCK>
+template <int BLOCK, bool NT = false>
 __global__ __launch_bounds__(BLOCK) void k_expand12(const u32 *__restrict__ par, uint4 *__restrict__ child,
                                                     size_t n_parents, size_t n_par_dw, size_t n_chunks,
                                                     size_t sp_dw, size_t sc_vec) {
@@ -96,7 +127,7 @@ __global__ __launch_bounds__(BLOCK) void k_expand12(const u32 *__restrict__ par,
         const size_t dw0 = tile * BLOCK + tid;   // this lane's parent dword within a plane
         __syncthreads();                          // previous tile's readers are done (and lut4 staged)
 #pragma unroll
-        for (int j = 0; j < kPlanes; ++j) s_stage[j * BLOCK + tid] = (dw0 < n_par_dw) ? par[(size_t)j * sp_dw + dw0] : 0u;
+        for (int j = 0; j < kPlanes; ++j) s_stage[j * BLOCK + tid] = (dw0 < n_par_dw) ? ld4<NT>(&par[(size_t)j * sp_dw + dw0]) : 0u;
         __syncthreads();
         const size_t q0 = tile * (3 * BLOCK);     // first child chunk of this tile
 #pragma unroll
@@ -111,7 +142,7 @@ __global__ __launch_bounds__(BLOCK) void k_expand12(const u32 *__restrict__ par,
                     o[i] = *reinterpret_cast<const u32 *>(lut4 + kbase + code * kActions + moff[r][i]);
                 }
                 const size_t q = q0 + tid + BLOCK * r;
-                if (q < n_chunks) child[(size_t)j * sc_vec + q] = make_uint4(o[0], o[1], o[2], o[3]);
+                if (q < n_chunks) st16<NT>(&child[(size_t)j * sc_vec + q], make_uint4(o[0], o[1], o[2], o[3]));
             }
         }
     }
@@ -128,6 +159,7 @@ __device__ __forceinline__ u32 zero_bytes_to_flags(u32 x) {
 }
 __device__ __forceinline__ u32 flags_to_bits(u32 f) { return ((f * 0x01020408u) >> 24) & 0xfu; }
 
+template <bool NT>
 __global__ __launch_bounds__(kBlock) void k_is_solved(const uint4 *__restrict__ soa, uint4 *__restrict__ flags,
                                                       u16 *__restrict__ mask16, u32 *__restrict__ count, size_t n,
                                                       size_t n_vec, size_t stride_vec) {
@@ -142,7 +174,7 @@ __global__ __launch_bounds__(kBlock) void k_is_solved(const uint4 *__restrict__ 
 #pragma unroll
             for (int j = 0; j < kPlanes; ++j) {
                 const u32 s = 0x01010101u * (u32)(u8)kTables.solved[j];
-                const uint4 v = soa[(size_t)j * stride_vec + g];
+                const uint4 v = ld16<NT>(&soa[(size_t)j * stride_vec + g]);
                 acc.x |= v.x ^ s; acc.y |= v.y ^ s; acc.z |= v.z ^ s; acc.w |= v.w ^ s;
             }
             uint4 f = make_uint4(zero_bytes_to_flags(acc.x), zero_bytes_to_flags(acc.y), zero_bytes_to_flags(acc.z),
@@ -179,7 +211,8 @@ __global__ __launch_bounds__(kBlock) void k_is_solved(const uint4 *__restrict__ 
 // lane emits 16-byte chunks of the row-major output: chunk c of a row covers the one-hot positions
 // of a single cubie (24 % 4 == 0, 24 % 8 == 0), so it needs exactly one staged byte.
 // =================================================================================================
-template <int SB, bool BF16>
+// (NT stores were measured here too: the write-only one-hot kernel loses 5-10 % with them, so it keeps plain stores)
+template <int SB, bool BF16, bool NT = false>
 __global__ __launch_bounds__(kBlock) void k_as_oh(const u32 *__restrict__ soa, uint4 *__restrict__ out, size_t n,
                                                   size_t n_dw, size_t stride_dw) {
     constexpr int CPR = BF16 ? 60 : 120;   // 16-byte chunks per row
@@ -216,7 +249,7 @@ __global__ __launch_bounds__(kBlock) void k_as_oh(const u32 *__restrict__ soa, u
             v.z = rel == 2 ? one : 0u;
             v.w = rel == 3 ? one : 0u;
         }
-        dst[x] = v;
+        st16<NT>(&dst[x], v);
     }
 }
 
@@ -360,7 +393,7 @@ static int as_oh_impl(const int8_t *soa, void *out, size_t n, size_t stride, rc_
     const size_t n_dw = round_up(n, 16) / 4;
     if (n >= ((size_t)1 << 16)) {
         constexpr int SB = 256;
-        hipLaunchKernelGGL((k_as_oh<SB, BF16>), dim3((unsigned)ceil_div(n, SB)), dim3(kBlock), 0, s, (const u32 *)soa,
+        hipLaunchKernelGGL((k_as_oh<SB, BF16, false>), dim3((unsigned)ceil_div(n, SB)), dim3(kBlock), 0, s, (const u32 *)soa,
                            (uint4 *)out, n, n_dw, stride / 4);
     } else {
         constexpr int SB = 64;
@@ -383,8 +416,10 @@ int rc_multi_rotate(const int8_t *in_soa, const uint8_t *actions, int8_t *out_so
     // 16 cubes per lane once there are enough of them to fill the chip; 4 per lane below that.
     if (n >= ((size_t)1 << 20)) {
         const size_t n_vec = ceil_div(n, 16);
-        hipLaunchKernelGGL(k_multi_rotate<4>, dim3(grid_for(n_vec)), dim3(kBlock), 0, s, (const uint4 *)in_soa,
-                           (const uint4 *)actions, (uint4 *)out_soa, n_vec, stride_in / 16, stride_out / 16);
+        // large batches: non-temporal loads and stores, one 16-cube vector per lane, no grid-stride cap
+        hipLaunchKernelGGL((k_multi_rotate<4, 3>), dim3((unsigned)ceil_div(n_vec, (size_t)kBlock)), dim3(kBlock), 0, s,
+                           (const uint4 *)in_soa, (const uint4 *)actions, (uint4 *)out_soa, n_vec, stride_in / 16,
+                           stride_out / 16);
     } else {
         const size_t n_vec = ceil_div(n, 4);
         hipLaunchKernelGGL(k_multi_rotate<1>, dim3(grid_for(n_vec)), dim3(kBlock), 0, s, (const u32 *)in_soa,
@@ -404,7 +439,7 @@ int rc_expand12(const int8_t *parents_soa, int8_t *children_soa, size_t n_parent
     if (n_parents >= ((size_t)1 << 18)) {
         constexpr int BLOCK = 256;
         const size_t tiles = ceil_div(n_parents, 4 * BLOCK);
-        hipLaunchKernelGGL(k_expand12<BLOCK>, dim3((unsigned)(tiles < 4096 ? tiles : 4096)), dim3(BLOCK), 0, s,
+        hipLaunchKernelGGL((k_expand12<BLOCK, true>), dim3((unsigned)(tiles < 4096 ? tiles : 4096)), dim3(BLOCK), 0, s,
                            (const u32 *)parents_soa, (uint4 *)children_soa, n_parents, n_par_dw, n_chunks, stride_p / 4,
                            stride_c / 16);
     } else {
@@ -424,8 +459,12 @@ int rc_is_solved(const int8_t *soa, uint8_t *flags, uint64_t *mask, uint32_t *co
     RC_REQUIRE(flags == nullptr || aligned16(flags), RC_ERR_ALIGN);
     RC_REQUIRE(mask == nullptr || aligned16(mask), RC_ERR_ALIGN);
     const size_t n_vec = ceil_div(n, 16);
-    hipLaunchKernelGGL(k_is_solved, dim3(grid_for(n_vec)), dim3(kBlock), 0, (hipStream_t)stream, (const uint4 *)soa,
-                       (uint4 *)flags, (u16 *)mask, count, n, n_vec, stride / 16);
+    if (n >= ((size_t)1 << 20))
+        hipLaunchKernelGGL(k_is_solved<true>, dim3((unsigned)ceil_div(n_vec, (size_t)kBlock)), dim3(kBlock), 0,
+                           (hipStream_t)stream, (const uint4 *)soa, (uint4 *)flags, (u16 *)mask, count, n, n_vec, stride / 16);
+    else
+        hipLaunchKernelGGL(k_is_solved<false>, dim3(grid_for(n_vec)), dim3(kBlock), 0, (hipStream_t)stream,
+                           (const uint4 *)soa, (uint4 *)flags, (u16 *)mask, count, n, n_vec, stride / 16);
     return launch_status();
 }
 
