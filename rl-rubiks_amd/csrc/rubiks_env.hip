@@ -12,8 +12,10 @@ namespace rubiks {
 // multi_rotate: out[j][i] = lut[act[i]][kind(j)][in[j][i]]        (librubiks/cube/cube.py:256-263)
 // Each lane owns 4*W consecutive cubes: one W-dword load per plane (W=4 -> 16 B/lane, 1 KiB/wave).
 // =================================================================================================
-// Streaming accesses of the large-batch variants are non-temporal (`nt`): every byte is touched once, so
-// keeping it out of the caches' replacement state is worth ~15 % of HBM bandwidth (5.15 -> 5.9 TB/s on multi_rotate).
+// Streaming accesses of the read-dominated large-batch kernels (multi_rotate, is_solved) are non-temporal (`nt`):
+// every byte is touched once, and keeping it out of the caches' replacement state is worth ~15 % of HBM bandwidth
+// (5.15 -> 5.9 TB/s on multi_rotate, interleaved A/B in one process).  The write-dominated kernels (expand12, as_oh)
+// measured 3-4 % SLOWER with nt stores in the same A/B, so they keep plain stores.
 typedef unsigned v4u __attribute__((ext_vector_type(4)));
 template <bool NT> __device__ __forceinline__ uint4 ld16(const uint4 *p) {
     if (NT) {
@@ -439,7 +441,7 @@ int rc_expand12(const int8_t *parents_soa, int8_t *children_soa, size_t n_parent
     if (n_parents >= ((size_t)1 << 18)) {
         constexpr int BLOCK = 256;
         const size_t tiles = ceil_div(n_parents, 4 * BLOCK);
-        hipLaunchKernelGGL((k_expand12<BLOCK, true>), dim3((unsigned)(tiles < 4096 ? tiles : 4096)), dim3(BLOCK), 0, s,
+        hipLaunchKernelGGL((k_expand12<BLOCK, false>), dim3((unsigned)(tiles < 4096 ? tiles : 4096)), dim3(BLOCK), 0, s,
                            (const u32 *)parents_soa, (uint4 *)children_soa, n_parents, n_par_dw, n_chunks, stride_p / 4,
                            stride_c / 16);
     } else {
