@@ -65,7 +65,7 @@ def env_roofline(log2n=24):
     res = []
     # HBM bytes per launch from the committed rocprofv3 PMC passes of these same launches (FETCH_SIZE and
     # WRITE_SIZE in separate runs, gfx950 corrections applied: tools/summarize_pmc.py); None if absent
-    pmc_path = os.path.join(ROOT, "profiles", "r1_env_pmc_traffic.json")
+    pmc_path = os.path.join(ROOT, "profiles", "r1b_env_pmc_traffic.json")
     pmc = json.load(open(pmc_path)) if os.path.exists(pmc_path) and log2n == 24 else {}
 
     def add(kernel, unit, unit_bytes, units, fn, reps=20):
@@ -75,7 +75,7 @@ def env_roofline(log2n=24):
                     "ms": round(mean, 4), "achieved": round(gbps, 1), "peak": HBM_PEAK_GBPS, "unit_rate": "GB/s",
                     "frac": round(gbps / HBM_PEAK_GBPS, 4), "Munits_per_s": round(units / (mean * 1e-3) / 1e6, 1),
                     "algorithmic_bytes": int(unit_bytes * units),
-                    "traffic": pmc.get(kernel, {}).get("traffic_bytes")})
+                    "traffic": pmc.get(kernel.split("(")[0] if kernel.startswith("is_solved") else kernel, {}).get("traffic_bytes")})
 
     add("multi_rotate", "state", 41, n, lambda: cubes.multi_rotate(act, out=out))
     npar = n // 4
