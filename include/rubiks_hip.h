@@ -170,7 +170,6 @@ typedef struct rc_mcts {
     uint16_t *L;         /* x12  virtual-loss COUNT; reference L = 100 * count (agents.py:427,433,589-591) */
     float *V;            /*      value       (agents.py:424) */
     uint8_t *leaf;       /*      is leaf     (agents.py:422) */
-    int32_t *stamp;      /*      scratch of rc_mcts_select: (iteration, first level) a node was seen on the path */
     int32_t *hash;       /* [B][hash_size] open addressing, slot = node index or 0; full-key compare via keys */
     /* per tree, [B] */
     int32_t *n_nodes;    /* len(agent) (agents.py:644-645) */
@@ -188,6 +187,7 @@ typedef struct rc_mcts {
     int32_t *child_idx;  /* [B][12] node index of every child of the expanded leaf */
     uint32_t *new_mask;  /* [B] bit k set iff child k was not in the tree before */
     uint8_t *expanded;   /* [B] 1 iff the tree expanded a leaf in the current iteration */
+    int32_t *select_stats; /* optional (may be NULL): [B][2] = first sequentially walked level, new path length */
 } rc_mcts_t;
 
 /* Inserts the B root states (SoA) as node 1 of each tree; a solved root gets RC_MCTS_ROOT_SOLVED.

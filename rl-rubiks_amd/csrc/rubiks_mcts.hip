@@ -237,56 +237,63 @@ __device__ __forceinline__ void l_count_add(u16 *L, size_t e) {
 // The descent restarts at the root every iteration (that is the algorithm), but consecutive descents
 // share long prefixes: only the nodes of the previous path changed (N + 1, max-backup of W).  So the
 // levels of the PREVIOUS path are re-validated in parallel, 16 levels per pass (one 16-lane row per
-// level): level k keeps its action iff the argmax at its node is unchanged.  This is exact as long as
-// no node occurs twice in the prefix, because then the only virtual loss a level can see is the one
-// of its own arrival edge; the first level that changes its action, repeats a node, or is the old
-// leaf becomes the start of the ordinary sequential descent (one memory round trip per level).
+// level): level k keeps its action iff the argmax at its node is unchanged, GIVEN that all levels above
+// kept theirs.  Under that premise the virtual loss level k sees is a function of the old path alone:
+// every earlier level j < k at the same node contributed +1 on its departure edge a_j and +1 on its
+// arrival edge rev(a_{j-1}), plus level k's own arrival edge (L is zero between iterations).  Deep lines
+// revisit states all the time (transpositions), so these counts are taken exactly, by scanning the
+// staged path in LDS.  The first level whose action changes -- or the old leaf, which has just been
+// expanded -- starts the ordinary sequential descent (one memory round trip per level); with a trained
+// network that tail is typically one or two levels instead of ~100.
 __global__ __launch_bounds__(kBlock) void k_mcts_select(rc_mcts_t m, double c, u32 level_budget) {
-    __shared__ int s_first;   // first level that has to be walked sequentially
+    __shared__ int s_first;                 // first level that has to be walked sequentially
+    __shared__ int s_node[2048];            // the old path (max_path <= 2048)
+    __shared__ u8 s_act[2048];
+    __shared__ u32 s_cnt[kBlock / 16][16];  // per level slot: virtual-loss count of each edge
     const u32 t = blockIdx.x, tid = threadIdx.x;
     if (m.status[t] != RC_MCTS_RUNNING) return;
     const size_t base = (size_t)t * (m.capacity + 1);
     int *pnode = m.path_node + (size_t)t * m.max_path;
     u8 *pact = m.path_act + (size_t)t * m.max_path;
     const int plen_old = m.path_len[t];
-    const int epoch = m.iterations[t];
     const u32 row = tid >> 4, rl = tid & 15;
     const bool ract = rl < kA;
     const u32 rla = ract ? rl : 0;
     const int resume = m.pending[t];   // uniform over the workgroup
+    if (tid == 0) s_first = plen_old - 1;   // the old leaf has just been expanded (or a suspended descent continues there)
     if (!resume) {
-    if (tid == 0) s_first = plen_old - 1;   // the old leaf has just been expanded: always re-evaluated
-    // first level at which every node of the old path occurs: larger key = later iteration, then earlier level
-    for (int k = tid; k < plen_old; k += kBlock) atomicMax(&m.stamp[base + pnode[k]], epoch * 2048 + 2047 - k);
-    // __syncthreads() alone does not wait for no-return atomics: drain them before the barrier publishes them
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    for (int k0 = 0; k0 < plen_old - 1; k0 += 16) {
+        for (int k = tid; k < plen_old; k += kBlock) {
+            s_node[k] = pnode[k];
+            s_act[k] = (k < plen_old - 1) ? pact[k] : (u8)0;
+        }
+        __syncthreads();
+        for (int k0 = 0; k0 < plen_old - 1; k0 += kBlock / 16) {
+            const int k = k0 + (int)row;
+            if (k < plen_old - 1) {   // the 16 lanes of a level sit in one wave: their LDS operations are ordered
+                s_cnt[row][rl] = 0;
+                const int node = s_node[k];
+                for (int j = (int)rl; j < k; j += 16)
+                    if (s_node[j] == node) {   // an earlier visit of this node: its departure and arrival edges
+                        atomicAdd(&s_cnt[row][s_act[j]], 1u);
+                        if (j > 0) atomicAdd(&s_cnt[row][s_act[j - 1] ^ 1], 1u);
+                    }
+                if (rl == 0 && k > 0) atomicAdd(&s_cnt[row][s_act[k - 1] ^ 1], 1u);   // this level's own arrival
+                const u32 l_cnt = s_cnt[row][rl];
+                const size_t r = (base + node) * kA + rla;
+                const int b = puct_argmax(c, m.N[r], m.P[r], m.W[r], l_cnt, ract, (int)rl);
+                if (rl == 0 && b != (int)s_act[k]) atomicMin(&s_first, k);
+            }
+        }
         __syncthreads();
         const int first = s_first;
-        __syncthreads();
-        if (k0 > first) break;
-        const int k = k0 + (int)row;
-        if (k < plen_old - 1) {
-            const int node = pnode[k], a_old = pact[k];
-            const int arrive = k > 0 ? (pact[k - 1] ^ 1) : -1;
-            const int seen = __hip_atomic_load(&m.stamp[base + node], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            const bool repeat = 2047 - (seen & 2047) < k;
-            const size_t r = (base + node) * kA + rla;
-            const int b = puct_argmax(c, m.N[r], m.P[r], m.W[r], (int)rl == arrive ? 1u : 0u, ract, (int)rl);
-            if (rl == 0 && (repeat || b != a_old)) atomicMin(&s_first, k);
+        // the kept prefix takes its virtual losses: L[n_k, a_k] += nu and L[n_k+1, rev a_k] += nu (agents.py:589-591)
+        for (int k = tid; k < first; k += kBlock) {
+            const int a = s_act[k];
+            l_count_add(m.L, (base + s_node[k]) * kA + a);
+            l_count_add(m.L, (base + s_node[k + 1]) * kA + (a ^ 1));
         }
-    }
-    __syncthreads();
-    const int first = s_first;
-    // the kept prefix takes its virtual losses: L[n_k, a_k] += nu and L[n_k+1, rev a_k] += nu (agents.py:589-591)
-    for (int k = tid; k < first; k += kBlock) {
-        const int a = pact[k];
-        l_count_add(m.L, (base + pnode[k]) * kA + a);
-        l_count_add(m.L, (base + pnode[k + 1]) * kA + (a ^ 1));
-    }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the adds must have reached L2 before wave 0 reads L
-    } else if (tid == 0) {
-        s_first = plen_old - 1;   // a suspended descent continues where it stopped
+        // __syncthreads() alone does not wait for no-return atomics: they must have reached L2 before wave 0 reads L
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     }
     __syncthreads();
     if (tid >= kWave) return;
@@ -339,6 +346,10 @@ __global__ __launch_bounds__(kBlock) void k_mcts_select(rc_mcts_t m, double c, u
         ++plen;
     }
     if (lane == 0) {
+        if (m.select_stats) {
+            m.select_stats[2 * t] = start;
+            m.select_stats[2 * t + 1] = plen;
+        }
         m.path_len[t] = plen;
         m.pending[t] = suspended;   // 1 = resume at path_len - 1 with no carried loss (encoding: carried + 2)
     }
@@ -385,7 +396,7 @@ using namespace rubiks;
 
 static int check_mcts(const rc_mcts_t *m) {
     RC_REQUIRE(m != nullptr, RC_ERR_NULL);
-    RC_REQUIRE(m->keys && m->nbr && m->P && m->W && m->N && m->L && m->V && m->leaf && m->stamp && m->hash && m->n_nodes &&
+    RC_REQUIRE(m->keys && m->nbr && m->P && m->W && m->N && m->L && m->V && m->leaf && m->hash && m->n_nodes &&
                    m->status && m->solved_idx && m->solved_action && m->iterations && m->path_len && m->path_node &&
                    m->pending && m->path_act && m->child_soa && m->child_idx && m->new_mask && m->expanded,
                RC_ERR_NULL);

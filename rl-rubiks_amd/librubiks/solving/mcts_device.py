@@ -24,11 +24,11 @@ N_ACT = 12
 
 class _McStruct(Structure):   # mirrors rc_mcts_t (include/rubiks_hip.h)
     _fields_ = [("n_trees", c_uint32), ("capacity", c_uint32), ("hash_size", c_uint32), ("max_path", c_uint32)] + \
-               [(name, c_void_p) for name in ("keys", "nbr", "P", "W", "N", "L", "V", "leaf", "stamp", "hash", "n_nodes",
+               [(name, c_void_p) for name in ("keys", "nbr", "P", "W", "N", "L", "V", "leaf", "hash", "n_nodes",
                                               "status", "solved_idx", "solved_action", "iterations", "path_len", "pending",
                                               "path_node", "path_act", "child_soa")] + \
                [("child_stride", c_size_t)] + \
-               [(name, c_void_p) for name in ("child_idx", "new_mask", "expanded")]
+               [(name, c_void_p) for name in ("child_idx", "new_mask", "expanded", "select_stats")]
 
 
 _hip.register({
@@ -69,7 +69,6 @@ class MCTSForest:
         self.L = z((rows, N_ACT), torch.int16)
         self.V = z((rows,), torch.float32)
         self.leaf = z((rows,), torch.uint8)
-        self.stamp = z((rows,), torch.int32)
         self.hash = z((B, self.hash_size), torch.int32)
         self.n_nodes, self.status = z((B,), torch.int32), z((B,), torch.int32)
         self.solved_idx, self.solved_action = z((B,), torch.int32), z((B,), torch.int32)
@@ -85,11 +84,13 @@ class MCTSForest:
         self.values = z((N_ACT * B,), torch.float32)
         s = _McStruct()
         s.n_trees, s.capacity, s.hash_size, s.max_path = B, C, self.hash_size, max_path
-        for name in ("keys", "nbr", "P", "W", "N", "L", "V", "leaf", "stamp", "hash", "n_nodes", "status", "solved_idx",
+        for name in ("keys", "nbr", "P", "W", "N", "L", "V", "leaf", "hash", "n_nodes", "status", "solved_idx",
                      "solved_action", "iterations", "path_len", "pending", "path_node", "path_act", "child_idx", "new_mask",
                      "expanded"):
             setattr(s, name, getattr(self, name).data_ptr())
         s.child_soa, s.child_stride = self.children.soa.data_ptr(), self.children.stride
+        self.select_stats = z((B, 2), torch.int32)   # diagnostics: where each descent became sequential, and its length
+        s.select_stats = self.select_stats.data_ptr()
         self.struct = s
         self.engine = None
         self._oh = None
@@ -125,7 +126,7 @@ class MCTSForest:
     def reset(self, roots: DeviceCubes):
         """Empties every tree and plants root t = roots[t] as node 1; evaluates the roots (agents.py:466-473)."""
         assert roots.n == self.B and self.engine is not None
-        for t in (self.nbr, self.N, self.L, self.hash, self.leaf, self.stamp):
+        for t in (self.nbr, self.N, self.L, self.hash, self.leaf):
             t.zero_()
         st = _hip.stream_ptr()
         _hip.check(self.lib.rc_mcts_init(ctypes.byref(self.struct), roots.soa.data_ptr(), roots.stride, st), "rc_mcts_init")
