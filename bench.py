@@ -198,7 +198,7 @@ def main():
     ap.add_argument("--solve-max-states", type=int, default=50000,
                     help="after the timed steps, search the same scrambles to completion with this per-tree cap and "
                          "report the solve rate (0 = skip)")
-    ap.add_argument("--level-budget", type=int, default=32,
+    ap.add_argument("--level-budget", type=int, default=0,
                     help="new tree levels a PUCT descent may walk per step before it is suspended (0 = strict lock step)")
     ap.add_argument("--first-layer-table", default="auto", choices=["auto", "f16", "bf16", "mfma", "onehot"],
                     help="input layer: fused gather-sum with an f16 / bf16 table, or the one-hot GEMM")

@@ -188,6 +188,10 @@ typedef struct rc_mcts {
     uint32_t *new_mask;  /* [B] bit k set iff child k was not in the tree before */
     uint8_t *expanded;   /* [B] 1 iff the tree expanded a leaf in the current iteration */
     int32_t *select_stats; /* optional (may be NULL): [B][2] = first sequentially walked level, new path length */
+    /* optional, only needed by rc_mcts_shorten (may be NULL otherwise) */
+    int32_t *bfs;        /* [B][capacity + 1][2] scratch: {claim, parent << 4 | action} */
+    uint8_t *short_act;  /* [B][max_path] shortened action queue of every solved tree */
+    int32_t *short_len;  /* [B] its length, -1 where no shortened queue was produced */
 } rc_mcts_t;
 
 /* Inserts the B root states (SoA) as node 1 of each tree; a solved root gets RC_MCTS_ROOT_SOLVED.
@@ -216,6 +220,11 @@ int rc_mcts_select(const rc_mcts_t *m, double c, uint32_t level_budget, rc_strea
 /* _complete_graph (agents.py:597-611) for every tree with status RC_MCTS_SOLVED: each leaf is linked, both
  * ways, to those of its 12 children that already exist in the tree (looked up in the tree's hash table). */
 int rc_mcts_complete_graph(const rc_mcts_t *m, rc_stream_t stream);
+/* _shorten_action_queue (agents.py:613-633) for every solved tree, after rc_mcts_complete_graph: breadth-first
+ * search over the tree's neighbour table from the root to the solved node, discovering nodes in exactly the
+ * order of the reference's FIFO queue (frontier order, then action order), so the returned queue is the
+ * reference's.  Overwrites the tree's hash table (used as the two frontier arrays). */
+int rc_mcts_shorten(const rc_mcts_t *m, rc_stream_t stream);
 
 /* ---- batched weighted A*: B independent problems, N expansions each per iteration --------------
  *

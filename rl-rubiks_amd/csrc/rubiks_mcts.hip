@@ -7,6 +7,8 @@
 // bandwidth-bound: the design goal is few dependent memory round trips per phase, 12 lanes of the
 // wave doing the per-action work in parallel (ballots / DPP reductions instead of loops), and
 // no atomics across trees (each tree owns its node arrays and its hash table).
+#include <limits.h>
+
 #include "rubiks_common.h"
 
 namespace rubiks {
@@ -390,6 +392,95 @@ __global__ __launch_bounds__(kBlock) void k_mcts_complete_graph(rc_mcts_t m) {
     }
 }
 
+// ---- _shorten_action_queue (agents.py:613-633): ordered BFS, one workgroup per solved tree --------------
+// Level-synchronous, but every node keeps the discoverer the reference's FIFO scan would give it: candidate
+// (frontier position i, action a) carries the scan index 12 i + a, the smallest index claims the node
+// (atomicMin), and the next frontier is the claimed nodes in scan-index order (block-wide ordered compaction).
+__global__ __launch_bounds__(kBlock) void k_mcts_shorten(rc_mcts_t m) {
+    __shared__ int s_scan[kBlock];
+    __shared__ int s_base, s_done;
+    const u32 t = blockIdx.x, tid = threadIdx.x;
+    if (tid == 0) m.short_len[t] = -1;
+    if (m.status[t] != RC_MCTS_SOLVED) return;
+    const int solved = m.solved_idx[t];
+    if (solved == 1) return;   // agents.py:614: the queue is kept
+    const size_t base = (size_t)t * (m.capacity + 1);
+    const int n = m.n_nodes[t];
+    const int *nbr = m.nbr + base * kA;
+    int *claim = m.bfs + base * 2;            // [node][0]
+    int *frontier_a = m.hash + (size_t)t * m.hash_size, *frontier_b = frontier_a + (m.capacity + 1);
+    for (int i = tid; i <= n; i += kBlock) {
+        claim[2 * i] = INT_MAX;
+        claim[2 * i + 1] = 0;   // parent << 4 | action; 0 = not visited
+    }
+    if (tid == 0) {
+        frontier_a[0] = 1;
+        s_done = 0;
+    }
+    __syncthreads();
+    if (tid == 0) claim[2 * 1 + 1] = -1;   // the root is visited and has no parent
+    int fsize = 1;
+    int *cur = frontier_a, *nxt = frontier_b;
+    while (fsize > 0) {
+        __syncthreads();
+        const int work = fsize * kA;
+        // phase 1: every unvisited neighbour is claimed by the smallest scan index that reaches it
+        for (int idx = tid; idx < work; idx += kBlock) {
+            const int c = nbr[(size_t)cur[idx / kA] * kA + idx % kA];
+            if (c != 0 && claim[2 * c + 1] == 0) atomicMin(&claim[2 * c], idx);
+        }
+        // the claims are no-return atomics executed at L2: drain them before the barrier, and read them back
+        // with L2-served loads (a plain load could hit a stale L1 line)
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        // phase 2: winners enter the next frontier in scan order
+        if (tid == 0) s_base = 0;
+        __syncthreads();
+        for (int idx0 = 0; idx0 < work; idx0 += kBlock) {
+            const int idx = idx0 + (int)tid;
+            int c = 0, win = 0, p = 0;
+            if (idx < work) {
+                p = cur[idx / kA];
+                c = nbr[(size_t)p * kA + idx % kA];
+                win = (c != 0 && claim[2 * c + 1] == 0 &&
+                       __hip_atomic_load(&claim[2 * c], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == idx) ? 1 : 0;
+            }
+            s_scan[tid] = win;
+            __syncthreads();
+            for (int o = 1; o < kBlock; o <<= 1) {
+                const int x = (tid >= (u32)o) ? s_scan[tid - o] : 0;
+                __syncthreads();
+                s_scan[tid] += x;
+                __syncthreads();
+            }
+            const int pos = s_base + s_scan[tid] - win;
+            if (win) {
+                nxt[pos] = c;
+                claim[2 * c + 1] = (p << 4) | (idx % kA);
+                if (c == solved) s_done = 1;
+            }
+            __syncthreads();
+            if (tid == kBlock - 1) s_base += s_scan[tid];
+            __syncthreads();
+        }
+        fsize = s_base;
+        if (s_done) break;
+        int *tmp = cur; cur = nxt; nxt = tmp;
+    }
+    __syncthreads();
+    if (tid == 0 && s_done) {   // walk the parent pointers back to the root, then reverse
+        u8 *out = m.short_act + (size_t)t * m.max_path;
+        int len = 0;
+        for (int v = solved; v != 1 && len < (int)m.max_path; v = claim[2 * v + 1] >> 4) out[len++] = (u8)(claim[2 * v + 1] & 15);
+        for (int i = 0; i < len / 2; ++i) {
+            const u8 x = out[i];
+            out[i] = out[len - 1 - i];
+            out[len - 1 - i] = x;
+        }
+        m.short_len[t] = len;
+    }
+}
+
 }  // namespace rubiks
 
 using namespace rubiks;
@@ -451,6 +542,13 @@ int rc_mcts_backup_head(const rc_mcts_t *m, const void *head, size_t ld, int hea
 int rc_mcts_complete_graph(const rc_mcts_t *m, rc_stream_t stream) {
     if (int rc = check_mcts(m)) return rc;
     hipLaunchKernelGGL(k_mcts_complete_graph, dim3(m->n_trees), dim3(kBlock), 0, (hipStream_t)stream, *m);
+    return launch_status();
+}
+
+int rc_mcts_shorten(const rc_mcts_t *m, rc_stream_t stream) {
+    if (int rc = check_mcts(m)) return rc;
+    RC_REQUIRE(m->bfs && m->short_act && m->short_len, RC_ERR_NULL);
+    hipLaunchKernelGGL(k_mcts_shorten, dim3(m->n_trees), dim3(kBlock), 0, (hipStream_t)stream, *m);
     return launch_status();
 }
 

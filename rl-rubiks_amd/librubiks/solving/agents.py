@@ -78,9 +78,9 @@ class MCTS(DeepAgent):
         level_budget: how many NEW tree levels a PUCT descent may walk per lock-step iteration before it is
         suspended until the next one (0 = unlimited).  Every tree still performs exactly the reference's
         sequence of iterations; a budget only stops the deepest descent of the batch from pacing all trees.
-        Measured on 1 024 depth-20 trees with trained weights (mean path 130 levels, sequential tails: mean 17,
-        p90 54, max ~140): 22.9 M nodes/s unlimited, 23.9 M at 32, 23.5 M at 64 -- a small gain, because a
-        suspended tree wastes its 12 network rows.  "auto" = 32 for batches of at least 64 trees, else unlimited.
+        Measured on 1 024 depth-20 trees with trained weights: over a fixed number of lock-step iterations a
+        budget of 32 gains 4 % (23.9 vs 22.9 M nodes/s), but a run to completion gets 2.5x SLOWER (6.1 s vs
+        2.4 s: the last stragglers are suspended over and over), so "auto" means 0 (strict lock step).
         """
         super().__init__(net)
         self.level_budget = level_budget
@@ -108,7 +108,7 @@ class MCTS(DeepAgent):
             torch.cuda.empty_cache()
             f = self.forest = md.MCTSForest(n_trees, capacity, self.max_path)
             f.set_net(self.net, self.net_dtype)
-        f.level_budget = (32 if n_trees >= 64 else 0) if self.level_budget == "auto" else int(self.level_budget)
+        f.level_budget = 0 if self.level_budget == "auto" else int(self.level_budget)
         return f
 
     @no_grad
@@ -147,14 +147,16 @@ class MCTS(DeepAgent):
         solved = (status == md.SOLVED) | (status == md.ROOT_SOLVED)
         queues = []
         self._tree = None
+        short_len = short_act = None
         if self.search_graph and (status == md.SOLVED).any():
-            forest.complete_graphs()   # _complete_graph of all solved trees in one launch
+            forest.complete_graphs()                          # _complete_graph of all solved trees in one launch
+            short_len, short_act = forest.shorten_queues()    # ... and their BFS shortening in another
         for t in range(forest.B):
             taken = [int(a) for a in pact[t, :plen[t] - 1]]
             if status[t] == md.SOLVED:
                 q = taken + [int(sol_act[t])]                      # agents.py:483
-                if self.search_graph:
-                    q = self._shortened_queue(forest.neighbors_of(t, int(nodes[t])), int(sol_idx[t]), q)
+                if self.search_graph and short_len[t] >= 0:
+                    q = [int(a) for a in short_act[t, :short_len[t]]]
             elif status[t] == md.ROOT_SOLVED:
                 q = []
             else:

@@ -28,7 +28,8 @@ class _McStruct(Structure):   # mirrors rc_mcts_t (include/rubiks_hip.h)
                                               "status", "solved_idx", "solved_action", "iterations", "path_len", "pending",
                                               "path_node", "path_act", "child_soa")] + \
                [("child_stride", c_size_t)] + \
-               [(name, c_void_p) for name in ("child_idx", "new_mask", "expanded", "select_stats")]
+               [(name, c_void_p) for name in ("child_idx", "new_mask", "expanded", "select_stats", "bfs", "short_act",
+                                              "short_len")]
 
 
 _hip.register({
@@ -39,6 +40,7 @@ _hip.register({
     "rc_mcts_backup_head": [POINTER(_McStruct), c_void_p, c_size_t, c_int, c_void_p],
     "rc_mcts_select": [POINTER(_McStruct), c_double, c_uint32, c_void_p],
     "rc_mcts_complete_graph": [POINTER(_McStruct), c_void_p],
+    "rc_mcts_shorten": [POINTER(_McStruct), c_void_p],
 })
 
 
@@ -91,6 +93,10 @@ class MCTSForest:
         s.child_soa, s.child_stride = self.children.soa.data_ptr(), self.children.stride
         self.select_stats = z((B, 2), torch.int32)   # diagnostics: where each descent became sequential, and its length
         s.select_stats = self.select_stats.data_ptr()
+        self.bfs = None   # BFS scratch of rc_mcts_shorten: allocated on first use (graph search only)
+        self.short_act = z((B, max_path), torch.uint8)
+        self.short_len = z((B,), torch.int32)
+        s.short_act, s.short_len = self.short_act.data_ptr(), self.short_len.data_ptr()
         self.struct = s
         self.engine = None
         self._oh = None
@@ -190,6 +196,14 @@ class MCTSForest:
     def complete_graphs(self):
         """_complete_graph of every solved tree, on the device (agents.py:597-611)."""
         _hip.check(self.lib.rc_mcts_complete_graph(ctypes.byref(self.struct), _hip.stream_ptr()), "rc_mcts_complete_graph")
+
+    def shorten_queues(self):
+        """_shorten_action_queue of every solved tree on the device -> (lengths[B] (-1 = keep the naive queue), actions[B, max_path])."""
+        if self.bfs is None:
+            self.bfs = torch.zeros((self.B * (self.C + 1), 2), dtype=torch.int32, device=self.device)
+            self.struct.bfs = self.bfs.data_ptr()
+        _hip.check(self.lib.rc_mcts_shorten(ctypes.byref(self.struct), _hip.stream_ptr()), "rc_mcts_shorten")
+        return self.short_len.cpu().numpy(), self.short_act.cpu().numpy()
 
     def neighbors_of(self, t: int, n: int) -> np.ndarray:
         lo = t * (self.C + 1)
