@@ -66,6 +66,24 @@ class BatchResult:
     def states_per_sec(self) -> float:
         return float(self.nodes.sum()) / max(self.seconds, 1e-12)
 
+    def select(self, mask: np.ndarray) -> "BatchResult":
+        idx = np.flatnonzero(mask)
+        return BatchResult(self.solved[idx], self.lengths[idx], self.nodes[idx], [self.queues[i] for i in idx],
+                           self.seconds, self.iterations[idx], self.status[idx])
+
+    @staticmethod
+    def merge(n: int, parts, seconds: float) -> "BatchResult":
+        """Reassembles per-game results from (original indices, BatchResult) pieces."""
+        solved, lengths = np.zeros(n, dtype=bool), np.full(n, -1, dtype=np.int64)
+        nodes, iters, status = np.zeros(n, dtype=np.int64), np.zeros(n, dtype=np.int64), np.zeros(n, dtype=np.int64)
+        queues = [None] * n
+        for owner, r in parts:
+            solved[owner], lengths[owner], nodes[owner] = r.solved, r.lengths, r.nodes
+            iters[owner], status[owner] = r.iterations, r.status
+            for o, q in zip(owner, r.queues):
+                queues[int(o)] = q
+        return BatchResult(solved, lengths, nodes, queues, seconds, iters, status)
+
 
 class MCTS(DeepAgent):
     """Batched PUCT graph search with virtual loss and max-backup (reference agents.py:415-645)."""
@@ -87,6 +105,7 @@ class MCTS(DeepAgent):
         self.c, self.search_graph = float(c), bool(search_graph)
         self.net_dtype, self.use_graph, self.max_path, self.sync_every = net_dtype, use_graph, max_path, sync_every
         self.forest = None
+        self._last_forest = None   # the forest the last search ended in (a compacted one after `compact`)
         self._tree = None      # host copy of tree 0, for the reference's inspectable attributes
         self._engine = None
 
@@ -113,11 +132,14 @@ class MCTS(DeepAgent):
 
     @no_grad
     def search_batch(self, states, time_limit: float = None, max_states: int = None,
-                     max_iterations: int = None) -> BatchResult:
+                     max_iterations: int = None, compact: bool = True) -> BatchResult:
         """
         One MCTS tree per row of `states` ((B,20) int8 NumPy array or DeviceCubes), all advanced in
         lock step.  `max_states` is the reference's per-tree cap (stop when len + 12 > max_states);
         `time_limit` bounds the wall time of the whole batch.
+        compact: whenever at most half of the trees are still running (and at least 128 remain), the
+        finished ones are harvested and the forest is compacted to the running trees, so the stragglers of a
+        run to completion continue on small batches instead of paying full-size network calls.
         """
         time_limit, max_states = self.reset(time_limit, max_states)
         roots = states if isinstance(states, DeviceCubes) else DeviceCubes.from_numpy(np.asarray(states))
@@ -125,6 +147,9 @@ class MCTS(DeepAgent):
         forest = self._forest_for(roots.n, max(cap_states, 16))
         self.tt.tick()
         forest.reset(roots)
+        B = roots.n
+        owner = np.arange(B)          # original game index of every tree of the current forest
+        harvested = []                # (owner ids, BatchResult) of trees dropped at compactions
         it = 0
         while True:
             if max_iterations is not None and it >= max_iterations:
@@ -132,18 +157,37 @@ class MCTS(DeepAgent):
             forest.step(self.c, cap_states, self.use_graph)
             it += 1
             if it % self.sync_every == 0 or (max_iterations is not None and it >= max_iterations):
-                if not forest.any_running() or self.tt.tock() >= time_limit:
+                running = forest.status == md.RUNNING
+                n_run = int(running.sum().item())
+                if n_run == 0 or self.tt.tock() >= time_limit:
                     break
+                if compact and forest.B >= 256 and n_run <= forest.B // 2:
+                    done = (~running).cpu().numpy()
+                    part = self._collect(forest, 0.0)
+                    harvested.append((owner[done], part.select(done)))
+                    keep = torch.nonzero(running).reshape(-1)
+                    small = forest.subset(keep)
+                    if forest is self.forest:   # keep the full-size forest's buffers for the next search, drop its graph
+                        forest._graph = None
+                    forest, owner = small, owner[~done]
         torch.cuda.synchronize()
         seconds = self.tt.tock()
-        return self._collect(forest, seconds)
+        last = self._collect(forest, seconds)
+        if not harvested:
+            result = last
+        else:
+            harvested.append((owner, last))
+            result = BatchResult.merge(B, harvested, seconds)
+        self._last_forest = forest
+        self._explored_states = int(result.nodes[0])
+        self.action_queue = result.queues[0]
+        return result
 
     def _collect(self, forest: md.MCTSForest, seconds: float) -> BatchResult:
         status = forest.status.cpu().numpy()
         nodes = forest.n_nodes.cpu().numpy().astype(np.int64)
         plen, pact = forest.paths()
         sol_act = forest.solved_action.cpu().numpy()
-        sol_idx = forest.solved_idx.cpu().numpy()
         solved = (status == md.SOLVED) | (status == md.ROOT_SOLVED)
         queues = []
         self._tree = None
@@ -163,8 +207,6 @@ class MCTS(DeepAgent):
                 q = taken                                          # best guess (agents.py:492)
             queues.append(deque(q))
         lengths = np.array([len(q) if s else -1 for q, s in zip(queues, solved)])
-        self._explored_states = int(nodes[0])
-        self.action_queue = queues[0]
         return BatchResult(solved, lengths, nodes, queues, seconds, forest.iterations.cpu().numpy(), status)
 
     # ---- solved-tree post-processing (agents.py:597-633) ----------------------------------------
@@ -206,7 +248,7 @@ class MCTS(DeepAgent):
 
     def _host_tree(self):
         if self._tree is None:   # after a solved graph search the device arrays already hold the completed graph
-            self._tree = self.forest.tree_arrays(0)
+            self._tree = self._last_forest.tree_arrays(0)
         return self._tree
 
     # inspectable attributes relied on by the reference's tests (tests/test_agents.py:54-92)

@@ -53,8 +53,12 @@ def unpack_keys(keys: np.ndarray) -> np.ndarray:
     return out
 
 
+_PER_NODE = ("keys", "nbr", "P", "W", "N", "L", "V", "leaf")
+_PER_TREE = ("n_nodes", "status", "solved_idx", "solved_action", "iterations", "path_len", "pending", "path_node", "path_act")
+
+
 class MCTSForest:
-    def __init__(self, n_trees: int, capacity: int, max_path: int = 1024, device=None):
+    def __init__(self, n_trees: int, capacity: int, max_path: int = 1024, device=None, _state: dict = None):
         self.lib = _hip.lib()
         dev = device or torch.device("cuda", torch.cuda.current_device())
         B, C = int(n_trees), int(capacity)
@@ -63,21 +67,21 @@ class MCTSForest:
         self.hash_size = 1 << int(np.ceil(np.log2(2 * (C + 1))))
         z = lambda shape, dt: torch.zeros(shape, dtype=dt, device=dev)   # noqa: E731
         rows = B * (C + 1)
-        self.keys = z((rows, 4), torch.int32)
-        self.nbr = z((rows, N_ACT), torch.int32)
-        self.P = z((rows, N_ACT), torch.float32)
-        self.W = z((rows, N_ACT), torch.float32)
-        self.N = z((rows, N_ACT), torch.int32)
-        self.L = z((rows, N_ACT), torch.int16)
-        self.V = z((rows,), torch.float32)
-        self.leaf = z((rows,), torch.uint8)
-        self.hash = z((B, self.hash_size), torch.int32)
-        self.n_nodes, self.status = z((B,), torch.int32), z((B,), torch.int32)
-        self.solved_idx, self.solved_action = z((B,), torch.int32), z((B,), torch.int32)
-        self.iterations, self.path_len = z((B,), torch.int32), z((B,), torch.int32)
-        self.pending = z((B,), torch.int32)
-        self.path_node = z((B, max_path), torch.int32)
-        self.path_act = z((B, max_path), torch.uint8)
+        layout = {   # search state: zero-initialised, or adopted from another forest (`subset`)
+            "keys": ((rows, 4), torch.int32), "nbr": ((rows, N_ACT), torch.int32), "P": ((rows, N_ACT), torch.float32),
+            "W": ((rows, N_ACT), torch.float32), "N": ((rows, N_ACT), torch.int32), "L": ((rows, N_ACT), torch.int16),
+            "V": ((rows,), torch.float32), "leaf": ((rows,), torch.uint8), "hash": ((B, self.hash_size), torch.int32),
+            "n_nodes": ((B,), torch.int32), "status": ((B,), torch.int32), "solved_idx": ((B,), torch.int32),
+            "solved_action": ((B,), torch.int32), "iterations": ((B,), torch.int32), "path_len": ((B,), torch.int32),
+            "pending": ((B,), torch.int32), "path_node": ((B, max_path), torch.int32), "path_act": ((B, max_path), torch.uint8),
+        }
+        for name, (shape, dt) in layout.items():
+            if _state is not None:
+                t = _state[name]
+                assert tuple(t.shape) == shape and t.dtype == dt and t.is_contiguous(), name
+            else:
+                t = z(shape, dt)
+            setattr(self, name, t)
         self.children = DeviceCubes.empty(N_ACT * B, dev)
         self.child_idx = z((B, N_ACT), torch.int32)
         self.new_mask = z((B,), torch.int32)
@@ -102,6 +106,25 @@ class MCTSForest:
         self._oh = None
         self._graph = None
         self._graph_key = None
+
+    def subset(self, keep: torch.Tensor) -> "MCTSForest":
+        """
+        A new, smaller forest holding only the trees `keep` (int64 indices), with their complete search state
+        copied on the device.  Used to drop finished trees from a batch: the survivors continue exactly where
+        they were, on GEMMs of len(keep) x 12 rows instead of B x 12.
+        """
+        B, C1 = self.B, self.C + 1
+        state = {}
+        for name in _PER_NODE:
+            t = getattr(self, name)
+            state[name] = t.view(B, C1, *t.shape[1:])[keep].reshape(len(keep) * C1, *t.shape[1:]).contiguous()
+        state["hash"] = self.hash[keep].contiguous()
+        for name in _PER_TREE:
+            state[name] = getattr(self, name)[keep].contiguous()
+        sub = MCTSForest(len(keep), self.C, self.max_path, self.device, _state=state)
+        sub.level_budget = self.level_budget
+        sub.set_net(self.engine, self.engine.dtype if hasattr(self.engine, "dtype") else torch.bfloat16)
+        return sub
 
     def bytes_allocated(self) -> int:
         return sum(t.numel() * t.element_size() for t in (self.keys, self.nbr, self.P, self.W, self.N, self.L, self.V,

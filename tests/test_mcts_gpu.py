@@ -216,3 +216,22 @@ def test_fused_head_backup_matches_generic_path():
     assert torch.equal(a.V, b.V) and torch.equal(a.W, b.W) and torch.equal(a.N, b.N)
     assert torch.allclose(a.P, b.P, rtol=0, atol=1e-6)
     assert torch.equal(a.path_len, b.path_len)
+
+
+def test_compaction_is_invisible(net_gpu):
+    """Dropping finished trees from the batch (forest.subset) must not change any per-game result."""
+    from librubiks.solving.agents import MCTS
+    np.random.seed(13)
+    states = np.array([oc.scramble(1 + i % 10, True)[0] for i in range(600)])
+    res = {}
+    for compact in (False, True):
+        agent = MCTS(net_gpu, c=0.6, search_graph=True, net_dtype=torch.float32, sync_every=4)
+        res[compact] = agent.search_batch(states, None, 600, compact=compact)
+        if compact:
+            assert agent._last_forest.B < 600      # the batch really was compacted
+    a, b = res[False], res[True]
+    assert np.array_equal(a.solved, b.solved) and np.array_equal(a.nodes, b.nodes)
+    assert np.array_equal(a.lengths, b.lengths) and np.array_equal(a.iterations, b.iterations)
+    assert np.array_equal(a.status, b.status)
+    assert all(list(x) == list(y) for x, y in zip(a.queues, b.queues))
+    assert 0.2 < a.solved.mean() < 1.0
