@@ -107,7 +107,6 @@ class MCTS(DeepAgent):
         self.forest = None
         self._last_forest = None   # the forest the last search ended in (a compacted one after `compact`)
         self._tree = None      # host copy of tree 0, for the reference's inspectable attributes
-        self._engine = None
 
     @classmethod
     def from_saved(cls, loc: str, use_best: bool, c: float, search_graph: bool, **kwargs):
@@ -137,7 +136,7 @@ class MCTS(DeepAgent):
         One MCTS tree per row of `states` ((B,20) int8 NumPy array or DeviceCubes), all advanced in
         lock step.  `max_states` is the reference's per-tree cap (stop when len + 12 > max_states);
         `time_limit` bounds the wall time of the whole batch.
-        compact: whenever at most half of the trees are still running (and at least 128 remain), the
+        compact: whenever at most half of the trees of a forest of 256 or more are still running, the
         finished ones are harvested and the forest is compacted to the running trees, so the stragglers of a
         run to completion continue on small batches instead of paying full-size network calls.
         """
@@ -208,38 +207,6 @@ class MCTS(DeepAgent):
             queues.append(deque(q))
         lengths = np.array([len(q) if s else -1 for q, s in zip(queues, solved)])
         return BatchResult(solved, lengths, nodes, queues, seconds, forest.iterations.cpu().numpy(), status)
-
-    # ---- solved-tree post-processing (agents.py:597-633) ----------------------------------------
-    @staticmethod
-    def _shortened_queue(nbr: np.ndarray, solved_idx: int, fallback):
-        """_shorten_action_queue (agents.py:613-633): BFS over the completed graph from the root to the
-        solved node, level-synchronous but in the scan order of the reference's FIFO queue."""
-        if solved_idx == 1:
-            return fallback
-        n = len(nbr) - 1
-        parent = np.zeros(n + 1, dtype=np.int64)
-        via = np.zeros(n + 1, dtype=np.int64)
-        seen = np.zeros(n + 1, dtype=bool)
-        seen[0] = seen[1] = True
-        frontier = np.array([1])
-        while len(frontier):
-            cand = nbr[frontier].ravel()                       # frontier order, then action order
-            src = np.repeat(frontier, 12)
-            act = np.tile(np.arange(12), len(frontier))
-            keep = ~seen[cand]
-            cand, src, act = cand[keep], src[keep], act[keep]
-            _, first = np.unique(cand, return_index=True)      # the first discoverer becomes the parent
-            order = np.sort(first)
-            cand, src, act = cand[order], src[order], act[order]
-            parent[cand], via[cand], seen[cand] = src, act, True
-            if seen[solved_idx]:
-                q, v = [], solved_idx
-                while v != 1:
-                    q.append(int(via[v]))
-                    v = int(parent[v])
-                return q[::-1]
-            frontier = cand
-        return fallback
 
     # ---- the reference's single-state API ----------------------------------------------------------
     def search(self, state: np.ndarray, time_limit: float = None, max_states: int = None) -> bool:
