@@ -8,8 +8,8 @@ Workload (BASELINE.json configs[1]): 1 024 depth-20 scrambles per GPU (np.random
 reference's scramble stream), MCTS c = 0.6 with graph search, fc_small policy/value net with
 glorot weights from torch.manual_seed(0) (no trained weights exist offline), bf16 inference engine.
 A "step" is one lock-step MCTS iteration of every tree on the rank: expand 12 children per leaf
-(HIP), one-hot (HIP), network forward (PyTorch-ROCm / hipBLASLt MFMA), backup + PUCT descent (HIP),
-replayed as one HIP graph.  value = unique states inserted into the trees by all ranks during the K
+(HIP), input layer fused with the one-hot encoding (HIP), remaining network GEMMs (PyTorch-ROCm / hipBLASLt
+MFMA) on the NEW children only (11 packed rows per tree), backup + PUCT descent (HIP), replayed as one HIP graph.  value = unique states inserted into the trees by all ranks during the K
 timed steps / max-over-ranks wall time (inputs resident in HBM before the timed region).
 Ranks own disjoint scramble slices (weak scaling); the only collectives are the barrier, the
 max/sum reductions of the result and one all_gather of per-tree node counts.
@@ -115,19 +115,20 @@ def phase_times(forest, c, max_states, reps):
         ev[0].record()
         _hip.check(lib.rc_mcts_expand(m, max_states, st))
         ev[1].record()
+        cubes, rows = forest._net_input()
         if forest._fused:
-            x1 = forest.engine.first_layer(forest.children, forest._x1)
+            x1 = forest.engine.first_layer(cubes, forest._x1[:rows])
         else:
-            forest.children.as_oh(out=forest._oh)
+            cubes.as_oh(out=forest._oh[:rows])
         ev[2].record()
         if forest._fused:
             head = forest.engine._run(forest.engine.layers[1:], x1)
         else:
-            logits, values = forest.engine(forest._oh)
+            logits, values = forest.engine(forest._oh[:rows])
         ev[3].record()
         if not forest._fused:
-            torch.softmax(logits, dim=1, out=forest.probs)
-            forest.values.copy_(values)
+            torch.softmax(logits, dim=1, out=forest.probs[:rows])
+            forest.values[:rows].copy_(values)
         ev[4].record()
         if forest._fused:   # softmax + value extraction happen inside the backup kernel
             _hip.check(lib.rc_mcts_backup_head(m, head.data_ptr(), head.stride(0), int(head.dtype == torch.bfloat16), st))
@@ -279,7 +280,7 @@ def main():
     # ---- solve rate: the same scrambles searched to completion (untimed for `value`) -----------------------
     if args.solve_max_states:
         phases_early = phase_times(forest, c, max_states, args.phase_reps) if (args.phase_reps and rank == 0) else {}
-        rows_early, eng_early, fused_early = 12 * roots.n, forest.engine, forest._fused
+        rows_early, eng_early, fused_early = forest.rows_per_tree * roots.n, forest.engine, forest._fused
         del forest
         agent.forest = None
         torch.cuda.empty_cache()
@@ -302,7 +303,7 @@ def main():
     if args.solve_max_states:
         rows, phases, eng, fused = rows_early, phases_early, eng_early, fused_early
     else:
-        rows = 12 * roots.n
+        rows = forest.rows_per_tree * roots.n
         phases = phase_times(forest, c, max_states, args.phase_reps) if args.phase_reps else {}
         eng, fused = forest.engine, forest._fused
     peak = MFMA_BF16_PEAK_TFLOPS if args.dtype == "bf16" else MFMA_F32_PEAK_TFLOPS

@@ -161,6 +161,7 @@ typedef struct rc_mcts {
     uint32_t capacity;   /* largest node index per tree */
     uint32_t hash_size;  /* slots per tree, power of two, >= 2 * (capacity + 1) */
     uint32_t max_path;   /* descent buffer length per tree */
+    uint32_t rows_per_tree; /* network rows reserved per tree and iteration: 12, or 11 with packed rows (below) */
     /* per node, [B][capacity + 1] (x12 where noted) */
     void *keys;          /* uint32[4]: the 20 codes packed 5 bits each (6 codes per dword) */
     int32_t *nbr;        /* x12  neighbors   (agents.py:421) */
@@ -182,7 +183,10 @@ typedef struct rc_mcts {
     int32_t *path_node;  /* [B][max_path] indices_visited (agents.py:581,592) */
     uint8_t *path_act;   /* [B][max_path] actions_taken   (agents.py:582,593) */
     /* per iteration staging */
-    int8_t *child_soa;   /* [20][child_stride]: child k of tree t at column 12 t + k (network input) */
+    int8_t *child_soa;   /* [20][child_stride]: network input.  rows_per_tree = 12: child k of tree t at column 12 t + k.
+                          * rows_per_tree = 11: only the NEW children, packed in child order at columns 11 t + rank.  A
+                          * non-root leaf always has a known child (its parent), so 11 rows suffice for every
+                          * iteration but the root's own expansion, which must run with 12 */
     size_t child_stride;
     int32_t *child_idx;  /* [B][12] node index of every child of the expanded leaf */
     uint32_t *new_mask;  /* [B] bit k set iff child k was not in the tree before */

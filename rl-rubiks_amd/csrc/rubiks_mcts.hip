@@ -26,7 +26,7 @@ __global__ __launch_bounds__(kBlock) void k_mcts_init(rc_mcts_t m, const u8 *__r
         const u32 code = roots[(size_t)j * stride + t] & 31u;
         key_set(w, j, code);
         solved &= code == (u32)(u8)kTables.solved[j];
-        m.child_soa[(size_t)j * m.child_stride + (size_t)kA * t] = (int8_t)code;
+        m.child_soa[(size_t)j * m.child_stride + (size_t)m.rows_per_tree * t] = (int8_t)code;
     }
     const uint4 key = make_uint4(w[0], w[1], w[2], w[3]);
     const size_t base = (size_t)t * (m.capacity + 1);
@@ -52,8 +52,8 @@ __global__ __launch_bounds__(kBlock) void k_mcts_root_eval(rc_mcts_t m, const fl
     if (i >= m.n_trees * kA) return;
     const u32 t = i / kA, a = i - t * kA;
     const size_t node = (size_t)t * (m.capacity + 1) + 1;
-    m.P[node * kA + a] = probs[(size_t)t * kA * kA + a];
-    if (a == 0) m.V[node] = values[(size_t)t * kA];
+    m.P[node * kA + a] = probs[(size_t)t * m.rows_per_tree * kA + a];
+    if (a == 0) m.V[node] = values[(size_t)t * m.rows_per_tree];
 }
 
 // ---- expand: one wave per tree, lane k < 12 owns child k ----------------------------------------
@@ -88,7 +88,6 @@ __global__ __launch_bounds__(kWave) void k_mcts_expand(rc_mcts_t m, u32 max_stat
         const u32 code = lut[a * (2 * kCodePad) + (j >= kCorners ? kCodePad : 0) + key_code(pk, j)];
         key_set(w, j, code);
         solved &= code == (u32)(u8)kTables.solved[j];
-        if (act) m.child_soa[(size_t)j * m.child_stride + (size_t)kA * t + lane] = (int8_t)code;
     }
     const uint4 ck = make_uint4(w[0], w[1], w[2], w[3]);
 
@@ -107,6 +106,13 @@ __global__ __launch_bounds__(kWave) void k_mcts_expand(rc_mcts_t m, u32 max_stat
     const u64 newm = __ballot(act && found == 0);
     const int rank = __popcll(newm & ((1ull << lane) - 1ull));
     const int idx = found ? found : n + 1 + rank;
+    // network input: all 12 children at 12 t + k, or only the new ones packed at 11 t + rank
+    const bool packed = m.rows_per_tree != (u32)kA;
+    if (act && (!packed || (!found && rank < 11))) {   // (rank < 11 always holds for a non-root leaf: its parent is known)
+        const size_t col = (size_t)m.rows_per_tree * t + (packed ? (u32)rank : lane);
+#pragma unroll
+        for (int j = 0; j < kPlanes; ++j) m.child_soa[(size_t)j * m.child_stride + col] = (int8_t)key_code(ck, j);
+    }
     if (act && !found) {
         keys[idx] = ck;
         for (;;) {   // claim the first free slot from where the lookup stopped (siblings race here)
@@ -165,7 +171,9 @@ __global__ __launch_bounds__(kWave) void k_mcts_backup(rc_mcts_t m, const void *
     const u32 newm = m.new_mask[t];
     const bool is_new = act && ((newm >> lane) & 1u);
     const int idx = act ? m.child_idx[(size_t)t * kA + lane] : 0;
-    const size_t row = (size_t)t * kA + lane;   // this child's row in the network output
+    // this child's row in the network output: 12 t + k, or 11 t + (rank among the new children) with packed rows
+    const size_t row = (size_t)t * m.rows_per_tree +
+                       (m.rows_per_tree == (u32)kA ? lane : (u32)__popc(newm & ((1u << lane) - 1u)));
 
     float v = 0.f;
     if (is_new) {
@@ -494,7 +502,8 @@ static int check_mcts(const rc_mcts_t *m) {
     RC_REQUIRE(m->n_trees > 0 && m->capacity >= 13 && m->max_path >= 2 && m->max_path <= 2048, RC_ERR_RANGE);
     RC_REQUIRE((m->hash_size & (m->hash_size - 1)) == 0 && m->hash_size >= 2 * (m->capacity + 1), RC_ERR_RANGE);
     RC_REQUIRE(aligned16(m->keys) && aligned16(m->child_soa) && (m->child_stride & 15u) == 0, RC_ERR_ALIGN);
-    RC_REQUIRE(m->child_stride >= round_up((size_t)m->n_trees * kActions, 16), RC_ERR_STRIDE);
+    RC_REQUIRE(m->rows_per_tree == 11 || m->rows_per_tree == 12, RC_ERR_RANGE);
+    RC_REQUIRE(m->child_stride >= round_up((size_t)m->n_trees * m->rows_per_tree, 16), RC_ERR_STRIDE);
     return RC_OK;
 }
 
