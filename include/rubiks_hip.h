@@ -130,6 +130,14 @@ int rc_first_layer_bf16(const int8_t *soa, size_t n, size_t stride, const uint16
 int rc_first_layer_mfma_bf16(const int8_t *soa, size_t n, size_t stride, const uint16_t *w1, const float *bias,
                              uint16_t *out, size_t H, int activation, float alpha, rc_stream_t stream);
 
+/* ---- network head: last activation + skinny output layer in one pass -----------------------------------------
+ * out[i][o] = bias[o] + sum_k w[o][k] * act(x[i][k])   for o < n_out <= 16   (float out, row pitch 16)
+ * Replaces the final activation pass and the 1024 -> 13 GEMM of the merged policy/value heads
+ * (librubiks/model.py:124-129,150-159): the 2 KB activation row is read once, the weights live in registers.
+ *   x: bf16 [n][K] raw pre-activations (bias already added), K = 1024;  w: bf16 [n_out][K];  bias: float[n_out]. */
+int rc_head_bf16(const uint16_t *x, size_t n, size_t K, const uint16_t *w, const float *bias, size_t n_out,
+                 float *out, int activation, float alpha, rc_stream_t stream);
+
 /* ---- Autodidactic-iteration targets (librubiks/train.py:292-325) ----------------------------------
  * For state i with children 12 i .. 12 i + 11 (rc_expand12 order):
  *   q[k]   = values[12 i + k] + (child_solved[12 i + k] ? win_reward : -1)

@@ -272,6 +272,54 @@ __global__ __launch_bounds__(kMfWaves * kWave) void k_first_layer_mfma(const u8 
     }
 }
 
+// =================================================================================================
+// Network head: out = W_head * act(x) + b for a skinny output layer (13 outputs), one wave per row.
+// A lane owns 16 of the 1024 inputs of a row (two 16-byte loads) and keeps its 16 x n_out weights in
+// registers for all the rows its wave processes; the n_out partial sums are reduced across the wave with
+// DPP row reductions + two cross-row steps.
+// =================================================================================================
+constexpr int kHeadK = 1024, kHeadEpl = kHeadK / kWave, kHeadMaxOut = 16;
+
+template <int ACT, int NOUT>
+__global__ __launch_bounds__(kBlock) void k_head(const uint4 *__restrict__ x, size_t n, const u16 *__restrict__ w,
+                                                 const float *__restrict__ bias, float *__restrict__ out, float alpha) {
+    const u32 lane = threadIdx.x & (kWave - 1);
+    const size_t wave = ((size_t)blockIdx.x * kBlock + threadIdx.x) / kWave, n_waves = (size_t)gridDim.x * kBlock / kWave;
+    // this lane's weights: inputs 16 lane .. 16 lane + 15 of every output
+    float wt[NOUT][kHeadEpl];
+#pragma unroll
+    for (int o = 0; o < NOUT; ++o)
+#pragma unroll
+        for (int e = 0; e < kHeadEpl; ++e) wt[o][e] = __uint_as_float((u32)w[(size_t)o * kHeadK + lane * kHeadEpl + e] << 16);
+    float bo = (lane < NOUT) ? bias[lane] : 0.f;
+    for (size_t row = wave; row < n; row += n_waves) {
+        const uint4 a = x[row * (kHeadK / 8) + 2 * lane], b = x[row * (kHeadK / 8) + 2 * lane + 1];
+        const u32 xw[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
+        float xv[kHeadEpl];
+#pragma unroll
+        for (int d = 0; d < 8; ++d) {
+            xv[2 * d] = act_apply(__uint_as_float(xw[d] << 16), ACT, alpha);
+            xv[2 * d + 1] = act_apply(__uint_as_float(xw[d] & 0xffff0000u), ACT, alpha);
+        }
+        float mine = 0.f;   // lane o ends up holding output o
+#pragma unroll
+        for (int o = 0; o < NOUT; ++o) {
+            float s = 0.f;
+#pragma unroll
+            for (int e = 0; e < kHeadEpl; ++e) s += wt[o][e] * xv[e];
+            // sum over the 64 lanes: within each 16-lane row by DPP, then across the four rows
+            s += dpp_float<kDppXor1>(s);
+            s += dpp_float<kDppXor2>(s);
+            s += dpp_float<kDppHalfMirror>(s);
+            s += dpp_float<kDppMirror>(s);
+            s += __shfl_xor(s, 16);
+            s += __shfl_xor(s, 32);
+            if ((int)lane == o) mine = s;
+        }
+        if (lane < kHeadMaxOut) out[row * kHeadMaxOut + lane] = (lane < NOUT) ? mine + bo : 0.f;
+    }
+}
+
 // ADI targets: 12-way segmented argmax of value + reward, with the goal-state fixes (train.py:292-325).
 __global__ __launch_bounds__(kBlock) void k_adi_targets(const float *__restrict__ values, const u8 *__restrict__ child_solved,
                                                         const u8 *__restrict__ state_solved, size_t n, size_t depth,
@@ -326,6 +374,23 @@ extern "C" int rc_first_layer_mfma_bf16(const int8_t *soa, size_t n, size_t stri
     else if (activation == RC_ACT_RELU) RC_LAUNCH_MF(RC_ACT_RELU);
     else RC_LAUNCH_MF(RC_ACT_NONE);
 #undef RC_LAUNCH_MF
+    return launch_status();
+}
+
+extern "C" int rc_head_bf16(const uint16_t *x, size_t n, size_t K, const uint16_t *w, const float *bias, size_t n_out,
+                            float *out, int activation, float alpha, rc_stream_t stream) {
+    if (n == 0) return RC_OK;
+    RC_REQUIRE(x && w && bias && out, RC_ERR_NULL);
+    RC_REQUIRE(aligned16(x) && aligned16(out), RC_ERR_ALIGN);
+    RC_REQUIRE(K == (size_t)kHeadK && n_out == 13 && activation >= RC_ACT_NONE && activation <= RC_ACT_ELU, RC_ERR_RANGE);
+    const unsigned grid = (unsigned)(ceil_div(n, kBlock / kWave) < 2048 ? ceil_div(n, kBlock / kWave) : 2048);
+    hipStream_t s = (hipStream_t)stream;
+    if (activation == RC_ACT_ELU)
+        hipLaunchKernelGGL((k_head<RC_ACT_ELU, 13>), dim3(grid), dim3(kBlock), 0, s, (const uint4 *)x, n, w, bias, out, alpha);
+    else if (activation == RC_ACT_RELU)
+        hipLaunchKernelGGL((k_head<RC_ACT_RELU, 13>), dim3(grid), dim3(kBlock), 0, s, (const uint4 *)x, n, w, bias, out, alpha);
+    else
+        hipLaunchKernelGGL((k_head<RC_ACT_NONE, 13>), dim3(grid), dim3(kBlock), 0, s, (const uint4 *)x, n, w, bias, out, alpha);
     return launch_status();
 }
 

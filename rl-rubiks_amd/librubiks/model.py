@@ -290,10 +290,35 @@ class InferenceNet:
                                                   _hip.stream_ptr()), "rc_first_layer_bf16")
         return out
 
+    def _fused_head_ok(self) -> bool:
+        """rc_head_bf16 applies the last hidden activation and the 1024 -> 13 output layer in one pass."""
+        W_out, _, act_out = self.layers[-1]
+        return (self.dtype == torch.bfloat16 and len(self.layers) >= 3 and act_out is None
+                and tuple(W_out.shape) == (N_ACTIONS + 1, 1024) and self.layers[-2][2] is not None and W_out.is_cuda)
+
     @torch.no_grad()
     def head_cubes(self, cubes, x1: torch.Tensor = None) -> torch.Tensor:
-        """Raw output of the merged head GEMM, [n, 13] in the engine's dtype: 12 policy logits, then the value."""
-        return self._run(self.layers[1:], self.first_layer(cubes, x1))
+        """
+        Output of the merged heads per row: 12 policy logits, then the value.  [n, 16] float32 when the fused head
+        kernel applies (last ELU + output layer in one pass over the raw 1024-wide activations), else the head
+        GEMM's [n, 13] tensor in the engine's dtype.
+        """
+        x = self.first_layer(cubes, x1)
+        if not self._fused_head_ok():
+            return self._run(self.layers[1:], x)
+        from librubiks import _hip
+        x = self._run(self.layers[1:-2], x)
+        W3, b3, act3 = self.layers[-2]
+        raw = torch.addmm(b3, x, W3.t())                      # pre-activation of the last hidden layer
+        W4, b4, _ = self.layers[-1]
+        if getattr(self, "_b4_f32", None) is None:
+            self._b4_f32 = b4.float().contiguous()
+        out = torch.empty((raw.shape[0], 16), dtype=torch.float32, device=raw.device)
+        code = 1 if isinstance(act3, nn.ReLU) else 2
+        _hip.check(_hip.lib().rc_head_bf16(raw.data_ptr(), raw.shape[0], raw.shape[1], W4.data_ptr(), self._b4_f32.data_ptr(),
+                                           N_ACTIONS + 1, out.data_ptr(), code, float(getattr(act3, "alpha", 1.0)),
+                                           _hip.stream_ptr()), "rc_head_bf16")
+        return out
 
     @torch.no_grad()
     def forward_cubes(self, cubes, x1: torch.Tensor = None):

@@ -94,3 +94,30 @@ def test_first_layer_argument_errors():
     assert lib.rc_first_layer_bf16(*args, 128, 7, 1.0, 0, None) == -4    # unknown activation
     assert lib.rc_first_layer_bf16(*args, 128, 2, 1.0, 0, None) == 0
     assert lib.rc_first_layer_bf16(*args, 128, 1, 1.0, 1, None) == 0
+
+
+@pytest.mark.parametrize("n", [1, 5, 1000, 11264])
+def test_fused_head_matches_gemm_path(n):
+    """
+    rc_head_bf16 (last ELU + 1024 -> 13 layer in fp32 from the raw bf16 activations) vs the ELU pass + head GEMM it
+    replaces.  The GEMM path rounds the activations to bf16 before the last layer, the kernel does not: the two
+    agree within 3e-2 absolute on O(1) logits / values, and the kernel is the one closer to an fp32 evaluation.
+    """
+    from librubiks.cube import DeviceCubes
+    from librubiks.model import InferenceNet
+    m = _model()
+    eng = InferenceNet(m, dtype=torch.bfloat16)
+    assert eng._fused_head_ok()
+    cubes = DeviceCubes.from_numpy(_states(n, seed=n + 3))
+    head = eng.head_cubes(cubes)
+    assert head.shape == (n, 16) and head.dtype == torch.float32
+    ref = eng._run(eng.layers[1:], eng.first_layer(cubes)).float()
+    assert torch.allclose(head[:, :13], ref, atol=3e-2)
+    assert (head[:, 13:] == 0).all()
+    # fp32 evaluation of the same last two layers from the same bf16 input of the last hidden layer
+    x = eng._run(eng.layers[1:-2], eng.first_layer(cubes)).float()
+    W3, b3, _ = eng.layers[-2]
+    W4, b4, _ = eng.layers[-1]
+    raw = (x @ W3.float().t() + b3.float()).to(torch.bfloat16).float()
+    exact = torch.nn.functional.elu(raw) @ W4.float().t() + b4.float()
+    assert float((head[:, :13] - exact).abs().max()) <= float((ref - exact).abs().max()) + 1e-3
