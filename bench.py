@@ -121,10 +121,20 @@ def phase_times(forest, c, max_states, reps):
         else:
             cubes.as_oh(out=forest._oh[:rows])
         ev[2].record()
-        if forest._fused:
-            head = forest.engine._run(forest.engine.layers[1:], x1)
+        if forest._fused:   # same calls as MCTSForest._iteration -> InferenceNet.head_cubes, split at the input layer
+            eng = forest.engine
+            if eng._fused_head_ok():
+                x = eng._run(eng.layers[1:-2], x1)
+                raw = torch.addmm(eng.layers[-2][1], x, eng.layers[-2][0].t())
+                ev_h = torch.cuda.Event(enable_timing=True)
+                ev_h.record()
+                head = eng.head_from_raw(raw)
+            else:
+                head = eng._run(eng.layers[1:], x1)
+                ev_h = None
         else:
             logits, values = forest.engine(forest._oh[:rows])
+            ev_h = None
         ev[3].record()
         if not forest._fused:
             torch.softmax(logits, dim=1, out=forest.probs[:rows])
@@ -140,6 +150,8 @@ def phase_times(forest, c, max_states, reps):
         torch.cuda.synchronize()
         for i, k in enumerate(names):
             acc[k] += ev[i].elapsed_time(ev[i + 1])
+        if ev_h is not None:
+            acc["head_kernel"] = acc.get("head_kernel", 0.0) + ev_h.elapsed_time(ev[3])
     return {k: round(v / reps, 4) for k, v in acc.items()}
 
 

@@ -273,50 +273,49 @@ __global__ __launch_bounds__(kMfWaves * kWave) void k_first_layer_mfma(const u8 
 }
 
 // =================================================================================================
-// Network head: out = W_head * act(x) + b for a skinny output layer (13 outputs), one wave per row.
-// A lane owns 16 of the 1024 inputs of a row (two 16-byte loads) and keeps its 16 x n_out weights in
-// registers for all the rows its wave processes; the n_out partial sums are reduced across the wave with
-// DPP row reductions + two cross-row steps.
+// Network head: out = W_head * act(x) + b for a skinny output layer (13 outputs of 1024 inputs).
+// One wave per 16 rows on the matrix cores: 32 k-steps of v_mfma_f32_16x16x32_bf16.
+//   A (16 rows x 32 k): lane l (r = l & 15, g = l >> 4) loads x[row r][32 ks + 8 g .. +7] (16 bytes), applies the
+//     activation in fp32 and repacks to bf16 -- the last hidden layer's ELU costs no pass over memory.
+//   B (32 k x 16 outputs): W_head[o = l & 15][32 ks + 8 g .. +7]; all 32 fragments of a lane (outputs >= 13 are zero)
+//     are loaded once and stay in registers for every tile the wave processes.
+//   D: lane holds output l & 15 of rows 4 g .. 4 g + 3.
 // =================================================================================================
-constexpr int kHeadK = 1024, kHeadEpl = kHeadK / kWave, kHeadMaxOut = 16;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+constexpr int kHeadK = 1024, kHeadSteps = kHeadK / 32, kHeadMaxOut = 16;
 
-template <int ACT, int NOUT>
-__global__ __launch_bounds__(kBlock) void k_head(const uint4 *__restrict__ x, size_t n, const u16 *__restrict__ w,
-                                                 const float *__restrict__ bias, float *__restrict__ out, float alpha) {
-    const u32 lane = threadIdx.x & (kWave - 1);
+template <int ACT>
+__global__ __launch_bounds__(kBlock) void k_head(const uint4 *__restrict__ x, size_t n, const uint4 *__restrict__ w,
+                                                 const float *__restrict__ bias, float *__restrict__ out, u32 n_out, float alpha) {
+    const u32 lane = threadIdx.x & (kWave - 1), r = lane & 15, g = lane >> 4;
     const size_t wave = ((size_t)blockIdx.x * kBlock + threadIdx.x) / kWave, n_waves = (size_t)gridDim.x * kBlock / kWave;
-    // this lane's weights: inputs 16 lane .. 16 lane + 15 of every output
-    float wt[NOUT][kHeadEpl];
+    uint4 bfrag[kHeadSteps];
 #pragma unroll
-    for (int o = 0; o < NOUT; ++o)
+    for (int ks = 0; ks < kHeadSteps; ++ks)
+        bfrag[ks] = (r < n_out) ? w[(size_t)r * (kHeadK / 8) + ks * 4 + g] : make_uint4(0, 0, 0, 0);
+    const float bo = (r < n_out) ? bias[r] : 0.f;
+    const size_t n_tiles = ceil_div(n, (size_t)16);
+    for (size_t tile = wave; tile < n_tiles; tile += n_waves) {
+        const size_t row = tile * 16 + r;
+        const uint4 *xr = x + (row < n ? row : n - 1) * (kHeadK / 8) + g;   // rows past the end: clamped, never stored
+        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-        for (int e = 0; e < kHeadEpl; ++e) wt[o][e] = __uint_as_float((u32)w[(size_t)o * kHeadK + lane * kHeadEpl + e] << 16);
-    float bo = (lane < NOUT) ? bias[lane] : 0.f;
-    for (size_t row = wave; row < n; row += n_waves) {
-        const uint4 a = x[row * (kHeadK / 8) + 2 * lane], b = x[row * (kHeadK / 8) + 2 * lane + 1];
-        const u32 xw[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
-        float xv[kHeadEpl];
+        for (int ks = 0; ks < kHeadSteps; ++ks) {
+            const uint4 a = xr[ks * 4];
+            const u32 aw[4] = {a.x, a.y, a.z, a.w};
+            u32 pk[4];
 #pragma unroll
-        for (int d = 0; d < 8; ++d) {
-            xv[2 * d] = act_apply(__uint_as_float(xw[d] << 16), ACT, alpha);
-            xv[2 * d + 1] = act_apply(__uint_as_float(xw[d] & 0xffff0000u), ACT, alpha);
+            for (int d = 0; d < 4; ++d)
+                pk[d] = pack_bf16(act_apply(__uint_as_float(aw[d] << 16), ACT, alpha),
+                                  act_apply(__uint_as_float(aw[d] & 0xffff0000u), ACT, alpha));
+            acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, make_uint4(pk[0], pk[1], pk[2], pk[3])),
+                                                          __builtin_bit_cast(bf16x8, bfrag[ks]), acc, 0, 0, 0);
         }
-        float mine = 0.f;   // lane o ends up holding output o
 #pragma unroll
-        for (int o = 0; o < NOUT; ++o) {
-            float s = 0.f;
-#pragma unroll
-            for (int e = 0; e < kHeadEpl; ++e) s += wt[o][e] * xv[e];
-            // sum over the 64 lanes: within each 16-lane row by DPP, then across the four rows
-            s += dpp_float<kDppXor1>(s);
-            s += dpp_float<kDppXor2>(s);
-            s += dpp_float<kDppHalfMirror>(s);
-            s += dpp_float<kDppMirror>(s);
-            s += __shfl_xor(s, 16);
-            s += __shfl_xor(s, 32);
-            if ((int)lane == o) mine = s;
+        for (int i = 0; i < 4; ++i) {
+            const size_t orow = tile * 16 + g * 4 + i;
+            if (orow < n) out[orow * kHeadMaxOut + r] = (r < n_out) ? acc[i] + bo : 0.f;
         }
-        if (lane < kHeadMaxOut) out[row * kHeadMaxOut + lane] = (lane < NOUT) ? mine + bo : 0.f;
     }
 }
 
@@ -381,16 +380,22 @@ extern "C" int rc_head_bf16(const uint16_t *x, size_t n, size_t K, const uint16_
                             float *out, int activation, float alpha, rc_stream_t stream) {
     if (n == 0) return RC_OK;
     RC_REQUIRE(x && w && bias && out, RC_ERR_NULL);
-    RC_REQUIRE(aligned16(x) && aligned16(out), RC_ERR_ALIGN);
-    RC_REQUIRE(K == (size_t)kHeadK && n_out == 13 && activation >= RC_ACT_NONE && activation <= RC_ACT_ELU, RC_ERR_RANGE);
-    const unsigned grid = (unsigned)(ceil_div(n, kBlock / kWave) < 2048 ? ceil_div(n, kBlock / kWave) : 2048);
+    RC_REQUIRE(aligned16(x) && aligned16(out) && aligned16(w), RC_ERR_ALIGN);
+    RC_REQUIRE(K == (size_t)kHeadK && n_out >= 1 && n_out <= kHeadMaxOut && activation >= RC_ACT_NONE &&
+                   activation <= RC_ACT_ELU, RC_ERR_RANGE);
+    // persistent waves (the weight fragments are loaded once per wave): one 16-row tile per wave up to 2 waves per SIMD
+    const size_t tiles = ceil_div(n, (size_t)16);
+    const unsigned grid = (unsigned)(ceil_div(tiles, (size_t)(kBlock / kWave)) < 512 ? ceil_div(tiles, (size_t)(kBlock / kWave)) : 512);
     hipStream_t s = (hipStream_t)stream;
     if (activation == RC_ACT_ELU)
-        hipLaunchKernelGGL((k_head<RC_ACT_ELU, 13>), dim3(grid), dim3(kBlock), 0, s, (const uint4 *)x, n, w, bias, out, alpha);
+        hipLaunchKernelGGL(k_head<RC_ACT_ELU>, dim3(grid), dim3(kBlock), 0, s, (const uint4 *)x, n, (const uint4 *)w, bias, out,
+                           (u32)n_out, alpha);
     else if (activation == RC_ACT_RELU)
-        hipLaunchKernelGGL((k_head<RC_ACT_RELU, 13>), dim3(grid), dim3(kBlock), 0, s, (const uint4 *)x, n, w, bias, out, alpha);
+        hipLaunchKernelGGL(k_head<RC_ACT_RELU>, dim3(grid), dim3(kBlock), 0, s, (const uint4 *)x, n, (const uint4 *)w, bias, out,
+                           (u32)n_out, alpha);
     else
-        hipLaunchKernelGGL((k_head<RC_ACT_NONE, 13>), dim3(grid), dim3(kBlock), 0, s, (const uint4 *)x, n, w, bias, out, alpha);
+        hipLaunchKernelGGL(k_head<RC_ACT_NONE>, dim3(grid), dim3(kBlock), 0, s, (const uint4 *)x, n, (const uint4 *)w, bias, out,
+                           (u32)n_out, alpha);
     return launch_status();
 }
 

@@ -306,10 +306,14 @@ class InferenceNet:
         x = self.first_layer(cubes, x1)
         if not self._fused_head_ok():
             return self._run(self.layers[1:], x)
-        from librubiks import _hip
         x = self._run(self.layers[1:-2], x)
-        W3, b3, act3 = self.layers[-2]
-        raw = torch.addmm(b3, x, W3.t())                      # pre-activation of the last hidden layer
+        W3, b3, _ = self.layers[-2]
+        return self.head_from_raw(torch.addmm(b3, x, W3.t()))   # pre-activation of the last hidden layer
+
+    @torch.no_grad()
+    def head_from_raw(self, raw: torch.Tensor) -> torch.Tensor:
+        from librubiks import _hip
+        act3 = self.layers[-2][2]
         W4, b4, _ = self.layers[-1]
         if getattr(self, "_b4_f32", None) is None:
             self._b4_f32 = b4.float().contiguous()
