@@ -168,7 +168,7 @@ typedef struct rc_mcts {
     uint32_t n_trees;    /* B */
     uint32_t capacity;   /* largest node index per tree */
     uint32_t hash_size;  /* slots per tree, power of two, >= 2 * (capacity + 1) */
-    uint32_t max_path;   /* descent buffer length per tree */
+    uint32_t max_path;   /* descent buffer length per tree (2 .. 4096) */
     uint32_t rows_per_tree; /* network rows reserved per tree and iteration: 12, or 11 with packed rows (below) */
     /* per node, [B][capacity + 1] (x12 where noted) */
     void *keys;          /* uint32[4]: the 20 codes packed 5 bits each (6 codes per dword) */

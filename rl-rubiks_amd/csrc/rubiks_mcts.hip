@@ -14,6 +14,7 @@
 namespace rubiks {
 
 constexpr int kA = kActions;   // 12
+constexpr int kMaxPath = 4096;  // longest PUCT descent the kernels stage in LDS (20 KiB per workgroup in select)
 
 // ---- init: root = node 1 ------------------------------------------------------------------------
 __global__ __launch_bounds__(kBlock) void k_mcts_init(rc_mcts_t m, const u8 *__restrict__ roots, size_t stride) {
@@ -257,8 +258,8 @@ __device__ __forceinline__ void l_count_add(u16 *L, size_t e) {
 // network that tail is typically one or two levels instead of ~100.
 __global__ __launch_bounds__(kBlock) void k_mcts_select(rc_mcts_t m, double c, u32 level_budget) {
     __shared__ int s_first;                 // first level that has to be walked sequentially
-    __shared__ int s_node[2048];            // the old path (max_path <= 2048)
-    __shared__ u8 s_act[2048];
+    __shared__ int s_node[kMaxPath];        // the old path
+    __shared__ u8 s_act[kMaxPath];
     __shared__ u32 s_cnt[kBlock / 16][16];  // per level slot: virtual-loss count of each edge
     const u32 t = blockIdx.x, tid = threadIdx.x;
     if (m.status[t] != RC_MCTS_RUNNING) return;
@@ -499,7 +500,7 @@ static int check_mcts(const rc_mcts_t *m) {
                    m->status && m->solved_idx && m->solved_action && m->iterations && m->path_len && m->path_node &&
                    m->pending && m->path_act && m->child_soa && m->child_idx && m->new_mask && m->expanded,
                RC_ERR_NULL);
-    RC_REQUIRE(m->n_trees > 0 && m->capacity >= 13 && m->max_path >= 2 && m->max_path <= 2048, RC_ERR_RANGE);
+    RC_REQUIRE(m->n_trees > 0 && m->capacity >= 13 && m->max_path >= 2 && m->max_path <= (uint32_t)kMaxPath, RC_ERR_RANGE);
     RC_REQUIRE((m->hash_size & (m->hash_size - 1)) == 0 && m->hash_size >= 2 * (m->capacity + 1), RC_ERR_RANGE);
     RC_REQUIRE(aligned16(m->keys) && aligned16(m->child_soa) && (m->child_stride & 15u) == 0, RC_ERR_ALIGN);
     RC_REQUIRE(m->rows_per_tree == 11 || m->rows_per_tree == 12, RC_ERR_RANGE);

@@ -91,8 +91,12 @@ class MCTS(DeepAgent):
     nu = 100
 
     def __init__(self, net, c: float, search_graph: bool, net_dtype=torch.bfloat16, use_graph: bool = True,
-                 max_path: int = 1024, sync_every: int = 16, level_budget="auto"):
+                 max_path: int = 4096, sync_every: int = 16, level_budget="auto"):
         """
+        max_path: longest PUCT descent a tree may make (the reference has no limit; a tree that would exceed it
+        ends unsolved with status PATH_OVERFLOW).  With the ADI-trained net, 39 of 1 024 depth-20 trees needed
+        more than 1 024 levels and none more than 2 048 (longest solution found: 804 moves); 4 096 is the
+        maximum the select kernel stages in LDS.
         level_budget: how many NEW tree levels a PUCT descent may walk per lock-step iteration before it is
         suspended until the next one (0 = unlimited).  Every tree still performs exactly the reference's
         sequence of iterations; a budget only stops the deepest descent of the batch from pacing all trees.

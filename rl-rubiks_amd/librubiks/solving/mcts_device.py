@@ -59,11 +59,11 @@ _PER_TREE = ("n_nodes", "status", "solved_idx", "solved_action", "iterations", "
 
 
 class MCTSForest:
-    def __init__(self, n_trees: int, capacity: int, max_path: int = 1024, device=None, _state: dict = None):
+    def __init__(self, n_trees: int, capacity: int, max_path: int = 4096, device=None, _state: dict = None):
         self.lib = _hip.lib()
         dev = device or torch.device("cuda", torch.cuda.current_device())
         B, C = int(n_trees), int(capacity)
-        assert B > 0 and C >= 13 and 2 <= max_path <= 2048
+        assert B > 0 and C >= 13 and 2 <= max_path <= 4096
         self.B, self.C, self.max_path, self.device = B, C, max_path, dev
         self.hash_size = 1 << int(np.ceil(np.log2(2 * (C + 1))))
         z = lambda shape, dt: torch.zeros(shape, dtype=dt, device=dev)   # noqa: E731
