@@ -301,6 +301,49 @@ int rc_astar_gather_new(const rc_astar_t *a, const int32_t *new_offset, int8_t *
 int rc_astar_push_relax(const rc_astar_t *a, const int32_t *new_offset, const float *values, double lambda,
                         rc_stream_t stream);
 
+/* ---- breadth-first search (one problem per call sequence, GPU-wide levels) -----------------------
+ *
+ * Replaces the FIFO loop of librubiks/solving/agents.py:92-131 (class BFS) with level-synchronous
+ * chunks that keep its bookkeeping exactly: nodes are numbered in discovery order (node 0 = the
+ * start state), child row 12 p + k = action k on the p-th parent of the chunk, a row is new iff its
+ * state is neither stored nor produced by a lower row, the first solved row ends the search, and
+ * the `len(self) < max_states` test before each pop (agents.py:105) becomes the "cutoff parent".
+ * Per chunk:  rc_bfs_expand -> [host reads result[0..4]] -> rc_bfs_commit (if neither solved nor cut).
+ * Device pointers; nothing needs initialising except through rc_bfs_init.
+ */
+typedef struct rc_bfs {
+    uint32_t capacity;   /* node slots; rc_bfs_expand needs n_nodes + 12 * n_parents <= capacity */
+    uint32_t hash_size;  /* power of two, >= 2 * capacity */
+    uint32_t chunk;      /* most parents per rc_bfs_expand */
+    uint32_t reserved;
+    void *keys;          /* uint32[4] packed state per node (as rc_mcts) */
+    uint32_t *parent;    /* agents.py:102,119: the state a node was reached from ... */
+    uint8_t *action;     /* ... and the action taken */
+    int32_t *hash;       /* [hash_size]: > 0 node index + 1, < 0 pending row -(row+1), 0 empty */
+    void *child_keys;    /* uint32[4] per row, [12 * chunk] */
+    int32_t *child_slot; /* [12 * chunk] */
+    uint32_t *flags;     /* [12 * chunk] 1 = new state */
+    uint32_t *prefix;    /* [12 * chunk] exclusive prefix sum of flags */
+    uint64_t *result;    /* [5]: first solved row (or ~0), new rows, cutoff parent (n_parents = none),
+                            new rows before the solved row, new rows before the cutoff parent */
+    void *scan_tmp;      /* rc_bfs_scan_bytes(chunk) bytes */
+    size_t scan_tmp_bytes;
+} rc_bfs_t;
+
+size_t rc_bfs_scan_bytes(uint32_t chunk);
+/* Clears the table and stores root_state (int8[20], device) as node 0.  result[0] = 0 if it is solved
+ * (agents.py:100), ~0 otherwise. */
+int rc_bfs_init(const rc_bfs_t *b, const int8_t *root_state, rc_stream_t stream);
+/* Expands parents lo .. lo + n_parents - 1 with n_nodes states stored so far; fills result. */
+int rc_bfs_expand(const rc_bfs_t *b, uint32_t lo, uint32_t n_parents, uint32_t n_nodes, uint32_t max_states,
+                  rc_stream_t stream);
+/* Appends the new states of the last rc_bfs_expand (same lo, n_parents, n_nodes) in row order. */
+int rc_bfs_commit(const rc_bfs_t *b, uint32_t lo, uint32_t n_parents, uint32_t n_nodes, rc_stream_t stream);
+/* Actions from the start state to `node`, last action first (agents.py:112-115); *out_len = ~0 if
+ * the chain is longer than max_len. */
+int rc_bfs_path(const rc_bfs_t *b, uint32_t node, uint8_t *out_actions, uint32_t *out_len, uint32_t max_len,
+                rc_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

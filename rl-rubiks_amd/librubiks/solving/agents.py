@@ -19,10 +19,12 @@ from librubiks import cube, gpu, no_grad
 from librubiks.cube.device import DeviceCubes
 from librubiks.model import Model
 from librubiks.solving import astar_device as ad
+from librubiks.solving import bfs_device as bd
 from librubiks.solving import mcts_device as md
 from librubiks.utils import TickTock
 
 DEFAULT_NODE_CAP = 1 << 18   # per-tree node capacity when a search is bounded by time only
+bd_MAX_STATES = 1 << 26      # BFS bounded by time only: node slots for 2^26 states (~4 GB)
 
 
 class Agent:
@@ -83,6 +85,56 @@ class BatchResult:
             for o, q in zip(owner, r.queues):
                 queues[int(o)] = q
         return BatchResult(solved, lengths, nodes, queues, seconds, iters, status)
+
+
+class BFS(Agent):
+    """
+    Breadth-first search (reference agents.py:92-131) with whole levels expanded on the GPU; solution,
+    `len(agent)` and the stop rule are those of the reference's FIFO loop (csrc/rubiks_bfs.hip).
+    `time_limit` is tested between launch sequences instead of before every pop.
+    """
+
+    def __init__(self, chunk: int = None):
+        super().__init__()
+        self.chunk = chunk
+        self._dev = None
+
+    def _device_for(self, max_states: int) -> bd.BFSDevice:
+        cap = int(min(max_states, bd_MAX_STATES))
+        if self._dev is None or self._dev.max_states < cap:
+            self._dev = None   # frees the old buffers first
+            self._dev = bd.BFSDevice(cap, self.chunk)
+        return self._dev
+
+    def search(self, state: np.ndarray, time_limit: float = None, max_states: int = None) -> bool:
+        time_limit, max_states = self.reset(time_limit, max_states)
+        self.tt.tick()
+        dev = self._device_for(max_states)
+        deadline = (lambda: self.tt.tock() >= time_limit) if time_limit < 1e10 else None
+        solved, actions, seen = dev.search(np.asarray(state), int(min(max_states, dev.max_states)), deadline)
+        self._explored_states = seen
+        self.action_queue = deque(actions)
+        return solved
+
+    def search_batch(self, states, time_limit: float = None, max_states: int = None) -> BatchResult:
+        """One search after the other (each one fills the GPU by itself); same result layout as the deep agents."""
+        states = states.numpy() if isinstance(states, DeviceCubes) else np.asarray(states)
+        B = len(states)
+        solved, lengths, nodes = np.zeros(B, dtype=bool), np.full(B, -1, dtype=np.int64), np.zeros(B, dtype=np.int64)
+        queues, levels = [], np.zeros(B, dtype=np.int64)
+        tt = TickTock()
+        tt.tick()
+        for g in range(B):
+            solved[g] = self.search(states[g], time_limit, max_states)
+            queues.append(self.action_queue)
+            nodes[g], levels[g] = len(self), self._dev.levels
+            if solved[g]:
+                lengths[g] = len(self.action_queue)
+        status = np.where(solved, np.where(nodes == 0, 4, 1), 2)
+        return BatchResult(solved, lengths, nodes, queues, tt.tock(), levels, status)
+
+    def __str__(self):
+        return "Breadth-first search"
 
 
 class MCTS(DeepAgent):
