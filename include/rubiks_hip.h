@@ -199,11 +199,16 @@ typedef struct rc_mcts {
     int32_t *child_idx;  /* [B][12] node index of every child of the expanded leaf */
     uint32_t *new_mask;  /* [B] bit k set iff child k was not in the tree before */
     uint8_t *expanded;   /* [B] 1 iff the tree expanded a leaf in the current iteration */
-    int32_t *select_stats; /* optional (may be NULL): [B][2] = first sequentially walked level, new path length */
+    int32_t *select_stats; /* optional (may be NULL): [B][8] = first sequentially walked level, new path length,
+                              10-ns ticks spent re-validating the old path, ticks and shader cycles spent in the
+                              sequential walk, levels decided in float64, levels whose hint was wrong, 1 spare */
     /* optional, only needed by rc_mcts_shorten (may be NULL otherwise) */
     int32_t *bfs;        /* [B][capacity + 1][2] scratch: {claim, parent << 4 | action} */
     uint8_t *short_act;  /* [B][max_path] shortened action queue of every solved tree */
     int32_t *short_len;  /* [B] its length, -1 where no shortened queue was produced */
+    /* per node, [B][capacity + 1]: 1 + the action the last descent took there, 0 = none.  Only ever used by
+     * rc_mcts_select to request the likely child's rows early; any content is valid. */
+    uint8_t *hint;
 } rc_mcts_t;
 
 /* Inserts the B root states (SoA) as node 1 of each tree; a solved root gets RC_MCTS_ROOT_SOLVED.

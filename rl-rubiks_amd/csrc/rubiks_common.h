@@ -135,6 +135,11 @@ template <int CTRL> __device__ __forceinline__ void argmax_step(double &score, i
     const int oa = dpp_int<CTRL>(arg);
     if (os > score || (os == score && oa < arg)) { score = os; arg = oa; }
 }
+template <int CTRL> __device__ __forceinline__ void argmax_step_f32(float &score, int &arg) {
+    const float os = dpp_float<CTRL>(score);
+    const int oa = dpp_int<CTRL>(arg);
+    if (os > score || (os == score && oa < arg)) { score = os; arg = oa; }
+}
 __device__ __forceinline__ int row16_argmax_first(double score, int arg) {
     argmax_step<kDppXor1>(score, arg);
     argmax_step<kDppXor2>(score, arg);

@@ -231,17 +231,98 @@ __global__ __launch_bounds__(kWave) void k_mcts_backup(rc_mcts_t m, const void *
 // ---- select: PUCT descent with virtual loss (agents.py:575-595) ---------------------------------
 // Scores of one node, NumPy's evaluation order in float64: ((c * P) * sqrt(sum N)) / (1 + N) + (W - L).
 // Runs on a 16-lane DPP row (lanes 12..15 carry neutral elements); every lane of the row gets the result.
-__device__ __forceinline__ int puct_argmax(double c, int n_a, float p_f, float w_f, u32 l_cnt, bool act, int lane_in_row) {
-    const int sum_n = row16_sum(act ? n_a : 0);
+__device__ __forceinline__ int puct_argmax_sum(double c, int sum_n, int n_a, float p_f, float w_f, u32 l_cnt, bool act,
+                                               int lane_in_row) {
     const double u = ((c * (double)p_f) * sqrt((double)sum_n)) / (double)(1 + n_a);
     const double score = act ? u + ((double)w_f - 100.0 * (double)l_cnt) : -INFINITY;
     return row16_argmax_first(score, act ? lane_in_row : 64);   // first maximum wins (agents.py:588)
+}
+__device__ __forceinline__ int puct_argmax(double c, int n_a, float p_f, float w_f, u32 l_cnt, bool act, int lane_in_row) {
+    return puct_argmax_sum(c, row16_sum(act ? n_a : 0), n_a, p_f, w_f, l_cnt, act, lane_in_row);
+}
+// The sequential walk of k_mcts_select is one wave executing a dependent chain, so its speed is its
+// instruction count (~4.7 cycles each).  The float64 argmax above is ~150 instructions; the walk evaluates
+// the same formula in float32 (hardware sqrt / reciprocal, max by four DPP steps, winner by ballot) and
+// ACCEPTS the float32 winner only if it leads every other action by more than the worst-case difference
+// between the float32 and float64 evaluations (kPuctEps * the magnitudes involved: c, sqrt, reciprocal and
+// four roundings are each within 2^-24 relative, 2^-20 leaves a factor of two).  Otherwise -- near ties
+// and exact ties, where the first-maximum rule decides -- it falls back to the float64 evaluation.  The
+// result is always the float64 argmax.  Lanes 0..11 of the wave hold the actions.
+constexpr float kPuctEps = 0x1p-20f;
+__device__ __forceinline__ int puct_argmax_walk(double c, float c32, int n_a, float p_f, float w_f, u32 l_cnt, bool act,
+                                                int lane, int &slow) {
+    int sum_n = act ? n_a : 0;
+    sum_n += dpp_int<kDppXor1>(sum_n);
+    sum_n += dpp_int<kDppXor2>(sum_n);
+    sum_n += dpp_int<kDppHalfMirror>(sum_n);
+    sum_n += dpp_int<kDppMirror>(sum_n);
+    const float loss = 100.0f * (float)l_cnt;   // exact: counts stay far below 2^24 / 100
+    const float u = c32 * p_f * __builtin_amdgcn_sqrtf((float)sum_n) * __builtin_amdgcn_rcpf((float)(1 + n_a));
+    const float mag = fabsf(u) + fabsf(w_f) + loss;
+    const float score = act ? u + (w_f - loss) : -INFINITY;
+    float best = score;
+    best = fmaxf(best, dpp_float<kDppXor1>(best));
+    best = fmaxf(best, dpp_float<kDppXor2>(best));
+    best = fmaxf(best, dpp_float<kDppHalfMirror>(best));
+    best = fmaxf(best, dpp_float<kDppMirror>(best));
+    const u32 winners = (u32)__builtin_amdgcn_ballot_w64(score == best) & 0xFFFu;
+    if (winners != 0) {
+        const int a = __builtin_ctz(winners);
+        const float mag_a = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(mag), a));
+        const bool close = act && lane != a && !(best - score > kPuctEps * (mag + mag_a));
+        if (((u32)__builtin_amdgcn_ballot_w64(close) & 0xFFFu) == 0) return a;
+    }
+    ++slow;
+    return __builtin_amdgcn_readfirstlane(puct_argmax_sum(c, sum_n, n_a, p_f, w_f, l_cnt, act, lane));
+}
+
+// Per-tree arrays as buffer resources (wave-uniform, in SGPRs): a row access is one instruction with one
+// shared 32-bit offset register instead of 64-bit address arithmetic per array.
+constexpr u32 kRsrcFlags = 0x00020000;   // raw buffer, 32-bit data format
+struct TreeBufs {
+    __amdgpu_buffer_rsrc_t N, nbr, P, W, L, leaf, hint;
+};
+__device__ __forceinline__ TreeBufs tree_bufs(const rc_mcts_t &m, size_t base) {
+    const int rows = (int)((m.capacity + 1) * kA);
+    TreeBufs b;
+    b.N = __builtin_amdgcn_make_buffer_rsrc((void *)(m.N + base * kA), 0, rows * 4, kRsrcFlags);
+    b.nbr = __builtin_amdgcn_make_buffer_rsrc((void *)(m.nbr + base * kA), 0, rows * 4, kRsrcFlags);
+    b.P = __builtin_amdgcn_make_buffer_rsrc((void *)(m.P + base * kA), 0, rows * 4, kRsrcFlags);
+    b.W = __builtin_amdgcn_make_buffer_rsrc((void *)(m.W + base * kA), 0, rows * 4, kRsrcFlags);
+    b.L = __builtin_amdgcn_make_buffer_rsrc((void *)(m.L + base * kA), 0, rows * 2, kRsrcFlags);
+    b.leaf = __builtin_amdgcn_make_buffer_rsrc((void *)(m.leaf + base), 0, (int)(m.capacity + 1), kRsrcFlags);
+    b.hint = __builtin_amdgcn_make_buffer_rsrc((void *)(m.hint + base), 0, (int)(m.capacity + 1), kRsrcFlags);
+    return b;
+}
+// The rows of one node as the sequential walk needs them (lane a < 12 holds action a's entries).
+struct NodeRows {
+    u32 is_leaf, hint, l_cnt;
+    int n_a, nb;
+    float p_f, w_f;
+};
+// L is read with sc1 (served by L2, not the CU's L1): the re-validation has just added the kept prefix's
+// losses with atomics, which live in L2.
+__device__ __forceinline__ NodeRows load_rows(const TreeBufs &tb, int node, u32 la) {
+    const u32 off = ((u32)node * kA + la) * 4u;
+    NodeRows x;
+    x.is_leaf = __builtin_amdgcn_raw_buffer_load_b8(tb.leaf, 0, node, 0);
+    x.hint = __builtin_amdgcn_raw_buffer_load_b8(tb.hint, 0, node, 0);
+    x.n_a = (int)__builtin_amdgcn_raw_buffer_load_b32(tb.N, off, 0, 0);
+    x.p_f = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(tb.P, off, 0, 0));
+    x.w_f = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(tb.W, off, 0, 0));
+    x.l_cnt = __builtin_amdgcn_raw_buffer_load_b16(tb.L, off >> 1, 0, 16);
+    x.nb = (int)__builtin_amdgcn_raw_buffer_load_b32(tb.nbr, off, 0, 0);
+    return x;
 }
 
 // L holds 16-bit counts; two of them share a dword, which is what the atomic unit adds to.
 __device__ __forceinline__ void l_count_add(u16 *L, size_t e) {
     atomicAdd(reinterpret_cast<u32 *>(L) + (e >> 1), 1u << (16 * (e & 1)));
 }
+
+constexpr int kSelHash = 2048;   // LDS chain heads of the select kernel
+constexpr int kSelUnroll = 4;
+__device__ __forceinline__ u32 sel_hash(int node) { return ((u32)node * 0x9E3779B1u) >> 21; }
 
 // One 256-thread workgroup per tree.
 //
@@ -252,17 +333,21 @@ __device__ __forceinline__ void l_count_add(u16 *L, size_t e) {
 // kept theirs.  Under that premise the virtual loss level k sees is a function of the old path alone:
 // every earlier level j < k at the same node contributed +1 on its departure edge a_j and +1 on its
 // arrival edge rev(a_{j-1}), plus level k's own arrival edge (L is zero between iterations).  Deep lines
-// revisit states all the time (transpositions), so these counts are taken exactly, by scanning the
-// staged path in LDS.  The first level whose action changes -- or the old leaf, which has just been
+// revisit states all the time (transpositions), so these counts are taken exactly: the staged path is
+// chained by node in an LDS hash table and a level walks the chain of its node (a linear scan of the
+// levels above was quadratic in the path length and dominated the stragglers of a run to completion,
+// whose depth-first lines are thousands of levels long).  The first level whose action changes -- or the old leaf, which has just been
 // expanded -- starts the ordinary sequential descent (one memory round trip per level); with a trained
 // network that tail is typically one or two levels instead of ~100.
 __global__ __launch_bounds__(kBlock) void k_mcts_select(rc_mcts_t m, double c, u32 level_budget) {
     __shared__ int s_first;                 // first level that has to be walked sequentially
     __shared__ int s_node[kMaxPath];        // the old path
     __shared__ u8 s_act[kMaxPath];
-    __shared__ u32 s_cnt[kBlock / 16][16];  // per level slot: virtual-loss count of each edge
+    __shared__ int s_head[kSelHash];        // chains of path levels by node (earlier visits of a state)
+    __shared__ u16 s_next[kMaxPath];
     const u32 t = blockIdx.x, tid = threadIdx.x;
     if (m.status[t] != RC_MCTS_RUNNING) return;
+    const unsigned long long t_begin = wall_clock64();
     const size_t base = (size_t)t * (m.capacity + 1);
     int *pnode = m.path_node + (size_t)t * m.max_path;
     u8 *pact = m.path_act + (size_t)t * m.max_path;
@@ -273,26 +358,50 @@ __global__ __launch_bounds__(kBlock) void k_mcts_select(rc_mcts_t m, double c, u
     const int resume = m.pending[t];   // uniform over the workgroup
     if (tid == 0) s_first = plen_old - 1;   // the old leaf has just been expanded (or a suspended descent continues there)
     if (!resume) {
+        for (int i = tid; i < kSelHash; i += kBlock) s_head[i] = -1;
         for (int k = tid; k < plen_old; k += kBlock) {
             s_node[k] = pnode[k];
             s_act[k] = (k < plen_old - 1) ? pact[k] : (u8)0;
         }
         __syncthreads();
-        for (int k0 = 0; k0 < plen_old - 1; k0 += kBlock / 16) {
-            const int k = k0 + (int)row;
-            if (k < plen_old - 1) {   // the 16 lanes of a level sit in one wave: their LDS operations are ordered
-                s_cnt[row][rl] = 0;
-                const int node = s_node[k];
-                for (int j = (int)rl; j < k; j += 16)
-                    if (s_node[j] == node) {   // an earlier visit of this node: its departure and arrival edges
-                        atomicAdd(&s_cnt[row][s_act[j]], 1u);
-                        if (j > 0) atomicAdd(&s_cnt[row][s_act[j - 1] ^ 1], 1u);
+        const int nlev = plen_old - 1;
+        for (int k = tid; k < nlev; k += kBlock) s_next[k] = (u16)atomicExch(&s_head[sel_hash(s_node[k])], k);
+        __syncthreads();
+        // kSelUnroll levels per 16-lane row are in flight together: their chain walks (LDS) come first,
+        // then their three row loads, then the argmaxes -- one memory round trip per 16 * kSelUnroll levels.
+        for (int k0 = 0; k0 < nlev; k0 += (kBlock / 16) * kSelUnroll) {
+            if (k0 > *(volatile int *)&s_first) break;   // levels below a change are walked anyway
+            int n_a[kSelUnroll];
+            float p_f[kSelUnroll], w_f[kSelUnroll];
+            u32 l_cnt[kSelUnroll];
+#pragma unroll
+            for (int u = 0; u < kSelUnroll; ++u) {
+                const int k = k0 + u * (kBlock / 16) + (int)row;
+                const bool live = k < nlev;
+                const int node = live ? s_node[k] : 0;
+                // virtual loss seen at level k: every earlier visit j < k of this node left +1 on its departure
+                // edge a_j and +1 on its arrival edge rev(a_{j-1}); plus this level's own arrival edge
+                u32 cnt = (live && k > 0 && (u32)(s_act[k - 1] ^ 1) == rl) ? 1u : 0u;
+                int j = live ? s_head[sel_hash(node)] : -1;
+                while (j >= 0) {
+                    if (j < k && s_node[j] == node) {
+                        cnt += (u32)s_act[j] == rl;
+                        if (j > 0) cnt += (u32)(s_act[j - 1] ^ 1) == rl;
                     }
-                if (rl == 0 && k > 0) atomicAdd(&s_cnt[row][s_act[k - 1] ^ 1], 1u);   // this level's own arrival
-                const u32 l_cnt = s_cnt[row][rl];
+                    const u32 nx = s_next[j];
+                    j = nx == 0xFFFFu ? -1 : (int)nx;
+                }
+                l_cnt[u] = cnt;
                 const size_t r = (base + node) * kA + rla;
-                const int b = puct_argmax(c, m.N[r], m.P[r], m.W[r], l_cnt, ract, (int)rl);
-                if (rl == 0 && b != (int)s_act[k]) atomicMin(&s_first, k);
+                n_a[u] = m.N[r];
+                p_f[u] = m.P[r];
+                w_f[u] = m.W[r];
+            }
+#pragma unroll
+            for (int u = 0; u < kSelUnroll; ++u) {
+                const int k = k0 + u * (kBlock / 16) + (int)row;
+                const int b = puct_argmax(c, n_a[u], p_f[u], w_f[u], l_cnt[u], ract, (int)rl);
+                if (k < nlev && rl == 0 && b != (int)s_act[k]) atomicMin(&s_first, k);
             }
         }
         __syncthreads();
@@ -306,63 +415,103 @@ __global__ __launch_bounds__(kBlock) void k_mcts_select(rc_mcts_t m, double c, u
         // __syncthreads() alone does not wait for no-return atomics: they must have reached L2 before wave 0 reads L
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     }
+    for (int i = tid; i < kSelHash; i += kBlock) s_head[i] = -1;   // from here on the chains index the NEW levels
     __syncthreads();
     if (tid >= kWave) return;
 
-    // sequential descent from level `first`, one wave, one dependent memory round trip per level: the
-    // leaf flag and the five 12-wide rows of the node are requested together, the neighbour comes out of
-    // a lane read, and the virtual-loss counts are updated from registers.
+    // Sequential descent from level `first`: one wave, one dependent memory round trip per level and NO
+    // stores inside the loop.  The leaf flag and the five 12-wide rows of a node are requested together and
+    // the neighbour comes out of a lane read.  The virtual loss a level sees is what memory holds (kept
+    // prefix, suspended earlier calls) plus what this walk itself has left at the node so far, which is read
+    // off the walked levels (chained by node in LDS, as in the re-validation) instead of being stored and
+    // re-read through L2; the walk's own losses and its path go to memory once, after the loop.
+    // A single wave's dependent chain runs at the speed of its instruction count: see puct_argmax_walk.
+    const unsigned long long t_walk = wall_clock64();
+    const long long c_walk = clock64();
+    int slow_levels = 0, wrong_hints = 0;
     const u32 lane = tid;
     const bool act = lane < kA;
     const u32 la = act ? lane : 0;
     const int start = s_first;
-    int cur = pnode[start], plen = start + 1;
-    int carried = resume ? resume - 2 : -1;   // action slot of `cur` whose L count still has to take the +1 of the incoming edge
+    const TreeBufs tb = tree_bufs(m, base);
+    const int max_path = (int)m.max_path;
+    int cur = __builtin_amdgcn_readfirstlane(pnode[start]), plen = start + 1;
+    int prev_act = -1;   // action that led to `cur` in THIS walk (level `start` has its arrival loss in memory already)
     u32 walked = 0;
     int suspended = 0;
+    const float c32 = (float)c;
+    NodeRows x = load_rows(tb, cur, la);
+    u32 h = sel_hash(cur);
+    int head = s_head[h];
     for (;;) {
-        const size_t r = (base + cur) * kA + la;
-        const u8 is_leaf = m.leaf[base + cur];
-        const int n_a = m.N[r];
-        const float p_f = m.P[r], w_f = m.W[r];
-        // L is the one array this descent both stores and may re-read (the graph has cycles): its loads
-        // bypass the CU's L1 (agent scope, served by L2), so they observe this wave's earlier write-through
-        // stores and the atomics above; vmcnt retires loads and stores in issue order, and every level
-        // waits for its loads, hence for all older stores.
-        u32 l_cnt = __hip_atomic_load(&m.L[r], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        const int nb = m.nbr[r];
-        if ((int)lane == carried) {   // L[cur, rev(a_prev)] += nu (agents.py:591), also when cur is a leaf
-            l_cnt += 1;
-            m.L[r] = (u16)l_cnt;
+        const int k = plen - 1;
+        // The rows of the child the last descent took from here are requested at once (a non-leaf has all
+        // twelve children, a leaf's request hits the sentinel row 0); the argmax then runs while they fly.
+        int pred = ((int)__builtin_amdgcn_readfirstlane(x.hint) - 1) & 15;
+        pred = pred < kA ? pred : 0;
+        NodeRows y = load_rows(tb, __builtin_amdgcn_readlane(x.nb, pred), la);
+        if (lane == 0) s_node[k] = cur;
+        u32 cnt = (prev_act >= 0 && (u32)(prev_act ^ 1) == lane) ? 1u : 0u;   // own arrival: L[cur, rev(a_prev)] += nu (agents.py:591)
+        for (int j = head; j >= 0;) {   // earlier visits of `cur` in this walk: departure edge a_j, arrival edge rev(a_{j-1})
+            if (s_node[j] == cur) {
+                cnt += (u32)s_act[j] == lane;
+                if (j > start) cnt += (u32)(s_act[j - 1] ^ 1) == lane;
+            }
+            const u32 nx = s_next[j];
+            j = nx == 0xFFFFu ? -1 : (int)nx;
         }
-        if (is_leaf) break;
-        if (plen >= (int)m.max_path) {
+        const u32 l_cnt = x.l_cnt + cnt;
+        if (__builtin_amdgcn_readfirstlane(x.is_leaf)) break;
+        if (plen >= max_path) {
             if (lane == 0) m.status[t] = RC_MCTS_PATH_OVERFLOW;
             break;
         }
         if (level_budget && walked >= level_budget) {   // out of budget at a non-leaf: resume here next call
-            suspended = 1;                              // (cur's arrival loss is stored already: carried = none)
+            suspended = 1;
             break;
         }
         ++walked;
-        const int arg = __builtin_amdgcn_readfirstlane(puct_argmax(c, n_a, p_f, w_f, l_cnt, act, (int)lane));
-        const int next = __builtin_amdgcn_readlane(nb, arg);
-        if ((int)lane == arg) m.L[r] = (u16)(l_cnt + 1);   // L[cur, a] += nu (agents.py:589)
-        if (lane == 0) {
-            pact[plen - 1] = (u8)arg;
-            pnode[plen] = next;
+        const int arg = puct_argmax_walk(c, c32, x.n_a, x.p_f, x.w_f, l_cnt, act, (int)lane, slow_levels);
+        const int next = __builtin_amdgcn_readlane(x.nb, arg);
+        if (arg != pred) {   // wave-uniform
+            __builtin_amdgcn_raw_buffer_store_b8((u8)(arg + 1), tb.hint, 0, cur, 0);
+            y = load_rows(tb, next, la);
+            ++wrong_hints;
         }
-        carried = arg ^ 1;
+        x = y;
+        if (lane == 0) {   // LDS operations of one wave are ordered: later levels see this entry
+            s_next[k] = (u16)head;
+            s_head[h] = k;
+            s_act[k] = (u8)arg;
+        }
+        h = sel_hash(next);
+        head = s_head[h];   // after the insertion above, so a colliding bucket is seen complete
+        prev_act = arg;
         cur = next;
         ++plen;
     }
+    // the walked levels go to memory: path, L[n_k, a_k] += nu (agents.py:589) and L[n_k+1, rev a_k] += nu (agents.py:591)
+    for (int k = start + (int)lane; k < plen; k += kWave) {
+        if (k > start) pnode[k] = s_node[k];
+        if (k < plen - 1) {
+            const int a = s_act[k];
+            pact[k] = (u8)a;
+            l_count_add(m.L, (base + s_node[k]) * kA + a);
+            l_count_add(m.L, (base + s_node[k + 1]) * kA + (a ^ 1));
+        }
+    }
     if (lane == 0) {
         if (m.select_stats) {
-            m.select_stats[2 * t] = start;
-            m.select_stats[2 * t + 1] = plen;
+            m.select_stats[8 * t] = start;
+            m.select_stats[8 * t + 1] = plen;
+            m.select_stats[8 * t + 2] = (int)(t_walk - t_begin);            // 10 ns ticks: staging + re-validation
+            m.select_stats[8 * t + 3] = (int)(wall_clock64() - t_walk);     // ... sequential walk
+            m.select_stats[8 * t + 4] = (int)(clock64() - c_walk);          // shader cycles of the walk
+            m.select_stats[8 * t + 5] = slow_levels;
+            m.select_stats[8 * t + 6] = wrong_hints;
         }
         m.path_len[t] = plen;
-        m.pending[t] = suspended;   // 1 = resume at path_len - 1 with no carried loss (encoding: carried + 2)
+        m.pending[t] = suspended;   // 1 = resume at path_len - 1 (its arrival loss is in memory)
     }
 }
 
@@ -564,6 +713,7 @@ int rc_mcts_shorten(const rc_mcts_t *m, rc_stream_t stream) {
 
 int rc_mcts_select(const rc_mcts_t *m, double c, uint32_t level_budget, rc_stream_t stream) {
     if (int rc = check_mcts(m)) return rc;
+    RC_REQUIRE(m->hint != nullptr, RC_ERR_NULL);
     hipLaunchKernelGGL(k_mcts_select, dim3(m->n_trees), dim3(kBlock), 0, (hipStream_t)stream, *m, c, level_budget);
     return launch_status();
 }

@@ -30,7 +30,7 @@ class _McStruct(Structure):   # mirrors rc_mcts_t (include/rubiks_hip.h)
                                               "path_node", "path_act", "child_soa")] + \
                [("child_stride", c_size_t)] + \
                [(name, c_void_p) for name in ("child_idx", "new_mask", "expanded", "select_stats", "bfs", "short_act",
-                                              "short_len")]
+                                              "short_len", "hint")]
 
 
 _hip.register({
@@ -102,12 +102,14 @@ class MCTSForest:
                      "expanded"):
             setattr(s, name, getattr(self, name).data_ptr())
         s.child_soa, s.child_stride = self.children.soa.data_ptr(), self.children.stride
-        self.select_stats = z((B, 2), torch.int32)   # diagnostics: where each descent became sequential, and its length
+        self.select_stats = z((B, 8), torch.int32)   # diagnostics: where each descent became sequential, its length, ticks
         s.select_stats = self.select_stats.data_ptr()
         self.bfs = None   # BFS scratch of rc_mcts_shorten: allocated on first use (graph search only)
         self.short_act = z((B, max_path), torch.uint8)
         self.short_len = z((B,), torch.int32)
         s.short_act, s.short_len = self.short_act.data_ptr(), self.short_len.data_ptr()
+        self.hint = z((rows,), torch.uint8)   # per node: 1 + last action taken there (prefetch hint of rc_mcts_select)
+        s.hint = self.hint.data_ptr()
         self.struct = s
         self.engine = None
         self._oh = None
