@@ -152,7 +152,21 @@ def phase_times(forest, c, max_states, reps):
             acc[k] += ev[i].elapsed_time(ev[i + 1])
         if ev_h is not None:
             acc["head_kernel"] = acc.get("head_kernel", 0.0) + ev_h.elapsed_time(ev[3])
-    return {k: round(v / reps, 4) for k, v in acc.items()}
+    out = {k: round(v / reps, 4) for k, v in acc.items()}
+    if forest._fused:   # the dominant single kernel by itself: the first hidden GEMM (hipBLASLt, bf16 MFMA)
+        eng = forest.engine
+        W, b, _ = eng.layers[1]
+        cubes, rows = forest._net_input()
+        x1 = forest._x1[:rows]
+        torch.addmm(b, x1, W.t())
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(reps):
+            torch.addmm(b, x1, W.t())
+        e1.record()
+        torch.cuda.synchronize()
+        out["gemm_hidden1"] = round(e0.elapsed_time(e1) / reps, 4)
+    return out
 
 
 def cpu_baseline(model, depth, budget_s=14.0, max_states=5000):
@@ -319,18 +333,28 @@ def main():
         phases = phase_times(forest, c, max_states, args.phase_reps) if args.phase_reps else {}
         eng, fused = forest.engine, forest._fused
     peak = MFMA_BF16_PEAK_TFLOPS if args.dtype == "bf16" else MFMA_F32_PEAK_TFLOPS
-    roofline = roofline_input = None
+    roofline = roofline_group = roofline_input = None
     if phases:
         # GEMM group actually executed on MFMA: every layer when the input is a one-hot matrix, layers 2..
         # when the input layer is the fused gather-sum kernel (which is HBM/LDS work, reported separately)
         gemm_layers = eng.layers[1:] if fused else eng.layers
         flops = 2 * sum(W.shape[0] * W.shape[1] for W, _, _ in gemm_layers) * rows
         tf = flops / (phases["net_forward"] * 1e-3) / 1e12
-        roofline = {"kernel": f"policy/value net GEMMs on {rows} child rows ({len(gemm_layers)} hipBLASLt GEMMs + bias + "
-                              "ELU passes, BatchNorm folded, heads merged)",
-                    "bound": "mfma", "achieved": round(tf, 1), "peak": peak, "unit": "TFLOP/s",
-                    "frac": round(tf / peak, 4), "traffic": None,
-                    "flops_per_launch": flops, "ms_per_launch": phases["net_forward"]}
+        roofline_group = {"kernel": f"policy/value net GEMMs on {rows} child rows ({len(gemm_layers)} hipBLASLt GEMMs + bias + "
+                                    "ELU passes, BatchNorm folded, heads merged)",
+                          "bound": "mfma", "achieved": round(tf, 1), "peak": peak, "unit": "TFLOP/s",
+                          "frac": round(tf / peak, 4), "traffic": None,
+                          "flops_per_launch": flops, "ms_per_launch": phases["net_forward"]}
+        roofline = roofline_group
+        if "gemm_hidden1" in phases:   # the dominant kernel of the step, alone
+            W1 = eng.layers[1][0]
+            f1 = 2 * W1.shape[0] * W1.shape[1] * rows
+            tf1 = f1 / (phases["gemm_hidden1"] * 1e-3) / 1e12
+            roofline = {"kernel": f"hidden GEMM [{rows} x {W1.shape[1]}] x [{W1.shape[1]} x {W1.shape[0]}] + bias, bf16 MFMA via hipBLASLt "
+                                  "(Cijk_..._MT256x192x64 in the rocprof summary): the dominant kernel of a step",
+                        "bound": "mfma", "achieved": round(tf1, 1), "peak": peak, "unit": "TFLOP/s",
+                        "frac": round(tf1 / peak, 4), "traffic": None, "flops_per_launch": f1,
+                        "ms_per_launch": phases["gemm_hidden1"]}
         if fused:
             H = eng._fused_first[4]
             nbytes = (20 + 2 * H) * rows
@@ -355,7 +379,7 @@ def main():
                        "nodes": int(np.sum(gathered["nodes"])), "seconds_rank0": round(solve_seconds, 2),
                        "note": "same scrambles searched to completion after the timed steps; not part of `value`"}
                       if args.solve_max_states else None),
-        "roofline": roofline, "roofline_input_layer": roofline_input, "phases_ms": phases,
+        "roofline": roofline, "roofline_net_group": roofline_group, "roofline_input_layer": roofline_input, "phases_ms": phases,
     }
     if not args.no_env_roofline and world == 1:
         agent.forest = None

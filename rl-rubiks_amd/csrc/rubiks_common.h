@@ -115,6 +115,26 @@ template <int CTRL> __device__ __forceinline__ double dpp_double(double v) {
     return __longlong_as_double(((long long)hi << 32) | (unsigned int)lo);
 }
 
+// The same reductions with the DPP permutation fused into the arithmetic instruction (hipcc emits a
+// v_mov_dpp + the operation + hazard nops per step): one instruction per step after a two-wait-state nop.
+// For dependent chains that are paced by instruction count (the sequential walk of k_mcts_select).
+#define RUBIKS_DPP_STEP(OP, CTRL, v) \
+    asm volatile("s_nop 1\n\t" OP " %0, %0, %0 " CTRL " row_mask:0xf bank_mask:0xf" : "+v"(v))
+__device__ __forceinline__ int row16_sum_fused(int v) {
+    RUBIKS_DPP_STEP("v_add_u32_dpp", "quad_perm:[1,0,3,2]", v);
+    RUBIKS_DPP_STEP("v_add_u32_dpp", "quad_perm:[2,3,0,1]", v);
+    RUBIKS_DPP_STEP("v_add_u32_dpp", "row_half_mirror", v);
+    RUBIKS_DPP_STEP("v_add_u32_dpp", "row_mirror", v);
+    return v;
+}
+__device__ __forceinline__ float row16_max_fused(float v) {
+    RUBIKS_DPP_STEP("v_max_f32_dpp", "quad_perm:[1,0,3,2]", v);
+    RUBIKS_DPP_STEP("v_max_f32_dpp", "quad_perm:[2,3,0,1]", v);
+    RUBIKS_DPP_STEP("v_max_f32_dpp", "row_half_mirror", v);
+    RUBIKS_DPP_STEP("v_max_f32_dpp", "row_mirror", v);
+    return v;
+}
+
 __device__ __forceinline__ int row16_sum(int v) {
     v += dpp_int<kDppXor1>(v);
     v += dpp_int<kDppXor2>(v);

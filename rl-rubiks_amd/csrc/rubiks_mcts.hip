@@ -251,27 +251,17 @@ __device__ __forceinline__ int puct_argmax(double c, int n_a, float p_f, float w
 constexpr float kPuctEps = 0x1p-20f;
 __device__ __forceinline__ int puct_argmax_walk(double c, float c32, int n_a, float p_f, float w_f, u32 l_cnt, bool act,
                                                 int lane, int &slow) {
-    int sum_n = act ? n_a : 0;
-    sum_n += dpp_int<kDppXor1>(sum_n);
-    sum_n += dpp_int<kDppXor2>(sum_n);
-    sum_n += dpp_int<kDppHalfMirror>(sum_n);
-    sum_n += dpp_int<kDppMirror>(sum_n);
+    const int sum_n = row16_sum_fused(act ? n_a : 0);
     const float loss = 100.0f * (float)l_cnt;   // exact: counts stay far below 2^24 / 100
     const float u = c32 * p_f * __builtin_amdgcn_sqrtf((float)sum_n) * __builtin_amdgcn_rcpf((float)(1 + n_a));
     const float mag = fabsf(u) + fabsf(w_f) + loss;
     const float score = act ? u + (w_f - loss) : -INFINITY;
-    float best = score;
-    best = fmaxf(best, dpp_float<kDppXor1>(best));
-    best = fmaxf(best, dpp_float<kDppXor2>(best));
-    best = fmaxf(best, dpp_float<kDppHalfMirror>(best));
-    best = fmaxf(best, dpp_float<kDppMirror>(best));
+    const float best = row16_max_fused(score);
     const u32 winners = (u32)__builtin_amdgcn_ballot_w64(score == best) & 0xFFFu;
-    if (winners != 0) {
-        const int a = __builtin_ctz(winners);
-        const float mag_a = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(mag), a));
-        const bool close = act && lane != a && !(best - score > kPuctEps * (mag + mag_a));
-        if (((u32)__builtin_amdgcn_ballot_w64(close) & 0xFFFu) == 0) return a;
-    }
+    const int a = winners ? __builtin_ctz(winners) : 0;   // no winner: NaN scores, decided below in float64
+    const float mag_a = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(mag), a));
+    const bool close = act && lane != a && !(best - score > kPuctEps * (mag + mag_a));
+    if ((((u32)__builtin_amdgcn_ballot_w64(close) & 0xFFFu) | (winners == 0)) == 0) return a;
     ++slow;
     return __builtin_amdgcn_readfirstlane(puct_argmax_sum(c, sum_n, n_a, p_f, w_f, l_cnt, act, lane));
 }
@@ -438,7 +428,7 @@ __global__ __launch_bounds__(kBlock) void k_mcts_select(rc_mcts_t m, double c, u
     int cur = __builtin_amdgcn_readfirstlane(pnode[start]), plen = start + 1;
     int prev_act = -1;   // action that led to `cur` in THIS walk (level `start` has its arrival loss in memory already)
     u32 walked = 0;
-    int suspended = 0;
+    int stop = 0;
     const float c32 = (float)c;
     NodeRows x = load_rows(tb, cur, la);
     u32 h = sel_hash(cur);
@@ -450,7 +440,7 @@ __global__ __launch_bounds__(kBlock) void k_mcts_select(rc_mcts_t m, double c, u
         int pred = ((int)__builtin_amdgcn_readfirstlane(x.hint) - 1) & 15;
         pred = pred < kA ? pred : 0;
         NodeRows y = load_rows(tb, __builtin_amdgcn_readlane(x.nb, pred), la);
-        if (lane == 0) s_node[k] = cur;
+        s_node[k] = cur;   // every lane stores the same value: no exec-mask detour
         u32 cnt = (prev_act >= 0 && (u32)(prev_act ^ 1) == lane) ? 1u : 0u;   // own arrival: L[cur, rev(a_prev)] += nu (agents.py:591)
         for (int j = head; j >= 0;) {   // earlier visits of `cur` in this walk: departure edge a_j, arrival edge rev(a_{j-1})
             if (s_node[j] == cur) {
@@ -461,15 +451,9 @@ __global__ __launch_bounds__(kBlock) void k_mcts_select(rc_mcts_t m, double c, u
             j = nx == 0xFFFFu ? -1 : (int)nx;
         }
         const u32 l_cnt = x.l_cnt + cnt;
-        if (__builtin_amdgcn_readfirstlane(x.is_leaf)) break;
-        if (plen >= max_path) {
-            if (lane == 0) m.status[t] = RC_MCTS_PATH_OVERFLOW;
-            break;
-        }
-        if (level_budget && walked >= level_budget) {   // out of budget at a non-leaf: resume here next call
-            suspended = 1;
-            break;
-        }
+        // one branch for the three ways a walk ends; which one is sorted out after the loop
+        stop = (int)__builtin_amdgcn_readfirstlane(x.is_leaf) ? 1 : plen >= max_path ? 2 : (level_budget && walked >= level_budget) ? 3 : 0;
+        if (stop) break;
         ++walked;
         const int arg = puct_argmax_walk(c, c32, x.n_a, x.p_f, x.w_f, l_cnt, act, (int)lane, slow_levels);
         const int next = __builtin_amdgcn_readlane(x.nb, arg);
@@ -479,17 +463,17 @@ __global__ __launch_bounds__(kBlock) void k_mcts_select(rc_mcts_t m, double c, u
             ++wrong_hints;
         }
         x = y;
-        if (lane == 0) {   // LDS operations of one wave are ordered: later levels see this entry
-            s_next[k] = (u16)head;
-            s_head[h] = k;
-            s_act[k] = (u8)arg;
-        }
+        s_next[k] = (u16)head;   // LDS operations of one wave are ordered: later levels see this entry
+        s_head[h] = k;
+        s_act[k] = (u8)arg;
         h = sel_hash(next);
         head = s_head[h];   // after the insertion above, so a colliding bucket is seen complete
         prev_act = arg;
         cur = next;
         ++plen;
     }
+    if (stop == 2 && lane == 0) m.status[t] = RC_MCTS_PATH_OVERFLOW;
+    const int suspended = stop == 3;   // out of budget at a non-leaf: resume here next call
     // the walked levels go to memory: path, L[n_k, a_k] += nu (agents.py:589) and L[n_k+1, rev a_k] += nu (agents.py:591)
     for (int k = start + (int)lane; k < plen; k += kWave) {
         if (k > start) pnode[k] = s_node[k];
