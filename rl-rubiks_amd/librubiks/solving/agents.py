@@ -141,6 +141,7 @@ class MCTS(DeepAgent):
     """Batched PUCT graph search with virtual loss and max-backup (reference agents.py:415-645)."""
 
     nu = 100
+    refill_level_budget = 64   # see search_batch(slots=...)
 
     def __init__(self, net, c: float, search_graph: bool, net_dtype=torch.bfloat16, use_graph: bool = True,
                  max_path: int = 4096, sync_every: int = 16, level_budget="auto"):
@@ -187,7 +188,7 @@ class MCTS(DeepAgent):
 
     @no_grad
     def search_batch(self, states, time_limit: float = None, max_states: int = None,
-                     max_iterations: int = None, compact: bool = True) -> BatchResult:
+                     max_iterations: int = None, compact: bool = True, slots: int = None) -> BatchResult:
         """
         One MCTS tree per row of `states` ((B,20) int8 NumPy array or DeviceCubes), all advanced in
         lock step.  `max_states` is the reference's per-tree cap (stop when len + 12 > max_states);
@@ -195,9 +196,17 @@ class MCTS(DeepAgent):
         compact: whenever at most half of the trees of a forest of 256 or more are still running, the
         finished ones are harvested and the forest is compacted to the running trees, so the stragglers of a
         run to completion continue on small batches instead of paying full-size network calls.
+        slots: run at most this many trees at a time and give the places of finished trees to the scrambles
+        still waiting (continuous batching): the GPU stays full until the last games, instead of idling on
+        the stragglers of every batch.  Per-game results are those of the plain batch (trees are independent).
+        While games are waiting, descents are cut at `refill_level_budget` new levels per iteration, so that the
+        few very deep descents of old trees do not pace the full batch (the budget is lifted for the tail).
         """
         time_limit, max_states = self.reset(time_limit, max_states)
         roots = states if isinstance(states, DeviceCubes) else DeviceCubes.from_numpy(np.asarray(states))
+        if slots is not None and slots < roots.n:
+            assert max_iterations is None, "max_iterations applies to lock-step batches only"
+            return self._search_refill(roots, time_limit, max_states, int(slots), compact)
         cap_states = int(max_states) if max_states < int(1e10) else DEFAULT_NODE_CAP
         forest = self._forest_for(roots.n, max(cap_states, 16))
         self.tt.tick()
@@ -233,6 +242,99 @@ class MCTS(DeepAgent):
         else:
             harvested.append((owner, last))
             result = BatchResult.merge(B, harvested, seconds)
+        self._last_forest = forest
+        self._explored_states = int(result.nodes[0])
+        self.action_queue = result.queues[0]
+        return result
+
+    def _search_refill(self, roots: DeviceCubes, time_limit: float, max_states: int, slots: int, compact: bool) -> BatchResult:
+        cap_states = int(max_states) if max_states < int(1e10) else DEFAULT_NODE_CAP
+        n_games = roots.n
+        forest = self._forest_for(slots, max(cap_states, 16))
+        self.tt.tick()
+        first = DeviceCubes.empty(slots)
+        first.soa[:, :slots] = roots.soa[:, :slots]
+        forest.reset(first)
+        owner = np.arange(slots)        # game index of every slot, -1 once its result has been taken and nobody moved in
+        next_game = slots
+        base_budget = forest.level_budget
+        if self.level_budget == "auto":
+            forest.level_budget = self.refill_level_budget
+        harvested = []
+        min_refill = max(8, slots // 32)
+        it = 0
+        stats = self.refill_stats = {"iterations": 0, "harvests": 0, "collect_s": 0.0, "refill_s": 0.0}
+        # Finished trees are copied out of the forest at once (their slots are needed), but turning them into
+        # results (graph completion, BFS shortening, host-side queues) is deferred by one sync period and runs
+        # on a side stream while the next iterations of the main forest are already queued.
+        side = torch.cuda.Stream()
+        deferred = []
+
+        def flush():
+            t_c = self.tt.tock()
+            for own, sub, ev in deferred:
+                with torch.cuda.stream(side):
+                    side.wait_event(ev)
+                    harvested.append((own, self._collect(sub, 0.0)))
+            deferred.clear()
+            stats["collect_s"] += self.tt.tock() - t_c
+
+        while True:
+            for _ in range(self.sync_every):
+                forest.step(self.c, cap_states, self.use_graph)
+            it += self.sync_every
+            flush()
+            status = forest.status.cpu().numpy()
+            stats["iterations"] = it
+            done = np.flatnonzero((status != md.RUNNING) & (owner >= 0))
+            n_run = int((status == md.RUNNING).sum())
+            out_of_time = self.tt.tock() >= time_limit
+            if len(done) and (len(done) >= min_refill or n_run == 0 or next_game >= n_games or out_of_time):
+                idx = torch.from_numpy(done).to(forest.status.device)
+                sub = forest.subset(idx)
+                ev = torch.cuda.Event()
+                ev.record()
+                deferred.append((owner[done].copy(), sub, ev))
+                owner[done] = -1
+                stats["harvests"] += 1
+                t_h = self.tt.tock()
+                k = min(len(done), n_games - next_game)
+                if k and not out_of_time:   # the waiting scrambles make their root iteration (12 rows per tree) apart
+                    fresh = DeviceCubes.empty(k)
+                    fresh.soa[:, :k] = roots.soa[:, next_game:next_game + k]
+                    small = md.MCTSForest(k, forest.C, forest.max_path)
+                    small.set_net(forest.engine, self.net_dtype)
+                    small.level_budget = forest.level_budget
+                    small.reset(fresh)
+                    small.step(self.c, cap_states, False)
+                    forest.adopt(small, idx[:k])
+                    owner[done[:k]] = np.arange(next_game, next_game + k)
+                    next_game += k
+                    n_run += k
+                    del small
+                    stats["refill_s"] += self.tt.tock() - t_h
+            if out_of_time or (n_run == 0 and next_game >= n_games):
+                break
+            if next_game >= n_games:
+                forest.level_budget = base_budget   # nobody is waiting any more: strict lock step for the tail
+            if compact and next_game >= n_games and forest.B >= 256 and n_run <= forest.B // 2:
+                keep = torch.from_numpy(np.flatnonzero(owner >= 0)).to(forest.status.device)   # running trees only by now
+                small = forest.subset(keep)
+                if forest is self.forest:
+                    forest._graph = None
+                forest, owner = small, owner[owner >= 0]
+        flush()
+        torch.cuda.synchronize()
+        seconds = self.tt.tock()
+        left = np.flatnonzero(owner >= 0)   # only when the time limit ended the run
+        if len(left):
+            idx = torch.from_numpy(left).to(forest.status.device)
+            harvested.append((owner[left], self._collect(forest.subset(idx), seconds)))
+        result = BatchResult.merge(n_games, harvested, seconds)
+        never = next_game < n_games     # games that never got a slot before the time limit: unsolved, nothing explored
+        if never:
+            result.queues[next_game:] = [deque() for _ in range(n_games - next_game)]
+            result.status[next_game:] = md.EXHAUSTED
         self._last_forest = forest
         self._explored_states = int(result.nodes[0])
         self.action_queue = result.queues[0]

@@ -12,6 +12,7 @@ do not draw random numbers themselves (MCTS, AStar).  `max_time` bounds every ga
 the reference, but the games of a depth run concurrently.  `times[d, g]` is the batch wall time
 divided by the number of games (a throughput-equivalent per-game time).
 """
+import inspect
 import json
 import os
 
@@ -22,8 +23,13 @@ from librubiks.utils import NullLogger, TickTock, bernoulli_error
 
 
 class Evaluator:
-    def __init__(self, n_games, scrambling_depths, max_time=None, max_states=None, logger=NullLogger()):
-        self.n_games, self.max_time, self.max_states = n_games, max_time, max_states
+    def __init__(self, n_games, scrambling_depths, max_time=None, max_states=None, logger=NullLogger(), slots: int = None):
+        """
+        slots: for agents whose `search_batch` takes `slots` (MCTS): the games of ALL depths form one pool that
+        is searched with at most `slots` concurrent trees, finished trees handing their place to waiting games
+        (continuous batching); `max_time`, if given, then bounds the whole pool at max_time x len(depths).
+        """
+        self.n_games, self.max_time, self.max_states, self.slots = n_games, max_time, max_states, slots
         self.tt = TickTock()
         self.log = logger
         # range(0) means "deep": every game draws its own depth uniformly in [100, 999] (evaluation.py:30,73-74)
@@ -38,6 +44,8 @@ class Evaluator:
     def eval(self, agent):
         """(res, states, times), each (len(scrambling_depths), n_games); res = solution length or -1."""
         res, states, times = [], [], []
+        if self.slots and hasattr(agent, "search_batch") and "slots" in inspect.signature(agent.search_batch).parameters:
+            return self._eval_pooled(agent)
         for d in self.scrambling_depths:
             depth = (lambda: np.random.randint(100, 1000)) if self._isdeep() else int(d)
             if hasattr(agent, "search_batch"):
@@ -60,6 +68,24 @@ class Evaluator:
                     s.append(len(agent))
                 res.append(r), states.append(s), times.append(t)
         res, states, times = np.array(res, dtype=np.int64), np.array(states, dtype=np.int64), np.array(times, dtype=float)
+        for i, d in enumerate(self.scrambling_depths):
+            self.log_this_depth(res[i], states[i], times[i], d)
+        return res, states, times
+
+    def _eval_pooled(self, agent):
+        """All depths' scrambles (drawn in the reference's order) as one pool with continuous batching."""
+        from librubiks.cube.device import DeviceCubes
+        D, G = len(self.scrambling_depths), self.n_games
+        pool = DeviceCubes.empty(D * G)
+        for i, d in enumerate(self.scrambling_depths):
+            depth = (lambda: np.random.randint(100, 1000)) if self._isdeep() else int(d)
+            cubes, _, _ = cube.scramble_batch(G, depth, True)
+            pool.soa[:, i * G:(i + 1) * G] = cubes.soa[:, :G]
+        self.tt.profile(f"Evaluation of {agent}. {D} depths pooled")
+        out = agent.search_batch(pool, self.max_time * D if self.max_time else None, self.max_states, slots=self.slots)
+        dt = self.tt.end_profile()
+        res, states = out.lengths.reshape(D, G).astype(np.int64), out.nodes.reshape(D, G).astype(np.int64)
+        times = np.full((D, G), dt / (D * G))
         for i, d in enumerate(self.scrambling_depths):
             self.log_this_depth(res[i], states[i], times[i], d)
         return res, states, times

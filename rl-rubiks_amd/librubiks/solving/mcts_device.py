@@ -136,6 +136,22 @@ class MCTSForest:
         sub.set_net(self.engine, self.engine.dtype if hasattr(self.engine, "dtype") else torch.bfloat16)
         return sub
 
+    def adopt(self, small: "MCTSForest", slots: torch.Tensor):
+        """
+        Overwrites the trees `slots` (int64 indices) with the trees of `small` -- complete search state, copied on
+        the device.  The inverse of `subset`: lets new scrambles, which have made their first (12-row) iteration
+        in a small forest of their own, take the places of finished trees of a running batch.
+        """
+        assert small.C == self.C and small.max_path == self.max_path and len(slots) == small.B
+        assert not small._root_phase and not self._root_phase
+        B, C1 = self.B, self.C + 1
+        for name in _PER_NODE + ("hint",):
+            dst, src = getattr(self, name), getattr(small, name)
+            dst.view(B, C1, *dst.shape[1:])[slots] = src.view(small.B, C1, *src.shape[1:])
+        self.hash[slots] = small.hash
+        for name in _PER_TREE:
+            getattr(self, name)[slots] = getattr(small, name)
+
     def bytes_allocated(self) -> int:
         return sum(t.numel() * t.element_size() for t in (self.keys, self.nbr, self.P, self.W, self.N, self.L, self.V,
                                                            self.leaf, self.hash, self.path_node, self.path_act))

@@ -60,3 +60,35 @@ def test_deep_mode_scrambles_follow_reference_stream():
     assert np.array_equal(np.random.get_state()[1], end)
     assert np.array_equal(cubes.numpy(), np.array(expect))
     assert faces.shape[1] == int((faces >= 0).sum(1).max())
+
+
+def test_mcts_continuous_batching_equals_plain_batches(standin_net):
+    """search_batch(slots=...) hands finished trees' places to waiting games; per-game results are unchanged."""
+    import torch
+    from librubiks.solving.agents import MCTS
+    from oracle import cube as oc
+    np.random.seed(21)
+    states = np.array([oc.scramble(1 + g % 7, True)[0] for g in range(150)])
+    states[17] = oc.get_solved()
+    agent = MCTS(standin_net.cuda(), c=0.6, search_graph=True, net_dtype=torch.float32, sync_every=4)
+    plain = agent.search_batch(states, None, 600)
+    for slots in (32, 64):
+        pooled = MCTS(standin_net.cuda(), c=0.6, search_graph=True, net_dtype=torch.float32, sync_every=4) \
+            .search_batch(states, None, 600, slots=slots)
+        assert np.array_equal(pooled.solved, plain.solved)
+        assert np.array_equal(pooled.lengths, plain.lengths)
+        assert np.array_equal(pooled.nodes, plain.nodes)
+        assert [list(q) for q in pooled.queues] == [list(q) for q in plain.queues]
+    assert 0 < plain.solved.sum() and not plain.solved[60:].all()   # both outcomes occur
+
+
+def test_evaluator_pooled_depths(standin_net):
+    import torch
+    from librubiks.solving.agents import MCTS
+    from librubiks.solving.evaluation import Evaluator
+    net = standin_net.cuda()
+    np.random.seed(5)
+    r0, s0, _ = Evaluator(40, [2, 4, 6], None, 500).eval(MCTS(net, 0.6, True, net_dtype=torch.float32, sync_every=4))
+    np.random.seed(5)
+    r1, s1, t1 = Evaluator(40, [2, 4, 6], None, 500, slots=32).eval(MCTS(net, 0.6, True, net_dtype=torch.float32, sync_every=4))
+    assert np.array_equal(r0, r1) and np.array_equal(s0, s1) and t1.shape == (3, 40)
