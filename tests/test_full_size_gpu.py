@@ -1,0 +1,183 @@
+"""
+BASELINE.json's configurations at FULL size on one MI355X, checked through size-independent properties
+(the oracle does not finish at these sizes; it checks seeded samples):
+
+  env kernels at the bench size (2^24 states): rotate / inverse round trip, expand12 == 12 multi_rotates,
+      solved rows found exactly, one-hot rows with 20 ones at 24 j + code
+  #2  1 024 depth-20 scrambles, MCTS            #3  4 096 depth-20 scrambles, A*
+  #4  ADI batch of 16 384 states (196 608 substates)
+  #5  one GPU's share of 65 536 trees: 8 192 depth-24 trees in lock step
+"""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import ROOT
+
+pytestmark = pytest.mark.gpu
+
+from oracle import cube as oc  # noqa: E402  (checker only)
+
+WEIGHTS = os.path.join(ROOT, "weights", "fc_small_r1")
+
+
+def _net():
+    from librubiks.model import Model, ModelConfig
+    if os.path.isdir(WEIGHTS):
+        return Model.load(WEIGHTS).eval()
+    torch.manual_seed(0)
+    return Model.create(ModelConfig()).eval()
+
+
+def _replay_ok(state, queue):
+    for a in queue:
+        state = oc.rotate(state, *oc.ACTION_SPACE[a])
+    return oc.is_solved(state)
+
+
+def test_env_kernels_at_bench_size():
+    from librubiks.cube.device import DeviceCubes
+    n = 1 << 24
+    rng = np.random.default_rng(0)
+    # 2^24 reachable states on the device: 2^12 seeds x 12 children, three times, tiled
+    seeds = np.array([oc.scramble(30)[0] for _ in range(4096)])
+    cubes = DeviceCubes.from_numpy(seeds)
+    for _ in range(3):
+        cubes = cubes.expand12()
+    assert cubes.n == 4096 * 12 ** 3
+    reps = -(-n // cubes.n)
+    big = DeviceCubes.empty(n)
+    for r in range(reps):
+        lo, hi = r * cubes.n, min(n, (r + 1) * cubes.n)
+        big.soa[:, lo:hi] = cubes.soa[:, :hi - lo]
+    actions = torch.from_numpy(rng.integers(0, 12, size=n).astype(np.uint8)).cuda()
+    moved = big.multi_rotate(actions)
+    back = moved.multi_rotate(actions ^ 1)                       # rev_action = a ^ 1 (cube.py:194-200)
+    assert torch.equal(back.soa[:, :n], big.soa[:, :n])
+    assert not torch.equal(moved.soa[:, :n], big.soa[:, :n])
+    # a seeded sample against the oracle
+    idx = rng.integers(0, n, size=4096)
+    sample = big.soa[:, torch.from_numpy(idx).cuda()].T.cpu().numpy()
+    a = actions[torch.from_numpy(idx).cuda()].cpu().numpy()
+    want = oc.multi_rotate_actions(sample, a)
+    assert np.array_equal(moved.soa[:, torch.from_numpy(idx).cuda()].T.cpu().numpy(), want)
+    # expand12 of 2^22 parents == the twelve single-action rotations, child k of parent p at column 12 p + k
+    parents = DeviceCubes(big.soa, n // 4)
+    kids = parents.expand12()
+    cols = torch.arange(parents.n, device="cuda") * 12
+    for k in (0, 5, 11):
+        one = parents.multi_rotate(torch.full((parents.n,), k, dtype=torch.uint8, device="cuda"))
+        assert torch.equal(kids.soa[:, cols + k], one.soa[:, :parents.n])
+    # solved rows planted at known positions are the only ones found
+    planted = np.sort(rng.choice(n, size=1000, replace=False))
+    solved = torch.from_numpy(oc.get_solved()).cuda()
+    probe = DeviceCubes(big.soa.clone(), n)
+    already = probe.is_solved().nonzero().reshape(-1).cpu().numpy()
+    probe.soa[:, torch.from_numpy(planted).cuda()] = solved[:, None]
+    found = probe.is_solved().nonzero().reshape(-1).cpu().numpy()
+    assert np.array_equal(found, np.union1d(planted, already))
+    # one-hot at 2^20 rows: exactly 20 ones per row, at 24 j + code
+    part = DeviceCubes(big.soa, 1 << 20)
+    oh = part.as_oh(torch.bfloat16)
+    assert oh.shape == (1 << 20, 480)
+    assert torch.equal(oh.float().sum(dim=1), torch.full((1 << 20,), 20.0, device="cuda"))
+    rows = torch.from_numpy(rng.integers(0, 1 << 20, size=2048)).cuda()
+    hot = oh[rows].float().nonzero()[:, 1].reshape(-1, 20).cpu().numpy()
+    assert np.array_equal(hot, oc.oh_indices(part.soa[:, rows].T.cpu().numpy()))
+
+
+def test_config2_mcts_1024_trees():
+    from librubiks import cube
+    from librubiks.solving.agents import MCTS
+    np.random.seed(0)
+    cubes, _, _ = cube.scramble_batch(1024, 20, True)
+    states = cubes.numpy()
+    agent = MCTS(_net(), c=0.6, search_graph=True)
+    cap = 20_000
+    res = agent.search_batch(cubes, None, cap)
+    assert res.nodes.shape == (1024,) and (res.nodes <= cap).all() and (res.nodes >= 13).all()
+    for t in np.flatnonzero(res.solved):
+        assert res.lengths[t] == len(res.queues[t]) and _replay_ok(states[t], res.queues[t])
+    for t in np.flatnonzero(~res.solved):
+        assert res.lengths[t] == -1 and (res.nodes[t] + 12 > cap or res.status[t] == 3)
+    if os.path.isdir(WEIGHTS):
+        assert res.solved.mean() > 0.7
+    # continuous batching on half the slots returns the same games
+    pooled = MCTS(_net(), c=0.6, search_graph=True).search_batch(cubes, None, cap, slots=512)
+    assert np.array_equal(pooled.solved, res.solved) and np.array_equal(pooled.nodes, res.nodes)
+    assert np.array_equal(pooled.lengths, res.lengths)
+
+
+def test_config3_astar_4096_problems():
+    from librubiks import cube
+    from librubiks.solving.agents import AStar
+    np.random.seed(0)
+    cubes, _, _ = cube.scramble_batch(4096, 20, True)
+    states = cubes.numpy()
+    cap, N = 50_000, 100
+    res = AStar(_net(), lambda_=0.2, expansions=N).search_batch(cubes, None, cap)
+    assert res.nodes.shape == (4096,) and (res.nodes <= cap).all()
+    for b in np.flatnonzero(res.solved):
+        assert res.lengths[b] == len(res.queues[b]) and _replay_ok(states[b], res.queues[b])
+    for b in np.flatnonzero(~res.solved):
+        assert res.nodes[b] + 12 * N > cap                        # the budget rule (agents.py:236)
+    if os.path.isdir(WEIGHTS):
+        assert res.solved.mean() > 0.8
+
+
+def test_config4_adi_batch_16384(standin_net):
+    """Exact against the restated reference on the integer-valued stand-in net (no rounding to argue about)."""
+    from librubiks.train import Train
+    from oracle import agents as oa
+    from oracle import train as ot
+    games, depth = 512, 32                                        # 16 384 states, 196 608 substates
+    net = standin_net.cuda()
+    for method in ("lapanfix", "paper"):
+        tr = Train(rollouts=1, batch_size=1000, rollout_games=games, rollout_depth=depth, optim_fn=torch.optim.Adam,
+                   alpha_update=0, lr=1e-4, gamma=1, update_interval=0, agent=None, evaluator=None, evaluation_interval=0,
+                   tau=1, reward_method=method)
+        np.random.seed(3)
+        oh, pol, val, w = tr.ADI_traindata(net, 0.25)
+        np.random.seed(3)
+        states, rpol, rval, rw = ot.adi_traindata(oa.TorchNet(net, device="cuda").value, games, depth, method, 0.25)
+        n = games * depth
+        assert oh.shape == (n, 480) and torch.equal(oh.sum(dim=1), torch.full((n,), 20.0, device=oh.device))
+        assert np.array_equal(oh.nonzero()[:, 1].reshape(n, 20).cpu().numpy(), oc.oh_indices(states))
+        assert np.array_equal(pol.cpu().numpy(), rpol)
+        assert np.array_equal(val.cpu().numpy(), rval)
+        assert np.allclose(w.cpu().numpy(), rw, rtol=1e-6)
+
+
+def test_config5_share_8192_trees_lockstep():
+    from librubiks import cube
+    from librubiks.model import InferenceNet
+    from librubiks.solving.mcts_device import MCTSForest, RUNNING
+    np.random.seed(0)
+    B, iters = 8192, 40
+    cubes, _, _ = cube.scramble_batch(B, 24, True)
+    forest = MCTSForest(B, 12 * (iters + 2) + 16)
+    forest.set_net(InferenceNet(_net(), torch.bfloat16))
+    forest.reset(cubes)
+    for _ in range(iters):
+        forest.step(0.6, forest.C, use_graph=True)
+    torch.cuda.synchronize()
+    status = forest.status.cpu().numpy()
+    nodes = forest.n_nodes.cpu().numpy()
+    its = forest.iterations.cpu().numpy()
+    assert ((status == RUNNING) | (status == 1)).all()
+    assert (its[status == RUNNING] == iters).all()
+    assert (nodes >= 13).all() and (nodes <= 1 + 12 * its).all()
+    roots = cubes.numpy()
+    for t in (0, 1, 4095, 8191):
+        a = forest.tree_arrays(t)
+        n = a["n"]
+        st, nb = a["states"], a["neighbors"]
+        assert np.array_equal(st[1], roots[t])
+        assert len({s.tobytes() for s in st[1:n + 1]}) == n          # every stored state is unique
+        kids = oc.expand12(st[1:n + 1]).reshape(n, 12, 20)
+        for i, k in zip(*np.nonzero(nb[1:n + 1])):
+            j = nb[1 + i, k]
+            assert 1 <= j <= n and np.array_equal(st[j], kids[i, k])  # links lead to the rotated state ...
+            assert nb[j, k ^ 1] == 1 + i                              # ... and back (agents.py:533-535)
