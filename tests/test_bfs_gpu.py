@@ -82,3 +82,29 @@ def test_bfs_solved_start_and_asserts():
         agent.search(oc.get_solved(), None, None)   # reference agents.py:54
     s = oc.rotate(oc.get_solved(), 0, 1)
     assert agent.search(s, 5.0, None) and list(agent.action_queue) == [1]
+
+
+def test_bfs_and_select_argument_errors():
+    """The C ABI refuses what would index out of its buffers (no launch happens)."""
+    import ctypes
+    import torch
+    from librubiks import _hip
+    from librubiks.solving.bfs_device import BFSDevice
+    from librubiks.solving.mcts_device import MCTSForest
+    dev = BFSDevice(1000, chunk=16)
+    lib, m = _hip.lib(), ctypes.byref(dev.struct)
+    assert lib.rc_bfs_expand(m, 0, 17, 1, 1000, None) == -4       # more parents than the chunk: RC_ERR_RANGE
+    assert lib.rc_bfs_expand(m, 5, 4, 6, 1000, None) == -4        # parents beyond the stored nodes
+    assert lib.rc_bfs_expand(m, 0, 16, dev.capacity - 10, 1000, None) == -4   # children would not fit
+    assert lib.rc_bfs_init(m, None, None) == -1                   # RC_ERR_NULL
+    assert lib.rc_bfs_path(m, dev.capacity, dev._path.data_ptr(), dev._path_len.data_ptr(), 64, None) == -4
+    broken = type(dev.struct)()
+    ctypes.memmove(ctypes.byref(broken), ctypes.byref(dev.struct), ctypes.sizeof(broken))
+    broken.hash_size = dev.hash_size - 1                          # not a power of two
+    assert lib.rc_bfs_init(ctypes.byref(broken), dev._root.data_ptr(), None) == -4
+    forest = MCTSForest(4, 64)
+    s = type(forest.struct)()
+    ctypes.memmove(ctypes.byref(s), ctypes.byref(forest.struct), ctypes.sizeof(s))
+    s.hint = None
+    assert lib.rc_mcts_select(ctypes.byref(s), 0.6, 0, None) == -1
+    torch.cuda.synchronize()
