@@ -227,7 +227,7 @@ def main():
                          "report the solve rate (0 = skip)")
     ap.add_argument("--level-budget", type=int, default=0,
                     help="new tree levels a PUCT descent may walk per step before it is suspended (0 = strict lock step)")
-    ap.add_argument("--first-layer-table", default="auto", choices=["auto", "f16", "bf16", "mfma", "onehot"],
+    ap.add_argument("--first-layer-table", default="auto", choices=["auto", "f16", "f16pair", "bf16", "mfma", "mfma16", "onehot"],
                     help="input layer: fused gather-sum with an f16 / bf16 table, or the one-hot GEMM")
     args = ap.parse_args()
 

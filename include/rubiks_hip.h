@@ -115,7 +115,8 @@ int rc_sequence_states(const uint8_t *moves, int8_t *out_soa, size_t games, size
  * the first nn.Linear of librubiks/model.py:123-127,150-157) without materialising the one-hot
  * matrix: a one-hot row has exactly 20 ones, so the product is a 20-row gather-sum of W1^T.
  *   w1t : [480][H] row-major 16-bit table (the Linear weight transposed): bf16, or IEEE f16 when
- *         table_is_f16 != 0 (11 mantissa bits instead of 8; one v_fma_mix_f32 converts and adds)
+ *         table_is_f16 != 0 (11 mantissa bits instead of 8; one v_fma_mix_f32 converts and adds);
+ *         table_is_f16 == 2 additionally adds PAIRS of table rows in half precision first (v_pk_add_f16)
  *   bias: float[H], out: bf16 [n][H];  H: multiple of 128;  activation: 0 = none, 1 = ReLU, 2 = ELU(alpha)
  * Algorithmic HBM bytes per state: 20 in + 2 H out (W1^T is 0.96 H KB, L2-resident). */
 #define RC_ACT_NONE 0
@@ -126,9 +127,10 @@ int rc_first_layer_bf16(const int8_t *soa, size_t n, size_t stride, const uint16
 /* The same layer on the matrix cores: out = act(as_oh(s) @ W1^T + bias) with the one-hot A-fragments of
  * v_mfma_f32_32x32x16_bf16 generated in registers from the cube codes (the one-hot matrix never exists in
  * memory) and a 128-column slice of W1 resident in LDS as the B operand.
- *   w1: bf16 [H][480] row-major = the nn.Linear weight as stored; other arguments as above. */
+ *   w1: bf16 (or IEEE half if table_is_f16 != 0: v_mfma_f32_32x32x16_f16) [H][480] row-major = the nn.Linear
+ *   weight as stored; other arguments as above. */
 int rc_first_layer_mfma_bf16(const int8_t *soa, size_t n, size_t stride, const uint16_t *w1, const float *bias,
-                             uint16_t *out, size_t H, int activation, float alpha, rc_stream_t stream);
+                             uint16_t *out, size_t H, int activation, float alpha, int table_is_f16, rc_stream_t stream);
 
 /* ---- network head: last activation + skinny output layer in one pass -----------------------------------------
  * out[i][o] = bias[o] + sum_k w[o][k] * act(x[i][k])   for o < n_out <= 16   (float out, row pitch 16)

@@ -26,7 +26,7 @@ __device__ __forceinline__ u32 pack_bf16(float lo, float hi) {
     return __builtin_bit_cast(u32, r);
 }
 
-template <int ACT, bool F16>
+template <int ACT, int F16>   // F16: 0 bf16 table, 1 f16 table, 2 f16 table with pairs of rows added in f16 first
 __global__ __launch_bounds__(kFLThreads) __attribute__((amdgpu_waves_per_eu(4, 4))) void k_first_layer(const u8 *__restrict__ soa, size_t n, size_t stride,
                                                             const uint4 *__restrict__ w1t, const float *__restrict__ bias,
                                                             uint4 *__restrict__ out, u32 H, u32 rows_per_block, float alpha) {
@@ -95,6 +95,19 @@ __global__ __launch_bounds__(kFLThreads) __attribute__((amdgpu_waves_per_eu(4, 4
 #pragma unroll
                 for (int j = 0; j < kFLBatch; ++j) w[j] = wslice[kk[q * kFLBatch + j]];
                 __builtin_amdgcn_sched_barrier(0);   // keep the batch's loads ahead of its adds, and the batches apart
+                if (F16 == 2) {   // two table rows meet in one packed f16 add (half the conversions): 3 instructions per 4 terms
+#pragma unroll
+                    for (int j = 0; j < kFLBatch; j += 2) {
+                        const u32 wa[4] = {w[j].x, w[j].y, w[j].z, w[j].w}, wb[4] = {w[j + 1].x, w[j + 1].y, w[j + 1].z, w[j + 1].w};
+#pragma unroll
+                        for (int d = 0; d < 4; ++d) {
+                            u32 t;
+                            asm volatile("v_pk_add_f16 %0, %1, %2" : "=v"(t) : "v"(wa[d]), "v"(wb[d]));
+                            asm volatile("v_fma_mix_f32 %0, %1, 1.0, %0 op_sel:[0,0,0] op_sel_hi:[1,0,0]" : "+v"(acc[2 * d]) : "v"(t));
+                            asm volatile("v_fma_mix_f32 %0, %1, 1.0, %0 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "+v"(acc[2 * d + 1]) : "v"(t));
+                        }
+                    }
+                } else {
 #pragma unroll
                 for (int j = 0; j < kFLBatch; ++j) {
                     const u32 ww[4] = {w[j].x, w[j].y, w[j].z, w[j].w};
@@ -108,6 +121,7 @@ __global__ __launch_bounds__(kFLThreads) __attribute__((amdgpu_waves_per_eu(4, 4
                             acc[2 * d + 1] += __uint_as_float(ww[d] & 0xffff0000u);
                         }
                     }
+                }
                 }
                 __builtin_amdgcn_sched_barrier(0);
             }
@@ -130,19 +144,22 @@ __global__ __launch_bounds__(kFLThreads) __attribute__((amdgpu_waves_per_eu(4, 4
 //     slice stored column-major-in-k with a 976-byte pitch (61 x 16 B, odd -> the 16 lanes of a ds_read_b128
 //     group hit 16 different bank quads).
 //   D: lane holds column l & 31 of states (reg & 3) + 8 (reg >> 2) + 4 h.
-// Epilogue: + bias, activation, bf16, transposed through a per-wave LDS tile so that global stores are 16 B
-// per lane along the output rows.
+// Epilogue: activation, bf16; a lane's four accumulator tiles are four ADJACENT columns, so a state's row segment
+// leaves as one 8-byte store per lane, 256 contiguous bytes per 32 lanes -- no LDS transposition, which keeps the
+// workgroup's LDS at the W1 slice alone and lets TWO waves share a SIMD: one wave's epilogue (VALU: ELU on 64
+// values per lane) runs under the other's MFMAs.
 // =================================================================================================
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(8))) _Float16 f16x8;
 typedef __attribute__((ext_vector_type(16))) float f32x16;
 
 constexpr int kMfCols = 128;                        // output columns per workgroup
 constexpr int kMfPitch = 976;                       // bytes per column of the LDS slice: 480 bf16 + 16 B pad
-constexpr int kMfWaves = 4;                         // one per SIMD
-constexpr int kMfTile = 32;                         // states per wave tile
-constexpr int kMfStage = kMfTile * kMfCols * 2;     // 8 KiB transposition tile per wave
+constexpr int kMfWaves = 8;                         // two per SIMD
+constexpr int kMfTile = 32;                         // states per MFMA tile
+constexpr int kMfSub = 1;                           // tiles a wave holds at once (they share the B fragments)
 
-template <int ACT>
+template <int ACT, bool F16>   // F16: W1 and the one-hot fragments in IEEE half (v_mfma_f32_32x32x16_f16), else bf16
 __global__ __launch_bounds__(kMfWaves * kWave) void k_first_layer_mfma(const u8 *__restrict__ soa, size_t n, size_t stride,
                                                                      const uint4 *__restrict__ w1, const float *__restrict__ bias,
                                                                      uint4 *__restrict__ out, u32 H, u32 rows_per_block,
@@ -150,8 +167,7 @@ __global__ __launch_bounds__(kMfWaves * kWave) void k_first_layer_mfma(const u8 
     extern __shared__ __attribute__((aligned(256))) unsigned char lds[];
     unsigned char *wslice = lds;                                                   // [128 slots][976 B]
     const u32 tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
-    unsigned char *stage = lds + kMfCols * kMfPitch + wave * kMfStage;             // [32 states][128 cols] bf16
-    uint4 *onehot = reinterpret_cast<uint4 *>(lds + kMfCols * kMfPitch + kMfWaves * kMfStage);   // [9] A fragments
+    uint4 *onehot = reinterpret_cast<uint4 *>(lds + kMfCols * kMfPitch);           // [9] A fragments
     const u32 col_tiles = H / kMfCols;
     const u32 ct = blockIdx.x % col_tiles, rg = blockIdx.x / col_tiles;
     const size_t row_lo = (size_t)rg * rows_per_block;
@@ -162,8 +178,8 @@ __global__ __launch_bounds__(kMfWaves * kWave) void k_first_layer_mfma(const u8 
     // (g % 4) * 32 + g / 4: MFMA column tile c, lane r then owns column 4 r + c, i.e. a lane's four accumulators
     // are four ADJACENT output columns (one 8-byte store per state in the epilogue), while the B reads of a
     // tile still walk 32 consecutive slots (conflict-free with the odd 16-byte pitch).
-    {   // 7 680 chunks / 256 threads = 30 per thread, requested ten at a time before the first LDS write
-        constexpr int kPer = kMfCols * 60 / (kMfWaves * kWave), kBatch = 10;
+    {   // 7 680 chunks / 512 threads = 15 per thread, requested five at a time before the first LDS write
+        constexpr int kPer = kMfCols * 60 / (kMfWaves * kWave), kBatch = 5;
 #pragma unroll
         for (int b0 = 0; b0 < kPer; b0 += kBatch) {
             uint4 tmp[kBatch];
@@ -182,7 +198,8 @@ __global__ __launch_bounds__(kMfWaves * kWave) void k_first_layer_mfma(const u8 
     }
     if (tid < 9) {   // A fragment "bf16 1.0 at position p" for p = 0..7, all zero for p = 8
         u32 w[4] = {0, 0, 0, 0};
-        if (tid < 8) w[tid >> 1] = (tid & 1) ? 0x3f800000u : 0x00003f80u;
+        const u32 one = F16 ? 0x3c00u : 0x3f80u;   // 1.0 in half / bf16
+        if (tid < 8) w[tid >> 1] = (tid & 1) ? one << 16 : one;
         onehot[tid] = make_uint4(w[0], w[1], w[2], w[3]);
     }
     const u32 r = lane & 31, h = lane >> 5;
@@ -191,84 +208,89 @@ __global__ __launch_bounds__(kMfWaves * kWave) void k_first_layer_mfma(const u8 
     for (int c = 0; c < 4; ++c) b[c] = bias[ct * kMfCols + 4 * r + c];
     __syncthreads();
 
-    // The next tile's cube codes travel while the current tile computes.  Rows past the end are clamped to the
-    // last state (their results are never stored), which keeps the 20 loads free of branches.
-    u32 code_next[kPlanes];
-    {
-        const size_t row = row_lo + (size_t)wave * kMfTile + r;
-        const u8 *p = soa + (row < n ? row : n - 1);
-#pragma unroll
-        for (int j = 0; j < kPlanes; ++j) code_next[j] = p[(size_t)j * stride];
-    }
+    // A wave works on kMfSub sub-tiles of 32 states at once: every B fragment read from LDS feeds kMfSub MFMAs, which
+    // halves the LDS traffic per state (with one sub-tile the k-loop is bound by the CU's 128 B/clk of LDS, not by
+    // the matrix cores).  The 20 codes of a state stay packed in five dwords; rows past the end are clamped to the
+    // last state (their results are never stored), which keeps the loads free of branches.
     const u32 off_a = h ? 8u : 0u, off_c = h ? 16u : 8u;   // this lane half's offsets in k-steps 3m and 3m + 2
-    for (size_t t0 = row_lo + (size_t)wave * kMfTile; t0 < row_hi; t0 += (size_t)kMfWaves * kMfTile) {
-        u32 code[kPlanes];
+    constexpr size_t kStep = (size_t)kMfWaves * kMfSub * kMfTile;
+    for (size_t t0 = row_lo + (size_t)wave * kMfSub * kMfTile; t0 < row_hi; t0 += kStep) {
+        u32 pk[kMfSub][5];
 #pragma unroll
-        for (int j = 0; j < kPlanes; ++j) code[j] = code_next[j] & 31u;
-        {
-            const size_t row = t0 + (size_t)kMfWaves * kMfTile + r;
+        for (int u = 0; u < kMfSub; ++u) {
+            const size_t row = t0 + (size_t)u * kMfTile + r;
             const u8 *p = soa + (row < n ? row : n - 1);
+            u32 raw[kPlanes];
 #pragma unroll
-            for (int j = 0; j < kPlanes; ++j) code_next[j] = p[(size_t)j * stride];
+            for (int j = 0; j < kPlanes; ++j) raw[j] = p[(size_t)j * stride];
+#pragma unroll
+            for (int q = 0; q < 5; ++q)
+                pk[u][q] = (raw[4 * q] & 31u) | (raw[4 * q + 1] & 31u) << 8 | (raw[4 * q + 2] & 31u) << 16 | (raw[4 * q + 3] & 31u) << 24;
         }
+        auto code = [&](int u, int j) -> u32 { return (pk[u][j >> 2] >> (8 * (j & 3))) & 0xffu; };
+        f32x16 acc[kMfSub][4];   // start from the bias: the epilogue needs no add
+#pragma unroll
+        for (int u = 0; u < kMfSub; ++u)
+#pragma unroll
+            for (int c = 0; c < 4; ++c)
+#pragma unroll
+                for (int i = 0; i < 16; ++i) acc[u][c][i] = b[c];
         // Three k-steps (48 one-hot positions) cover two cubies.  Lane half h = 0 sees (cubie 2m, offset 0),
-        // (2m, 16), (2m+1, 8); half h = 1 sees (2m, 8), (2m+1, 0), (2m+1, 16): only the middle step depends on
-        // the half in WHICH cubie it reads, so that select is done once per cubie pair.
-        u32 mid[kPlanes / 2];
-#pragma unroll
-        for (int m2 = 0; m2 < kPlanes / 2; ++m2) mid[m2] = h ? code[2 * m2 + 1] : code[2 * m2] - 16u;
-        f32x16 acc[4];   // start from the bias: the epilogue needs no add
-#pragma unroll
-        for (int c = 0; c < 4; ++c)
-#pragma unroll
-            for (int i = 0; i < 16; ++i) acc[c][i] = b[c];
-        // Software pipeline over the 30 k-steps: while the four MFMAs of step ks run, the B fragments of step
-        // ks + 1 are already on their way from LDS and so is its one-hot A fragment, so no MFMA waits for an
-        // LDS round trip or sits behind the hazard slots of a freshly written operand.
-        auto a_frag = [&](int ks) -> uint4 {
+        // (2m, 16), (2m+1, 8); half h = 1 sees (2m, 8), (2m+1, 0), (2m+1, 16).
+        // Software pipeline over the 30 k-steps: while the MFMAs of step ks run, the B fragments of step ks + 1 are
+        // already on their way from LDS and so are its one-hot A fragments.
+        auto a_frag = [&](int u, int ks) -> uint4 {
             const int m2 = ks / 3, ph = ks % 3;
-            const u32 pos = ph == 0 ? code[2 * m2] - off_a : ph == 1 ? mid[m2] : code[2 * m2 + 1] - off_c;
+            const u32 pos = ph == 0 ? code(u, 2 * m2) - off_a : ph == 1 ? (h ? code(u, 2 * m2 + 1) : code(u, 2 * m2) - 16u)
+                                                                         : code(u, 2 * m2 + 1) - off_c;
             return onehot[min(pos, 8u)];                    // pos in 0..7 iff the 1 falls into this fragment
         };
         const unsigned char *bbase = wslice + r * kMfPitch + 16 * h;   // + c * 32 * pitch + 32 * ks
-        uint4 a_cur = a_frag(0), b_cur[4];
+        uint4 a_cur[kMfSub], b_cur[4];
+#pragma unroll
+        for (int u = 0; u < kMfSub; ++u) a_cur[u] = a_frag(u, 0);
 #pragma unroll
         for (int c = 0; c < 4; ++c) b_cur[c] = *reinterpret_cast<const uint4 *>(bbase + c * 32 * kMfPitch);
 #pragma unroll
         for (int ks = 0; ks < 30; ++ks) {
-            uint4 a_nxt = a_cur, b_nxt[4] = {b_cur[0], b_cur[1], b_cur[2], b_cur[3]};
+            uint4 a_nxt[kMfSub], b_nxt[4] = {b_cur[0], b_cur[1], b_cur[2], b_cur[3]};
+#pragma unroll
+            for (int u = 0; u < kMfSub; ++u) a_nxt[u] = a_cur[u];
             if (ks + 1 < 30) {
 #pragma unroll
                 for (int c = 0; c < 4; ++c) b_nxt[c] = *reinterpret_cast<const uint4 *>(bbase + c * 32 * kMfPitch + 32 * (ks + 1));
-                a_nxt = a_frag(ks + 1);
+#pragma unroll
+                for (int u = 0; u < kMfSub; ++u) a_nxt[u] = a_frag(u, ks + 1);
             }
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int c = 0; c < 4; ++c)
-                acc[c] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a_cur),
-                                                                 __builtin_bit_cast(bf16x8, b_cur[c]), acc[c], 0, 0, 0);
+#pragma unroll
+                for (int u = 0; u < kMfSub; ++u) {
+                    if (F16)
+                        acc[u][c] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a_cur[u]),
+                                                                           __builtin_bit_cast(f16x8, b_cur[c]), acc[u][c], 0, 0, 0);
+                    else
+                        acc[u][c] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a_cur[u]),
+                                                                            __builtin_bit_cast(bf16x8, b_cur[c]), acc[u][c], 0, 0, 0);
+                }
             __builtin_amdgcn_sched_barrier(0);
-            a_cur = a_nxt;
+#pragma unroll
+            for (int u = 0; u < kMfSub; ++u) a_cur[u] = a_nxt[u];
 #pragma unroll
             for (int c = 0; c < 4; ++c) b_cur[c] = b_nxt[c];
         }
-        // epilogue: activation -> bf16; the lane's columns 4 r .. 4 r + 3 of one state are one 8-byte LDS write into
-        // the per-wave tile [state][col]; the tile is then read back along rows for 16-byte coalesced global stores
+        // epilogue: activation -> bf16; the lane's columns 4 r .. 4 r + 3 of one state are one 8-byte global store
+        uint2 *out2 = reinterpret_cast<uint2 *>(out);
 #pragma unroll
-        for (int i = 0; i < 16; ++i) {
-            const u32 st = (i & 3) + 8 * (i >> 2) + 4 * h;
-            const uint2 v = make_uint2(pack_bf16(act_apply(acc[0][i], ACT, alpha), act_apply(acc[1][i], ACT, alpha)),
-                                       pack_bf16(act_apply(acc[2][i], ACT, alpha), act_apply(acc[3][i], ACT, alpha)));
-            *reinterpret_cast<uint2 *>(stage + st * (kMfCols * 2) + r * 8) = v;
-        }
-        // (a wave only ever touches its own tile, and LDS operations of one wave complete in order)
+        for (int u = 0; u < kMfSub; ++u)
 #pragma unroll
-        for (int q = 0; q < 8; ++q) {
-            const u32 chunk = q * 64 + lane;            // 16-byte chunk of the 32 x 256-byte tile
-            const u32 st = chunk >> 4, cc = chunk & 15;
-            const uint4 v = *reinterpret_cast<const uint4 *>(stage + st * (kMfCols * 2) + cc * 16);
-            if (t0 + st < n) out[(t0 + st) * (H / 8) + ct * 16 + cc] = v;
-        }
+            for (int i = 0; i < 16; ++i) {
+                const size_t row = t0 + (size_t)u * kMfTile + (i & 3) + 8 * (i >> 2) + 4 * h;
+                const uint2 v = make_uint2(pack_bf16(act_apply(acc[u][0][i], ACT, alpha), act_apply(acc[u][1][i], ACT, alpha)),
+                                           pack_bf16(act_apply(acc[u][2][i], ACT, alpha), act_apply(acc[u][3][i], ACT, alpha)));
+                if (row < n) out2[row * (H / 4) + ct * (kMfCols / 4) + r] = v;
+            }
     }
 }
 
@@ -344,7 +366,8 @@ __global__ __launch_bounds__(kBlock) void k_adi_targets(const float *__restrict_
 using namespace rubiks;
 
 extern "C" int rc_first_layer_mfma_bf16(const int8_t *soa, size_t n, size_t stride, const uint16_t *w1, const float *bias,
-                                        uint16_t *out, size_t H, int activation, float alpha, rc_stream_t stream) {
+                                        uint16_t *out, size_t H, int activation, float alpha, int table_is_f16,
+                                        rc_stream_t stream) {
     if (n == 0) return RC_OK;
     RC_CHECK_SOA(soa, n, stride);
     RC_REQUIRE(w1 && bias && out, RC_ERR_NULL);
@@ -352,26 +375,32 @@ extern "C" int rc_first_layer_mfma_bf16(const int8_t *soa, size_t n, size_t stri
     RC_REQUIRE(H >= kMfCols && H % kMfCols == 0 && activation >= RC_ACT_NONE && activation <= RC_ACT_ELU, RC_ERR_RANGE);
     const u32 col_tiles = (u32)(H / kMfCols);
     u32 row_groups = (256 + col_tiles - 1) / col_tiles;   // one workgroup per CU (LDS), every W1 slice staged once per row group
-    u32 rows_per_block = (u32)round_up(ceil_div(n, row_groups), kMfWaves * kMfTile);
+    u32 rows_per_block = (u32)round_up(ceil_div(n, row_groups), kMfWaves * kMfSub * kMfTile);
     row_groups = (u32)ceil_div(n, rows_per_block);
-    const size_t lds_bytes = (size_t)kMfCols * kMfPitch + (size_t)kMfWaves * kMfStage + 9 * 16;
+    const size_t lds_bytes = (size_t)kMfCols * kMfPitch + 9 * 16;
     const dim3 grid(col_tiles * row_groups), block(kMfWaves * kWave);
     hipStream_t s = (hipStream_t)stream;
-#define RC_LAUNCH_MF(ACT)                                                                                          \
+#define RC_LAUNCH_MF(ACT, F16)                                                                                     \
     do {                                                                                                           \
         static bool attr_set = false;                                                                              \
         if (!attr_set) {                                                                                           \
-            hipError_t e = hipFuncSetAttribute((const void *)k_first_layer_mfma<ACT>,                               \
+            hipError_t e = hipFuncSetAttribute((const void *)k_first_layer_mfma<ACT, F16>,                          \
                                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);        \
             if (e != hipSuccess) return hip_rc(e);                                                                 \
             attr_set = true;                                                                                       \
         }                                                                                                          \
-        hipLaunchKernelGGL(k_first_layer_mfma<ACT>, grid, block, lds_bytes, s, (const u8 *)soa, n, stride,          \
+        hipLaunchKernelGGL((k_first_layer_mfma<ACT, F16>), grid, block, lds_bytes, s, (const u8 *)soa, n, stride,   \
                            (const uint4 *)w1, bias, (uint4 *)out, (u32)H, rows_per_block, alpha);                  \
     } while (0)
-    if (activation == RC_ACT_ELU) RC_LAUNCH_MF(RC_ACT_ELU);
-    else if (activation == RC_ACT_RELU) RC_LAUNCH_MF(RC_ACT_RELU);
-    else RC_LAUNCH_MF(RC_ACT_NONE);
+#define RC_LAUNCH_MF_ACT(F16)                                        \
+    do {                                                             \
+        if (activation == RC_ACT_ELU) RC_LAUNCH_MF(RC_ACT_ELU, F16);  \
+        else if (activation == RC_ACT_RELU) RC_LAUNCH_MF(RC_ACT_RELU, F16); \
+        else RC_LAUNCH_MF(RC_ACT_NONE, F16);                         \
+    } while (0)
+    if (table_is_f16) RC_LAUNCH_MF_ACT(true);
+    else RC_LAUNCH_MF_ACT(false);
+#undef RC_LAUNCH_MF_ACT
 #undef RC_LAUNCH_MF
     return launch_status();
 }
@@ -450,8 +479,9 @@ extern "C" int rc_first_layer_bf16(const int8_t *soa, size_t n, size_t stride, c
         else if (activation == RC_ACT_RELU) RC_LAUNCH_FL(RC_ACT_RELU, F16); \
         else RC_LAUNCH_FL(RC_ACT_NONE, F16);                        \
     } while (0)
-    if (table_is_f16) RC_LAUNCH_FL_ACT(true);
-    else RC_LAUNCH_FL_ACT(false);
+    if (table_is_f16 == 2) RC_LAUNCH_FL_ACT(2);
+    else if (table_is_f16) RC_LAUNCH_FL_ACT(1);
+    else RC_LAUNCH_FL_ACT(0);
 #undef RC_LAUNCH_FL_ACT
 #undef RC_LAUNCH_FL
     return launch_status();

@@ -245,13 +245,16 @@ class InferenceNet:
             # weight fits its range (11 mantissa bits, i.e. closer to fp32 than bf16, and the kernel
             # converts + adds in one v_fma_mix_f32), bf16 otherwise
             W1_full = layers[0][0].to(device)
-            if first_layer_table == "mfma":
-                # matrix-core variant: the Linear weight as stored, bf16 [H][480]; mode 2 selects rc_first_layer_mfma_bf16
-                table, mode = W1_full.to(torch.bfloat16).contiguous(), 2
+            half_ok = bool(torch.isfinite(W1_full).all()) and float(W1_full.abs().max()) < 3.0e4
+            # mode: 0 / 1 gather-sum with a bf16 / f16 table, 3 f16 table with pairs of rows added in f16 first,
+            #       2 / 4 matrix-core variant with the Linear weight as stored in bf16 / f16
+            if first_layer_table in ("mfma", "mfma16") or (first_layer_table == "auto" and half_ok):
+                use_f16 = first_layer_table != "mfma" and half_ok
+                table, mode = W1_full.to(torch.float16 if use_f16 else torch.bfloat16).contiguous(), 4 if use_f16 else 2
             else:
-                use_f16 = first_layer_table in ("auto", "f16") and bool(torch.isfinite(W1_full).all()) \
-                    and float(W1_full.abs().max()) < 6.0e4
-                table, mode = W1_full.t().to(torch.float16 if use_f16 else torch.bfloat16).contiguous(), int(use_f16)
+                use_f16 = first_layer_table in ("f16", "f16pair") and half_ok
+                table = W1_full.t().to(torch.float16 if use_f16 else torch.bfloat16).contiguous()
+                mode = (1 if first_layer_table == "f16" else 3) if use_f16 else 0
             self._fused_first = (table, layers[0][1].to(device).float().contiguous(), code,
                                  float(getattr(act1, "alpha", 1.0)), W1.shape[0], mode)
 
@@ -280,13 +283,13 @@ class InferenceNet:
         w1t, b1, code, alpha, H, is_f16 = self._fused_first
         if out is None:
             out = torch.empty((cubes.n, H), dtype=torch.bfloat16, device=w1t.device)
-        if is_f16 == 2:
+        if is_f16 in (2, 4):
             _hip.check(_hip.lib().rc_first_layer_mfma_bf16(cubes.soa.data_ptr(), cubes.n, cubes.stride, w1t.data_ptr(),
-                                                           b1.data_ptr(), out.data_ptr(), H, code, alpha,
+                                                           b1.data_ptr(), out.data_ptr(), H, code, alpha, int(is_f16 == 4),
                                                            _hip.stream_ptr()), "rc_first_layer_mfma_bf16")
             return out
         _hip.check(_hip.lib().rc_first_layer_bf16(cubes.soa.data_ptr(), cubes.n, cubes.stride, w1t.data_ptr(),
-                                                  b1.data_ptr(), out.data_ptr(), H, code, alpha, is_f16,
+                                                  b1.data_ptr(), out.data_ptr(), H, code, alpha, 2 if is_f16 == 3 else is_f16,
                                                   _hip.stream_ptr()), "rc_first_layer_bf16")
         return out
 

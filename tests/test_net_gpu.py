@@ -33,7 +33,7 @@ def _model(act=None, seed=0):
 
 @pytest.mark.parametrize("n", [1, 17, 512, 513, 4099, 12288])
 @pytest.mark.parametrize("act", ["elu", "relu"])
-@pytest.mark.parametrize("table", ["bf16", "f16", "mfma"])
+@pytest.mark.parametrize("table", ["bf16", "f16", "f16pair", "mfma", "mfma16"])
 def test_first_layer_matches_onehot_gemm(n, act, table):
     """
     rc_first_layer_bf16 == act(as_oh(s) @ W1^T + b1) computed in fp32 from the SAME bf16 weights,
@@ -44,20 +44,21 @@ def test_first_layer_matches_onehot_gemm(n, act, table):
     from librubiks.model import InferenceNet
     m = _model(torch.nn.ELU() if act == "elu" else torch.nn.ReLU())
     eng = InferenceNet(m, dtype=torch.bfloat16, first_layer_table=table)
-    assert eng.supports_cubes and eng._fused_first[5] == {"bf16": 0, "f16": 1, "mfma": 2}[table]
+    assert eng.supports_cubes and eng._fused_first[5] == {"bf16": 0, "f16": 1, "mfma": 2, "f16pair": 3, "mfma16": 4}[table]
     s = _states(n, seed=n)
     cubes = DeviceCubes.from_numpy(s)
     got = eng.first_layer(cubes).float()
     oh = torch.from_numpy(oc.as_oh(s)).cuda()
     # reference: the SAME 16-bit table and fp32 bias, accumulated in fp32 by a dense product
-    table_kc = eng._fused_first[0].float() if table != "mfma" else eng._fused_first[0].float().t()   # [480][H]
+    table_kc = eng._fused_first[0].float() if not table.startswith("mfma") else eng._fused_first[0].float().t()   # [480][H]
     ref = oh @ table_kc + eng._fused_first[1]
     ref = torch.nn.functional.elu(ref) if act == "elu" else torch.relu(ref)
     ref = ref.to(torch.bfloat16).float()
     assert got.shape == (n, 4096)
     assert torch.allclose(got, ref, rtol=2 ** -7, atol=1e-3), float((got - ref).abs().max())
-    # exactly equal on the overwhelming majority of elements
-    assert float((got == ref).float().mean()) > 0.98
+    # exactly equal on the overwhelming majority of elements ("f16pair" rounds ten pair sums to half precision
+    # before the fp32 accumulation: a few more results land on the neighbouring bf16 value)
+    assert float((got == ref).float().mean()) > (0.85 if table == "f16pair" else 0.98)
 
 
 def test_engine_paths_agree_and_track_fp32():
