@@ -296,11 +296,11 @@ __global__ __launch_bounds__(kMfWaves * kWave) void k_first_layer_mfma(const u8 
 
 // =================================================================================================
 // Network head: out = W_head * act(x) + b for a skinny output layer (13 outputs of 1024 inputs).
-// One wave per 16 rows on the matrix cores: 32 k-steps of v_mfma_f32_16x16x32_bf16.
+// One workgroup per 16 rows on the matrix cores: 32 k-steps of v_mfma_f32_16x16x32_bf16, eight per wave.
 //   A (16 rows x 32 k): lane l (r = l & 15, g = l >> 4) loads x[row r][32 ks + 8 g .. +7] (16 bytes), applies the
 //     activation in fp32 and repacks to bf16 -- the last hidden layer's ELU costs no pass over memory.
-//   B (32 k x 16 outputs): W_head[o = l & 15][32 ks + 8 g .. +7]; all 32 fragments of a lane (outputs >= 13 are zero)
-//     are loaded once and stay in registers for every tile the wave processes.
+//   B (32 k x 16 outputs): W_head[o = l & 15][32 ks + 8 g .. +7]; a wave's eight fragments (outputs >= 13 are zero)
+//     are loaded once and stay in registers for every tile the workgroup processes.
 //   D: lane holds output l & 15 of rows 4 g .. 4 g + 3.
 // =================================================================================================
 typedef __attribute__((ext_vector_type(4))) float f32x4;
@@ -309,22 +309,27 @@ constexpr int kHeadK = 1024, kHeadSteps = kHeadK / 32, kHeadMaxOut = 16;
 template <int ACT>
 __global__ __launch_bounds__(kBlock) void k_head(const uint4 *__restrict__ x, size_t n, const uint4 *__restrict__ w,
                                                  const float *__restrict__ bias, float *__restrict__ out, u32 n_out, float alpha) {
-    const u32 lane = threadIdx.x & (kWave - 1), r = lane & 15, g = lane >> 4;
-    const size_t wave = ((size_t)blockIdx.x * kBlock + threadIdx.x) / kWave, n_waves = (size_t)gridDim.x * kBlock / kWave;
-    uint4 bfrag[kHeadSteps];
+    // One 16-row tile per workgroup pass; the tile's K = 1024 is split over the four waves (8 k-steps each), so the
+    // ELU of the 16 384 inputs of a tile is spread over four SIMDs and a wave keeps only its quarter of the weights
+    // in registers; the four partial 16 x 16 products meet in LDS.
+    __shared__ float s_part[kBlock / kWave][16][17];
+    constexpr int kSteps = kHeadSteps / (kBlock / kWave);   // 8
+    const u32 tid = threadIdx.x, wv = tid / kWave, lane = tid & (kWave - 1), r = lane & 15, g = lane >> 4;
+    uint4 bfrag[kSteps];
 #pragma unroll
-    for (int ks = 0; ks < kHeadSteps; ++ks)
-        bfrag[ks] = (r < n_out) ? w[(size_t)r * (kHeadK / 8) + ks * 4 + g] : make_uint4(0, 0, 0, 0);
-    const float bo = (r < n_out) ? bias[r] : 0.f;
+    for (int ks = 0; ks < kSteps; ++ks)
+        bfrag[ks] = (r < n_out) ? w[(size_t)r * (kHeadK / 8) + (wv * kSteps + ks) * 4 + g] : make_uint4(0, 0, 0, 0);
     const size_t n_tiles = ceil_div(n, (size_t)16);
-    for (size_t tile = wave; tile < n_tiles; tile += n_waves) {
+    for (size_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
         const size_t row = tile * 16 + r;
-        const uint4 *xr = x + (row < n ? row : n - 1) * (kHeadK / 8) + g;   // rows past the end: clamped, never stored
+        const uint4 *xr = x + (row < n ? row : n - 1) * (kHeadK / 8) + wv * kSteps * 4 + g;   // rows past the end: clamped, never stored
+        uint4 a[kSteps];
+#pragma unroll
+        for (int ks = 0; ks < kSteps; ++ks) a[ks] = xr[ks * 4];
         f32x4 acc = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-        for (int ks = 0; ks < kHeadSteps; ++ks) {
-            const uint4 a = xr[ks * 4];
-            const u32 aw[4] = {a.x, a.y, a.z, a.w};
+        for (int ks = 0; ks < kSteps; ++ks) {
+            const u32 aw[4] = {a[ks].x, a[ks].y, a[ks].z, a[ks].w};
             u32 pk[4];
 #pragma unroll
             for (int d = 0; d < 4; ++d)
@@ -333,10 +338,15 @@ __global__ __launch_bounds__(kBlock) void k_head(const uint4 *__restrict__ x, si
             acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, make_uint4(pk[0], pk[1], pk[2], pk[3])),
                                                           __builtin_bit_cast(bf16x8, bfrag[ks]), acc, 0, 0, 0);
         }
+        __syncthreads();   // the previous tile's partial sums have been read
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const size_t orow = tile * 16 + g * 4 + i;
-            if (orow < n) out[orow * kHeadMaxOut + r] = (r < n_out) ? acc[i] + bo : 0.f;
+        for (int i = 0; i < 4; ++i) s_part[wv][g * 4 + i][r] = acc[i];   // D: lane holds output r of rows 4 g .. 4 g + 3
+        __syncthreads();
+        {   // 256 threads = 16 rows x 16 outputs
+            const u32 orow = tid >> 4, o = tid & 15;
+            const float v = s_part[0][orow][o] + s_part[1][orow][o] + s_part[2][orow][o] + s_part[3][orow][o];
+            const size_t grow = tile * 16 + orow;
+            if (grow < n) out[grow * kHeadMaxOut + o] = (o < n_out) ? v + bias[o] : 0.f;
         }
     }
 }
@@ -412,9 +422,9 @@ extern "C" int rc_head_bf16(const uint16_t *x, size_t n, size_t K, const uint16_
     RC_REQUIRE(aligned16(x) && aligned16(out) && aligned16(w), RC_ERR_ALIGN);
     RC_REQUIRE(K == (size_t)kHeadK && n_out >= 1 && n_out <= kHeadMaxOut && activation >= RC_ACT_NONE &&
                    activation <= RC_ACT_ELU, RC_ERR_RANGE);
-    // persistent waves (the weight fragments are loaded once per wave): one 16-row tile per wave up to 2 waves per SIMD
+    // one 16-row tile per workgroup pass (four waves split its K); up to 8 workgroups per CU, grid-stride beyond
     const size_t tiles = ceil_div(n, (size_t)16);
-    const unsigned grid = (unsigned)(ceil_div(tiles, (size_t)(kBlock / kWave)) < 512 ? ceil_div(tiles, (size_t)(kBlock / kWave)) : 512);
+    const unsigned grid = (unsigned)(tiles < 2048 ? tiles : 2048);
     hipStream_t s = (hipStream_t)stream;
     if (activation == RC_ACT_ELU)
         hipLaunchKernelGGL(k_head<RC_ACT_ELU>, dim3(grid), dim3(kBlock), 0, s, (const uint4 *)x, n, (const uint4 *)w, bias, out,
