@@ -132,6 +132,10 @@ int rc_first_layer_bf16(const int8_t *soa, size_t n, size_t stride, const uint16
 int rc_first_layer_mfma_bf16(const int8_t *soa, size_t n, size_t stride, const uint16_t *w1, const float *bias,
                              uint16_t *out, size_t H, int activation, float alpha, int table_is_f16, rc_stream_t stream);
 
+/* In-place ReLU / ELU(alpha) of a contiguous bf16 tensor of n elements (n % 8 == 0): the activation pass between
+ * two library GEMMs (model.py:150-157: Linear -> activation), 16 bytes per lane.  4 B of HBM traffic per element. */
+int rc_act_bf16_inplace(uint16_t *x, size_t n, int activation, float alpha, rc_stream_t stream);
+
 /* ---- network head: last activation + skinny output layer in one pass -----------------------------------------
  * out[i][o] = bias[o] + sum_k w[o][k] * act(x[i][k])   for o < n_out <= 16   (float out, row pitch 16)
  * Replaces the final activation pass and the 1024 -> 13 GEMM of the merged policy/value heads

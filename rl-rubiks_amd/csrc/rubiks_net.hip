@@ -438,6 +438,43 @@ extern "C" int rc_head_bf16(const uint16_t *x, size_t n, size_t K, const uint16_
     return launch_status();
 }
 
+// In-place activation of a bf16 tensor (the pass between two library GEMMs, which have no ELU epilogue):
+// 16 bytes per lane, four independent chunks in flight per thread.
+template <int ACT>
+__global__ __launch_bounds__(kBlock) void k_act_bf16(uint4 *__restrict__ x, size_t n16, float alpha) {
+    const size_t stride = (size_t)gridDim.x * kBlock;
+    for (size_t i0 = (size_t)blockIdx.x * kBlock + threadIdx.x; i0 < n16; i0 += 4 * stride) {
+        uint4 v[4];
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+            if (i0 + t * stride < n16) v[t] = x[i0 + t * stride];
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            if (i0 + t * stride >= n16) continue;
+            const u32 w[4] = {v[t].x, v[t].y, v[t].z, v[t].w};
+            u32 o[4];
+#pragma unroll
+            for (int d = 0; d < 4; ++d)
+                o[d] = pack_bf16(act_apply(__uint_as_float(w[d] << 16), ACT, alpha), act_apply(__uint_as_float(w[d] & 0xffff0000u), ACT, alpha));
+            x[i0 + t * stride] = make_uint4(o[0], o[1], o[2], o[3]);
+        }
+    }
+}
+
+extern "C" int rc_act_bf16_inplace(uint16_t *x, size_t n, int activation, float alpha, rc_stream_t stream) {
+    if (n == 0 || activation == RC_ACT_NONE) return RC_OK;
+    RC_REQUIRE(x != nullptr, RC_ERR_NULL);
+    RC_REQUIRE(aligned16(x) && n % 8 == 0, RC_ERR_ALIGN);
+    RC_REQUIRE(activation == RC_ACT_RELU || activation == RC_ACT_ELU, RC_ERR_RANGE);
+    const size_t n16 = n / 8;
+    const unsigned grid = grid_for(ceil_div(n16, (size_t)4), kBlock, 256 * 16);
+    if (activation == RC_ACT_ELU)
+        hipLaunchKernelGGL(k_act_bf16<RC_ACT_ELU>, dim3(grid), dim3(kBlock), 0, (hipStream_t)stream, (uint4 *)x, n16, alpha);
+    else
+        hipLaunchKernelGGL(k_act_bf16<RC_ACT_RELU>, dim3(grid), dim3(kBlock), 0, (hipStream_t)stream, (uint4 *)x, n16, alpha);
+    return launch_status();
+}
+
 extern "C" int rc_adi_targets(const float *values, const uint8_t *child_solved, const uint8_t *state_solved, size_t n,
                               size_t depth, float win_reward, int fix_mode, int64_t *policy_target, float *value_target,
                               rc_stream_t stream) {

@@ -268,7 +268,7 @@ class InferenceNet:
         for W, b, act in self.layers:
             x = torch.addmm(b, x, W.t())
             if act is not None:
-                x = F.relu_(x) if isinstance(act, nn.ReLU) else F.elu_(x, alpha=act.alpha)
+                x = _activate_(x, act)
         out = x.float()
         return out[:, :N_ACTIONS], out[:, N_ACTIONS]
 
@@ -342,13 +342,24 @@ class InferenceNet:
         for W, b, act in layers:
             x = torch.addmm(b, x, W.t())
             if act is not None:
-                x = F.relu_(x) if isinstance(act, nn.ReLU) else F.elu_(x, alpha=act.alpha)
+                x = _activate_(x, act)
         return x
 
     @torch.no_grad()
     def value(self, oh: torch.Tensor) -> torch.Tensor:
         """Value head only, float32[n]."""
         return self._run(self.value_layers, oh).float().reshape(-1)
+
+
+def _activate_(x: torch.Tensor, act: nn.Module) -> torch.Tensor:
+    """In-place activation; bf16 tensors on the GPU go through rc_act_bf16_inplace (16-byte lanes), the rest through torch."""
+    if x.dtype == torch.bfloat16 and x.is_cuda and x.is_contiguous() and x.numel() % 8 == 0:
+        from librubiks import _hip
+        relu = isinstance(act, nn.ReLU)
+        _hip.check(_hip.lib().rc_act_bf16_inplace(x.data_ptr(), x.numel(), 1 if relu else 2, 0.0 if relu else float(act.alpha),
+                                                  _hip.stream_ptr()), "rc_act_bf16_inplace")
+        return x
+    return F.relu_(x) if isinstance(act, nn.ReLU) else F.elu_(x, alpha=act.alpha)
 
 
 class GenericNet:

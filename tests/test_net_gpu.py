@@ -122,3 +122,19 @@ def test_fused_head_matches_gemm_path(n):
     raw = (x @ W3.float().t() + b3.float()).to(torch.bfloat16).float()
     exact = torch.nn.functional.elu(raw) @ W4.float().t() + b4.float()
     assert float((head[:, :13] - exact).abs().max()) <= float((ref - exact).abs().max()) + 1e-3
+
+
+@pytest.mark.parametrize("n", [8, 1000 * 8, 11264 * 2048])
+def test_inplace_activation_kernel(n):
+    """rc_act_bf16_inplace == torch's ELU / ReLU evaluated in fp32 and rounded to bf16 (1 bf16 ulp: exp differs)."""
+    from librubiks import _hip
+    g = torch.Generator(device="cuda").manual_seed(n)
+    x = (torch.randn(n, device="cuda", generator=g) * 3).to(torch.bfloat16)
+    for code, ref in ((2, lambda t: torch.nn.functional.elu(t.float(), alpha=1.0)), (1, lambda t: torch.relu(t.float()))):
+        y = x.clone()
+        _hip.check(_hip.lib().rc_act_bf16_inplace(y.data_ptr(), n, code, 1.0, _hip.stream_ptr()), "rc_act_bf16_inplace")
+        want = ref(x).to(torch.bfloat16)
+        assert torch.allclose(y.float(), want.float(), rtol=2 ** -7, atol=1e-6)
+        assert float((y == want).float().mean()) > 0.99
+    assert _hip.lib().rc_act_bf16_inplace(x.data_ptr(), 12, 2, 1.0, None) == -2      # n % 8 != 0
+    assert _hip.lib().rc_act_bf16_inplace(x.data_ptr(), 8, 7, 1.0, None) == -4       # unknown activation
