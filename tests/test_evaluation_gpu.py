@@ -92,3 +92,21 @@ def test_evaluator_pooled_depths(standin_net):
     np.random.seed(5)
     r1, s1, t1 = Evaluator(40, [2, 4, 6], None, 500, slots=32).eval(MCTS(net, 0.6, True, net_dtype=torch.float32, sync_every=4))
     assert np.array_equal(r0, r1) and np.array_equal(s0, s1) and t1.shape == (3, 40)
+
+
+def test_continuous_batching_time_limit(standin_net):
+    """A time limit ends a pooled run early: every game still gets a well-formed (unsolved or solved) result."""
+    import torch
+    from librubiks.solving.agents import MCTS
+    from oracle import cube as oc
+    np.random.seed(8)
+    states = np.array([oc.scramble(12, True)[0] for _ in range(96)])
+    agent = MCTS(standin_net.cuda(), c=0.6, search_graph=True, net_dtype=torch.float32, sync_every=4)
+    res = agent.search_batch(states, 1e-4, 100_000, slots=32)       # the limit passes at the first status read
+    assert res.solved.shape == (96,) and len(res.queues) == 96 and all(q is not None for q in res.queues)
+    assert (res.lengths[~res.solved] == -1).all() and (res.nodes[64:] == 0).all()   # games 32.. never got a slot
+    for g in np.flatnonzero(res.solved):
+        s = states[g]
+        for a in res.queues[g]:
+            s = oc.rotate(s, *oc.ACTION_SPACE[a])
+        assert oc.is_solved(s)
