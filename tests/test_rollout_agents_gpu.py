@@ -74,3 +74,23 @@ def test_egvm_reference_traces(standin_net):
         assert len(agent) == int(n), pre
         assert list(agent.action_queue) == list(g[pre + "queue"]), pre
     assert str(agent).startswith("EGVM (e=")
+
+
+def test_reference_generic_agent_test_restated():
+    """tests/test_agents.py:18-36 of the reference: every agent, a depth-4 scramble, 50 ms, queue replays to `solved`."""
+    from librubiks import cube
+    from librubiks.model import Model, ModelConfig
+    from librubiks.solving.agents import BFS, EGVM, PolicySearch, RandomSearch, ValueSearch
+    torch.manual_seed(0)
+    np.random.seed(0)
+    net = Model.create(ModelConfig()).eval()
+    agents = [RandomSearch(), BFS(), PolicySearch(net, sample_policy=False), PolicySearch(net, sample_policy=True),
+              ValueSearch(net), EGVM(net, 0.1, 4, 12)]
+    for agent in agents:
+        state, _, _ = cube.scramble(4)
+        found = agent.search(state, .05)
+        assert all(0 <= a < cube.action_dim for a in agent.action_queue)
+        for a in agent.action_queue:
+            state = cube.rotate(state, *cube.action_space[a])
+        assert found == cube.is_solved(state), str(agent)
+    assert str(agents[1]) == "Breadth-first search"
