@@ -14,7 +14,6 @@ else is integer work in csrc/.
 """
 import json
 import os
-from copy import deepcopy
 from time import time
 
 import torch

@@ -15,7 +15,7 @@ from collections import deque
 import numpy as np
 import torch
 
-from librubiks import cube, gpu, no_grad
+from librubiks import gpu, no_grad
 from librubiks.cube.device import DeviceCubes
 from librubiks.model import Model
 from librubiks.solving import astar_device as ad

@@ -38,7 +38,6 @@ def main():
     args = ap.parse_args()
     os.makedirs(args.out, exist_ok=True)
 
-    from librubiks import cube
     from librubiks.model import Model, ModelConfig
     from librubiks.solving.agents import MCTS, AStar, PolicySearch, ValueSearch
     from librubiks.solving.evaluation import Evaluator
