@@ -276,18 +276,22 @@ class InferenceNet:
         return self._fused_first is not None
 
     @torch.no_grad()
-    def first_layer(self, cubes, out: torch.Tensor = None) -> torch.Tensor:
-        """act(Linear(as_oh(cubes))) as one HIP kernel: bf16 [n, H] without a one-hot matrix."""
+    def first_layer(self, cubes, out: torch.Tensor = None, lo: int = 0, n: int = None) -> torch.Tensor:
+        """act(Linear(as_oh(cubes[lo:lo+n]))) as one HIP kernel: bf16 [n, H] without a one-hot matrix (lo % 16 == 0)."""
         from librubiks import _hip
         w1t, b1, code, alpha, H, is_f16 = self._fused_first
+        if lo or n is not None:   # a column window of the SoA: the same planes, shifted base pointer
+            n = cubes.n - lo if n is None else n
+            assert lo % 16 == 0 and 0 <= lo and lo + n <= cubes.n
+            cubes = _CubeWindow(cubes.soa.data_ptr() + lo, n, cubes.stride)
         if out is None:
             out = torch.empty((cubes.n, H), dtype=torch.bfloat16, device=w1t.device)
         if is_f16 in (2, 4):
-            _hip.check(_hip.lib().rc_first_layer_mfma_bf16(cubes.soa.data_ptr(), cubes.n, cubes.stride, w1t.data_ptr(),
+            _hip.check(_hip.lib().rc_first_layer_mfma_bf16(_soa_ptr(cubes), cubes.n, cubes.stride, w1t.data_ptr(),
                                                            b1.data_ptr(), out.data_ptr(), H, code, alpha, int(is_f16 == 4),
                                                            _hip.stream_ptr()), "rc_first_layer_mfma_bf16")
             return out
-        _hip.check(_hip.lib().rc_first_layer_bf16(cubes.soa.data_ptr(), cubes.n, cubes.stride, w1t.data_ptr(),
+        _hip.check(_hip.lib().rc_first_layer_bf16(_soa_ptr(cubes), cubes.n, cubes.stride, w1t.data_ptr(),
                                                   b1.data_ptr(), out.data_ptr(), H, code, alpha, 2 if is_f16 == 3 else is_f16,
                                                   _hip.stream_ptr()), "rc_first_layer_bf16")
         return out
@@ -333,8 +337,9 @@ class InferenceNet:
         return out[:, :N_ACTIONS], out[:, N_ACTIONS]
 
     @torch.no_grad()
-    def value_cubes(self, cubes, x1: torch.Tensor = None) -> torch.Tensor:
-        return self._run(self.value_layers[1:], self.first_layer(cubes, x1)).float().reshape(-1)
+    def value_cubes(self, cubes, x1: torch.Tensor = None, lo: int = 0, n: int = None) -> torch.Tensor:
+        """Value head only, float32[n], straight from device-resident cube states (optionally the window lo..lo+n)."""
+        return self._run(self.value_layers[1:], self.first_layer(cubes, x1, lo, n)).float().reshape(-1)
 
     @staticmethod
     def _run(layers, x):
@@ -348,6 +353,18 @@ class InferenceNet:
     def value(self, oh: torch.Tensor) -> torch.Tensor:
         """Value head only, float32[n]."""
         return self._run(self.value_layers, oh).float().reshape(-1)
+
+
+class _CubeWindow:
+    """Rows lo .. lo + n of a DeviceCubes batch as (base pointer, n, stride) for the fused input layer."""
+    __slots__ = ("ptr", "n", "stride")
+
+    def __init__(self, ptr: int, n: int, stride: int):
+        self.ptr, self.n, self.stride = ptr, n, stride
+
+
+def _soa_ptr(cubes) -> int:
+    return cubes.ptr if isinstance(cubes, _CubeWindow) else cubes.soa.data_ptr()
 
 
 def _activate_(x: torch.Tensor, act: nn.Module) -> torch.Tensor:

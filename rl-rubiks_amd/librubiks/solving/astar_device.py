@@ -81,7 +81,11 @@ class AStarBatch:
     def set_net(self, net, dtype=torch.bfloat16):
         self.engine = make_inference_net(net, dtype)
         rows = min(NET_CHUNK, self.B * self.N * N_ACT)
-        self._oh = torch.empty((rows, 480), dtype=self.engine.input_dtype, device=self.device)
+        if getattr(self.engine, "supports_cubes", False):
+            self._oh = None
+            self._x1 = torch.empty((rows, self.engine._fused_first[4]), dtype=torch.bfloat16, device=self.device)
+        else:
+            self._oh = torch.empty((rows, 480), dtype=self.engine.input_dtype, device=self.device)
 
     def reset(self, roots: DeviceCubes):
         assert roots.n == self.B and self.engine is not None
@@ -94,6 +98,11 @@ class AStarBatch:
         """Value head on the `total` compacted new states, chunked through the one-hot buffer."""
         lib, st = self.lib, _hip.stream_ptr()
         soa = self.new_states.soa
+        if getattr(self.engine, "supports_cubes", False):   # input layer fused with the one-hot encoding: no (n, 480) matrix
+            for lo in range(0, total, NET_CHUNK):
+                n = min(NET_CHUNK, total - lo)
+                self.values[lo:lo + n] = self.engine.value_cubes(self.new_states, self._x1[:n], lo, n)
+            return
         for lo in range(0, total, NET_CHUNK):
             n = min(NET_CHUNK, total - lo)
             oh = self._oh[:n]
