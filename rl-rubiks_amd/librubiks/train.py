@@ -86,6 +86,9 @@ class Train:
             net.config.architecture.startswith("fc") and self.adi_net_dtype != torch.float32 else None
         for lo in range(0, 12 * n, self.adi_chunk):   # chunked like the reference's adi_ff_batches (train.py:301-310)
             m = min(self.adi_chunk, 12 * n - lo)
+            if engine is not None and engine.supports_cubes and lo % 16 == 0:
+                values[lo:lo + m] = engine.value_cubes(kids, None, lo, m)   # a column window of the SoA, no copy
+                continue
             part = DeviceCubes(kids.soa[:, lo:lo + ((m + 15) // 16) * 16].contiguous(), m) if (lo or m < 12 * n) else kids
             if engine is not None and engine.supports_cubes:
                 values[lo:lo + m] = engine.value_cubes(part)
