@@ -126,6 +126,10 @@ class Train:
             self.tt.profile("Training loop")
             net.train()
             batches = self._get_batches(len(data), self.batch_size)
+            # the logged losses are summed on the device and read once per rollout: a host read per step (as the
+            # reference does with float(...)) would stall the launch queue 2 x len(batches) times per rollout
+            p_acc = torch.zeros((), dtype=torch.float64, device=data.device)
+            v_acc = torch.zeros((), dtype=torch.float64, device=data.device)
             for batch in batches:
                 optimizer.zero_grad()
                 policy_pred, value_pred = net(data[batch], policy=True, value=True)
@@ -134,8 +138,9 @@ class Train:
                 torch.mean(policy_loss + value_loss).backward()
                 average_gradients(net)
                 optimizer.step()
-                self.policy_losses[rollout] += float(policy_loss.detach().mean()) / len(batches)
-                self.value_losses[rollout] += float(value_loss.detach().mean()) / len(batches)
+                p_acc += policy_loss.detach().mean().double() / len(batches)
+                v_acc += value_loss.detach().mean().double() / len(batches)
+            self.policy_losses[rollout], self.value_losses[rollout] = float(p_acc), float(v_acc)
             self.train_losses[rollout] = self.policy_losses[rollout] + self.value_losses[rollout]
             self.tt.end_profile("Training loop")
             if rollout and self.update_interval and rollout % self.update_interval == 0:   # train.py:190-200

@@ -69,7 +69,7 @@ def main():
             torch.cuda.synchronize()
             b = time.perf_counter()
             net.train()
-            tot = 0.0
+            tot = torch.zeros((), dtype=torch.float64, device=data.device)
             batches = tr._get_batches(len(data), args.batch)
             for sl in batches:
                 optimizer.zero_grad()
@@ -79,12 +79,12 @@ def main():
                 loss = torch.mean(pl + vl)
                 loss.backward()
                 optimizer.step()
-                tot += float(loss.detach())
+                tot += loss.detach().double()
             torch.cuda.synchronize()
             c = time.perf_counter()
             t_adi += b - a
             t_opt += c - b
-            losses.append(tot / len(batches))
+            losses.append(float(tot) / len(batches))
             if rollout and rollout % 100 == 0:
                 scheduler.step()
             if rollout % 25 == 0:
