@@ -10,23 +10,19 @@ Mirrors reference librubiks/__init__.py:5-21 (`cpu`, `gpu`, `reset_cuda`, `no_gr
 There is NO CPU implementation of the cube environment in this package: without an MI355X and the
 built librubiks_hip.so every cube / agent call raises.
 """
-import functools
-
 import torch
 
-cpu = torch.device("cpu")
-gpu = torch.device("cuda" if torch.cuda.is_available() else "cpu")
+_HAS_GPU = torch.cuda.is_available()
+cpu, gpu = torch.device("cpu"), torch.device("cuda" if _HAS_GPU else "cpu")
 
 
-def reset_cuda():
+def reset_cuda() -> None:
+    """Returns cached allocator blocks to the driver and waits for the device (reference: same name, same effect)."""
     torch.cuda.empty_cache()
-    if torch.cuda.is_available():
+    if _HAS_GPU:
         torch.cuda.synchronize()
 
 
 def no_grad(fun):
-    @functools.wraps(fun)
-    def wrapper(*args, **kwargs):
-        with torch.no_grad():
-            return fun(*args, **kwargs)
-    return wrapper
+    """Decorator: run `fun` without autograd (torch.no_grad used as a decorator keeps the wrapped signature)."""
+    return torch.no_grad()(fun)
