@@ -359,10 +359,16 @@ def main():
             H = eng._fused_first[4]
             nbytes = (20 + 2 * H) * rows
             gbps = nbytes / (phases["input_layer"] * 1e-3) / 1e9
-            roofline_input = {"kernel": "rc_first_layer_bf16 (one-hot x W1 as 20-row gather-sum from LDS + bias + ELU)",
+            mode = eng._fused_first[5]
+            name = ("rc_first_layer_mfma_bf16 (one-hot x W1 on the matrix cores, one-hot fragments generated from the cube codes, "
+                    "W1 slice in LDS, + bias + ELU)") if mode in (2, 4) else \
+                "rc_first_layer_bf16 (one-hot x W1 as 20-row gather-sum from LDS + bias + ELU)"
+            roofline_input = {"kernel": name, "table": {0: "bf16", 1: "f16", 2: "bf16", 3: "f16 pairs", 4: "f16"}[mode],
                               "bound": "hbm", "achieved": round(gbps, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                               "frac": round(gbps / HBM_PEAK_GBPS, 4), "algorithmic_bytes": nbytes,
-                              "bytes_per_unit": 20 + 2 * H, "traffic": None, "ms_per_launch": phases["input_layer"]}
+                              "bytes_per_unit": 20 + 2 * H, "traffic": None, "ms_per_launch": phases["input_layer"],
+                              "note": "algorithmic bytes: 20 B of cube codes in, 2 H B of activations out per row; the kernel is "
+                                      "LDS-feed / issue bound, not HBM bound (DESIGN.md section 3)"}
     result = {
         "metric": "MCTS node expansions/sec, depth-20 scrambles", "value": round(nodes / seconds, 1),
         "unit": "node expansions/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
