@@ -19,7 +19,13 @@ import os
 import numpy as np
 
 from librubiks import cube
+from librubiks.solving.sharding import sharded_search_batch
 from librubiks.utils import NullLogger, TickTock, bernoulli_error
+
+
+def _world_size() -> int:
+    import torch.distributed as dist
+    return dist.get_world_size() if (dist.is_available() and dist.is_initialized()) else 1
 
 
 class Evaluator:
@@ -49,12 +55,17 @@ class Evaluator:
         for d in self.scrambling_depths:
             depth = (lambda: np.random.randint(100, 1000)) if self._isdeep() else int(d)
             if hasattr(agent, "search_batch"):
-                cubes, _, _ = cube.scramble_batch(self.n_games, depth, True)
+                cubes, _, _ = cube.scramble_batch(self.n_games, depth, True)   # every rank draws the same scrambles
                 self.tt.profile(f"Evaluation of {agent}. Depth {'100 - 999' if self._isdeep() else d}")
-                out = agent.search_batch(cubes, self.max_time, self.max_states)
+                if _world_size() > 1:   # one process per GPU: each searches its slice of the games, results are all-gathered
+                    got = sharded_search_batch(agent, cubes.numpy(), self.max_time, self.max_states, device=cubes.soa.device)
+                    lengths, nodes = got["lengths"], got["nodes"]
+                else:
+                    out = agent.search_batch(cubes, self.max_time, self.max_states)
+                    lengths, nodes = out.lengths, out.nodes
                 dt = self.tt.end_profile()
-                res.append(out.lengths)
-                states.append(out.nodes)
+                res.append(lengths)
+                states.append(nodes)
                 times.append(np.full(self.n_games, dt / self.n_games))
             else:   # agents without a batched search: the reference's game-by-game loop
                 r, s, t = [], [], []

@@ -40,6 +40,25 @@ def gather_results(local: dict, n_total: int, device=None) -> dict:
     return out
 
 
+def sharded_search_batch(agent, states: np.ndarray, time_limit=None, max_states=None, device=None, **kwargs) -> dict:
+    """
+    One batched search over `states` ((n, 20) int8, the SAME array on every rank) with the games split over the
+    ranks of the default process group: rank r runs agent.search_batch on its contiguous slice, then the per-game
+    vectors are all-gathered.  Returns {"solved", "lengths", "nodes"} for all n games, in game order, on every rank.
+    With a single process this is agent.search_batch on everything.
+    """
+    states = np.asarray(states)
+    world = dist.get_world_size() if (dist.is_available() and dist.is_initialized()) else 1
+    rank = dist.get_rank() if world > 1 else 0
+    lo, hi = shard_range(len(states), rank, world)
+    if hi > lo:
+        out = agent.search_batch(states[lo:hi], time_limit, max_states, **kwargs)
+        local = {"solved": np.asarray(out.solved), "lengths": np.asarray(out.lengths), "nodes": np.asarray(out.nodes)}
+    else:   # more ranks than games
+        local = {"solved": np.zeros(0, dtype=bool), "lengths": np.zeros(0, dtype=np.int64), "nodes": np.zeros(0, dtype=np.int64)}
+    return gather_results(local, len(states), device=device)
+
+
 def summarize(results: dict, seconds: float) -> dict:
     """Evaluator-style summary (librubiks/solving/evaluation.py:96-125): solve rate +/- 95 % half-width, nodes/s."""
     solved = np.asarray(results["solved"]).astype(bool)

@@ -86,3 +86,44 @@ def test_data_parallel_gradient_average():
         for i, m in enumerate(mean):
             assert np.allclose(np.array(got[r][2][i]), m, atol=1e-6)
     assert not np.allclose(np.array(got[0][1][0]), np.array(got[1][1][0]))   # local gradients did differ
+
+
+class _ToyAgent:
+    """search_batch on host arrays with a deterministic per-game outcome (stands in for the GPU agents on the CPU)."""
+
+    def search_batch(self, states, time_limit=None, max_states=None):
+        from types import SimpleNamespace
+        key = states.astype(np.int64).sum(axis=1)
+        solved = key % 2 == 0
+        return SimpleNamespace(solved=solved, lengths=np.where(solved, key % 17, -1), nodes=1000 + key)
+
+
+def _search_worker(rank, world, port, states, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from librubiks.solving.sharding import sharded_search_batch
+    got = sharded_search_batch(_ToyAgent(), states, None, 100)
+    q.put((rank, {k: v.tolist() for k, v in got.items()}))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_sharded_search_batch_two_ranks():
+    """Every rank ends with the results of ALL games, equal to the single-process search."""
+    from librubiks.solving.sharding import sharded_search_batch
+    rng = np.random.default_rng(0)
+    states = rng.integers(0, 24, size=(41, 20)).astype(np.int8)
+    whole = sharded_search_batch(_ToyAgent(), states, None, 100)      # no process group: plain search
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_search_worker, args=(r, 2, port, states, q)) for r in range(2)]
+    [p.start() for p in procs]
+    got = sorted(q.get(timeout=120) for _ in range(2))
+    [p.join(60) for p in procs]
+    assert all(p.exitcode == 0 for p in procs)
+    for _, full in got:
+        for k in ("solved", "lengths", "nodes"):
+            assert full[k] == whole[k].tolist()
