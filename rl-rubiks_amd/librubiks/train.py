@@ -36,6 +36,23 @@ def average_gradients(net: torch.nn.Module):
         offset += g.numel()
 
 
+def average_buffers(net: torch.nn.Module):
+    """Mean of the floating-point buffers (BatchNorm running statistics) over all ranks: each rank normalises its own
+    games, so without this the replicas' eval-mode networks drift apart although their weights are identical."""
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+        return
+    bufs = [b for b in net.buffers() if b.dtype.is_floating_point]
+    if not bufs:
+        return
+    flat = torch.cat([b.reshape(-1) for b in bufs])
+    dist.all_reduce(flat, op=dist.ReduceOp.SUM)
+    flat /= dist.get_world_size()
+    offset = 0
+    for b in bufs:
+        b.copy_(flat[offset:offset + b.numel()].view_as(b))
+        offset += b.numel()
+
+
 class Train:
     def __init__(self, rollouts: int, batch_size: int, rollout_games: int, rollout_depth: int, optim_fn,
                  alpha_update: float, lr: float, gamma: float, update_interval: int, agent, evaluator,
@@ -107,9 +124,23 @@ class Train:
             torch.from_numpy(loss_weights).float().to(values.device)
 
     # ---- training loop (train.py:111-255) ----------------------------------------------------------
+    def _shard_over_ranks(self):
+        """Data-parallel ADI: with W ranks every rank generates rollout_games / W games per rollout from its own NumPy
+        stream (the common seed + rank); gradients are averaged per step.  Single process: nothing changes."""
+        if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1 or self._sharded:
+            return
+        world, rank = dist.get_world_size(), dist.get_rank()
+        self.rollout_games = -(-self.rollout_games // world)
+        self.states_per_rollout = self.rollout_depth * self.rollout_games
+        np.random.seed((int(np.random.get_state()[1][0]) + rank) % (2 ** 32))
+        self._sharded = True
+
+    _sharded = False
+
     def train(self, net: Model):
         self.tt.reset()
         self.tt.tick()
+        self._shard_over_ranks()
         best_solve, best_net = 0, net.clone()
         self.agent.net = net
         generator_net = net.clone()
@@ -140,6 +171,7 @@ class Train:
                 optimizer.step()
                 p_acc += policy_loss.detach().mean().double() / len(batches)
                 v_acc += value_loss.detach().mean().double() / len(batches)
+            average_buffers(net)
             self.policy_losses[rollout], self.value_losses[rollout] = float(p_acc), float(v_acc)
             self.train_losses[rollout] = self.policy_losses[rollout] + self.value_losses[rollout]
             self.tt.end_profile("Training loop")

@@ -91,3 +91,48 @@ def test_short_training_run():
     assert list(tr.evaluation_rollouts) == [0, 1, 2] and len(tr.sol_percents) == 3
     assert all(0 <= s <= 1 for s in tr.sol_percents)
     assert isinstance(best, Model)
+
+
+def _train_rank(rank, world, port, q):
+    import os
+    import sys
+    import torch.distributed as dist
+    here = os.path.dirname(os.path.abspath(__file__))
+    sys.path[:0] = [here, os.path.dirname(here), os.path.join(os.path.dirname(here), "rl-rubiks_amd")]
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from librubiks.model import Model, ModelConfig
+    from librubiks.solving.agents import MCTS
+    from librubiks.train import Train
+    torch.manual_seed(0)
+    np.random.seed(0)
+    net = Model.create(ModelConfig())
+    tr = Train(rollouts=2, batch_size=128, rollout_games=32, rollout_depth=8, optim_fn=torch.optim.Adam, alpha_update=0,
+               lr=1e-4, gamma=1, update_interval=0, agent=MCTS(net, c=0.6, search_graph=False), evaluator=None,
+               evaluation_interval=0, tau=1, reward_method="lapanfix")
+    net, _ = tr.train(net)
+    first_draw = int(np.random.randint(0, 2 ** 31))      # the rank's NumPy stream after training
+    q.put((rank, tr.rollout_games, net.get_params().double().sum().item(), net.get_params()[:64].cpu().tolist(), first_draw,
+           tr.train_losses.tolist()))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_data_parallel_training_two_ranks():
+    """Config #4 layout: ranks generate different games (half each), average gradients, keep identical weights."""
+    import socket
+    import torch.multiprocessing as mp
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_train_rank, args=(r, 2, port, q)) for r in range(2)]
+    [p.start() for p in procs]
+    got = sorted(q.get(timeout=300) for _ in range(2))
+    [p.join(120) for p in procs]
+    assert all(p.exitcode == 0 for p in procs)
+    (_, g0, sum0, head0, draw0, loss0), (_, g1, sum1, head1, draw1, loss1) = got
+    assert g0 == g1 == 16                                  # 32 games per rollout split over two ranks
+    assert sum0 == sum1 and head0 == head1                 # the same averaged gradients -> the same weights
+    assert draw0 != draw1 and loss0 != loss1               # ... from different games
