@@ -127,6 +127,11 @@ def shape():
     return (N_PLANES,)
 
 
+def as_correct(t):
+    """Reference cube.py:135-137: the conv net's input form, defined for the 6x8x6 representation only."""
+    raise NotImplementedError("as_correct belongs to the 6x8x6 representation, which is out of scope on MI355X")
+
+
 def get_oh_shape() -> int:
     return OH_WIDTH
 
