@@ -1,0 +1,59 @@
+"""
+tests/test_rubiks.py of the reference restated for this build (CPU, no kernel is launched): the `no_grad` decorator and
+the representation switches, which exist for API compatibility -- only the 20x24 representation is implemented, so
+selecting the 6x8x6 one raises instead of silently computing something else.
+"""
+import pytest
+import torch
+
+
+def test_no_grad_decorator():
+    from librubiks import no_grad
+
+    class Probe:
+        @no_grad
+        def grad_enabled(self, extra=0):
+            """doc"""
+            return torch.is_grad_enabled(), extra
+
+    torch.set_grad_enabled(True)
+    assert torch.is_grad_enabled()
+    assert Probe().grad_enabled(extra=3) == (False, 3)
+    assert torch.is_grad_enabled()
+    assert Probe.grad_enabled.__name__ == "grad_enabled" and Probe.grad_enabled.__doc__ == "doc"
+
+
+def test_representation_switches():
+    from librubiks import cube
+    assert cube.get_is2024() is True
+    cube.store_repr()
+    cube.set_is2024(True)
+    cube.restore_repr()
+    assert cube.get_is2024() is True
+    with pytest.raises(NotImplementedError):
+        cube.set_is2024(False)
+    assert cube.get_is2024() is True
+    with pytest.raises(NotImplementedError):
+        cube.as_correct(torch.zeros(1, 6, 8, 6))
+
+    class User:
+        is2024 = True
+
+        @cube.with_used_repr
+        def which(self):
+            return cube.get_is2024()
+
+    u = User()
+    assert u.which() is True
+    u.is2024 = False
+    with pytest.raises(NotImplementedError):
+        u.which()
+    assert cube.shape() == (20,) and cube.get_oh_shape() == 480 and cube.action_dim == 12
+    assert cube.action_names == ("F", "B", "T", "D", "L", "R") and len(cube.action_space) == 12
+
+
+def test_devices_and_reset():
+    import librubiks
+    assert librubiks.cpu == torch.device("cpu")
+    assert librubiks.gpu.type in ("cuda", "cpu")
+    librubiks.reset_cuda()   # harmless without a GPU
