@@ -77,3 +77,31 @@ def test_make_inference_net_dispatch():
     assert isinstance(make_inference_net(StandInNet(0)), GenericNet)
     assert isinstance(make_inference_net(Model(ModelConfig()), torch.float32), InferenceNet)
     assert isinstance(make_inference_net(Model(ModelConfig(architecture="res_small"))), GenericNet)
+
+
+def test_reference_model_tests_restated(tmp_path):
+    """tests/test_model.py:13-59 of the reference: every architecture runs in eval and train mode, every init works,
+    ModelConfig survives its JSON form."""
+    import json
+    x = torch.randn(2, 480)
+    for arch in ("fc_small", "res_big"):
+        m = Model(ModelConfig(architecture=arch))
+        m.eval()
+        p, v = m(x)
+        assert p.shape == (2, 12) and v.shape == (2, 1)
+        m.train()
+        p, v = m(x)
+        assert p.shape == (2, 12) and v.shape == (2, 1) and torch.isfinite(p).all()
+    for init in ("glorot", "he", 0, 1.123123123e-3):
+        m = Model(ModelConfig(init=init))
+        m(x)
+        if not isinstance(init, str):
+            assert float(m.shared_net[0].weight.min()) == float(m.shared_net[0].weight.max()) == float(np.float32(init))
+    cf = ModelConfig(torch.nn.ReLU())
+    path = tmp_path / "cfg.json"
+    path.write_text(json.dumps(cf.as_json_dict()))
+    cf2 = ModelConfig.from_json_dict(json.loads(path.read_text()))
+    assert type(cf2.activation_function) is torch.nn.ReLU and cf2.architecture == cf.architecture and cf2.batchnorm == cf.batchnorm
+    # value-only / policy-only calls (model.py:131-141)
+    m = Model(ModelConfig()).eval()
+    assert m(x, policy=True, value=False).shape == (2, 12) and m(x, policy=False, value=True).shape == (2, 1)
