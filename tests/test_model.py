@@ -96,7 +96,8 @@ def test_reference_model_tests_restated(tmp_path):
         m = Model(ModelConfig(init=init))
         m(x)
         if not isinstance(init, str):
-            assert float(m.shared_net[0].weight.min()) == float(m.shared_net[0].weight.max()) == float(np.float32(init))
+            w0 = m.shared_net[0].weight.detach()
+            assert float(w0.min()) == float(w0.max()) == float(np.float32(init))
     cf = ModelConfig(torch.nn.ReLU())
     path = tmp_path / "cfg.json"
     path.write_text(json.dumps(cf.as_json_dict()))
