@@ -57,3 +57,27 @@ def test_devices_and_reset():
     assert librubiks.cpu == torch.device("cpu")
     assert librubiks.gpu.type in ("cuda", "cpu")
     librubiks.reset_cuda()   # harmless without a GPU
+
+
+def test_ticktock_restated():
+    """tests/test_ticktock.py of the reference: nested sections sum their own wall time."""
+    from time import sleep
+    import numpy as np
+    from librubiks.utils import TickTock
+    tt = TickTock()
+    tt.profile("test0")
+    sleep(.01)
+    tt.profile("test1")
+    sleep(.01)
+    tt.end_profile("test1")
+    sleep(.01)
+    tt.end_profile("test0")
+    assert np.isclose(0.03, tt.profiles["test0"].sum(), 1)
+    assert np.isclose(0.01, tt.profiles["test1"].sum(), 1)
+    assert tt.profiles["test0"].sum() > tt.profiles["test1"].sum() > 0.009
+    assert "test1" in str(tt) and len(tt.profiles["test0"]) == 1
+    tt.tick()
+    sleep(.005)
+    assert tt.tock() >= 0.005
+    tt.reset()
+    assert tt.profiles == {}
