@@ -136,3 +136,22 @@ def test_data_parallel_training_two_ranks():
     assert g0 == g1 == 16                                  # 32 games per rollout split over two ranks
     assert sum0 == sum1 and head0 == head1                 # the same averaged gradients -> the same weights
     assert draw0 != draw1 and loss0 != loss1               # ... from different games
+
+
+def test_reference_train_test_restated():
+    """tests/test_train.py:13-24 of the reference (its arguments, minus the analysis / plot that are out of scope)."""
+    from librubiks.model import Model, ModelConfig
+    from librubiks.solving.agents import PolicySearch
+    from librubiks.solving.evaluation import Evaluator
+    from librubiks.train import Train
+    torch.manual_seed(42)
+    np.random.seed(42)
+    net = Model.create(ModelConfig())
+    evaluator = Evaluator(2, max_time=.02, max_states=None, scrambling_depths=[2])
+    train = Train(rollouts=2, batch_size=2, tau=0.1, alpha_update=.5, gamma=1, rollout_games=2, rollout_depth=3,
+                  optim_fn=torch.optim.Adam, agent=PolicySearch(None), lr=1e-6, evaluation_interval=1, evaluator=evaluator,
+                  update_interval=1, with_analysis=False, reward_method="schultzfix")
+    net, min_net = train.train(net)
+    assert isinstance(net, Model) and isinstance(min_net, Model)
+    assert len(train.train_losses) == 2 and np.isfinite(train.train_losses).all()
+    assert len(train.sol_percents) == len(train.evaluation_rollouts) and all(0 <= s <= 1 for s in train.sol_percents)
