@@ -206,7 +206,49 @@ def cpu_baseline(model, depth, budget_s=14.0, max_states=5000):
             "host_cpus": os.cpu_count(), "kind": "port",
             "sample": f"{games} depth-{depth} scrambles x max_states={max_states}, single-tree MCTS c=0.6 "
                       f"(oracle/agents.py on NumPy + torch CPU fp32, {best[1]} torch threads picked by calibration), "
-                      f"{dt:.1f} s"}
+                      f"{dt:.1f} s",
+            "env_ops": cpu_env_ops(), "bfs_config1": cpu_bfs_config1()}
+
+
+def cpu_env_ops(sizes=(10_000, 196_608), warm=5, reps=20):
+    """The reference's NumPy cube expressions (restated in oracle/cube.py) on ONE host core, median of `reps`
+    (N = 10 000 is the reference's own multi_op_size, 196 608 = 16 384 x 12 of config #4)."""
+    from oracle import cube as oc
+    out = {"cores": 1, "unit": "M states/s", "reps": reps}
+    rng = np.random.RandomState(0)
+    for n in sizes:
+        base = np.tile(oc.get_solved(), (n, 1))
+        for _ in range(30):
+            base = oc.multi_rotate_actions(base, rng.randint(0, 12, n))
+        acts = rng.randint(0, 12, n)
+        faces, dirs = acts // 2, 1 - acts % 2
+        row = {}
+        for name, fn in (("multi_rotate", lambda: oc.multi_rotate(base, faces, dirs)),
+                         ("multi_is_solved", lambda: oc.multi_is_solved(base)),
+                         ("as_oh", lambda: oc.as_oh(base))):
+            for _ in range(warm):
+                fn()
+            ts = []
+            for _ in range(reps):
+                t = time.perf_counter()
+                fn()
+                ts.append(time.perf_counter() - t)
+            row[name] = round(n / float(np.median(ts)) / 1e6, 2)
+        out[str(n)] = row
+    return out
+
+
+def cpu_bfs_config1():
+    """BASELINE config #1 (10 depth-5 scrambles after set_seeds(), BFS) on the restated FIFO loop, one host core."""
+    from oracle import agents as oa
+    g = np.load(os.path.join(ROOT, "tests", "golden", "bfs_golden.npz"))
+    agent, seen, t0 = oa.BFS(), 0, time.perf_counter()
+    for s in g["states"]:
+        agent.search(s, 10_000_000)
+        seen += len(agent)
+    dt = time.perf_counter() - t0
+    return {"games": int(len(g["states"])), "states_seen": int(seen), "seconds": round(dt, 3),
+            "states_per_sec": round(seen / dt, 1), "cores": 1}
 
 
 def main():
