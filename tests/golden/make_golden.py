@@ -4,7 +4,7 @@ Generates the golden fixtures under tests/golden/ by IMPORTING THE REFERENCE (pe
 Run only in the build container, where the reference is mounted read-only:
 
     cd /tmp && PYTHONDONTWRITEBYTECODE=1 MPLBACKEND=Agg PYTHONPATH=/root/reference \
-        python /root/repo/tests/golden/make_golden.py [cube] [bfs] [agents]
+        python /root/repo/tests/golden/make_golden.py [cube] [bfs] [bfs_cut] [agents] [adi] [simple]
 
 The fixtures are DATA (inputs + the reference's outputs).  No reference source travels with them.
 The GPU box never runs this script (it has no /root/reference); it only reads the committed files.
@@ -129,13 +129,34 @@ def make_bfs():
                         lengths=np.array(lengths), seen=np.array(seen), queues=np.array(queues))
 
 
+def make_bfs_cut():
+    """BFS searches of the reference that END BY THE max_states TEST (and a few that just make it): pins len(agent) there."""
+    from librubiks import cube
+    from librubiks.solving.agents import BFS
+    np.random.seed(77)
+    agent = BFS()
+    rows = []
+    for depth in (3, 4, 5, 6, 7):
+        s, _, _ = cube.scramble(depth, True)
+        for cap in (1, 2, 13, 14, 100, 1000, 1234, 20000):
+            ok = agent.search(s, None, cap)
+            q = list(agent.action_queue)
+            rows.append((s, cap, int(ok), len(agent), q + [-1] * (8 - len(q))))
+    np.savez_compressed(os.path.join(OUT, "bfs_cut_golden.npz"), states=np.array([r[0] for r in rows]),
+                        caps=np.array([r[1] for r in rows]), solved=np.array([r[2] for r in rows]),
+                        seen=np.array([r[3] for r in rows]), queues=np.array([r[4] for r in rows]))
+    print("bfs_cut_golden.npz:", len(rows), "searches,", sum(r[2] for r in rows), "solved")
+
+
 if __name__ == "__main__":
-    what = sys.argv[1:] or ["cube", "bfs", "agents", "adi", "simple"]
+    what = sys.argv[1:] or ["cube", "bfs", "bfs_cut", "agents", "adi", "simple"]
     assert os.path.isdir("/root/reference"), "needs the mounted reference"
     if "cube" in what:
         make_cube()
     if "bfs" in what:
         make_bfs()
+    if "bfs_cut" in what:
+        make_bfs_cut()
     if "agents" in what:
         from make_golden_agents import make_agents
         make_agents()

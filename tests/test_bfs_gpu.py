@@ -108,3 +108,17 @@ def test_bfs_and_select_argument_errors():
     s.hint = None
     assert lib.rc_mcts_select(ctypes.byref(s), 0.6, 0, None) == -1
     torch.cuda.synchronize()
+
+
+@pytest.mark.parametrize("chunk", [None, 3, 100])
+def test_bfs_max_states_cut_reference_runs(chunk):
+    """The same 40 reference searches on the device BFS, for several chunkings of a level."""
+    import os
+    from conftest import GOLDEN
+    from librubiks.solving.agents import BFS
+    g = np.load(os.path.join(GOLDEN, "bfs_cut_golden.npz"))
+    agent = BFS(chunk=chunk)
+    for s, cap, solved, seen, queue in zip(g["states"], g["caps"], g["solved"], g["seen"], g["queues"]):
+        assert agent.search(s, None, int(cap)) == bool(solved)
+        assert len(agent) == seen
+        assert list(agent.action_queue) == [a for a in queue if a >= 0]

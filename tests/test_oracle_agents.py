@@ -118,3 +118,14 @@ def test_value_search_and_egvm_traces(standin_net):
         assert list(agent.action_queue) == list(g[pre + "queue"])
         n_solved += int(solved)
     assert n_solved >= 2
+
+
+def test_bfs_max_states_cut_reference_runs():
+    """40 BFS searches of the reference, 32 of them ended by its `len(self) < max_states` test (bfs_cut_golden.npz)."""
+    g = np.load(f"{GOLDEN}/bfs_cut_golden.npz")
+    agent = oa.BFS()
+    for s, cap, solved, seen, queue in zip(g["states"], g["caps"], g["solved"], g["seen"], g["queues"]):
+        assert agent.search(s, int(cap)) == bool(solved)
+        assert len(agent) == seen
+        assert list(agent.action_queue) == [a for a in queue if a >= 0]
+    assert (g["solved"] == 0).sum() >= 30
