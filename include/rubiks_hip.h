@@ -34,7 +34,7 @@
 extern "C" {
 #endif
 
-#define RC_ABI_VERSION 1
+#define RC_ABI_VERSION 2
 
 #define RC_OK 0
 #define RC_ERR_NULL (-1)      /* required pointer is NULL */
@@ -207,14 +207,17 @@ typedef struct rc_mcts {
     uint8_t *expanded;   /* [B] 1 iff the tree expanded a leaf in the current iteration */
     int32_t *select_stats; /* optional (may be NULL): [B][8] = first sequentially walked level, new path length,
                               10-ns ticks spent re-validating the old path, ticks and shader cycles spent in the
-                              sequential walk, levels decided in float64, levels whose hint was wrong, 1 spare */
+                              sequential walk, revisited levels that fell back to float64, revisited levels, 1 spare */
     /* optional, only needed by rc_mcts_shorten (may be NULL otherwise) */
     int32_t *bfs;        /* [B][capacity + 1][2] scratch: {claim, parent << 4 | action} */
     uint8_t *short_act;  /* [B][max_path] shortened action queue of every solved tree */
     int32_t *short_len;  /* [B] its length, -1 where no shortened queue was produced */
-    /* per node, [B][capacity + 1]: 1 + the action the last descent took there, 0 = none.  Only ever used by
-     * rc_mcts_select to request the likely child's rows early; any content is valid. */
-    uint8_t *hint;
+    /* per node, [B][capacity + 1]: 16-byte walk record, owned by the kernels (16-byte aligned):
+     *   uint32 {neighbour through best0, neighbour through best1, best0 | best1 << 8 | leaf << 16, 0}
+     * best0 = the action a PUCT descent takes at the node while no virtual loss is pending there, best1 = the same
+     * with one loss on best0 (the descent arrived through rev(best0)).  rc_mcts_init / rc_mcts_expand write leaf
+     * records, rc_mcts_select refreshes the records of the path it re-validates and walks by them. */
+    void *rec;
 } rc_mcts_t;
 
 /* Inserts the B root states (SoA) as node 1 of each tree; a solved root gets RC_MCTS_ROOT_SOLVED.

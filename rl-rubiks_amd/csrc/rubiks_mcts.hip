@@ -16,6 +16,14 @@ namespace rubiks {
 constexpr int kA = kActions;   // 12
 constexpr int kMaxPath = 4096;  // longest PUCT descent the kernels stage in LDS (20 KiB per workgroup in select)
 
+// Walk record of a node (16 B, rc_mcts_t::rec): what a PUCT descent does at the node while no virtual loss
+// other than its own arrival edge is pending there.
+//   x = neighbour through best0, y = neighbour through best1, z = best0 | best1 << 8 | kRecLeaf, w = 0
+//   best0 = argmax_a U(a) + W(a)                          (every L = 0)
+//   best1 = the same with one virtual loss on best0       (the descent arrived through rev(best0))
+// A leaf's record is {0, 0, kRecLeaf, 0}.  rc_mcts_select keeps the records exact (see k_mcts_select).
+constexpr u32 kRecLeaf = 1u << 16;
+
 // ---- init: root = node 1 ------------------------------------------------------------------------
 __global__ __launch_bounds__(kBlock) void k_mcts_init(rc_mcts_t m, const u8 *__restrict__ roots, size_t stride) {
     const u32 t = blockIdx.x * kBlock + threadIdx.x;
@@ -35,6 +43,8 @@ __global__ __launch_bounds__(kBlock) void k_mcts_init(rc_mcts_t m, const u8 *__r
     m.hash[(size_t)t * m.hash_size + (key_hash(key) & (m.hash_size - 1))] = 1;
     m.leaf[base + 1] = 1;
     m.leaf[base] = 1;   // row 0 is never expanded; the reference's leaves[0] stays True as well
+    reinterpret_cast<uint4 *>(m.rec)[base] = make_uint4(0, 0, kRecLeaf, 0);
+    reinterpret_cast<uint4 *>(m.rec)[base + 1] = make_uint4(0, 0, kRecLeaf, 0);
     m.n_nodes[t] = 1;
     m.status[t] = solved ? RC_MCTS_ROOT_SOLVED : RC_MCTS_RUNNING;
     m.solved_idx[t] = solved ? 1 : -1;
@@ -121,6 +131,7 @@ __global__ __launch_bounds__(kWave) void k_mcts_expand(rc_mcts_t m, u32 max_stat
             h = (h + 1) & mask;
         }
         m.leaf[base + idx] = 1;
+        reinterpret_cast<uint4 *>(m.rec)[base + idx] = make_uint4(0, 0, kRecLeaf, 0);
     }
     if (act) {   // links both ways, for seen children too (agents.py:533-535)
         m.nbr[(base + leaf) * kA + lane] = idx;
@@ -269,8 +280,9 @@ __device__ __forceinline__ int puct_argmax_walk(double c, float c32, int n_a, fl
 // Per-tree arrays as buffer resources (wave-uniform, in SGPRs): a row access is one instruction with one
 // shared 32-bit offset register instead of 64-bit address arithmetic per array.
 constexpr u32 kRsrcFlags = 0x00020000;   // raw buffer, 32-bit data format
+typedef u32 u32x4 __attribute__((ext_vector_type(4)));
 struct TreeBufs {
-    __amdgpu_buffer_rsrc_t N, nbr, P, W, L, leaf, hint;
+    __amdgpu_buffer_rsrc_t N, nbr, P, W, rec;
 };
 __device__ __forceinline__ TreeBufs tree_bufs(const rc_mcts_t &m, size_t base) {
     const int rows = (int)((m.capacity + 1) * kA);
@@ -279,30 +291,26 @@ __device__ __forceinline__ TreeBufs tree_bufs(const rc_mcts_t &m, size_t base) {
     b.nbr = __builtin_amdgcn_make_buffer_rsrc((void *)(m.nbr + base * kA), 0, rows * 4, kRsrcFlags);
     b.P = __builtin_amdgcn_make_buffer_rsrc((void *)(m.P + base * kA), 0, rows * 4, kRsrcFlags);
     b.W = __builtin_amdgcn_make_buffer_rsrc((void *)(m.W + base * kA), 0, rows * 4, kRsrcFlags);
-    b.L = __builtin_amdgcn_make_buffer_rsrc((void *)(m.L + base * kA), 0, rows * 2, kRsrcFlags);
-    b.leaf = __builtin_amdgcn_make_buffer_rsrc((void *)(m.leaf + base), 0, (int)(m.capacity + 1), kRsrcFlags);
-    b.hint = __builtin_amdgcn_make_buffer_rsrc((void *)(m.hint + base), 0, (int)(m.capacity + 1), kRsrcFlags);
+    b.rec = __builtin_amdgcn_make_buffer_rsrc((void *)(reinterpret_cast<uint4 *>(m.rec) + base), 0, (int)(m.capacity + 1) * 16,
+                                              kRsrcFlags);
     return b;
 }
-// The rows of one node as the sequential walk needs them (lane a < 12 holds action a's entries).
+// The rows of one node as a full PUCT evaluation needs them (lane a < 12 holds action a's entries).
 struct NodeRows {
-    u32 is_leaf, hint, l_cnt;
     int n_a, nb;
     float p_f, w_f;
 };
-// L is read with sc1 (served by L2, not the CU's L1): the re-validation has just added the kept prefix's
-// losses with atomics, which live in L2.
 __device__ __forceinline__ NodeRows load_rows(const TreeBufs &tb, int node, u32 la) {
     const u32 off = ((u32)node * kA + la) * 4u;
     NodeRows x;
-    x.is_leaf = __builtin_amdgcn_raw_buffer_load_b8(tb.leaf, 0, node, 0);
-    x.hint = __builtin_amdgcn_raw_buffer_load_b8(tb.hint, 0, node, 0);
     x.n_a = (int)__builtin_amdgcn_raw_buffer_load_b32(tb.N, off, 0, 0);
     x.p_f = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(tb.P, off, 0, 0));
     x.w_f = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(tb.W, off, 0, 0));
-    x.l_cnt = __builtin_amdgcn_raw_buffer_load_b16(tb.L, off >> 1, 0, 16);
     x.nb = (int)__builtin_amdgcn_raw_buffer_load_b32(tb.nbr, off, 0, 0);
     return x;
+}
+__device__ __forceinline__ u32x4 load_rec(const TreeBufs &tb, int node) {
+    return __builtin_amdgcn_raw_buffer_load_b128(tb.rec, (u32)node * 16u, 0, 0);
 }
 
 // L holds 16-bit counts; two of them share a dword, which is what the atomic unit adds to.
@@ -316,22 +324,29 @@ __device__ __forceinline__ u32 sel_hash(int node) { return ((u32)node * 0x9E3779
 
 // One 256-thread workgroup per tree.
 //
-// The descent restarts at the root every iteration (that is the algorithm), but consecutive descents
-// share long prefixes: only the nodes of the previous path changed (N + 1, max-backup of W).  So the
-// levels of the PREVIOUS path are re-validated in parallel, 16 levels per pass (one 16-lane row per
-// level): level k keeps its action iff the argmax at its node is unchanged, GIVEN that all levels above
-// kept theirs.  Under that premise the virtual loss level k sees is a function of the old path alone:
-// every earlier level j < k at the same node contributed +1 on its departure edge a_j and +1 on its
-// arrival edge rev(a_{j-1}), plus level k's own arrival edge (L is zero between iterations).  Deep lines
-// revisit states all the time (transpositions), so these counts are taken exactly: the staged path is
-// chained by node in an LDS hash table and a level walks the chain of its node (a linear scan of the
-// levels above was quadratic in the path length and dominated the stragglers of a run to completion,
-// whose depth-first lines are thousands of levels long).  The first level whose action changes -- or the old leaf, which has just been
-// expanded -- starts the ordinary sequential descent (one memory round trip per level); with a trained
-// network that tail is typically one or two levels instead of ~100.
+// The descent restarts at the root every iteration (that is the algorithm), and with a trained network it is
+// hundreds of levels deep, so its cost per level is what bounds a tree's iteration rate.  Two facts make it cheap:
+//
+// (1) Between descents every virtual loss is zero (the backup clears the path's), and inside a descent the only
+//     loss pending at a node the descent has NOT been at before is the one on its arrival edge.  So what the
+//     descent does at such a node is a function of the node's rows alone: best0 (no loss) unless it arrived through
+//     rev(best0), then best1 (one loss on best0).  Both, and the neighbours they lead to, are kept in a 16-byte
+//     walk record per node.  A node's rows change only while it is on the path being backed up, so refreshing the
+//     records of the previous path's nodes (below, in parallel) keeps every record of the tree exact.
+// (2) Consecutive descents share long prefixes.  Level k of the previous path keeps its action iff its decision is
+//     unchanged GIVEN that all levels above kept theirs -- a premise under which its pending losses are a function
+//     of the old path alone.  So all levels are re-decided in parallel (one 16-lane row per level, the same pass
+//     that refreshes the records); the first level whose action changes starts the sequential walk.
+//
+// A node the descent revisits (deep lines loop through transpositions all the time) carries more losses: every
+// earlier visit j left +1 on its departure edge a_j and +1 on its arrival edge rev(a_{j-1}).  Those levels are
+// decided by a full float64 PUCT evaluation with the exact counts, taken from the path itself, which is chained
+// by node in an LDS hash table.  The sequential walk is therefore one 16-byte load per level (the next record,
+// requested before the revisit test of the current level is done) and no stores; path and virtual losses go
+// to memory once, after the loop.
 __global__ __launch_bounds__(kBlock) void k_mcts_select(rc_mcts_t m, double c, u32 level_budget) {
     __shared__ int s_first;                 // first level that has to be walked sequentially
-    __shared__ int s_node[kMaxPath];        // the old path
+    __shared__ int s_node[kMaxPath];        // the path: old levels, then the walked ones
     __shared__ u8 s_act[kMaxPath];
     __shared__ int s_head[kSelHash];        // chains of path levels by node (earlier visits of a state)
     __shared__ u16 s_next[kMaxPath];
@@ -341,40 +356,41 @@ __global__ __launch_bounds__(kBlock) void k_mcts_select(rc_mcts_t m, double c, u
     const size_t base = (size_t)t * (m.capacity + 1);
     int *pnode = m.path_node + (size_t)t * m.max_path;
     u8 *pact = m.path_act + (size_t)t * m.max_path;
+    uint4 *rec = reinterpret_cast<uint4 *>(m.rec) + base;
     const int plen_old = m.path_len[t];
+    const int nlev = plen_old - 1;     // levels 0 .. nlev - 1 carry an action; level nlev is the old leaf
     const u32 row = tid >> 4, rl = tid & 15;
     const bool ract = rl < kA;
     const u32 rla = ract ? rl : 0;
-    const int resume = m.pending[t];   // uniform over the workgroup
-    if (tid == 0) s_first = plen_old - 1;   // the old leaf has just been expanded (or a suspended descent continues there)
+    const int resume = m.pending[t];   // uniform over the workgroup: a suspended descent continues at its last node
+    for (int i = tid; i < kSelHash; i += kBlock) s_head[i] = -1;
+    for (int k = tid; k < plen_old; k += kBlock) {
+        s_node[k] = pnode[k];
+        s_act[k] = (k < nlev) ? pact[k] : (u8)0;
+    }
+    if (tid == 0) s_first = nlev;
+    __syncthreads();
+    for (int k = tid; k < nlev; k += kBlock) s_next[k] = (u16)atomicExch(&s_head[sel_hash(s_node[k])], k);
+    __syncthreads();
     if (!resume) {
-        for (int i = tid; i < kSelHash; i += kBlock) s_head[i] = -1;
-        for (int k = tid; k < plen_old; k += kBlock) {
-            s_node[k] = pnode[k];
-            s_act[k] = (k < plen_old - 1) ? pact[k] : (u8)0;
-        }
-        __syncthreads();
-        const int nlev = plen_old - 1;
-        for (int k = tid; k < nlev; k += kBlock) s_next[k] = (u16)atomicExch(&s_head[sel_hash(s_node[k])], k);
-        __syncthreads();
-        // kSelUnroll levels per 16-lane row are in flight together: their chain walks (LDS) come first,
-        // then their three row loads, then the argmaxes -- one memory round trip per 16 * kSelUnroll levels.
-        for (int k0 = 0; k0 < nlev; k0 += (kBlock / 16) * kSelUnroll) {
-            if (k0 > *(volatile int *)&s_first) break;   // levels below a change are walked anyway
-            int n_a[kSelUnroll];
+        // kSelUnroll levels per 16-lane row are in flight together: chain walks (LDS) first, then the row loads,
+        // then the argmaxes -- one memory round trip per 16 * kSelUnroll levels.
+        for (int k0 = 0; k0 <= nlev; k0 += (kBlock / 16) * kSelUnroll) {
+            int n_a[kSelUnroll], nb[kSelUnroll];
             float p_f[kSelUnroll], w_f[kSelUnroll];
             u32 l_cnt[kSelUnroll];
+            bool seen[kSelUnroll];
 #pragma unroll
             for (int u = 0; u < kSelUnroll; ++u) {
                 const int k = k0 + u * (kBlock / 16) + (int)row;
-                const bool live = k < nlev;
+                const bool live = k <= nlev;
                 const int node = live ? s_node[k] : 0;
-                // virtual loss seen at level k: every earlier visit j < k of this node left +1 on its departure
-                // edge a_j and +1 on its arrival edge rev(a_{j-1}); plus this level's own arrival edge
-                u32 cnt = (live && k > 0 && (u32)(s_act[k - 1] ^ 1) == rl) ? 1u : 0u;
+                u32 cnt = (live && k > 0 && (u32)(s_act[k - 1] ^ 1) == rl) ? 1u : 0u;   // own arrival edge
+                bool dup = false;
                 int j = live ? s_head[sel_hash(node)] : -1;
                 while (j >= 0) {
                     if (j < k && s_node[j] == node) {
+                        dup = true;
                         cnt += (u32)s_act[j] == rl;
                         if (j > 0) cnt += (u32)(s_act[j - 1] ^ 1) == rl;
                     }
@@ -382,16 +398,37 @@ __global__ __launch_bounds__(kBlock) void k_mcts_select(rc_mcts_t m, double c, u
                     j = nx == 0xFFFFu ? -1 : (int)nx;
                 }
                 l_cnt[u] = cnt;
+                seen[u] = dup;
                 const size_t r = (base + node) * kA + rla;
                 n_a[u] = m.N[r];
                 p_f[u] = m.P[r];
                 w_f[u] = m.W[r];
+                nb[u] = m.nbr[r];
             }
 #pragma unroll
             for (int u = 0; u < kSelUnroll; ++u) {
                 const int k = k0 + u * (kBlock / 16) + (int)row;
-                const int b = puct_argmax(c, n_a[u], p_f[u], w_f[u], l_cnt[u], ract, (int)rl);
-                if (k < nlev && rl == 0 && b != (int)s_act[k]) atomicMin(&s_first, k);
+                const bool live = k <= nlev;
+                const int sum_n = row16_sum(ract ? n_a[u] : 0);
+                const double ud = ((c * (double)p_f[u]) * sqrt((double)sum_n)) / (double)(1 + n_a[u]);
+                const double s0 = ract ? ud + ((double)w_f[u] - 100.0 * 0.0) : -INFINITY;
+                const int idx = ract ? (int)rl : 64;
+                const int b0 = row16_argmax_first(s0, idx);
+                const double s1 = ((int)rl == b0) ? ud + ((double)w_f[u] - 100.0 * 1.0) : s0;
+                const int b1 = row16_argmax_first(s1, idx);
+                int d = (live && k > 0 && (int)(s_act[live && k > 0 ? k - 1 : 0] ^ 1) == b0) ? b1 : b0;
+                if (__builtin_amdgcn_ballot_w64(seen[u])) {   // some row of this wave revisits a node: exact counts
+                    const double sx = ract ? ud + ((double)w_f[u] - 100.0 * (double)l_cnt[u]) : -INFINITY;
+                    const int bx = row16_argmax_first(sx, idx);
+                    if (seen[u]) d = bx;
+                }
+                const u32 lane0 = (tid & 63u) & ~15u;
+                const int nb0 = __builtin_amdgcn_ds_bpermute((int)((lane0 + (u32)b0) << 2), nb[u]);
+                const int nb1 = __builtin_amdgcn_ds_bpermute((int)((lane0 + (u32)b1) << 2), nb[u]);
+                if (live && rl == 0) {
+                    rec[s_node[k]] = make_uint4((u32)nb0, (u32)nb1, (u32)b0 | ((u32)b1 << 8), 0u);
+                    if (k < nlev && d != (int)s_act[k]) atomicMin(&s_first, k);
+                }
             }
         }
         __syncthreads();
@@ -402,72 +439,79 @@ __global__ __launch_bounds__(kBlock) void k_mcts_select(rc_mcts_t m, double c, u
             l_count_add(m.L, (base + s_node[k]) * kA + a);
             l_count_add(m.L, (base + s_node[k + 1]) * kA + (a ^ 1));
         }
-        // __syncthreads() alone does not wait for no-return atomics: they must have reached L2 before wave 0 reads L
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (first < nlev) {   // from here on the chains hold the kept levels only; the walk appends its own
+            for (int i = tid; i < kSelHash; i += kBlock) s_head[i] = -1;
+            __syncthreads();
+            for (int k = tid; k < first; k += kBlock) s_next[k] = (u16)atomicExch(&s_head[sel_hash(s_node[k])], k);
+        }
     }
-    for (int i = tid; i < kSelHash; i += kBlock) s_head[i] = -1;   // from here on the chains index the NEW levels
-    __syncthreads();
+    __syncthreads();   // also: the records written above are visible to wave 0 from here on
     if (tid >= kWave) return;
 
-    // Sequential descent from level `first`: one wave, one dependent memory round trip per level and NO
-    // stores inside the loop.  The leaf flag and the five 12-wide rows of a node are requested together and
-    // the neighbour comes out of a lane read.  The virtual loss a level sees is what memory holds (kept
-    // prefix, suspended earlier calls) plus what this walk itself has left at the node so far, which is read
-    // off the walked levels (chained by node in LDS, as in the re-validation) instead of being stored and
-    // re-read through L2; the walk's own losses and its path go to memory once, after the loop.
-    // A single wave's dependent chain runs at the speed of its instruction count: see puct_argmax_walk.
     const unsigned long long t_walk = wall_clock64();
     const long long c_walk = clock64();
-    int slow_levels = 0, wrong_hints = 0;
+    int slow_levels = 0, revisits = 0;
     const u32 lane = tid;
     const bool act = lane < kA;
     const u32 la = act ? lane : 0;
     const int start = s_first;
     const TreeBufs tb = tree_bufs(m, base);
     const int max_path = (int)m.max_path;
-    int cur = __builtin_amdgcn_readfirstlane(pnode[start]), plen = start + 1;
-    int prev_act = -1;   // action that led to `cur` in THIS walk (level `start` has its arrival loss in memory already)
+    int cur = __builtin_amdgcn_readfirstlane(s_node[start]), plen = start + 1;
+    int prev_act = start > 0 ? __builtin_amdgcn_readfirstlane((int)s_act[start - 1]) : -1;   // action that led to `cur`
     u32 walked = 0;
     int stop = 0;
     const float c32 = (float)c;
-    NodeRows x = load_rows(tb, cur, la);
+    u32x4 x = load_rec(tb, cur);
     u32 h = sel_hash(cur);
     int head = s_head[h];
     for (;;) {
         const int k = plen - 1;
-        // The rows of the child the last descent took from here are requested at once (a non-leaf has all
-        // twelve children, a leaf's request hits the sentinel row 0); the argmax then runs while they fly.
-        int pred = ((int)__builtin_amdgcn_readfirstlane(x.hint) - 1) & 15;
-        pred = pred < kA ? pred : 0;
-        NodeRows y = load_rows(tb, __builtin_amdgcn_readlane(x.nb, pred), la);
+        const u32 z = (u32)__builtin_amdgcn_readfirstlane((int)x.z);
+        const int b0 = (int)(z & 15u), b1 = (int)((z >> 8) & 15u);
+        const bool back = prev_act >= 0 && (prev_act ^ 1) == b0;   // arrived through rev(best0): that edge carries a loss
+        const int a_f = back ? b1 : b0;
+        const int next_f = __builtin_amdgcn_readfirstlane((int)(back ? x.y : x.x));
+        // the next record is requested at once; the revisit test of this level runs while it flies
+        u32x4 y = load_rec(tb, next_f);
+        u32 hn = sel_hash(next_f);
+        int headn = s_head[hn];
         s_node[k] = cur;   // every lane stores the same value: no exec-mask detour
         u32 cnt = (prev_act >= 0 && (u32)(prev_act ^ 1) == lane) ? 1u : 0u;   // own arrival: L[cur, rev(a_prev)] += nu (agents.py:591)
-        for (int j = head; j >= 0;) {   // earlier visits of `cur` in this walk: departure edge a_j, arrival edge rev(a_{j-1})
+        bool visited = false;
+        for (int j = head; j >= 0;) {   // earlier visits of `cur` in this descent: departure edge a_j, arrival edge rev(a_{j-1})
             if (s_node[j] == cur) {
+                visited = true;
                 cnt += (u32)s_act[j] == lane;
-                if (j > start) cnt += (u32)(s_act[j - 1] ^ 1) == lane;
+                if (j > 0) cnt += (u32)(s_act[j - 1] ^ 1) == lane;
             }
             const u32 nx = s_next[j];
             j = nx == 0xFFFFu ? -1 : (int)nx;
         }
-        const u32 l_cnt = x.l_cnt + cnt;
         // one branch for the three ways a walk ends; which one is sorted out after the loop
-        stop = (int)__builtin_amdgcn_readfirstlane(x.is_leaf) ? 1 : plen >= max_path ? 2 : (level_budget && walked >= level_budget) ? 3 : 0;
+        stop = (z & kRecLeaf) ? 1 : plen >= max_path ? 2 : (level_budget && walked >= level_budget) ? 3 : 0;
         if (stop) break;
         ++walked;
-        const int arg = puct_argmax_walk(c, c32, x.n_a, x.p_f, x.w_f, l_cnt, act, (int)lane, slow_levels);
-        const int next = __builtin_amdgcn_readlane(x.nb, arg);
-        if (arg != pred) {   // wave-uniform
-            __builtin_amdgcn_raw_buffer_store_b8((u8)(arg + 1), tb.hint, 0, cur, 0);
-            y = load_rows(tb, next, la);
-            ++wrong_hints;
+        int arg = a_f, next = next_f;
+        if (visited) {   // wave-uniform: full evaluation with the exact loss counts
+            const NodeRows r = load_rows(tb, cur, la);
+            arg = puct_argmax_walk(c, c32, r.n_a, r.p_f, r.w_f, cnt, act, (int)lane, slow_levels);
+            next = __builtin_amdgcn_readlane(r.nb, arg);
+            ++revisits;
         }
-        x = y;
         s_next[k] = (u16)head;   // LDS operations of one wave are ordered: later levels see this entry
         s_head[h] = k;
         s_act[k] = (u8)arg;
-        h = sel_hash(next);
-        head = s_head[h];   // after the insertion above, so a colliding bucket is seen complete
+        if (next != next_f) {   // wave-uniform
+            y = load_rec(tb, next);
+            hn = sel_hash(next);
+            headn = s_head[hn];   // after the insertion above, so a colliding bucket is seen complete
+        } else if (hn == h) {
+            headn = k;            // ... as here, where the early read missed it
+        }
+        x = y;
+        h = hn;
+        head = headn;
         prev_act = arg;
         cur = next;
         ++plen;
@@ -492,10 +536,10 @@ __global__ __launch_bounds__(kBlock) void k_mcts_select(rc_mcts_t m, double c, u
             m.select_stats[8 * t + 3] = (int)(wall_clock64() - t_walk);     // ... sequential walk
             m.select_stats[8 * t + 4] = (int)(clock64() - c_walk);          // shader cycles of the walk
             m.select_stats[8 * t + 5] = slow_levels;
-            m.select_stats[8 * t + 6] = wrong_hints;
+            m.select_stats[8 * t + 6] = revisits;
         }
         m.path_len[t] = plen;
-        m.pending[t] = suspended;   // 1 = resume at path_len - 1 (its arrival loss is in memory)
+        m.pending[t] = suspended;   // 1 = resume at path_len - 1
     }
 }
 
@@ -631,11 +675,11 @@ static int check_mcts(const rc_mcts_t *m) {
     RC_REQUIRE(m != nullptr, RC_ERR_NULL);
     RC_REQUIRE(m->keys && m->nbr && m->P && m->W && m->N && m->L && m->V && m->leaf && m->hash && m->n_nodes &&
                    m->status && m->solved_idx && m->solved_action && m->iterations && m->path_len && m->path_node &&
-                   m->pending && m->path_act && m->child_soa && m->child_idx && m->new_mask && m->expanded,
+                   m->pending && m->path_act && m->child_soa && m->child_idx && m->new_mask && m->expanded && m->rec,
                RC_ERR_NULL);
     RC_REQUIRE(m->n_trees > 0 && m->capacity >= 13 && m->max_path >= 2 && m->max_path <= (uint32_t)kMaxPath, RC_ERR_RANGE);
     RC_REQUIRE((m->hash_size & (m->hash_size - 1)) == 0 && m->hash_size >= 2 * (m->capacity + 1), RC_ERR_RANGE);
-    RC_REQUIRE(aligned16(m->keys) && aligned16(m->child_soa) && (m->child_stride & 15u) == 0, RC_ERR_ALIGN);
+    RC_REQUIRE(aligned16(m->keys) && aligned16(m->rec) && aligned16(m->child_soa) && (m->child_stride & 15u) == 0, RC_ERR_ALIGN);
     RC_REQUIRE(m->rows_per_tree == 11 || m->rows_per_tree == 12, RC_ERR_RANGE);
     RC_REQUIRE(m->child_stride >= round_up((size_t)m->n_trees * m->rows_per_tree, 16), RC_ERR_STRIDE);
     return RC_OK;
@@ -697,7 +741,6 @@ int rc_mcts_shorten(const rc_mcts_t *m, rc_stream_t stream) {
 
 int rc_mcts_select(const rc_mcts_t *m, double c, uint32_t level_budget, rc_stream_t stream) {
     if (int rc = check_mcts(m)) return rc;
-    RC_REQUIRE(m->hint != nullptr, RC_ERR_NULL);
     hipLaunchKernelGGL(k_mcts_select, dim3(m->n_trees), dim3(kBlock), 0, (hipStream_t)stream, *m, c, level_budget);
     return launch_status();
 }

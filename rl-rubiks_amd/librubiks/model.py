@@ -397,6 +397,21 @@ class GenericNet:
         return self.module(oh, policy=False, value=True).float().reshape(-1)
 
 
+def net_fingerprint(net, dtype=None):
+    """
+    Identity of the function an engine built from `net` would compute: the object, the requested dtype and, for a
+    trainable `Model`, the storage and in-place version counter of every parameter and buffer (optimizer steps,
+    `load_state_dict` and `.data` swaps all change it).  Engines (`InferenceNet`, `GenericNet`) are frozen or call
+    their module live, so their identity is enough.  Search engines are rebuilt whenever this changes.
+    """
+    if isinstance(net, (InferenceNet, GenericNet)):
+        return (id(net),)
+    if isinstance(net, Model) and net.config.architecture.startswith("fc"):
+        tensors = list(net.parameters()) + list(net.buffers())
+        return (id(net), str(dtype)) + tuple((t.data_ptr(), t._version) for t in tensors)
+    return (id(net), str(dtype))   # any other module is called live through GenericNet
+
+
 def make_inference_net(net, dtype=torch.bfloat16):
     """The fastest engine that preserves `net`'s eval-mode function."""
     if isinstance(net, (InferenceNet, GenericNet)):

@@ -182,7 +182,7 @@ class MCTS(DeepAgent):
             self.forest = None
             torch.cuda.empty_cache()
             f = self.forest = md.MCTSForest(n_trees, capacity, self.max_path)
-            f.set_net(self.net, self.net_dtype)
+        f.set_net(self.net, self.net_dtype)   # every search: `net` may have been trained or replaced since the last one
         f.level_budget = 0 if self.level_budget == "auto" else int(self.level_budget)
         return f
 
@@ -421,7 +421,7 @@ class AStar(DeepAgent):
             self.batch = None
             torch.cuda.empty_cache()
             b = self.batch = ad.AStarBatch(n_problems, capacity, self.expansions)
-            b.set_net(self.net, self.net_dtype)
+        b.set_net(self.net, self.net_dtype)   # every search: `net` may have been trained or replaced since the last one
         return b
 
     @no_grad

@@ -16,7 +16,7 @@ import torch
 
 from librubiks import _hip
 from librubiks.cube.device import DeviceCubes
-from librubiks.model import make_inference_net
+from librubiks.model import make_inference_net, net_fingerprint
 from librubiks.solving.mcts_device import unpack_keys
 
 RUNNING, SOLVED, EXHAUSTED, OPEN_EMPTY, ROOT_SOLVED = 0, 1, 2, 3, 4
@@ -76,9 +76,15 @@ class AStarBatch:
             setattr(s, name, getattr(self, name).data_ptr())
         self.struct = s
         self.engine = None
+        self._net_fp = None
         self._oh = None
 
     def set_net(self, net, dtype=torch.bfloat16):
+        """Builds the inference engine for `net`; a no-op when the batch already runs exactly these weights."""
+        fp = net_fingerprint(net, dtype)
+        if self.engine is not None and fp == self._net_fp:
+            return
+        self._net_fp = fp
         self.engine = make_inference_net(net, dtype)
         rows = min(NET_CHUNK, self.B * self.N * N_ACT)
         if getattr(self.engine, "supports_cubes", False):

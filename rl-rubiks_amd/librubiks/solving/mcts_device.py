@@ -5,8 +5,9 @@ on torch's current stream and reads results back; no cube arithmetic happens on 
 
 Per node (tree-major, 1-based, row 0 = "no neighbour" sentinel like the reference's arrays,
 librubiks/solving/agents.py:417-459):  packed state 16 B, neighbors 12 x i32, P / W 12 x f32,
-N 12 x i32, virtual-loss count 12 x u16, V f32, leaf u8, plus 2 hash slots x i32  ->  ~270 B,
-so 1 024 trees x 175 000 nodes (the reference's default max_states) is ~48 GB of the 288 GB HBM3E.
+N 12 x i32, virtual-loss count 12 x u16, V f32, leaf u8, a 16-byte walk record (what a PUCT descent does at the
+node, see csrc/rubiks_mcts.hip) plus 2 hash slots x i32  ->  ~285 B, so 1 024 trees x 175 000 nodes (the
+reference's default max_states) is ~51 GB of the 288 GB HBM3E.
 """
 import ctypes
 from ctypes import POINTER, Structure, c_double, c_int, c_size_t, c_uint32, c_void_p
@@ -16,7 +17,7 @@ import torch
 
 from librubiks import _hip
 from librubiks.cube.device import DeviceCubes
-from librubiks.model import make_inference_net
+from librubiks.model import make_inference_net, net_fingerprint
 
 RUNNING, SOLVED, EXHAUSTED, PATH_OVERFLOW, ROOT_SOLVED = 0, 1, 2, 3, 4
 N_ACT = 12
@@ -30,7 +31,7 @@ class _McStruct(Structure):   # mirrors rc_mcts_t (include/rubiks_hip.h)
                                               "path_node", "path_act", "child_soa")] + \
                [("child_stride", c_size_t)] + \
                [(name, c_void_p) for name in ("child_idx", "new_mask", "expanded", "select_stats", "bfs", "short_act",
-                                              "short_len", "hint")]
+                                              "short_len", "rec")]
 
 
 _hip.register({
@@ -54,7 +55,7 @@ def unpack_keys(keys: np.ndarray) -> np.ndarray:
     return out
 
 
-_PER_NODE = ("keys", "nbr", "P", "W", "N", "L", "V", "leaf")
+_PER_NODE = ("keys", "nbr", "P", "W", "N", "L", "V", "leaf", "rec")
 _PER_TREE = ("n_nodes", "status", "solved_idx", "solved_action", "iterations", "path_len", "pending", "path_node", "path_act")
 
 
@@ -71,7 +72,7 @@ class MCTSForest:
         layout = {   # search state: zero-initialised, or adopted from another forest (`subset`)
             "keys": ((rows, 4), torch.int32), "nbr": ((rows, N_ACT), torch.int32), "P": ((rows, N_ACT), torch.float32),
             "W": ((rows, N_ACT), torch.float32), "N": ((rows, N_ACT), torch.int32), "L": ((rows, N_ACT), torch.int16),
-            "V": ((rows,), torch.float32), "leaf": ((rows,), torch.uint8), "hash": ((B, self.hash_size), torch.int32),
+            "V": ((rows,), torch.float32), "leaf": ((rows,), torch.uint8), "rec": ((rows, 4), torch.int32), "hash": ((B, self.hash_size), torch.int32),
             "n_nodes": ((B,), torch.int32), "status": ((B,), torch.int32), "solved_idx": ((B,), torch.int32),
             "solved_action": ((B,), torch.int32), "iterations": ((B,), torch.int32), "path_len": ((B,), torch.int32),
             "pending": ((B,), torch.int32), "path_node": ((B, max_path), torch.int32), "path_act": ((B, max_path), torch.uint8),
@@ -97,7 +98,7 @@ class MCTSForest:
         # into 11 row slots per tree (-8.3 % network work).  `subset` forests start in the packed regime.
         self._root_phase = _state is None
         self.children11 = DeviceCubes(self.children.soa, 11 * B)   # the same buffer seen as 11 B columns
-        for name in ("keys", "nbr", "P", "W", "N", "L", "V", "leaf", "hash", "n_nodes", "status", "solved_idx",
+        for name in ("keys", "nbr", "P", "W", "N", "L", "V", "leaf", "rec", "hash", "n_nodes", "status", "solved_idx",
                      "solved_action", "iterations", "path_len", "pending", "path_node", "path_act", "child_idx", "new_mask",
                      "expanded"):
             setattr(s, name, getattr(self, name).data_ptr())
@@ -108,10 +109,9 @@ class MCTSForest:
         self.short_act = z((B, max_path), torch.uint8)
         self.short_len = z((B,), torch.int32)
         s.short_act, s.short_len = self.short_act.data_ptr(), self.short_len.data_ptr()
-        self.hint = z((rows,), torch.uint8)   # per node: 1 + last action taken there (prefetch hint of rc_mcts_select)
-        s.hint = self.hint.data_ptr()
         self.struct = s
         self.engine = None
+        self._net_fp = None
         self._oh = None
         self._graph = None
         self._graph_key = None
@@ -145,7 +145,7 @@ class MCTSForest:
         assert small.C == self.C and small.max_path == self.max_path and len(slots) == small.B
         assert not small._root_phase and not self._root_phase
         B, C1 = self.B, self.C + 1
-        for name in _PER_NODE + ("hint",):
+        for name in _PER_NODE:
             dst, src = getattr(self, name), getattr(small, name)
             dst.view(B, C1, *dst.shape[1:])[slots] = src.view(small.B, C1, *src.shape[1:])
         self.hash[slots] = small.hash
@@ -158,6 +158,11 @@ class MCTSForest:
 
     # ---- network ---------------------------------------------------------------------------------
     def set_net(self, net, dtype=torch.bfloat16):
+        """Builds the inference engine for `net`; a no-op when the forest already runs exactly these weights."""
+        fp = net_fingerprint(net, dtype)
+        if self.engine is not None and fp == self._net_fp:
+            return
+        self._net_fp = fp
         self.engine = make_inference_net(net, dtype)
         self._fused = bool(getattr(self.engine, "supports_cubes", False))
         if self._fused:   # the input layer reads the child SoA directly: no one-hot matrix

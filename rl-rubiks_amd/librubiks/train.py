@@ -8,8 +8,10 @@ so the rollout's (games * depth * 12) substates never exist on the host (the ref
 in NumPy and ships a 377 MB one-hot matrix to the GPU every rollout at BASELINE config #4).
 The optimisation loop is stock PyTorch, like the reference's.  Plots and TrainAnalysis are out of
 scope.  Data-parallel training over several GPUs: every rank generates games / world_size games of
-each rollout and gradients are averaged with one all_reduce per step (`average_gradients`).
+each rollout from its own NumPy stream and gradients are averaged over the ranks (`average_gradients`).
 """
+from contextlib import contextmanager
+
 import numpy as np
 import torch
 import torch.distributed as dist
@@ -132,10 +134,28 @@ class Train:
         world, rank = dist.get_world_size(), dist.get_rank()
         self.rollout_games = -(-self.rollout_games // world)
         self.states_per_rollout = self.rollout_depth * self.rollout_games
-        np.random.seed((int(np.random.get_state()[1][0]) + rank) % (2 ** 32))
+        # The rank's own stream feeds the ADI scrambles only.  The global np.random stream stays COMMON to all ranks:
+        # the evaluator draws its scrambles from it and shards them over the ranks (evaluation.py, sharding.py), which
+        # is only a partition of one scramble set if every rank draws the same one.
+        self._adi_stream = np.random.RandomState((int(np.random.get_state()[1][0]) + rank) % (2 ** 32)).get_state()
         self._sharded = True
 
     _sharded = False
+    _adi_stream = None
+
+    @contextmanager
+    def _rank_stream(self):
+        """Inside: np.random is this rank's private ADI stream; outside: the stream all ranks share."""
+        if self._adi_stream is None:
+            yield
+            return
+        common = np.random.get_state()
+        np.random.set_state(self._adi_stream)
+        try:
+            yield
+        finally:
+            self._adi_stream = np.random.get_state()
+            np.random.set_state(common)
 
     def train(self, net: Model):
         self.tt.reset()
@@ -152,7 +172,8 @@ class Train:
         for rollout in range(self.rollouts):
             generator_net = self._update_gen_net(generator_net, net) if self.tau != 1 else net
             self.tt.profile("ADI training data")
-            data, policy_targets, value_targets, loss_weights = self.ADI_traindata(generator_net, alpha)
+            with self._rank_stream():
+                data, policy_targets, value_targets, loss_weights = self.ADI_traindata(generator_net, alpha)
             self.tt.end_profile("ADI training data")
             self.tt.profile("Training loop")
             net.train()

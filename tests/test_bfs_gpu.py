@@ -105,7 +105,7 @@ def test_bfs_and_select_argument_errors():
     forest = MCTSForest(4, 64)
     s = type(forest.struct)()
     ctypes.memmove(ctypes.byref(s), ctypes.byref(forest.struct), ctypes.sizeof(s))
-    s.hint = None
+    s.rec = None
     assert lib.rc_mcts_select(ctypes.byref(s), 0.6, 0, None) == -1
     torch.cuda.synchronize()
 
