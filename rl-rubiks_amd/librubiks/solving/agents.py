@@ -57,6 +57,51 @@ class DeepAgent(Agent):
         return cls(Model.load(loc, load_best=use_best).to(gpu), **kwargs)
 
 
+class QueueTable:
+    """
+    Action queues of a batch kept as rows of a (games, max_len) uint8 array plus a length per game; a
+    `deque` of ints is only built for the games somebody indexes (`table[g]`, iteration).  Behaves like
+    the list of deques it replaces.
+    """
+
+    def __init__(self, acts: np.ndarray = None, lens: np.ndarray = None, n: int = None):
+        if acts is not None:
+            self._rows = [(acts, i) for i in range(len(lens))]
+            self._lens = np.asarray(lens, dtype=np.int64).copy()
+        else:
+            self._rows = [None] * n
+            self._lens = np.zeros(n, dtype=np.int64)
+
+    def put(self, g: int, other: "QueueTable", i: int):
+        self._rows[g], self._lens[g] = other._rows[i], other._lens[i]
+
+    def lengths(self) -> np.ndarray:
+        return self._lens
+
+    def __len__(self):
+        return len(self._rows)
+
+    def __getitem__(self, g):
+        if isinstance(g, slice):
+            return [self[i] for i in range(*g.indices(len(self)))]
+        src = self._rows[g]
+        if src is None:
+            return deque()
+        acts, i = src
+        return deque(int(a) for a in acts[i, :self._lens[g]])
+
+    def __setitem__(self, g, q):
+        if isinstance(g, slice):
+            for i, qq in zip(range(*g.indices(len(self))), q):
+                self[i] = qq
+            return
+        arr = np.fromiter(q, dtype=np.uint8, count=len(q)).reshape(1, -1)
+        self._rows[g], self._lens[g] = (arr, 0), len(q)
+
+    def __iter__(self):
+        return (self[g] for g in range(len(self)))
+
+
 class BatchResult:
     """Per-scramble outcome of a batched search (shapes (B,)); `queues[t]` is tree t's action queue."""
 
@@ -70,7 +115,13 @@ class BatchResult:
 
     def select(self, mask: np.ndarray) -> "BatchResult":
         idx = np.flatnonzero(mask)
-        return BatchResult(self.solved[idx], self.lengths[idx], self.nodes[idx], [self.queues[i] for i in idx],
+        if isinstance(self.queues, QueueTable):
+            queues = QueueTable(n=len(idx))
+            for o, i in enumerate(idx):
+                queues.put(o, self.queues, int(i))
+        else:
+            queues = [self.queues[i] for i in idx]
+        return BatchResult(self.solved[idx], self.lengths[idx], self.nodes[idx], queues,
                            self.seconds, self.iterations[idx], self.status[idx])
 
     @staticmethod
@@ -78,12 +129,15 @@ class BatchResult:
         """Reassembles per-game results from (original indices, BatchResult) pieces."""
         solved, lengths = np.zeros(n, dtype=bool), np.full(n, -1, dtype=np.int64)
         nodes, iters, status = np.zeros(n, dtype=np.int64), np.zeros(n, dtype=np.int64), np.zeros(n, dtype=np.int64)
-        queues = [None] * n
+        queues = QueueTable(n=n)
         for owner, r in parts:
             solved[owner], lengths[owner], nodes[owner] = r.solved, r.lengths, r.nodes
             iters[owner], status[owner] = r.iterations, r.status
-            for o, q in zip(owner, r.queues):
-                queues[int(o)] = q
+            for i, o in enumerate(owner):
+                if isinstance(r.queues, QueueTable):
+                    queues.put(int(o), r.queues, i)
+                else:
+                    queues[int(o)] = r.queues[i]
         return BatchResult(solved, lengths, nodes, queues, seconds, iters, status)
 
 
@@ -137,6 +191,62 @@ class BFS(Agent):
         return "Breadth-first search"
 
 
+class _Harvest:
+    """
+    The trees of `forest` on their way to becoming per-game results: graph completion and BFS shortening of the
+    solved trees (device kernels), then asynchronous copies of the per-tree words and paths into pinned host
+    memory, all on the current stream; `result()` assembles the BatchResult once the copies have landed.
+    """
+    _pinned = {}
+
+    @classmethod
+    def _host_like(cls, t: torch.Tensor) -> torch.Tensor:
+        key = (tuple(t.shape), t.dtype)
+        free = cls._pinned.setdefault(key, [])
+        return free.pop() if free else torch.empty(t.shape, dtype=t.dtype, pin_memory=True)
+
+    def __init__(self, agent, forest: md.MCTSForest, games: np.ndarray):
+        self.games, self.graph = games, agent.search_graph
+        src = {"status": forest.status, "nodes": forest.n_nodes, "iterations": forest.iterations,
+               "plen": forest.path_len, "sol": forest.solved_action, "pact": forest.path_act}
+        if self.graph:
+            forest.complete_graphs()       # _complete_graph of all solved trees in one launch
+            forest.shorten_launch()        # ... and their BFS shortening in another
+            src["slen"], src["sact"] = forest.short_len, forest.short_act
+        self.host = {}
+        for name, t in src.items():
+            self.host[name] = self._host_like(t)
+            self.host[name].copy_(t, non_blocking=True)
+        self.event = torch.cuda.Event()
+        self.event.record()
+        self.forest = forest   # keeps the buffers alive until the copies have landed
+
+    def ready(self) -> bool:
+        return self.event.query()
+
+    def result(self) -> BatchResult:
+        self.event.synchronize()
+        h = {k: v.numpy() for k, v in self.host.items()}
+        status, plen = h["status"].astype(np.int64), h["plen"].astype(np.int64)
+        acts = h["pact"].copy()
+        lens = plen - 1                                   # the actions taken: the best guess of an unsolved tree (agents.py:492)
+        won = np.flatnonzero(status == md.SOLVED)
+        acts[won, plen[won] - 1] = h["sol"][won]          # agents.py:483
+        lens[won] = plen[won]
+        if self.graph and len(won):
+            short = won[h["slen"][won] >= 0]
+            acts[short] = h["sact"][short]
+            lens[short] = h["slen"][short]
+        lens[status == md.ROOT_SOLVED] = 0
+        solved = (status == md.SOLVED) | (status == md.ROOT_SOLVED)
+        out = BatchResult(solved, np.where(solved, lens, -1), h["nodes"].astype(np.int64), QueueTable(acts, lens), 0.0,
+                          h["iterations"].astype(np.int64), status)
+        for name, t in self.host.items():
+            self._pinned[(tuple(t.shape), t.dtype)].append(t)
+        self.host, self.forest = None, None
+        return out
+
+
 class MCTS(DeepAgent):
     """Batched PUCT graph search with virtual loss and max-backup (reference agents.py:415-645)."""
 
@@ -163,7 +273,8 @@ class MCTS(DeepAgent):
         self.net_dtype, self.use_graph, self.max_path, self.sync_every = net_dtype, use_graph, max_path, sync_every
         self.forest = None
         self._last_forest = None   # the forest the last search ended in (a compacted one after `compact`)
-        self._tree = None      # host copy of tree 0, for the reference's inspectable attributes
+        self._tree = None      # host copy of game 0's tree, for the reference's inspectable attributes
+        self._tree_src = None  # (forest, tree index) holding game 0's tree after the last search
 
     @classmethod
     def from_saved(cls, loc: str, use_best: bool, c: float, search_graph: bool, **kwargs):
@@ -190,181 +301,151 @@ class MCTS(DeepAgent):
     def search_batch(self, states, time_limit: float = None, max_states: int = None,
                      max_iterations: int = None, compact: bool = True, slots: int = None) -> BatchResult:
         """
-        One MCTS tree per row of `states` ((B,20) int8 NumPy array or DeviceCubes), all advanced in
-        lock step.  `max_states` is the reference's per-tree cap (stop when len + 12 > max_states);
-        `time_limit` bounds the wall time of the whole batch.
-        compact: whenever at most half of the trees of a forest of 256 or more are still running, the
-        finished ones are harvested and the forest is compacted to the running trees, so the stragglers of a
-        run to completion continue on small batches instead of paying full-size network calls.
+        One MCTS tree per row of `states` ((G,20) int8 NumPy array or DeviceCubes).  `max_states` is the
+        reference's per-tree cap (stop when len + 12 > max_states); `time_limit` bounds the wall time of the
+        whole batch.  All trees of the forest advance in lock step, `sync_every` iterations per round; the host
+        never waits for the round it has just queued: it reads the tree states of the PREVIOUS round (an
+        asynchronous copy) while the GPU works on the current one, so the launch queue never runs dry.
         slots: run at most this many trees at a time and give the places of finished trees to the scrambles
-        still waiting (continuous batching): the GPU stays full until the last games, instead of idling on
-        the stragglers of every batch.  Per-game results are those of the plain batch (trees are independent).
+        still waiting (continuous batching): the GPU stays full until the last games instead of idling on the
+        stragglers of every batch.  Per-game results are those of a plain batch (trees are independent).
         While games are waiting, descents are cut at `refill_level_budget` new levels per iteration, so that the
         few very deep descents of old trees do not pace the full batch (the budget is lifted for the tail).
+        compact: once nobody is waiting and at most half of the trees of a forest of 256 or more are still
+        running, the finished ones are harvested and the forest is compacted to the running trees, so the
+        stragglers continue on small batches instead of paying full-size network calls.
         """
         time_limit, max_states = self.reset(time_limit, max_states)
         roots = states if isinstance(states, DeviceCubes) else DeviceCubes.from_numpy(np.asarray(states))
-        if slots is not None and slots < roots.n:
-            assert max_iterations is None, "max_iterations applies to lock-step batches only"
-            return self._search_refill(roots, time_limit, max_states, int(slots), compact)
-        cap_states = int(max_states) if max_states < int(1e10) else DEFAULT_NODE_CAP
-        forest = self._forest_for(roots.n, max(cap_states, 16))
-        self.tt.tick()
-        forest.reset(roots)
-        B = roots.n
-        owner = np.arange(B)          # original game index of every tree of the current forest
-        harvested = []                # (owner ids, BatchResult) of trees dropped at compactions
-        it = 0
-        while True:
-            if max_iterations is not None and it >= max_iterations:
-                break
-            forest.step(self.c, cap_states, self.use_graph)
-            it += 1
-            if it % self.sync_every == 0 or (max_iterations is not None and it >= max_iterations):
-                running = forest.status == md.RUNNING
-                n_run = int(running.sum().item())
-                if n_run == 0 or self.tt.tock() >= time_limit:
-                    break
-                if compact and forest.B >= 256 and n_run <= forest.B // 2:
-                    done = (~running).cpu().numpy()
-                    part = self._collect(forest, 0.0)
-                    harvested.append((owner[done], part.select(done)))
-                    keep = torch.nonzero(running).reshape(-1)
-                    small = forest.subset(keep)
-                    if forest is self.forest:   # keep the full-size forest's buffers for the next search, drop its graph
-                        forest._graph = None
-                    forest, owner = small, owner[~done]
-        torch.cuda.synchronize()
-        seconds = self.tt.tock()
-        last = self._collect(forest, seconds)
-        if not harvested:
-            result = last
-        else:
-            harvested.append((owner, last))
-            result = BatchResult.merge(B, harvested, seconds)
-        self._last_forest = forest
-        self._explored_states = int(result.nodes[0])
-        self.action_queue = result.queues[0]
-        return result
-
-    def _search_refill(self, roots: DeviceCubes, time_limit: float, max_states: int, slots: int, compact: bool) -> BatchResult:
         cap_states = int(max_states) if max_states < int(1e10) else DEFAULT_NODE_CAP
         n_games = roots.n
-        forest = self._forest_for(slots, max(cap_states, 16))
+        S = n_games if slots is None else max(1, min(int(slots), n_games))
+        assert max_iterations is None or S == n_games, "max_iterations applies to lock-step batches only"
+        forest = self._forest_for(S, max(cap_states, 16))
         self.tt.tick()
-        first = DeviceCubes.empty(slots)
-        first.soa[:, :slots] = roots.soa[:, :slots]
-        forest.reset(first)
-        owner = np.arange(slots)        # game index of every slot, -1 once its result has been taken and nobody moved in
-        next_game = slots
+        if S == n_games:
+            forest.reset(roots)
+        else:
+            first = DeviceCubes.empty(S)
+            first.soa[:, :S] = roots.soa[:, :S]
+            forest.reset(first)
+        owner = np.arange(S)          # game index of every slot; -1 once its result has been taken and nobody moved in
+        stale_until = np.full(S, -1)  # snapshots up to this index predate the tree that now lives in the slot
+        next_game = S
         base_budget = forest.level_budget
-        if self.level_budget == "auto":
+        if next_game < n_games and self.level_budget == "auto":
             forest.level_budget = self.refill_level_budget
-        harvested = []
-        min_refill = max(8, slots // 32)
-        it = 0
-        stats = self.refill_stats = {"iterations": 0, "harvests": 0, "collect_s": 0.0, "refill_s": 0.0}
-        # Finished trees are copied out of the forest at once (their slots are needed), but turning them into
-        # results (graph completion, BFS shortening, host-side queues) is deferred by one sync period and runs
-        # on a side stream while the next iterations of the main forest are already queued.
+        min_refill = max(8, S // 32)
+        stats = self.refill_stats = {"iterations": 0, "harvests": 0, "refills": 0, "compactions": 0}
         side = torch.cuda.Stream()
-        deferred = []
+        harvests = []                 # _Harvest objects in flight or done
+        parts = []                    # (game ids, BatchResult)
+        self._tree, self._tree_src = None, None
+        snapshots = deque()           # (index, forest, event, pinned status) of rounds whose status has not been looked at
+        it, q = 0, 0
 
-        def flush():
-            t_c = self.tt.tock()
-            for own, sub, ev in deferred:
-                with torch.cuda.stream(side):
-                    side.wait_event(ev)
-                    harvested.append((own, self._collect(sub, 0.0)))
-            deferred.clear()
-            stats["collect_s"] += self.tt.tock() - t_c
+        def drain(block: bool):
+            for h in list(harvests):
+                if block or h.ready():
+                    parts.append((h.games, h.result()))
+                    harvests.remove(h)
 
-        while True:
-            for _ in range(self.sync_every):
+        def harvest(idx_np):
+            """Copies the finished trees `idx_np` out of the forest (their slots are needed or dropped) and starts
+            turning them into results on the side stream."""
+            idx = torch.from_numpy(idx_np).to(forest.status.device)
+            sub = forest.subset(idx)
+            ev = torch.cuda.Event()
+            ev.record()
+            with torch.cuda.stream(side):
+                side.wait_event(ev)
+                h = _Harvest(self, sub, owner[idx_np].copy())
+            harvests.append(h)
+            if self._tree_src is None and (owner[idx_np] == 0).any():
+                self._tree_src = (sub, int(np.flatnonzero(owner[idx_np] == 0)[0]))
+            stats["harvests"] += 1
+
+        done_all = False
+        while not done_all:
+            n_steps = min(self.sync_every, max(1, it))   # short first rounds: a batch that is solved at once ends at once
+            if max_iterations is not None:
+                n_steps = min(n_steps, max_iterations - it)
+            for _ in range(n_steps):
                 forest.step(self.c, cap_states, self.use_graph)
-            it += self.sync_every
-            flush()
-            status = forest.status.cpu().numpy()
+            it += n_steps
             stats["iterations"] = it
-            done = np.flatnonzero((status != md.RUNNING) & (owner >= 0))
-            n_run = int((status == md.RUNNING).sum())
-            out_of_time = self.tt.tock() >= time_limit
-            if len(done) and (len(done) >= min_refill or n_run == 0 or next_game >= n_games or out_of_time):
-                idx = torch.from_numpy(done).to(forest.status.device)
-                sub = forest.subset(idx)
-                ev = torch.cuda.Event()
-                ev.record()
-                deferred.append((owner[done].copy(), sub, ev))
-                owner[done] = -1
-                stats["harvests"] += 1
-                t_h = self.tt.tock()
-                k = min(len(done), n_games - next_game)
-                if k and not out_of_time:   # the waiting scrambles make their root iteration (12 rows per tree) apart
-                    fresh = DeviceCubes.empty(k)
-                    fresh.soa[:, :k] = roots.soa[:, next_game:next_game + k]
-                    small = md.MCTSForest(k, forest.C, forest.max_path)
-                    small.set_net(forest.engine, self.net_dtype)
-                    small.level_budget = forest.level_budget
-                    small.reset(fresh)
-                    small.step(self.c, cap_states, False)
-                    forest.adopt(small, idx[:k])
-                    owner[done[:k]] = np.arange(next_game, next_game + k)
-                    next_game += k
-                    n_run += k
-                    del small
-                    stats["refill_s"] += self.tt.tock() - t_h
-            if out_of_time or (n_run == 0 and next_game >= n_games):
+            snapshots.append((q, forest, *forest.status_snapshot()))
+            q += 1
+            if max_iterations is not None and it >= max_iterations:
                 break
-            if next_game >= n_games:
-                forest.level_budget = base_budget   # nobody is waiting any more: strict lock step for the tail
-            if compact and next_game >= n_games and forest.B >= 256 and n_run <= forest.B // 2:
-                keep = torch.from_numpy(np.flatnonzero(owner >= 0)).to(forest.status.device)   # running trees only by now
+            if len(snapshots) < 2 and it > 1:
+                continue      # look at round r - 1 while round r runs
+            qi, f_snap, ev, st_host = snapshots.popleft()
+            ev.synchronize()
+            if f_snap is not forest:
+                continue      # taken before a compaction
+            status = st_host.numpy()
+            live = owner >= 0
+            fresh = stale_until < qi
+            running = (status == md.RUNNING) | (live & ~fresh)      # a slot refilled after the snapshot runs by definition
+            done = np.flatnonzero(live & fresh & (status != md.RUNNING))
+            n_run = int((running & live).sum())
+            out_of_time = self.tt.tock() >= time_limit
+            waiting = next_game < n_games
+            drain(False)
+            if out_of_time or (n_run == 0 and not waiting):
+                done_all = True
+                break
+            if waiting and len(done) and (len(done) >= min_refill or n_run == 0):
+                harvest(done)
+                k = min(len(done), n_games - next_game)
+                idx = torch.from_numpy(done[:k]).to(forest.status.device)
+                fresh_roots = DeviceCubes.empty(k)
+                fresh_roots.soa[:, :k] = roots.soa[:, next_game:next_game + k]
+                small = md.MCTSForest(k, forest.C, forest.max_path)   # the waiting scrambles make their root iteration apart
+                small.set_net(forest.engine, self.net_dtype)
+                small.level_budget = forest.level_budget
+                small.reset(fresh_roots)
+                small.step(self.c, cap_states, False)
+                forest.adopt(small, idx)
+                owner[done] = -1
+                owner[done[:k]] = np.arange(next_game, next_game + k)
+                stale_until[done[:k]] = q - 1     # every snapshot queued so far predates the adoption
+                next_game += k
+                stats["refills"] += 1
+                del small
+                if next_game >= n_games:
+                    forest.level_budget = base_budget   # nobody is waiting any more: strict lock step for the tail
+            elif not waiting and compact and forest.B >= 256 and n_run <= forest.B // 2:
+                if len(done):
+                    harvest(done)
+                    owner[done] = -1
+                keep_np = np.flatnonzero(owner >= 0)
+                keep = torch.from_numpy(keep_np).to(forest.status.device)
                 small = forest.subset(keep)
-                if forest is self.forest:
+                if forest is self.forest:   # keep the full-size forest's buffers for the next search, drop its graph
                     forest._graph = None
-                forest, owner = small, owner[owner >= 0]
-        flush()
+                forest, owner, stale_until = small, owner[keep_np], stale_until[keep_np]
+                stats["compactions"] += 1
         torch.cuda.synchronize()
         seconds = self.tt.tock()
-        left = np.flatnonzero(owner >= 0)   # only when the time limit ended the run
+        left = np.flatnonzero(owner >= 0)
         if len(left):
-            idx = torch.from_numpy(left).to(forest.status.device)
-            harvested.append((owner[left], self._collect(forest.subset(idx), seconds)))
-        result = BatchResult.merge(n_games, harvested, seconds)
-        never = next_game < n_games     # games that never got a slot before the time limit: unsolved, nothing explored
-        if never:
-            result.queues[next_game:] = [deque() for _ in range(n_games - next_game)]
+            if len(left) == forest.B:
+                h = _Harvest(self, forest, owner.copy())
+                if self._tree_src is None and (owner == 0).any():
+                    self._tree_src = (forest, int(np.flatnonzero(owner == 0)[0]))
+                harvests.append(h)
+            else:
+                harvest(left)
+        drain(True)
+        result = BatchResult.merge(n_games, parts, seconds)
+        if next_game < n_games:   # games that never got a slot before the time limit: unsolved, nothing explored
             result.status[next_game:] = md.EXHAUSTED
         self._last_forest = forest
         self._explored_states = int(result.nodes[0])
         self.action_queue = result.queues[0]
         return result
-
-    def _collect(self, forest: md.MCTSForest, seconds: float) -> BatchResult:
-        status = forest.status.cpu().numpy()
-        nodes = forest.n_nodes.cpu().numpy().astype(np.int64)
-        plen, pact = forest.paths()
-        sol_act = forest.solved_action.cpu().numpy()
-        solved = (status == md.SOLVED) | (status == md.ROOT_SOLVED)
-        queues = []
-        self._tree = None
-        short_len = short_act = None
-        if self.search_graph and (status == md.SOLVED).any():
-            forest.complete_graphs()                          # _complete_graph of all solved trees in one launch
-            short_len, short_act = forest.shorten_queues()    # ... and their BFS shortening in another
-        for t in range(forest.B):
-            taken = [int(a) for a in pact[t, :plen[t] - 1]]
-            if status[t] == md.SOLVED:
-                q = taken + [int(sol_act[t])]                      # agents.py:483
-                if self.search_graph and short_len[t] >= 0:
-                    q = [int(a) for a in short_act[t, :short_len[t]]]
-            elif status[t] == md.ROOT_SOLVED:
-                q = []
-            else:
-                q = taken                                          # best guess (agents.py:492)
-            queues.append(deque(q))
-        lengths = np.array([len(q) if s else -1 for q, s in zip(queues, solved)])
-        return BatchResult(solved, lengths, nodes, queues, seconds, forest.iterations.cpu().numpy(), status)
 
     # ---- the reference's single-state API ----------------------------------------------------------
     def search(self, state: np.ndarray, time_limit: float = None, max_states: int = None) -> bool:
@@ -372,8 +453,11 @@ class MCTS(DeepAgent):
         return bool(res.solved[0])
 
     def _host_tree(self):
-        if self._tree is None:   # after a solved graph search the device arrays already hold the completed graph
-            self._tree = self._last_forest.tree_arrays(0)
+        """Game 0's tree, read from the forest it was harvested in (after a solved graph search the device arrays
+        hold the completed graph)."""
+        if self._tree is None:
+            forest, t = self._tree_src
+            self._tree = forest.tree_arrays(t)
         return self._tree
 
     # inspectable attributes relied on by the reference's tests (tests/test_agents.py:54-92)

@@ -270,13 +270,25 @@ class MCTSForest:
         """_complete_graph of every solved tree, on the device (agents.py:597-611)."""
         _hip.check(self.lib.rc_mcts_complete_graph(ctypes.byref(self.struct), _hip.stream_ptr()), "rc_mcts_complete_graph")
 
-    def shorten_queues(self):
-        """_shorten_action_queue of every solved tree on the device -> (lengths[B] (-1 = keep the naive queue), actions[B, max_path])."""
+    def shorten_launch(self):
+        """_shorten_action_queue of every solved tree on the device -> short_len[B] (-1 = keep the naive queue), short_act[B, max_path]."""
         if self.bfs is None:
             self.bfs = torch.zeros((self.B * (self.C + 1), 2), dtype=torch.int32, device=self.device)
             self.struct.bfs = self.bfs.data_ptr()
         _hip.check(self.lib.rc_mcts_shorten(ctypes.byref(self.struct), _hip.stream_ptr()), "rc_mcts_shorten")
+
+    def shorten_queues(self):
+        """shorten_launch + the two result arrays on the host."""
+        self.shorten_launch()
         return self.short_len.cpu().numpy(), self.short_act.cpu().numpy()
+
+    def status_snapshot(self):
+        """(event, pinned int32[B]): the per-tree status as of the work queued so far, readable once the event has passed."""
+        host = torch.empty(self.B, dtype=torch.int32, pin_memory=True)
+        host.copy_(self.status, non_blocking=True)
+        ev = torch.cuda.Event()
+        ev.record()
+        return ev, host
 
     def neighbors_of(self, t: int, n: int) -> np.ndarray:
         lo = t * (self.C + 1)

@@ -111,7 +111,7 @@ def _train_rank(rank, world, port, q):
                lr=1e-4, gamma=1, update_interval=0, agent=MCTS(net, c=0.6, search_graph=False), evaluator=None,
                evaluation_interval=0, tau=1, reward_method="lapanfix")
     net, _ = tr.train(net)
-    first_draw = int(np.random.randint(0, 2 ** 31))      # the rank's NumPy stream after training
+    first_draw = int(np.random.randint(0, 2 ** 31))      # the global NumPy stream after training
     q.put((rank, tr.rollout_games, net.get_params().double().sum().item(), net.get_params()[:64].cpu().tolist(), first_draw,
            tr.train_losses.tolist()))
     dist.barrier()
@@ -135,7 +135,8 @@ def test_data_parallel_training_two_ranks():
     (_, g0, sum0, head0, draw0, loss0), (_, g1, sum1, head1, draw1, loss1) = got
     assert g0 == g1 == 16                                  # 32 games per rollout split over two ranks
     assert sum0 == sum1 and head0 == head1                 # the same averaged gradients -> the same weights
-    assert draw0 != draw1 and loss0 != loss1               # ... from different games
+    assert loss0 != loss1                                  # ... from different games (rank-private ADI streams)
+    assert draw0 == draw1                                  # the global stream stays common: evaluation scrambles are shared
 
 
 def test_reference_train_test_restated():
