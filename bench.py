@@ -4,20 +4,31 @@ bench.py -- MCTS node expansions/sec on depth-20 scrambles (BASELINE.json metric
     python bench.py --gpus 1 --steps K --warmup W
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
 
-Workload (BASELINE.json configs[1]): 1 024 depth-20 scrambles per GPU (np.random.seed(0), the
-reference's scramble stream), MCTS c = 0.6 with graph search, fc_small policy/value net with
-glorot weights from torch.manual_seed(0) (no trained weights exist offline), bf16 inference engine.
-A "step" is one lock-step MCTS iteration of every tree on the rank: expand 12 children per leaf
-(HIP), input layer fused with the one-hot encoding (HIP), remaining network GEMMs (PyTorch-ROCm / hipBLASLt
-MFMA) on the NEW children only (11 packed rows per tree), backup + PUCT descent (HIP), replayed as one HIP graph.  value = unique states inserted into the trees by all ranks during the K
-timed steps / max-over-ranks wall time (inputs resident in HBM before the timed region).
-Ranks own disjoint scramble slices (weak scaling); the only collectives are the barrier, the
-max/sum reductions of the result and one all_gather of per-tree node counts.
+Workload (BASELINE.json configs[1]): 1 024 concurrent depth-20 MCTS trees per GPU (np.random.seed(0), the
+reference's scramble stream), MCTS c = 0.6 with graph search, max_states 50 000, fc_small policy/value net with
+the ADI-trained weights of weights/fc_small_r1 (glorot weights from torch.manual_seed(0) if absent).
+A "step" is one lock-step MCTS iteration of every tree on the rank: expand the leaf's 12 children (HIP), policy /
+value network on the NEW children (11 packed rows per tree; PyTorch-ROCm GEMMs), backup + PUCT descent (HIP).
+
+What is timed.  The 1 024 tree slots are fed from a pool of `--pool-factor` x 1 024 scrambles: a finished tree
+hands its slot to the next waiting scramble (continuous batching), so the slots hold trees of every age.  The
+pool is first advanced UNTIMED until as many scrambles again as there are slots have been started (the age mix
+is then that of a long-running evaluation), then W warm-up steps, then EXACTLY K steps are timed between
+barrier + synchronize on both sides, harvesting and refilling included:
+  value = unique states inserted into the trees of all ranks during the K timed steps / max-over-ranks seconds.
+This is done once per network precision (a "leg"):
+  f32   the reference's arithmetic (its net runs in fp32, librubiks/model.py:131-141)  ->  `value`, `dtype`
+  bf16  the production engine (BatchNorm folded, bf16 MFMA, fused input layer and head)  ->  `legs.bf16`
+Each leg also reports (sum of len(agent) / wall seconds of the batched search):
+  pool_run           the whole pool searched to completion / its wall time (prep, window and tail included)
+  run_to_completion  BASELINE configs[1] itself: the first 1 024 scrambles as ONE batch, to completion, + solve rate
+Ranks own disjoint scramble slices (weak scaling); the only collectives are the barrier, the max/sum reductions
+of the result and one all_gather of per-game results.
 
 Also printed on the same JSON line:
-  roofline      dominant kernel group of the timed step = the network's GEMMs (MFMA bound)
-  roofline_env  the hand-written environment kernels in isolation at 2^24 states (HBM bound;
-                multi_rotate is the north_star's roofline target)
+  roofline      dominant kernel of the headline leg's step = the first hidden GEMM (MFMA bound)
+  roofline_env  the hand-written environment kernels in isolation (HBM bound; multi_rotate is the north_star's
+                roofline target) at 2^14 .. 2^26 states
   phases        per-phase milliseconds of one MCTS step (HIP events, eager replay of the same step)
   cpu_baseline  the restated reference agent (oracle/, NumPy + torch CPU) on this box's host cores
 """
@@ -37,6 +48,11 @@ sys.path[:0] = [ROOT, os.path.join(ROOT, "rl-rubiks_amd")]
 HBM_PEAK_GBPS = 8000.0      # MI355X_MICROARCH.md: HBM3E peak
 MFMA_BF16_PEAK_TFLOPS = 2500.0   # dense bf16
 MFMA_F32_PEAK_TFLOPS = 157.3
+# `traffic` of roofline_env is NOT measured inside this run: it is the stored figure of separate rocprofv3 --pmc passes
+# (FETCH_SIZE / WRITE_SIZE, gfx950 corrections applied by tools/summarize_pmc.py) of the same launches at 2^24 states
+PMC_FILE = "r2_env_pmc_traffic.json" if os.path.exists(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles",
+                                                                  "r2_env_pmc_traffic.json")) else "r1b_env_pmc_traffic.json"
+PMC_SOURCE = f"stored PMC figure: profiles/{PMC_FILE} (separate rocprofv3 --pmc passes of these launches, not this run)"
 
 
 def event_ms(fn, reps, warm=2):
@@ -53,7 +69,7 @@ def event_ms(fn, reps, warm=2):
 
 
 def env_roofline(log2n=24):
-    """Environment kernels alone, HBM-resident inputs, HIP events on the launch stream."""
+    """Environment kernels alone, HBM-resident inputs, HIP events on the launch stream (N = 2^14 .. 2^26)."""
     from librubiks.cube import DeviceCubes
     n = 1 << log2n
     g = torch.Generator(device="cuda").manual_seed(0)
@@ -65,7 +81,7 @@ def env_roofline(log2n=24):
     res = []
     # HBM bytes per launch from the committed rocprofv3 PMC passes of these same launches (FETCH_SIZE and
     # WRITE_SIZE in separate runs, gfx950 corrections applied: tools/summarize_pmc.py); None if absent
-    pmc_path = os.path.join(ROOT, "profiles", "r1b_env_pmc_traffic.json")
+    pmc_path = os.path.join(ROOT, "profiles", PMC_FILE)
     pmc = json.load(open(pmc_path)) if os.path.exists(pmc_path) and log2n == 24 else {}
 
     def add(kernel, unit, unit_bytes, units, fn, reps=20):
@@ -75,7 +91,8 @@ def env_roofline(log2n=24):
                     "ms": round(mean, 4), "achieved": round(gbps, 1), "peak": HBM_PEAK_GBPS, "unit_rate": "GB/s",
                     "frac": round(gbps / HBM_PEAK_GBPS, 4), "Munits_per_s": round(units / (mean * 1e-3) / 1e6, 1),
                     "algorithmic_bytes": int(unit_bytes * units),
-                    "traffic": pmc.get(kernel.split("(")[0] if kernel.startswith("is_solved") else kernel, {}).get("traffic_bytes")})
+                    "traffic": pmc.get(kernel.split("(")[0] if kernel.startswith("is_solved") else kernel, {}).get("traffic_bytes"),
+                    "traffic_source": (PMC_SOURCE if pmc else None)})
 
     add("multi_rotate", "state", 41, n, lambda: cubes.multi_rotate(act, out=out))
     npar = n // 4
@@ -106,6 +123,7 @@ def phase_times(forest, c, max_states, reps):
     """Per-phase HIP-event timing of the eager step (same launches the captured graph replays)."""
     import ctypes
     from librubiks import _hip
+    from librubiks.model import InferenceNet
     lib, m = forest.lib, ctypes.byref(forest.struct)
     names = ["expand", "input_layer", "net_forward", "softmax+copy", "backup", "select"]
     acc = {k: 0.0 for k in names}
@@ -153,11 +171,12 @@ def phase_times(forest, c, max_states, reps):
         if ev_h is not None:
             acc["head_kernel"] = acc.get("head_kernel", 0.0) + ev_h.elapsed_time(ev[3])
     out = {k: round(v / reps, 4) for k, v in acc.items()}
-    if forest._fused:   # the dominant single kernel by itself: the first hidden GEMM (hipBLASLt, bf16 MFMA)
+    if isinstance(forest.engine, InferenceNet):   # the dominant single kernel by itself: the first hidden GEMM (hipBLASLt MFMA)
         eng = forest.engine
         W, b, _ = eng.layers[1]
         cubes, rows = forest._net_input()
-        x1 = forest._x1[:rows]
+        x1 = forest._x1[:rows] if forest._fused else torch.randn((rows, W.shape[1]), dtype=W.dtype, device=W.device)
+        out["gemm_hidden1_weight"] = (int(W.shape[0]), int(W.shape[1]))
         torch.addmm(b, x1, W.t())
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
@@ -251,27 +270,189 @@ def cpu_bfs_config1():
             "states_per_sec": round(seen / dt, 1), "cores": 1}
 
 
+def run_leg(name, model, pool_roots, config_roots, args, world, coll_device):
+    """
+    One network precision: steady-state window of K steps on the continuously refilled pool, the whole pool to
+    completion, and BASELINE configs[1] (the first `trees` scrambles as one batch) to completion.
+    Returns (dict for the JSON line, engine, agent).
+    """
+    from librubiks.model import InferenceNet
+    from librubiks.solving.agents import MCTS
+    net_dtype = torch.bfloat16 if name == "bf16" else torch.float32
+    engine = InferenceNet(model, dtype=net_dtype, first_layer_table=args.first_layer_table)
+    agent = MCTS(engine, c=0.6, search_graph=True, net_dtype=net_dtype, level_budget=args.level_budget)
+    cap = args.solve_max_states
+
+    def barrier():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    # ---- pool: untimed prep, warm-up, timed window, rest of the pool ------------------------------------
+    barrier()
+    t_pool = time.perf_counter()
+    run = agent.start_batch(pool_roots, None, cap, slots=args.trees)
+    while not run.done and run.next_game < min(2 * args.trees, run.n_games) and run.it < args.prep_cap:
+        run.round()
+    prep_iters = run.it
+    left = max(args.warmup, 1)
+    while left > 0 and not run.done:
+        before = run.it
+        run.round(left)
+        left -= run.it - before
+    barrier()
+    nodes0, refills0, it0 = run.nodes_now(), run.stats["refills"], run.it
+    barrier()
+    t0 = time.perf_counter()
+    left = args.steps
+    while left > 0 and not run.done:
+        before = run.it
+        run.round(left)
+        left -= run.it - before
+    barrier()
+    seconds = time.perf_counter() - t0
+    nodes = run.nodes_now() - nodes0
+    steps_done = run.it - it0
+    status = run.forest.status.cpu().numpy()
+    running_in_window = int(((status == 0) & (run.owner >= 0)).sum())
+    plen = run.forest.path_len.cpu().numpy()
+    mean_path = float(plen[(status == 0) & (run.owner >= 0)].mean()) if running_in_window else 0.0
+    refills_in_window = run.stats["refills"] - refills0
+    pool = None
+    if not args.window_only:
+        while not run.done:
+            run.round()
+        res = run.finish()
+        torch.cuda.synchronize()
+        pool_seconds = time.perf_counter() - t_pool
+        pool = {"games": int(run.n_games), "slots": args.trees, "nodes": int(res.nodes.sum()), "seconds": round(pool_seconds, 3),
+                "nodes_per_sec": round(float(res.nodes.sum()) / pool_seconds, 1), "solve_rate": float(res.solved.mean()),
+                "iterations": int(run.it), **{k: v for k, v in run.stats.items() if k != "iterations"}}
+    del run
+    # ---- BASELINE configs[1]: the first `trees` scrambles as one batch, to completion -----------------------
+    rtc = local = None
+    if not args.window_only:
+        agent.forest = None
+        torch.cuda.empty_cache()
+        barrier()
+        t1 = time.perf_counter()
+        full = agent.search_batch(config_roots, None, cap)
+        torch.cuda.synchronize()
+        rtc_seconds = time.perf_counter() - t1
+        local = {"nodes": full.nodes, "solved": full.solved, "lengths": full.lengths}
+        rtc = {"seconds": rtc_seconds, "nodes": int(full.nodes.sum())}
+    stats = torch.tensor([seconds, float(nodes), float(steps_done), rtc["seconds"] if rtc else 0.0,
+                          float(pool["nodes"]) if pool else 0.0, float(pool["seconds"]) if pool else 0.0],
+                         dtype=torch.float64, device=coll_device)
+    if world > 1:
+        mx, sm = stats.clone(), stats.clone()
+        dist.all_reduce(mx, op=dist.ReduceOp.MAX)
+        dist.all_reduce(sm, op=dist.ReduceOp.SUM)
+        seconds, nodes, rtc_s = float(mx[0]), int(sm[1]), float(mx[3])
+        pool_nodes, pool_s = int(sm[4]), float(mx[5])
+    else:
+        rtc_s, pool_nodes, pool_s = float(stats[3]), int(stats[4]), float(stats[5])
+    out = {"dtype": name, "value": round(nodes / seconds, 1), "ms_per_step": round(seconds / max(steps_done, 1) * 1e3, 4),
+           "nodes_in_window": nodes, "steps_timed": steps_done, "prep_iterations_untimed": prep_iters,
+           "refills_in_window": refills_in_window, "running_trees_rank0": running_in_window,
+           "mean_descent_depth_rank0": round(mean_path, 1)}
+    if pool:
+        out["pool_run"] = dict(pool, nodes=pool_nodes, seconds=round(pool_s, 3), nodes_per_sec=round(pool_nodes / pool_s, 1),
+                               games=int(pool["games"]) * world,
+                               note="whole pool searched to completion on `slots` tree slots; wall time includes prep, window and tail")
+    if rtc:
+        from librubiks.solving.sharding import gather_results
+        total = args.trees * world
+        g = gather_results(local, total, device=coll_device)
+        p = float(np.mean(g["solved"]))
+        out["run_to_completion"] = {
+            "games": int(total), "max_states_per_tree": cap, "nodes": int(np.sum(g["nodes"])), "seconds": round(rtc_s, 3),
+            "nodes_per_sec": round(float(np.sum(g["nodes"])) / rtc_s, 1), "solve_rate": p,
+            "ci95": float(1.959963984540054 * np.sqrt(p * (1 - p) / total)),
+            "mean_solution_length": float(np.mean(g["lengths"][g["solved"].astype(bool)])) if np.any(g["solved"]) else None,
+            "note": "BASELINE configs[1] as ONE batch: sum len(agent) / wall seconds of the batched search (SURVEY 8(d)(i))"}
+    return out, engine, agent
+
+
+def step_rooflines(engine, agent, roots, args, name):
+    """Per-phase times of one lock-step iteration on a young forest of `trees` trees + the rooflines derived from them."""
+    c = 0.6
+    capacity = 12 * (args.phase_reps + 40) + 64
+    agent.forest = None
+    torch.cuda.empty_cache()
+    forest = agent._forest_for(roots.n, capacity)
+    forest.reset(roots)
+    for _ in range(20):
+        forest.step(c, forest.C, use_graph=False)
+    torch.cuda.synchronize()
+    phases = phase_times(forest, c, forest.C, args.phase_reps)
+    rows, eng, fused = forest.rows_per_tree * roots.n, forest.engine, forest._fused
+    peak = MFMA_BF16_PEAK_TFLOPS if name == "bf16" else MFMA_F32_PEAK_TFLOPS
+    gemm_layers = eng.layers[1:] if fused else eng.layers
+    flops = 2 * sum(W.shape[0] * W.shape[1] for W, _, _ in gemm_layers) * rows
+    tf = flops / (phases["net_forward"] * 1e-3) / 1e12
+    lib_name = "bf16 MFMA via hipBLASLt" if name == "bf16" else "fp32 MFMA via hipBLASLt (v_mfma_f32_*_f32, 1/16 of the bf16 rate)"
+    group = {"kernel": f"policy/value net GEMMs on {rows} child rows ({len(gemm_layers)} GEMMs + bias + ELU passes, BatchNorm folded, "
+                       f"heads merged), {lib_name}",
+             "bound": "mfma", "achieved": round(tf, 1), "peak": peak, "unit": "TFLOP/s", "frac": round(tf / peak, 4), "traffic": None,
+             "flops_per_launch": flops, "ms_per_launch": phases["net_forward"]}
+    roofline, roofline_input = group, None
+    if "gemm_hidden1" in phases:   # the dominant kernel of the step, alone
+        W1 = phases.pop("gemm_hidden1_weight")
+        f1 = 2 * W1[0] * W1[1] * rows
+        tf1 = f1 / (phases["gemm_hidden1"] * 1e-3) / 1e12
+        roofline = {"kernel": f"hidden GEMM [{rows} x {W1[1]}] x [{W1[1]} x {W1[0]}] + bias, {lib_name}: the dominant kernel of a step",
+                    "bound": "mfma", "achieved": round(tf1, 1), "peak": peak, "unit": "TFLOP/s", "frac": round(tf1 / peak, 4),
+                    "traffic": None, "flops_per_launch": f1, "ms_per_launch": phases["gemm_hidden1"]}
+    if fused:
+        H = eng._fused_first[4]
+        mode = eng._fused_first[5]
+        mfma = mode in (2, 4)
+        kname = ("rc_first_layer_mfma_bf16 (one-hot x W1 on the matrix cores, one-hot fragments generated from the cube codes, "
+                 "W1 slice in LDS, + bias + ELU)") if mfma else "rc_first_layer_bf16 (one-hot x W1 as 20-row gather-sum from LDS + bias + ELU)"
+        f_in = 2 * 480 * H * rows
+        tf_in = f_in / (phases["input_layer"] * 1e-3) / 1e12
+        nbytes = (20 + 2 * H) * rows
+        roofline_input = {"kernel": kname, "table": {0: "bf16", 1: "f16", 2: "bf16", 3: "f16 pairs", 4: "f16"}[mode],
+                          "bound": "mfma" if mfma else "lds", "achieved": round(tf_in, 1), "peak": MFMA_BF16_PEAK_TFLOPS,
+                          "unit": "TFLOP/s", "frac": round(tf_in / MFMA_BF16_PEAK_TFLOPS, 4), "flops_per_launch": f_in,
+                          "traffic": None, "ms_per_launch": phases["input_layer"], "algorithmic_bytes": nbytes,
+                          "note": "dense-equivalent flops of the 480-wide one-hot product; the kernel is bound by feeding the MFMAs "
+                                  "from LDS (DESIGN.md section 3), its HBM traffic (20 B in, 2 H B out per row) is far from the HBM roof"}
+    del forest
+    agent.forest = None
+    torch.cuda.empty_cache()
+    return phases, roofline, group, roofline_input, rows
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--steps", type=int, default=400)
     ap.add_argument("--warmup", type=int, default=20)
-    ap.add_argument("--trees", type=int, default=1024, help="MCTS trees (scrambles) per GPU")
+    ap.add_argument("--trees", type=int, default=1024, help="concurrent MCTS trees (slots) per GPU")
     ap.add_argument("--depth", type=int, default=20)
-    ap.add_argument("--dtype", default="bf16", choices=["bf16", "f32"])
+    ap.add_argument("--legs", default="f32,bf16", help="network precisions to measure; the FIRST one is the headline `value`")
+    ap.add_argument("--pool-factor", type=int, default=8, help="scrambles in the pool per tree slot")
+    ap.add_argument("--prep-cap", type=int, default=4000, help="most untimed iterations before the timed window")
+    ap.add_argument("--window-only", action="store_true", help="skip the pool's tail and the run to completion")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-env-roofline", action="store_true")
     ap.add_argument("--phase-reps", type=int, default=20)
     ap.add_argument("--weights", default=os.path.join(ROOT, "weights", "fc_small_r1"),
                     help="checkpoint directory (model.pt + config.json); random-init weights if it does not exist")
-    ap.add_argument("--solve-max-states", type=int, default=50000,
-                    help="after the timed steps, search the same scrambles to completion with this per-tree cap and "
-                         "report the solve rate (0 = skip)")
-    ap.add_argument("--level-budget", type=int, default=0,
-                    help="new tree levels a PUCT descent may walk per step before it is suspended (0 = strict lock step)")
+    ap.add_argument("--solve-max-states", type=int, default=50000, help="per-tree cap (the reference's max_states)")
+    ap.add_argument("--level-budget", default="auto",
+                    help="new tree levels a PUCT descent may walk per step before it is suspended (0 = strict lock step; "
+                         "auto = the agent's default: a budget while scrambles are waiting for a slot, none for the tail)")
     ap.add_argument("--first-layer-table", default="auto", choices=["auto", "f16", "f16pair", "bf16", "mfma", "mfma16", "onehot"],
-                    help="input layer: fused gather-sum with an f16 / bf16 table, or the one-hot GEMM")
+                    help="bf16 engine's input layer: fused gather-sum with an f16 / bf16 table, or the one-hot GEMM")
     args = ap.parse_args()
+    if args.level_budget != "auto":
+        args.level_budget = int(args.level_budget)
+    legs = [x for x in args.legs.split(",") if x]
+    assert legs and all(x in ("f32", "bf16") for x in legs)
 
     rank, world = int(os.environ.get("RANK", 0)), int(os.environ.get("WORLD_SIZE", 1))
     local_rank = int(os.environ.get("LOCAL_RANK", 0))
@@ -290,16 +471,20 @@ def main():
     from librubiks import cube
     from librubiks.cube import DeviceCubes
     from librubiks.model import Model, ModelConfig
-    from librubiks.solving.agents import MCTS
-    from librubiks.solving.sharding import gather_results, shard_range
+    from librubiks.solving.sharding import shard_range
 
-    # ---- synthetic inputs: the reference's scramble stream, sliced by rank ------------------------
+    # ---- synthetic inputs: the reference's scramble stream; every rank draws all of it and keeps its slice -----
+    # games 0 .. trees*world - 1 are BASELINE configs[1]'s scrambles (rank r: its `trees`), the pool continues the stream
     np.random.seed(0)
-    total = args.trees * world
-    all_cubes, _, _ = cube.scramble_batch(total, args.depth, True)
-    lo, hi = shard_range(total, rank, world)
-    roots = DeviceCubes.empty(hi - lo)
-    roots.soa[:, :hi - lo] = all_cubes.soa[:, lo:hi]
+    per_rank = args.trees * args.pool_factor
+    all_cubes, _, _ = cube.scramble_batch(per_rank * world, args.depth, True)
+    lo, hi = shard_range(args.trees * world, rank, world)
+    config_roots = DeviceCubes.empty(hi - lo)
+    config_roots.soa[:, :hi - lo] = all_cubes.soa[:, lo:hi]
+    pool_roots = DeviceCubes.empty(per_rank)
+    pool_roots.soa[:, :hi - lo] = config_roots.soa[:, :hi - lo]           # the pool starts with the rank's config scrambles ...
+    rest_lo = args.trees * world + rank * (per_rank - args.trees)        # ... and continues with its slice of the rest
+    pool_roots.soa[:, hi - lo:per_rank] = all_cubes.soa[:, rest_lo:rest_lo + per_rank - (hi - lo)]
     del all_cubes
 
     torch.manual_seed(0)
@@ -309,58 +494,15 @@ def main():
     else:
         model = Model.create(ModelConfig()).eval()
         weights_note = "random-init (glorot, torch.manual_seed(0))"
-    net_dtype = torch.bfloat16 if args.dtype == "bf16" else torch.float32
-    c = 0.6
-    capacity = 12 * (args.warmup + args.steps + args.phase_reps + 8) + 64
-    from librubiks.model import InferenceNet
-    engine = InferenceNet(model, dtype=net_dtype, first_layer_table=args.first_layer_table)
-    agent = MCTS(engine, c=c, search_graph=True, net_dtype=net_dtype, level_budget=args.level_budget)
-    forest = agent._forest_for(roots.n, capacity)
-    max_states = forest.C
-    forest.reset(roots)
 
-    # ---- warm-up (first step runs eagerly and captures the HIP graph), then the timed region ------
-    for _ in range(max(args.warmup, 1)):
-        forest.step(c, max_states, use_graph=True)
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    nodes0 = int(forest.n_nodes.sum().item())
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        forest.step(c, max_states, use_graph=True)
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
-    seconds = time.perf_counter() - t0
-    nodes = int(forest.n_nodes.sum().item()) - nodes0
-    mean_path = float(forest.path_len.float().mean().item())
-
-    stats = torch.tensor([seconds, float(nodes)], dtype=torch.float64, device=coll_device)
-    if world > 1:
-        tmax = stats[:1].clone()
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        nsum = stats[1:].clone()
-        dist.all_reduce(nsum, op=dist.ReduceOp.SUM)
-        seconds, nodes = float(tmax.item()), int(nsum.item())
-    # ---- solve rate: the same scrambles searched to completion (untimed for `value`) -----------------------
-    if args.solve_max_states:
-        phases_early = phase_times(forest, c, max_states, args.phase_reps) if (args.phase_reps and rank == 0) else {}
-        rows_early, eng_early, fused_early = forest.rows_per_tree * roots.n, forest.engine, forest._fused
-        del forest
-        agent.forest = None
+    results, extras = {}, {}
+    for name in legs:
+        leg, engine, agent = run_leg(name, model, pool_roots, config_roots, args, world, coll_device)
+        results[name] = leg
+        if rank == 0 and args.phase_reps:
+            extras[name] = step_rooflines(engine, agent, config_roots, args, name)
+        del engine, agent
         torch.cuda.empty_cache()
-        t_solve = time.perf_counter()
-        full = agent.search_batch(roots, None, args.solve_max_states)
-        solve_seconds = time.perf_counter() - t_solve
-        local = {"nodes": full.nodes, "solved": full.solved, "lengths": full.lengths}
-    else:
-        status = forest.status.cpu().numpy()
-        local = {"nodes": forest.n_nodes.cpu().numpy(), "solved": status == 1, "lengths": np.full(hi - lo, -1)}
-    # final aggregation of per-tree results: the one data collective of an evaluation run (RCCL all_gather)
-    gathered = gather_results(local, total, device=coll_device)
 
     if rank != 0:
         if world > 1:
@@ -368,71 +510,38 @@ def main():
             dist.destroy_process_group()
         return
 
-    if args.solve_max_states:
-        rows, phases, eng, fused = rows_early, phases_early, eng_early, fused_early
-    else:
-        rows = forest.rows_per_tree * roots.n
-        phases = phase_times(forest, c, max_states, args.phase_reps) if args.phase_reps else {}
-        eng, fused = forest.engine, forest._fused
-    peak = MFMA_BF16_PEAK_TFLOPS if args.dtype == "bf16" else MFMA_F32_PEAK_TFLOPS
-    roofline = roofline_group = roofline_input = None
-    if phases:
-        # GEMM group actually executed on MFMA: every layer when the input is a one-hot matrix, layers 2..
-        # when the input layer is the fused gather-sum kernel (which is HBM/LDS work, reported separately)
-        gemm_layers = eng.layers[1:] if fused else eng.layers
-        flops = 2 * sum(W.shape[0] * W.shape[1] for W, _, _ in gemm_layers) * rows
-        tf = flops / (phases["net_forward"] * 1e-3) / 1e12
-        roofline_group = {"kernel": f"policy/value net GEMMs on {rows} child rows ({len(gemm_layers)} hipBLASLt GEMMs + bias + "
-                                    "ELU passes, BatchNorm folded, heads merged)",
-                          "bound": "mfma", "achieved": round(tf, 1), "peak": peak, "unit": "TFLOP/s",
-                          "frac": round(tf / peak, 4), "traffic": None,
-                          "flops_per_launch": flops, "ms_per_launch": phases["net_forward"]}
-        roofline = roofline_group
-        if "gemm_hidden1" in phases:   # the dominant kernel of the step, alone
-            W1 = eng.layers[1][0]
-            f1 = 2 * W1.shape[0] * W1.shape[1] * rows
-            tf1 = f1 / (phases["gemm_hidden1"] * 1e-3) / 1e12
-            roofline = {"kernel": f"hidden GEMM [{rows} x {W1.shape[1]}] x [{W1.shape[1]} x {W1.shape[0]}] + bias, bf16 MFMA via hipBLASLt "
-                                  "(Cijk_..._MT256x192x64 in the rocprof summary): the dominant kernel of a step",
-                        "bound": "mfma", "achieved": round(tf1, 1), "peak": peak, "unit": "TFLOP/s",
-                        "frac": round(tf1 / peak, 4), "traffic": None, "flops_per_launch": f1,
-                        "ms_per_launch": phases["gemm_hidden1"]}
-        if fused:
-            H = eng._fused_first[4]
-            nbytes = (20 + 2 * H) * rows
-            gbps = nbytes / (phases["input_layer"] * 1e-3) / 1e9
-            mode = eng._fused_first[5]
-            name = ("rc_first_layer_mfma_bf16 (one-hot x W1 on the matrix cores, one-hot fragments generated from the cube codes, "
-                    "W1 slice in LDS, + bias + ELU)") if mode in (2, 4) else \
-                "rc_first_layer_bf16 (one-hot x W1 as 20-row gather-sum from LDS + bias + ELU)"
-            roofline_input = {"kernel": name, "table": {0: "bf16", 1: "f16", 2: "bf16", 3: "f16 pairs", 4: "f16"}[mode],
-                              "bound": "hbm", "achieved": round(gbps, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                              "frac": round(gbps / HBM_PEAK_GBPS, 4), "algorithmic_bytes": nbytes,
-                              "bytes_per_unit": 20 + 2 * H, "traffic": None, "ms_per_launch": phases["input_layer"],
-                              "note": "algorithmic bytes: 20 B of cube codes in, 2 H B of activations out per row; the kernel is "
-                                      "LDS-feed / issue bound, not HBM bound (DESIGN.md section 3)"}
+    head = results[legs[0]]
     result = {
-        "metric": "MCTS node expansions/sec, depth-20 scrambles", "value": round(nodes / seconds, 1),
+        "metric": "MCTS node expansions/sec, depth-20 scrambles", "value": head["value"],
         "unit": "node expansions/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-        "ms_per_step": round(seconds / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak",
-        "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
-        "config": {"workload": f"{args.trees} depth-{args.depth} scrambles per GPU, MCTS agent (c=0.6, graph search), "
-                               f"fc_small net, weights: {weights_note}", "trees_per_gpu": args.trees, "select_level_budget": args.level_budget,
-                   "scramble_depth": args.depth, "net_rows_per_step": rows, "parallelism": f"scramble-sharded x{world}"},
-        "nodes_expanded": nodes, "mean_descent_depth": round(mean_path, 2), "solve_rate": float(np.mean(gathered["solved"])),
-        "solve_run": ({"max_states_per_tree": args.solve_max_states, "games": int(total),
-                       "ci95": float(1.959963984540054 * np.sqrt(np.mean(gathered["solved"]) * (1 - np.mean(gathered["solved"])) / total)),
-                       "mean_solution_length": float(np.mean(gathered["lengths"][gathered["solved"].astype(bool)]))
-                       if np.any(gathered["solved"]) else None,
-                       "nodes": int(np.sum(gathered["nodes"])), "seconds_rank0": round(solve_seconds, 2),
-                       "note": "same scrambles searched to completion after the timed steps; not part of `value`"}
-                      if args.solve_max_states else None),
-        "roofline": roofline, "roofline_net_group": roofline_group, "roofline_input_layer": roofline_input, "phases_ms": phases,
+        "ms_per_step": head["ms_per_step"], "higher_is_better": True, "scaling": "weak",
+        "vs_baseline": None, "dtype": head["dtype"], "data": "synthetic",
+        "config": {"workload": f"{args.trees} concurrent depth-{args.depth} MCTS trees per GPU (c=0.6, graph search, max_states "
+                               f"{args.solve_max_states}), slots refilled from a pool of {args.pool_factor} x {args.trees} scrambles "
+                               f"per GPU; fc_small net, weights: {weights_note}",
+                   "trees_per_gpu": args.trees, "pool_scrambles_per_gpu": per_rank, "select_level_budget": args.level_budget,
+                   "scramble_depth": args.depth, "parallelism": f"scramble-sharded x{world}",
+                   "timed_region": "K lock-step iterations of the stationary pool (harvest + refill included), barrier + "
+                                   "synchronize on both sides; prep and warm-up untimed"},
+        "value_note": f"headline = the '{legs[0]}' leg (the reference's network arithmetic is fp32); other precisions under `legs`",
+        "value_run_to_completion": (head.get("run_to_completion") or {}).get("nodes_per_sec"),
+        "value_pool_run": (head.get("pool_run") or {}).get("nodes_per_sec"),
+        "solve_rate": (head.get("run_to_completion") or {}).get("solve_rate"),
+        "legs": results,
     }
+    for name in legs:
+        if name in extras:
+            phases, roofline, group, roofline_input, rows = extras[name]
+            results[name]["phases_ms"] = phases
+            results[name]["roofline"] = roofline
+            results[name]["roofline_net_group"] = group
+            results[name]["net_rows_per_step"] = rows
+            if roofline_input:
+                results[name]["roofline_input_layer"] = roofline_input
+    result["roofline"] = results[legs[0]].get("roofline")
     if not args.no_env_roofline and world == 1:
-        agent.forest = None
         torch.cuda.empty_cache()
-        result["roofline_env"] = env_roofline()
+        result["roofline_env"] = [r for log2n in (14, 20, 24, 26) for r in env_roofline(log2n)]
     if not args.no_cpu_baseline and world == 1:
         result["cpu_baseline"] = cpu_baseline(model, args.depth)
     print(json.dumps(result))

@@ -207,7 +207,8 @@ typedef struct rc_mcts {
     uint8_t *expanded;   /* [B] 1 iff the tree expanded a leaf in the current iteration */
     int32_t *select_stats; /* optional (may be NULL): [B][8] = first sequentially walked level, new path length,
                               10-ns ticks spent re-validating the old path, ticks and shader cycles spent in the
-                              sequential walk, revisited levels that fell back to float64, revisited levels, 1 spare */
+                              sequential walk, revisited levels that fell back to float64, revisited levels,
+                              line-following rounds << 16 | levels they appended */
     /* optional, only needed by rc_mcts_shorten (may be NULL otherwise) */
     int32_t *bfs;        /* [B][capacity + 1][2] scratch: {claim, parent << 4 | action} */
     uint8_t *short_act;  /* [B][max_path] shortened action queue of every solved tree */
@@ -218,6 +219,13 @@ typedef struct rc_mcts {
      * with one loss on best0 (the descent arrived through rev(best0)).  rc_mcts_init / rc_mcts_expand write leaf
      * records, rc_mcts_select refreshes the records of the path it re-validates and walks by them. */
     void *rec;
+    /* per tree: the last ring_k descent paths ("lines"), used by rc_mcts_select to validate the likely continuation of
+     * a descent many levels at a time.  Path number s (= the tree's iteration count when it was walked) lives in slot
+     * s % ring_k; zero-initialised by the caller, owned by the kernels.  ring_k: a power of two, 1 .. 64. */
+    uint32_t ring_k;
+    int32_t *ring_node;  /* [B][ring_k][max_path] */
+    uint8_t *ring_act;   /* [B][ring_k][max_path] action taken at each level, 15 at the path's leaf */
+    int32_t *ring_len;   /* [B][ring_k] */
 } rc_mcts_t;
 
 /* Inserts the B root states (SoA) as node 1 of each tree; a solved root gets RC_MCTS_ROOT_SOLVED.

@@ -18,11 +18,16 @@ constexpr int kMaxPath = 4096;  // longest PUCT descent the kernels stage in LDS
 
 // Walk record of a node (16 B, rc_mcts_t::rec): what a PUCT descent does at the node while no virtual loss
 // other than its own arrival edge is pending there.
-//   x = neighbour through best0, y = neighbour through best1, z = best0 | best1 << 8 | kRecLeaf, w = 0
+//   x = neighbour through best0, y = neighbour through best1, z = best0 | best1 << 8 | kRecLeaf, w = line tag
 //   best0 = argmax_a U(a) + W(a)                          (every L = 0)
 //   best1 = the same with one virtual loss on best0       (the descent arrived through rev(best0))
 // A leaf's record is {0, 0, kRecLeaf, 0}.  rc_mcts_select keeps the records exact (see k_mcts_select).
+// Line tag: where the node last lay on a descent path -- path number (16 bits, 0 = never) << 16 | level << 4 |
+// action taken there (15 = it was that path's leaf).  The last ring_k paths of a tree are kept in a ring; the tag
+// only ever selects CANDIDATES for parallel validation, so a stale or aliased tag costs time, never correctness.
 constexpr u32 kRecLeaf = 1u << 16;
+constexpr u32 kNoAct = 15;
+__device__ __forceinline__ u32 line_tag(u32 seq, int level, u32 act) { return (seq << 16) | ((u32)level << 4) | act; }
 
 // ---- init: root = node 1 ------------------------------------------------------------------------
 __global__ __launch_bounds__(kBlock) void k_mcts_init(rc_mcts_t m, const u8 *__restrict__ roots, size_t stride) {
@@ -350,9 +355,11 @@ __global__ __launch_bounds__(kBlock) void k_mcts_select(rc_mcts_t m, double c, u
     __shared__ u8 s_act[kMaxPath];
     __shared__ int s_head[kSelHash];        // chains of path levels by node (earlier visits of a state)
     __shared__ u16 s_next[kMaxPath];
+    __shared__ int s_seg[256];              // line following: smallest lane per node bucket of a candidate segment
     const u32 t = blockIdx.x, tid = threadIdx.x;
     if (m.status[t] != RC_MCTS_RUNNING) return;
     const unsigned long long t_begin = wall_clock64();
+    const u32 seq = (u32)m.iterations[t] & 0xFFFFu;   // number of the path this call builds (its expansion count)
     const size_t base = (size_t)t * (m.capacity + 1);
     int *pnode = m.path_node + (size_t)t * m.max_path;
     u8 *pact = m.path_act + (size_t)t * m.max_path;
@@ -426,7 +433,8 @@ __global__ __launch_bounds__(kBlock) void k_mcts_select(rc_mcts_t m, double c, u
                 const int nb0 = __builtin_amdgcn_ds_bpermute((int)((lane0 + (u32)b0) << 2), nb[u]);
                 const int nb1 = __builtin_amdgcn_ds_bpermute((int)((lane0 + (u32)b1) << 2), nb[u]);
                 if (live && rl == 0) {
-                    rec[s_node[k]] = make_uint4((u32)nb0, (u32)nb1, (u32)b0 | ((u32)b1 << 8), 0u);
+                    rec[s_node[k]] = make_uint4((u32)nb0, (u32)nb1, (u32)b0 | ((u32)b1 << 8),   // the old path is line seq - 1
+                                                line_tag((seq - 1) & 0xFFFFu, k, k < nlev ? (u32)s_act[k] : kNoAct));
                     if (k < nlev && d != (int)s_act[k]) atomicMin(&s_first, k);
                 }
             }
@@ -450,7 +458,8 @@ __global__ __launch_bounds__(kBlock) void k_mcts_select(rc_mcts_t m, double c, u
 
     const unsigned long long t_walk = wall_clock64();
     const long long c_walk = clock64();
-    int slow_levels = 0, revisits = 0;
+    int slow_levels = 0, revisits = 0, line_rounds = 0, line_levels = 0;
+    const u32 ring_k = m.ring_k;
     const u32 lane = tid;
     const bool act = lane < kA;
     const u32 la = act ? lane : 0;
@@ -502,6 +511,71 @@ __global__ __launch_bounds__(kBlock) void k_mcts_select(rc_mcts_t m, double c, u
         s_next[k] = (u16)head;   // LDS operations of one wave are ordered: later levels see this entry
         s_head[h] = k;
         s_act[k] = (u8)arg;
+        // Line following.  If this node lay on one of the tree's last ring_k descent paths and left it by the same
+        // action, the levels that followed it there are the likely continuation: up to 64 of them are validated at
+        // once, one lane per level -- the level's record gives its decision for the line's arrival edge, and it must
+        // be the line's action, lead to the line's next node, and the node must be new to this descent (no chain
+        // entry, no earlier lane of the segment in its bucket).  The leading run of valid levels is appended in one
+        // step: two memory round trips (line, records) instead of one per level.
+        const u32 tag = (u32)__builtin_amdgcn_readfirstlane((int)x.w);
+        const u32 tseq = tag >> 16, age = (seq - tseq) & 0xFFFFu;
+        int room = max_path - plen - 1;
+        if (level_budget) room = min(room, (int)level_budget - (int)walked);
+        if (!visited && tseq != 0 && age >= 1 && age <= ring_k && (tag & 15u) == (u32)arg && room > 0) {
+            const size_t line = ((size_t)t * ring_k + (tseq & (ring_k - 1))) * (size_t)max_path;
+            const int llen = m.ring_len[(size_t)t * ring_k + (tseq & (ring_k - 1))];
+            const int li = (int)((tag >> 4) & 0xFFFu) + 1 + (int)lane;     // lane i validates level k + 1 + i
+            const bool in_line = li < llen && (int)lane < room;
+            const int node_i = in_line ? m.ring_node[line + li] : 0;
+            const u32 act_i = in_line ? (u32)m.ring_act[line + li] : kNoAct;
+            const u32 arr_i = (lane == 0 || !in_line) ? (u32)arg : (u32)m.ring_act[line + li - 1];
+            const u32x4 r = load_rec(tb, node_i);
+            for (int i = lane; i < 256; i += kWave) s_seg[i] = kWave;
+            const u32 rb0 = r.z & 15u, rb1 = (r.z >> 8) & 15u;
+            const bool rback = (arr_i ^ 1u) == rb0;
+            const u32 d_i = rback ? rb1 : rb0;
+            const int nx_i = (int)(rback ? r.y : r.x);
+            bool vis = false;
+            for (int j = in_line ? s_head[sel_hash(node_i)] : -1; j >= 0;) {
+                vis |= s_node[j] == node_i;
+                const u32 nx = s_next[j];
+                j = nx == 0xFFFFu ? -1 : (int)nx;
+            }
+            const u32 hb = ((u32)node_i * 0x9E3779B1u) >> 24;
+            if (in_line) atomicMin(&s_seg[hb], (int)lane);
+            const int from = __shfl_up(nx_i, 1);
+            const bool first_in_bucket = s_seg[hb] >= (int)lane;
+            const bool ok = in_line && act_i != kNoAct && !(r.z & kRecLeaf) && !vis && first_in_bucket && d_i == act_i &&
+                            (lane == 0 ? next : from) == node_i;
+            const u64 okm = __ballot(ok);
+            const int q = ~okm ? __builtin_ctzll(~okm) : kWave;
+            ++line_rounds;
+            if (q > 0) {
+                if ((int)lane < q) {
+                    const int kk = k + 1 + (int)lane;
+                    s_node[kk] = node_i;
+                    s_act[kk] = (u8)act_i;
+                }
+                if ((int)lane < q) s_next[k + 1 + lane] = (u16)atomicExch(&s_head[sel_hash(node_i)], k + 1 + (int)lane);
+                cur = __builtin_amdgcn_readlane(nx_i, q - 1);
+                prev_act = (int)__builtin_amdgcn_readlane((int)act_i, q - 1);
+                const bool have = q < kWave && ((__ballot(in_line && node_i == cur) >> q) & 1ull);
+                if (have) {
+                    x.x = (u32)__builtin_amdgcn_readlane((int)r.x, q & 63);
+                    x.y = (u32)__builtin_amdgcn_readlane((int)r.y, q & 63);
+                    x.z = (u32)__builtin_amdgcn_readlane((int)r.z, q & 63);
+                    x.w = (u32)__builtin_amdgcn_readlane((int)r.w, q & 63);
+                } else {
+                    x = load_rec(tb, cur);
+                }
+                h = sel_hash(cur);
+                head = s_head[h];
+                plen += 1 + q;
+                walked += (u32)q;
+                line_levels += q;
+                continue;
+            }
+        }
         if (next != next_f) {   // wave-uniform
             y = load_rec(tb, next);
             hn = sel_hash(next);
@@ -528,6 +602,18 @@ __global__ __launch_bounds__(kBlock) void k_mcts_select(rc_mcts_t m, double c, u
             l_count_add(m.L, (base + s_node[k + 1]) * kA + (a ^ 1));
         }
     }
+    // the whole path becomes line `seq` of the ring, and every node on it is tagged with its place there
+    if (seq != 0) {
+        const size_t slot = (size_t)t * ring_k + (seq & (ring_k - 1));
+        u32 *rec_w = reinterpret_cast<u32 *>(m.rec) + base * 4 + 3;
+        for (int k = (int)lane; k < plen; k += kWave) {
+            const u32 a = k < plen - 1 ? (u32)s_act[k] : kNoAct;
+            m.ring_node[slot * max_path + k] = s_node[k];
+            m.ring_act[slot * max_path + k] = (u8)a;
+            rec_w[(size_t)s_node[k] * 4] = line_tag(seq, k, a);
+        }
+        if (lane == 0) m.ring_len[slot] = plen;
+    }
     if (lane == 0) {
         if (m.select_stats) {
             m.select_stats[8 * t] = start;
@@ -537,6 +623,7 @@ __global__ __launch_bounds__(kBlock) void k_mcts_select(rc_mcts_t m, double c, u
             m.select_stats[8 * t + 4] = (int)(clock64() - c_walk);          // shader cycles of the walk
             m.select_stats[8 * t + 5] = slow_levels;
             m.select_stats[8 * t + 6] = revisits;
+            m.select_stats[8 * t + 7] = (line_rounds << 16) | min(line_levels, 0xFFFF);
         }
         m.path_len[t] = plen;
         m.pending[t] = suspended;   // 1 = resume at path_len - 1
@@ -675,12 +762,14 @@ static int check_mcts(const rc_mcts_t *m) {
     RC_REQUIRE(m != nullptr, RC_ERR_NULL);
     RC_REQUIRE(m->keys && m->nbr && m->P && m->W && m->N && m->L && m->V && m->leaf && m->hash && m->n_nodes &&
                    m->status && m->solved_idx && m->solved_action && m->iterations && m->path_len && m->path_node &&
-                   m->pending && m->path_act && m->child_soa && m->child_idx && m->new_mask && m->expanded && m->rec,
+                   m->pending && m->path_act && m->child_soa && m->child_idx && m->new_mask && m->expanded && m->rec && m->ring_node && m->ring_act &&
+                   m->ring_len,
                RC_ERR_NULL);
     RC_REQUIRE(m->n_trees > 0 && m->capacity >= 13 && m->max_path >= 2 && m->max_path <= (uint32_t)kMaxPath, RC_ERR_RANGE);
     RC_REQUIRE((m->hash_size & (m->hash_size - 1)) == 0 && m->hash_size >= 2 * (m->capacity + 1), RC_ERR_RANGE);
     RC_REQUIRE(aligned16(m->keys) && aligned16(m->rec) && aligned16(m->child_soa) && (m->child_stride & 15u) == 0, RC_ERR_ALIGN);
     RC_REQUIRE(m->rows_per_tree == 11 || m->rows_per_tree == 12, RC_ERR_RANGE);
+    RC_REQUIRE(m->ring_k >= 1 && m->ring_k <= 64 && (m->ring_k & (m->ring_k - 1)) == 0, RC_ERR_RANGE);
     RC_REQUIRE(m->child_stride >= round_up((size_t)m->n_trees * m->rows_per_tree, 16), RC_ERR_STRIDE);
     return RC_OK;
 }

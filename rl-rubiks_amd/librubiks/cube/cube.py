@@ -210,17 +210,22 @@ def scramble_batch(games: int, depth, force_not_solved: bool = False):
     if games == 0 or width == 0:
         return cubes, faces, dirs
     start, redraw = 0, False
-    while start < games:
-        stop = min(games, start + _SCRAMBLE_PASS)
-        after_draw = []   # RNG state right after game g's draws, needed only if g must be redrawn
-        for g in range(start, stop):
-            if sampler and not (redraw and g == start):   # a redrawn game keeps its depth (the recursion is inside scramble)
+
+    def draw(lo, hi, keep_first_depth):
+        for g in range(lo, hi):
+            if sampler and not (keep_first_depth and g == lo):   # a redrawn game keeps its depth (the recursion is inside scramble)
                 depths[g] = sampler()
             d = depths[g]
             faces[g, :d] = np.random.randint(6, size=(d,))
             dirs[g, :d] = np.random.randint(2, size=(d,))
-            if force_not_solved:
-                after_draw.append(np.random.get_state())
+
+    while start < games:
+        stop = min(games, start + _SCRAMBLE_PASS)
+        # RNG state at the start of the pass: if game g must be redrawn, the stream position right after its first
+        # draw is recovered by replaying the draws of start..g from here (rare), instead of snapshotting the
+        # 624-word state after every game
+        state0 = np.random.get_state() if force_not_solved else None
+        draw(start, stop, redraw)
         # moves beyond a game's own depth are action 12: identity padding of the kernels' move table
         acts = np.where(np.arange(width)[None, :] < depths[start:stop, None],
                         _actions_of(np.maximum(faces[start:stop], 0), dirs[start:stop]), 12).astype(np.uint8)
@@ -231,11 +236,12 @@ def scramble_batch(games: int, depth, force_not_solved: bool = False):
             else np.zeros(stop - start, dtype=bool)
         first = int(np.argmax(solved)) if solved.any() else stop - start
         cubes.soa[:, start:start + first] = part.soa[:, :first]
-        redraw = first < stop - start
+        was_redraw, redraw = redraw, first < stop - start
         if redraw:
             # game start+first came out solved: the reference redraws it from the stream position
             # right after its first draw, and every later game follows that (cube.py:213-214)
-            np.random.set_state(after_draw[first])
+            np.random.set_state(state0)
+            draw(start, start + first + 1, was_redraw)
         start += first
     if sampler:
         w = max(1, int(depths.max()))

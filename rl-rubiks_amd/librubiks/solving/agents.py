@@ -303,149 +303,26 @@ class MCTS(DeepAgent):
         """
         One MCTS tree per row of `states` ((G,20) int8 NumPy array or DeviceCubes).  `max_states` is the
         reference's per-tree cap (stop when len + 12 > max_states); `time_limit` bounds the wall time of the
-        whole batch.  All trees of the forest advance in lock step, `sync_every` iterations per round; the host
-        never waits for the round it has just queued: it reads the tree states of the PREVIOUS round (an
-        asynchronous copy) while the GPU works on the current one, so the launch queue never runs dry.
+        whole batch.  See `MCTSRun` for how the batch is driven.
         slots: run at most this many trees at a time and give the places of finished trees to the scrambles
         still waiting (continuous batching): the GPU stays full until the last games instead of idling on the
         stragglers of every batch.  Per-game results are those of a plain batch (trees are independent).
-        While games are waiting, descents are cut at `refill_level_budget` new levels per iteration, so that the
-        few very deep descents of old trees do not pace the full batch (the budget is lifted for the tail).
         compact: once nobody is waiting and at most half of the trees of a forest of 256 or more are still
         running, the finished ones are harvested and the forest is compacted to the running trees, so the
         stragglers continue on small batches instead of paying full-size network calls.
         """
+        run = self.start_batch(states, time_limit, max_states, compact=compact, slots=slots)
+        assert max_iterations is None or run.S == run.n_games, "max_iterations applies to lock-step batches only"
+        while not run.done and (max_iterations is None or run.it < max_iterations):
+            run.round(None if max_iterations is None else max_iterations - run.it)
+        return run.finish()
+
+    @no_grad
+    def start_batch(self, states, time_limit: float = None, max_states: int = None, compact: bool = True,
+                    slots: int = None) -> "MCTSRun":
         time_limit, max_states = self.reset(time_limit, max_states)
         roots = states if isinstance(states, DeviceCubes) else DeviceCubes.from_numpy(np.asarray(states))
-        cap_states = int(max_states) if max_states < int(1e10) else DEFAULT_NODE_CAP
-        n_games = roots.n
-        S = n_games if slots is None else max(1, min(int(slots), n_games))
-        assert max_iterations is None or S == n_games, "max_iterations applies to lock-step batches only"
-        forest = self._forest_for(S, max(cap_states, 16))
-        self.tt.tick()
-        if S == n_games:
-            forest.reset(roots)
-        else:
-            first = DeviceCubes.empty(S)
-            first.soa[:, :S] = roots.soa[:, :S]
-            forest.reset(first)
-        owner = np.arange(S)          # game index of every slot; -1 once its result has been taken and nobody moved in
-        stale_until = np.full(S, -1)  # snapshots up to this index predate the tree that now lives in the slot
-        next_game = S
-        base_budget = forest.level_budget
-        if next_game < n_games and self.level_budget == "auto":
-            forest.level_budget = self.refill_level_budget
-        min_refill = max(8, S // 32)
-        stats = self.refill_stats = {"iterations": 0, "harvests": 0, "refills": 0, "compactions": 0}
-        side = torch.cuda.Stream()
-        harvests = []                 # _Harvest objects in flight or done
-        parts = []                    # (game ids, BatchResult)
-        self._tree, self._tree_src = None, None
-        snapshots = deque()           # (index, forest, event, pinned status) of rounds whose status has not been looked at
-        it, q = 0, 0
-
-        def drain(block: bool):
-            for h in list(harvests):
-                if block or h.ready():
-                    parts.append((h.games, h.result()))
-                    harvests.remove(h)
-
-        def harvest(idx_np):
-            """Copies the finished trees `idx_np` out of the forest (their slots are needed or dropped) and starts
-            turning them into results on the side stream."""
-            idx = torch.from_numpy(idx_np).to(forest.status.device)
-            sub = forest.subset(idx)
-            ev = torch.cuda.Event()
-            ev.record()
-            with torch.cuda.stream(side):
-                side.wait_event(ev)
-                h = _Harvest(self, sub, owner[idx_np].copy())
-            harvests.append(h)
-            if self._tree_src is None and (owner[idx_np] == 0).any():
-                self._tree_src = (sub, int(np.flatnonzero(owner[idx_np] == 0)[0]))
-            stats["harvests"] += 1
-
-        done_all = False
-        while not done_all:
-            n_steps = min(self.sync_every, max(1, it))   # short first rounds: a batch that is solved at once ends at once
-            if max_iterations is not None:
-                n_steps = min(n_steps, max_iterations - it)
-            for _ in range(n_steps):
-                forest.step(self.c, cap_states, self.use_graph)
-            it += n_steps
-            stats["iterations"] = it
-            snapshots.append((q, forest, *forest.status_snapshot()))
-            q += 1
-            if max_iterations is not None and it >= max_iterations:
-                break
-            if len(snapshots) < 2 and it > 1:
-                continue      # look at round r - 1 while round r runs
-            qi, f_snap, ev, st_host = snapshots.popleft()
-            ev.synchronize()
-            if f_snap is not forest:
-                continue      # taken before a compaction
-            status = st_host.numpy()
-            live = owner >= 0
-            fresh = stale_until < qi
-            running = (status == md.RUNNING) | (live & ~fresh)      # a slot refilled after the snapshot runs by definition
-            done = np.flatnonzero(live & fresh & (status != md.RUNNING))
-            n_run = int((running & live).sum())
-            out_of_time = self.tt.tock() >= time_limit
-            waiting = next_game < n_games
-            drain(False)
-            if out_of_time or (n_run == 0 and not waiting):
-                done_all = True
-                break
-            if waiting and len(done) and (len(done) >= min_refill or n_run == 0):
-                harvest(done)
-                k = min(len(done), n_games - next_game)
-                idx = torch.from_numpy(done[:k]).to(forest.status.device)
-                fresh_roots = DeviceCubes.empty(k)
-                fresh_roots.soa[:, :k] = roots.soa[:, next_game:next_game + k]
-                small = md.MCTSForest(k, forest.C, forest.max_path)   # the waiting scrambles make their root iteration apart
-                small.set_net(forest.engine, self.net_dtype)
-                small.level_budget = forest.level_budget
-                small.reset(fresh_roots)
-                small.step(self.c, cap_states, False)
-                forest.adopt(small, idx)
-                owner[done] = -1
-                owner[done[:k]] = np.arange(next_game, next_game + k)
-                stale_until[done[:k]] = q - 1     # every snapshot queued so far predates the adoption
-                next_game += k
-                stats["refills"] += 1
-                del small
-                if next_game >= n_games:
-                    forest.level_budget = base_budget   # nobody is waiting any more: strict lock step for the tail
-            elif not waiting and compact and forest.B >= 256 and n_run <= forest.B // 2:
-                if len(done):
-                    harvest(done)
-                    owner[done] = -1
-                keep_np = np.flatnonzero(owner >= 0)
-                keep = torch.from_numpy(keep_np).to(forest.status.device)
-                small = forest.subset(keep)
-                if forest is self.forest:   # keep the full-size forest's buffers for the next search, drop its graph
-                    forest._graph = None
-                forest, owner, stale_until = small, owner[keep_np], stale_until[keep_np]
-                stats["compactions"] += 1
-        torch.cuda.synchronize()
-        seconds = self.tt.tock()
-        left = np.flatnonzero(owner >= 0)
-        if len(left):
-            if len(left) == forest.B:
-                h = _Harvest(self, forest, owner.copy())
-                if self._tree_src is None and (owner == 0).any():
-                    self._tree_src = (forest, int(np.flatnonzero(owner == 0)[0]))
-                harvests.append(h)
-            else:
-                harvest(left)
-        drain(True)
-        result = BatchResult.merge(n_games, parts, seconds)
-        if next_game < n_games:   # games that never got a slot before the time limit: unsolved, nothing explored
-            result.status[next_game:] = md.EXHAUSTED
-        self._last_forest = forest
-        self._explored_states = int(result.nodes[0])
-        self.action_queue = result.queues[0]
-        return result
+        return MCTSRun(self, roots, time_limit, max_states, compact, slots)
 
     # ---- the reference's single-state API ----------------------------------------------------------
     def search(self, state: np.ndarray, time_limit: float = None, max_states: int = None) -> bool:
@@ -474,6 +351,160 @@ class MCTS(DeepAgent):
     def indices(self) -> dict:
         tree = self._host_tree()
         return {s.tobytes(): i for i, s in enumerate(tree["states"][1:tree["n"] + 1], start=1)}
+
+
+class MCTSRun:
+    """
+    A batched MCTS search in progress: `round()` queues the next lock-step iterations, `finish()` returns the
+    per-game BatchResult.  All trees of the forest advance together, `sync_every` iterations per round; the host
+    never waits for the round it has just queued: it reads the tree states of the PREVIOUS round (an asynchronous
+    copy into pinned memory) while the GPU works on the current one, so the launch queue never runs dry.
+    Finished trees are copied out of the forest (`subset`) and turned into results on a side stream; with
+    `slots` < games their places go to the scrambles still waiting, which make their root iteration in a small
+    forest of their own and are then adopted.  While games are waiting, descents are cut at the agent's
+    `refill_level_budget` new levels per iteration, so that the few very deep descents of old trees do not pace
+    the full batch (the budget is lifted for the tail).
+    """
+
+    def __init__(self, agent: "MCTS", roots: DeviceCubes, time_limit: float, max_states: int, compact: bool, slots):
+        self.agent, self.roots, self.time_limit, self.compact = agent, roots, time_limit, compact
+        self.cap_states = int(max_states) if max_states < int(1e10) else DEFAULT_NODE_CAP
+        self.n_games = roots.n
+        S = self.S = self.n_games if slots is None else max(1, min(int(slots), self.n_games))
+        forest = self.forest = agent._forest_for(S, max(self.cap_states, 16))
+        agent.tt.tick()
+        if S == self.n_games:
+            forest.reset(roots)
+        else:
+            first = DeviceCubes.empty(S)
+            first.soa[:, :S] = roots.soa[:, :S]
+            forest.reset(first)
+        self.owner = np.arange(S)          # game index of every slot; -1 once its result has been taken and nobody moved in
+        self.stale_until = np.full(S, -1)  # snapshots up to this index predate the tree that now lives in the slot
+        self.next_game = S
+        self.base_budget = forest.level_budget
+        if self.next_game < self.n_games and agent.level_budget == "auto":
+            forest.level_budget = agent.refill_level_budget
+        self.min_refill = max(8, S // 32)
+        self.stats = agent.refill_stats = {"iterations": 0, "harvests": 0, "refills": 0, "compactions": 0}
+        self.side = torch.cuda.Stream()
+        self.harvests = []                 # _Harvest objects in flight
+        self.parts = []                    # (game ids, BatchResult)
+        agent._tree, agent._tree_src = None, None
+        self.snapshots = deque()           # (index, forest, event, pinned status) of rounds nobody has looked at yet
+        self.it, self.q, self.done = 0, 0, False
+
+    def _drain(self, block: bool):
+        for h in list(self.harvests):
+            if block or h.ready():
+                self.parts.append((h.games, h.result()))
+                self.harvests.remove(h)
+
+    def _harvest(self, idx_np: np.ndarray):
+        """Copies the finished trees `idx_np` out of the forest (their slots are needed or dropped) and starts
+        turning them into results on the side stream."""
+        forest, agent = self.forest, self.agent
+        idx = torch.from_numpy(idx_np).to(forest.status.device)
+        sub = forest.subset(idx)
+        ev = torch.cuda.Event()
+        ev.record()
+        games = self.owner[idx_np].copy()
+        with torch.cuda.stream(self.side):
+            self.side.wait_event(ev)
+            self.harvests.append(_Harvest(agent, sub, games))
+        if agent._tree_src is None and (games == 0).any():
+            agent._tree_src = (sub, int(np.flatnonzero(games == 0)[0]))
+        self.stats["harvests"] += 1
+
+    def round(self, max_steps: int = None):
+        """Queues up to `sync_every` iterations, then acts on the tree states of the round before."""
+        agent, forest = self.agent, self.forest
+        n_steps = min(agent.sync_every, max(1, self.it))   # short first rounds: a batch that is solved at once ends at once
+        if max_steps is not None:
+            n_steps = min(n_steps, max_steps)
+        for _ in range(n_steps):
+            forest.step(agent.c, self.cap_states, agent.use_graph)
+        self.it += n_steps
+        self.stats["iterations"] = self.it
+        self.snapshots.append((self.q, forest, *forest.status_snapshot()))
+        self.q += 1
+        if len(self.snapshots) < 2 and self.it > 1:
+            return            # look at round r - 1 while round r runs
+        qi, f_snap, ev, st_host = self.snapshots.popleft()
+        ev.synchronize()
+        if f_snap is not forest:
+            return            # taken before a compaction
+        status = st_host.numpy()
+        owner = self.owner
+        live = owner >= 0
+        fresh = self.stale_until < qi
+        running = live & ((status == md.RUNNING) | ~fresh)      # a slot refilled after the snapshot runs by definition
+        done = np.flatnonzero(live & fresh & (status != md.RUNNING))
+        n_run = int(running.sum())
+        out_of_time = agent.tt.tock() >= self.time_limit
+        waiting = self.next_game < self.n_games
+        self._drain(False)
+        if out_of_time or (n_run == 0 and not waiting):
+            self.done = True
+            return
+        if waiting and len(done) and (len(done) >= self.min_refill or n_run == 0):
+            self._harvest(done)
+            k = min(len(done), self.n_games - self.next_game)
+            idx = torch.from_numpy(done[:k]).to(forest.status.device)
+            fresh_roots = DeviceCubes.empty(k)
+            fresh_roots.soa[:, :k] = self.roots.soa[:, self.next_game:self.next_game + k]
+            small = md.MCTSForest(k, forest.C, forest.max_path)   # the waiting scrambles make their root iteration apart
+            small.set_net(forest.engine, agent.net_dtype)
+            small.level_budget = forest.level_budget
+            small.reset(fresh_roots)
+            small.step(agent.c, self.cap_states, False)
+            forest.adopt(small, idx)
+            owner[done] = -1
+            owner[done[:k]] = np.arange(self.next_game, self.next_game + k)
+            self.stale_until[done[:k]] = self.q - 1     # every snapshot queued so far predates the adoption
+            self.next_game += k
+            self.stats["refills"] += 1
+            del small
+            if self.next_game >= self.n_games:
+                forest.level_budget = self.base_budget   # nobody is waiting any more: strict lock step for the tail
+        elif not waiting and self.compact and forest.B >= 256 and n_run <= forest.B // 2:
+            if len(done):
+                self._harvest(done)
+                owner[done] = -1
+            keep_np = np.flatnonzero(owner >= 0)
+            keep = torch.from_numpy(keep_np).to(forest.status.device)
+            small = forest.subset(keep)
+            if forest is agent.forest:   # keep the full-size forest's buffers for the next search, drop its graph
+                forest._graph = None
+            self.forest, self.owner, self.stale_until = small, owner[keep_np], self.stale_until[keep_np]
+            self.stats["compactions"] += 1
+
+    def nodes_now(self) -> int:
+        """Nodes in the trees currently in the forest plus those of the trees already harvested (synchronises)."""
+        self._drain(True)
+        live = torch.from_numpy(self.owner >= 0).to(self.forest.n_nodes.device)
+        return int(self.forest.n_nodes[live].sum().item()) + sum(int(r.nodes.sum()) for _, r in self.parts)
+
+    def finish(self) -> BatchResult:
+        agent, forest, owner = self.agent, self.forest, self.owner
+        torch.cuda.synchronize()
+        seconds = agent.tt.tock()
+        left = np.flatnonzero(owner >= 0)
+        if len(left) == forest.B:
+            self.harvests.append(_Harvest(agent, forest, owner.copy()))
+            if agent._tree_src is None and (owner == 0).any():
+                agent._tree_src = (forest, int(np.flatnonzero(owner == 0)[0]))
+        elif len(left):
+            self._harvest(left)
+        self._drain(True)
+        result = BatchResult.merge(self.n_games, self.parts, seconds)
+        if self.next_game < self.n_games:   # games that never got a slot before the time limit: unsolved, nothing explored
+            result.status[self.next_game:] = md.EXHAUSTED
+        agent._last_forest = forest
+        agent._explored_states = int(result.nodes[0])
+        agent.action_queue = result.queues[0]
+        self.done = True
+        return result
 
 
 class AStar(DeepAgent):

@@ -31,7 +31,8 @@ class _McStruct(Structure):   # mirrors rc_mcts_t (include/rubiks_hip.h)
                                               "path_node", "path_act", "child_soa")] + \
                [("child_stride", c_size_t)] + \
                [(name, c_void_p) for name in ("child_idx", "new_mask", "expanded", "select_stats", "bfs", "short_act",
-                                              "short_len", "rec")]
+                                              "short_len", "rec")] + \
+               [("ring_k", c_uint32)] + [(name, c_void_p) for name in ("ring_node", "ring_act", "ring_len")]
 
 
 _hip.register({
@@ -56,7 +57,9 @@ def unpack_keys(keys: np.ndarray) -> np.ndarray:
 
 
 _PER_NODE = ("keys", "nbr", "P", "W", "N", "L", "V", "leaf", "rec")
-_PER_TREE = ("n_nodes", "status", "solved_idx", "solved_action", "iterations", "path_len", "pending", "path_node", "path_act")
+_PER_TREE = ("n_nodes", "status", "solved_idx", "solved_action", "iterations", "path_len", "pending", "path_node", "path_act",
+             "ring_node", "ring_act", "ring_len")
+RING_K = 8   # descent paths kept per tree for line following (rc_mcts_t::ring_k)
 
 
 class MCTSForest:
@@ -76,6 +79,8 @@ class MCTSForest:
             "n_nodes": ((B,), torch.int32), "status": ((B,), torch.int32), "solved_idx": ((B,), torch.int32),
             "solved_action": ((B,), torch.int32), "iterations": ((B,), torch.int32), "path_len": ((B,), torch.int32),
             "pending": ((B,), torch.int32), "path_node": ((B, max_path), torch.int32), "path_act": ((B, max_path), torch.uint8),
+            "ring_node": ((B, RING_K, max_path), torch.int32), "ring_act": ((B, RING_K, max_path), torch.uint8),
+            "ring_len": ((B, RING_K), torch.int32),
         }
         for name, (shape, dt) in layout.items():
             if _state is not None:
@@ -93,6 +98,7 @@ class MCTSForest:
         s = _McStruct()
         s.n_trees, s.capacity, s.hash_size, s.max_path = B, C, self.hash_size, max_path
         s.rows_per_tree = N_ACT if _state is None else 11
+        s.ring_k = RING_K
         # Network rows per tree: the root's expansion creates 12 new children, every later leaf at most 11 (its
         # parent is a known child), so after the first iteration only the new children are evaluated, packed
         # into 11 row slots per tree (-8.3 % network work).  `subset` forests start in the packed regime.
@@ -100,7 +106,7 @@ class MCTSForest:
         self.children11 = DeviceCubes(self.children.soa, 11 * B)   # the same buffer seen as 11 B columns
         for name in ("keys", "nbr", "P", "W", "N", "L", "V", "leaf", "rec", "hash", "n_nodes", "status", "solved_idx",
                      "solved_action", "iterations", "path_len", "pending", "path_node", "path_act", "child_idx", "new_mask",
-                     "expanded"):
+                     "expanded", "ring_node", "ring_act", "ring_len"):
             setattr(s, name, getattr(self, name).data_ptr())
         s.child_soa, s.child_stride = self.children.soa.data_ptr(), self.children.stride
         self.select_stats = z((B, 8), torch.int32)   # diagnostics: where each descent became sequential, its length, ticks
