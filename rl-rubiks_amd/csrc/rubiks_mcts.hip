@@ -282,6 +282,63 @@ __device__ __forceinline__ int puct_argmax_walk(double c, float c32, int n_a, fl
     return __builtin_amdgcn_readfirstlane(puct_argmax_sum(c, sum_n, n_a, p_f, w_f, l_cnt, act, lane));
 }
 
+// ---- PUCT of one node evaluated by ONE lane (all twelve actions in registers), float32 ------------------------
+// Same arithmetic and the same acceptance rule as puct_argmax_walk: the float32 winner is taken only if it leads
+// every other action by more than the worst-case float32-vs-float64 difference; ties, near ties and NaNs report
+// `certain = false` and are decided in float64 by the caller.  One lane per tree level turns the re-validation of
+// a 1 000-level path into four passes of a 256-thread workgroup.
+struct LaneEval {
+    float u[kA], w[kA];
+};
+__device__ __forceinline__ void load_row12(const void *base, size_t row, u32 (&out)[kA]) {
+    const uint4 *p = reinterpret_cast<const uint4 *>(reinterpret_cast<const u32 *>(base) + row);   // rows are 48 B, 16-B aligned
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        const uint4 v = p[i];
+        out[4 * i] = v.x, out[4 * i + 1] = v.y, out[4 * i + 2] = v.z, out[4 * i + 3] = v.w;
+    }
+}
+__device__ __forceinline__ LaneEval lane_prepare(float c32, const rc_mcts_t &m, size_t row) {
+    u32 n[kA], p[kA], w[kA];
+    load_row12(m.N, row, n);
+    load_row12(m.P, row, p);
+    load_row12(m.W, row, w);
+    int sum = 0;
+#pragma unroll
+    for (int a = 0; a < kA; ++a) sum += (int)n[a];
+    const float sq = __builtin_amdgcn_sqrtf((float)sum);
+    LaneEval e;
+#pragma unroll
+    for (int a = 0; a < kA; ++a) {
+        e.u[a] = c32 * __uint_as_float(p[a]) * sq * __builtin_amdgcn_rcpf((float)(1 + (int)n[a]));
+        e.w[a] = __uint_as_float(w[a]);
+    }
+    return e;
+}
+// cnt5: virtual-loss count of action a in bits 5a .. 5a+4
+__device__ __forceinline__ int lane_pick(const LaneEval &e, u64 cnt5, bool &certain) {
+    float sc[kA], mg[kA];
+    float best = -INFINITY, mbest = 0.f;
+    int arg = 0;
+    bool ok = true;
+#pragma unroll
+    for (int a = 0; a < kA; ++a) {
+        const float loss = 100.0f * (float)((u32)(cnt5 >> (5 * a)) & 31u);
+        sc[a] = e.u[a] + (e.w[a] - loss);
+        mg[a] = fabsf(e.u[a]) + fabsf(e.w[a]) + loss;
+        ok &= sc[a] == sc[a];
+        if (sc[a] > best) { best = sc[a]; arg = a; mbest = mg[a]; }
+    }
+#pragma unroll
+    for (int a = 0; a < kA; ++a) ok &= (a == arg) | (best - sc[a] > kPuctEps * (mg[a] + mbest));
+    certain = ok;
+    return arg;
+}
+__device__ __forceinline__ void cnt5_add(u64 &cnt5, bool &overflow, u32 a) {
+    overflow |= ((u32)(cnt5 >> (5 * a)) & 31u) >= 30u;
+    cnt5 += 1ull << (5 * a);
+}
+
 // Per-tree arrays as buffer resources (wave-uniform, in SGPRs): a row access is one instruction with one
 // shared 32-bit offset register instead of 64-bit address arithmetic per array.
 constexpr u32 kRsrcFlags = 0x00020000;   // raw buffer, 32-bit data format
@@ -324,7 +381,6 @@ __device__ __forceinline__ void l_count_add(u16 *L, size_t e) {
 }
 
 constexpr int kSelHash = 2048;   // LDS chain heads of the select kernel
-constexpr int kSelUnroll = 4;
 __device__ __forceinline__ u32 sel_hash(int node) { return ((u32)node * 0x9E3779B1u) >> 21; }
 
 // One 256-thread workgroup per tree.
@@ -356,6 +412,7 @@ __global__ __launch_bounds__(kBlock) void k_mcts_select(rc_mcts_t m, double c, u
     __shared__ int s_head[kSelHash];        // chains of path levels by node (earlier visits of a state)
     __shared__ u16 s_next[kMaxPath];
     __shared__ int s_seg[256];              // line following: smallest lane per node bucket of a candidate segment
+    __shared__ u32 s_unc[kMaxPath / 32];    // re-validation: levels float32 could not settle
     const u32 t = blockIdx.x, tid = threadIdx.x;
     if (m.status[t] != RC_MCTS_RUNNING) return;
     const unsigned long long t_begin = wall_clock64();
@@ -380,63 +437,82 @@ __global__ __launch_bounds__(kBlock) void k_mcts_select(rc_mcts_t m, double c, u
     for (int k = tid; k < nlev; k += kBlock) s_next[k] = (u16)atomicExch(&s_head[sel_hash(s_node[k])], k);
     __syncthreads();
     if (!resume) {
-        // kSelUnroll levels per 16-lane row are in flight together: chain walks (LDS) first, then the row loads,
-        // then the argmaxes -- one memory round trip per 16 * kSelUnroll levels.
-        for (int k0 = 0; k0 <= nlev; k0 += (kBlock / 16) * kSelUnroll) {
-            int n_a[kSelUnroll], nb[kSelUnroll];
-            float p_f[kSelUnroll], w_f[kSelUnroll];
-            u32 l_cnt[kSelUnroll];
-            bool seen[kSelUnroll];
-#pragma unroll
-            for (int u = 0; u < kSelUnroll; ++u) {
-                const int k = k0 + u * (kBlock / 16) + (int)row;
-                const bool live = k <= nlev;
-                const int node = live ? s_node[k] : 0;
-                u32 cnt = (live && k > 0 && (u32)(s_act[k - 1] ^ 1) == rl) ? 1u : 0u;   // own arrival edge
-                bool dup = false;
-                int j = live ? s_head[sel_hash(node)] : -1;
-                while (j >= 0) {
-                    if (j < k && s_node[j] == node) {
-                        dup = true;
-                        cnt += (u32)s_act[j] == rl;
-                        if (j > 0) cnt += (u32)(s_act[j - 1] ^ 1) == rl;
-                    }
-                    const u32 nx = s_next[j];
-                    j = nx == 0xFFFFu ? -1 : (int)nx;
+        // Pass A: one lane per level, float32 with the acceptance rule of lane_pick.  Levels it cannot settle (near
+        // ties, NaNs, loss counts beyond 5 bits) are flagged for pass B.
+        for (int i = tid; i < kMaxPath / 32; i += kBlock) s_unc[i] = 0;
+        __syncthreads();
+        const float c32v = (float)c;
+        for (int k = tid; k <= nlev; k += kBlock) {
+            const int node = s_node[k];
+            const int arr = k > 0 ? (int)(s_act[k - 1] ^ 1) : -1;   // own arrival edge
+            u64 cnt5 = 0;
+            bool dup = false, ovf = false;
+            for (int j = s_head[sel_hash(node)]; j >= 0;) {
+                if (j < k && s_node[j] == node) {
+                    dup = true;
+                    cnt5_add(cnt5, ovf, (u32)s_act[j]);
+                    if (j > 0) cnt5_add(cnt5, ovf, (u32)(s_act[j - 1] ^ 1));
                 }
-                l_cnt[u] = cnt;
-                seen[u] = dup;
-                const size_t r = (base + node) * kA + rla;
-                n_a[u] = m.N[r];
-                p_f[u] = m.P[r];
-                w_f[u] = m.W[r];
-                nb[u] = m.nbr[r];
+                const u32 nx = s_next[j];
+                j = nx == 0xFFFFu ? -1 : (int)nx;
             }
-#pragma unroll
-            for (int u = 0; u < kSelUnroll; ++u) {
-                const int k = k0 + u * (kBlock / 16) + (int)row;
-                const bool live = k <= nlev;
-                const int sum_n = row16_sum(ract ? n_a[u] : 0);
-                const double ud = ((c * (double)p_f[u]) * sqrt((double)sum_n)) / (double)(1 + n_a[u]);
-                const double s0 = ract ? ud + ((double)w_f[u] - 100.0 * 0.0) : -INFINITY;
-                const int idx = ract ? (int)rl : 64;
-                const int b0 = row16_argmax_first(s0, idx);
-                const double s1 = ((int)rl == b0) ? ud + ((double)w_f[u] - 100.0 * 1.0) : s0;
-                const int b1 = row16_argmax_first(s1, idx);
-                int d = (live && k > 0 && (int)(s_act[live && k > 0 ? k - 1 : 0] ^ 1) == b0) ? b1 : b0;
-                if (__builtin_amdgcn_ballot_w64(seen[u])) {   // some row of this wave revisits a node: exact counts
-                    const double sx = ract ? ud + ((double)w_f[u] - 100.0 * (double)l_cnt[u]) : -INFINITY;
-                    const int bx = row16_argmax_first(sx, idx);
-                    if (seen[u]) d = bx;
+            const size_t r = (base + node) * kA;
+            const LaneEval e = lane_prepare(c32v, m, r);
+            bool c0, c1, c2 = true;
+            const int b0 = lane_pick(e, 0, c0);
+            const int b1 = lane_pick(e, 1ull << (5 * b0), c1);
+            int d = (arr == b0) ? b1 : b0;
+            if (dup) {
+                if (arr >= 0) cnt5_add(cnt5, ovf, (u32)arr);
+                d = lane_pick(e, cnt5, c2);
+            }
+            if (c0 && c1 && c2 && !ovf) {
+                rec[node] = make_uint4((u32)m.nbr[r + b0], (u32)m.nbr[r + b1], (u32)b0 | ((u32)b1 << 8),   // the old path is line seq - 1
+                                       line_tag((seq - 1) & 0xFFFFu, k, k < nlev ? (u32)s_act[k] : kNoAct));
+                if (k < nlev && d != (int)s_act[k]) atomicMin(&s_first, k);
+            } else {
+                atomicOr(&s_unc[k >> 5], 1u << (k & 31));
+            }
+        }
+        __syncthreads();
+        // Pass B: the flagged levels in float64, NumPy's evaluation order, one 16-lane row per level.
+        for (int k0 = 0; k0 <= nlev; k0 += kBlock / 16) {
+            if (((s_unc[k0 >> 5] >> (k0 & 31)) & 0xFFFFu) == 0) continue;   // uniform over the workgroup
+            const int k = k0 + (int)row;
+            const bool live = k <= nlev && ((s_unc[k >> 5] >> (k & 31)) & 1u);
+            const int node = live ? s_node[k] : 0;
+            u32 cnt = (live && k > 0 && (u32)(s_act[k - 1] ^ 1) == rl) ? 1u : 0u;   // own arrival edge
+            bool dup = false;
+            int j = live ? s_head[sel_hash(node)] : -1;
+            while (j >= 0) {
+                if (j < k && s_node[j] == node) {
+                    dup = true;
+                    cnt += (u32)s_act[j] == rl;
+                    if (j > 0) cnt += (u32)(s_act[j - 1] ^ 1) == rl;
                 }
-                const u32 lane0 = (tid & 63u) & ~15u;
-                const int nb0 = __builtin_amdgcn_ds_bpermute((int)((lane0 + (u32)b0) << 2), nb[u]);
-                const int nb1 = __builtin_amdgcn_ds_bpermute((int)((lane0 + (u32)b1) << 2), nb[u]);
-                if (live && rl == 0) {
-                    rec[s_node[k]] = make_uint4((u32)nb0, (u32)nb1, (u32)b0 | ((u32)b1 << 8),   // the old path is line seq - 1
-                                                line_tag((seq - 1) & 0xFFFFu, k, k < nlev ? (u32)s_act[k] : kNoAct));
-                    if (k < nlev && d != (int)s_act[k]) atomicMin(&s_first, k);
-                }
+                const u32 nx = s_next[j];
+                j = nx == 0xFFFFu ? -1 : (int)nx;
+            }
+            const size_t r = (base + node) * kA + rla;
+            const int n_a = m.N[r], nb = m.nbr[r];
+            const float p_f = m.P[r], w_f = m.W[r];
+            const int sum_n = row16_sum(ract ? n_a : 0);
+            const double ud = ((c * (double)p_f) * sqrt((double)sum_n)) / (double)(1 + n_a);
+            const double s0 = ract ? ud + ((double)w_f - 100.0 * 0.0) : -INFINITY;
+            const int idx = ract ? (int)rl : 64;
+            const int b0 = row16_argmax_first(s0, idx);
+            const double s1 = ((int)rl == b0) ? ud + ((double)w_f - 100.0 * 1.0) : s0;
+            const int b1 = row16_argmax_first(s1, idx);
+            const double sx = ract ? ud + ((double)w_f - 100.0 * (double)cnt) : -INFINITY;
+            const int bx = row16_argmax_first(sx, idx);
+            const int d = dup ? bx : (live && k > 0 && (int)(s_act[live && k > 0 ? k - 1 : 0] ^ 1) == b0) ? b1 : b0;
+            const u32 lane0 = (tid & 63u) & ~15u;
+            const int nb0 = __builtin_amdgcn_ds_bpermute((int)((lane0 + (u32)b0) << 2), nb);
+            const int nb1 = __builtin_amdgcn_ds_bpermute((int)((lane0 + (u32)b1) << 2), nb);
+            if (live && rl == 0) {
+                rec[node] = make_uint4((u32)nb0, (u32)nb1, (u32)b0 | ((u32)b1 << 8),
+                                       line_tag((seq - 1) & 0xFFFFu, k, k < nlev ? (u32)s_act[k] : kNoAct));
+                if (k < nlev && d != (int)s_act[k]) atomicMin(&s_first, k);
             }
         }
         __syncthreads();
@@ -512,11 +588,13 @@ __global__ __launch_bounds__(kBlock) void k_mcts_select(rc_mcts_t m, double c, u
         s_head[h] = k;
         s_act[k] = (u8)arg;
         // Line following.  If this node lay on one of the tree's last ring_k descent paths and left it by the same
-        // action, the levels that followed it there are the likely continuation: up to 64 of them are validated at
-        // once, one lane per level -- the level's record gives its decision for the line's arrival edge, and it must
-        // be the line's action, lead to the line's next node, and the node must be new to this descent (no chain
-        // entry, no earlier lane of the segment in its bucket).  The leading run of valid levels is appended in one
-        // step: two memory round trips (line, records) instead of one per level.
+        // action, the levels that followed it there are the likely continuation: up to 64 of them are checked at
+        // once, one lane per level.  A level passes if its record's decision for the line's arrival edge is the
+        // line's action, it is the node the level above leads to, and the node is new to this descent (no chain
+        // entry, no earlier lane of the segment in its bucket).  Runs of passing levels are appended in one step; a
+        // level that only fails the "new to this descent" test is a revisit and gets the exact evaluation (one row
+        // load), after which the lanes behind it -- already loaded -- carry on.  Per segment of up to 64 levels that is
+        // two memory round trips (line, records) plus one per revisit, instead of one per level.
         const u32 tag = (u32)__builtin_amdgcn_readfirstlane((int)x.w);
         const u32 tseq = tag >> 16, age = (seq - tseq) & 0xFFFFu;
         int room = max_path - plen - 1;
@@ -524,7 +602,7 @@ __global__ __launch_bounds__(kBlock) void k_mcts_select(rc_mcts_t m, double c, u
         if (!visited && tseq != 0 && age >= 1 && age <= ring_k && (tag & 15u) == (u32)arg && room > 0) {
             const size_t line = ((size_t)t * ring_k + (tseq & (ring_k - 1))) * (size_t)max_path;
             const int llen = m.ring_len[(size_t)t * ring_k + (tseq & (ring_k - 1))];
-            const int li = (int)((tag >> 4) & 0xFFFu) + 1 + (int)lane;     // lane i validates level k + 1 + i
+            const int li = (int)((tag >> 4) & 0xFFFu) + 1 + (int)lane;     // lane i checks level k + 1 + i
             const bool in_line = li < llen && (int)lane < room;
             const int node_i = in_line ? m.ring_node[line + li] : 0;
             const u32 act_i = in_line ? (u32)m.ring_act[line + li] : kNoAct;
@@ -544,35 +622,78 @@ __global__ __launch_bounds__(kBlock) void k_mcts_select(rc_mcts_t m, double c, u
             const u32 hb = ((u32)node_i * 0x9E3779B1u) >> 24;
             if (in_line) atomicMin(&s_seg[hb], (int)lane);
             const int from = __shfl_up(nx_i, 1);
-            const bool first_in_bucket = s_seg[hb] >= (int)lane;
-            const bool ok = in_line && act_i != kNoAct && !(r.z & kRecLeaf) && !vis && first_in_bucket && d_i == act_i &&
-                            (lane == 0 ? next : from) == node_i;
-            const u64 okm = __ballot(ok);
-            const int q = ~okm ? __builtin_ctzll(~okm) : kWave;
+            const bool again = vis || s_seg[hb] < (int)lane;   // possibly seen before in this descent (conservative)
+            const bool inner = in_line && act_i != kNoAct && !(r.z & kRecLeaf);
+            const u64 inm = __ballot(in_line);
+            const u64 fastm = __ballot(inner && !again && d_i == act_i);
+            const u64 revm = __ballot(inner && again);
+            const u64 linkm = __ballot((lane == 0 ? next : from) == node_i);
             ++line_rounds;
-            if (q > 0) {
-                if ((int)lane < q) {
-                    const int kk = k + 1 + (int)lane;
-                    s_node[kk] = node_i;
-                    s_act[kk] = (u8)act_i;
+            int p = 0;                         // lanes 0 .. p - 1 are decided
+            u64 linkfix = 0;                   // lanes whose link was checked by hand (behind an exact step)
+            int new_cur = next, new_prev = arg;
+            for (;;) {
+                const u64 rest = ~((fastm & (linkm | linkfix)) >> p);
+                const int run = rest ? __builtin_ctzll(rest) : kWave;
+                if (run > 0) {
+                    if ((int)lane >= p && (int)lane < p + run) {
+                        const int kk = k + 1 + (int)lane;
+                        s_node[kk] = node_i;
+                        s_act[kk] = (u8)act_i;
+                        s_next[kk] = (u16)atomicExch(&s_head[sel_hash(node_i)], kk);
+                    }
+                    new_prev = (int)__builtin_amdgcn_readlane((int)act_i, p + run - 1);
+                    new_cur = __builtin_amdgcn_readlane(nx_i, p + run - 1);
+                    p += run;
                 }
-                if ((int)lane < q) s_next[k + 1 + lane] = (u16)atomicExch(&s_head[sel_hash(node_i)], k + 1 + (int)lane);
-                cur = __builtin_amdgcn_readlane(nx_i, q - 1);
-                prev_act = (int)__builtin_amdgcn_readlane((int)act_i, q - 1);
-                const bool have = q < kWave && ((__ballot(in_line && node_i == cur) >> q) & 1ull);
+                if (p >= kWave || !((inm >> p) & 1ull)) break;                 // segment or line exhausted
+                if (!((((linkm | linkfix) & revm) >> p) & 1ull)) break;       // another decision, a leaf, or off the line
+                // lane p: a node this descent has (probably) been at before -- exact decision with its loss counts
+                const int kk = k + 1 + p;
+                const int node_p = __builtin_amdgcn_readlane(node_i, p);
+                u32 cnt_p = ((u32)(new_prev ^ 1) == lane) ? 1u : 0u;
+                const u32 hp = sel_hash(node_p);
+                const int head_p = s_head[hp];
+                for (int j = head_p; j >= 0;) {
+                    if (s_node[j] == node_p) {
+                        cnt_p += (u32)s_act[j] == lane;
+                        if (j > 0) cnt_p += (u32)(s_act[j - 1] ^ 1) == lane;
+                    }
+                    const u32 nx = s_next[j];
+                    j = nx == 0xFFFFu ? -1 : (int)nx;
+                }
+                const NodeRows rr = load_rows(tb, node_p, la);
+                const int a_p = puct_argmax_walk(c, c32, rr.n_a, rr.p_f, rr.w_f, cnt_p, act, (int)lane, slow_levels);
+                const int nxt = __builtin_amdgcn_readlane(rr.nb, a_p);
+                ++revisits;
+                s_node[kk] = node_p;
+                s_act[kk] = (u8)a_p;
+                s_next[kk] = (u16)head_p;
+                s_head[hp] = kk;
+                new_prev = a_p;
+                new_cur = nxt;
+                const int line_act = (int)__builtin_amdgcn_readlane((int)act_i, p);
+                ++p;
+                if (a_p != line_act || p >= kWave || !((inm >> p) & 1ull) || __builtin_amdgcn_readlane(node_i, p & 63) != nxt) break;
+                linkfix |= 1ull << p;
+            }
+            if (p > 0) {
+                cur = new_cur;
+                prev_act = new_prev;
+                const bool have = p < kWave && ((__ballot(in_line && node_i == cur) >> p) & 1ull);
                 if (have) {
-                    x.x = (u32)__builtin_amdgcn_readlane((int)r.x, q & 63);
-                    x.y = (u32)__builtin_amdgcn_readlane((int)r.y, q & 63);
-                    x.z = (u32)__builtin_amdgcn_readlane((int)r.z, q & 63);
-                    x.w = (u32)__builtin_amdgcn_readlane((int)r.w, q & 63);
+                    x.x = (u32)__builtin_amdgcn_readlane((int)r.x, p & 63);
+                    x.y = (u32)__builtin_amdgcn_readlane((int)r.y, p & 63);
+                    x.z = (u32)__builtin_amdgcn_readlane((int)r.z, p & 63);
+                    x.w = (u32)__builtin_amdgcn_readlane((int)r.w, p & 63);
                 } else {
                     x = load_rec(tb, cur);
                 }
                 h = sel_hash(cur);
                 head = s_head[h];
-                plen += 1 + q;
-                walked += (u32)q;
-                line_levels += q;
+                plen += 1 + p;
+                walked += (u32)p;
+                line_levels += p;
                 continue;
             }
         }

@@ -40,4 +40,5 @@ for it in range(1, 4400):
               f"p90 {np.percentile(tail, 90):.0f} max {tail.max()} | step {dt * 1e3:.3f} ms | slowest tree: plen {plen[w]} "
               f"validate {st[run, 2][w] / 100:.0f} us, walk {st[run, 3][w] / 100:.0f} us for {tail[w]} levels, "
               f"{st[run, 4][w] / max(tail[w], 1):.0f} cycles/level at {st[run, 4][w] / max(st[run, 3][w], 1) / 10:.2f} GHz, "
-              f"{st[run, 5][w]} float64 fallbacks, {st[run, 6][w]} revisited levels", flush=True)
+              f"{st[run, 5][w]} float64 fallbacks, {st[run, 6][w]} revisited levels, "
+              f"{st[run, 7][w] >> 16} line rounds appended {st[run, 7][w] & 0xFFFF} levels", flush=True)
