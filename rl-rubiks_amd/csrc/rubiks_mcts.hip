@@ -411,8 +411,8 @@ __global__ __launch_bounds__(kBlock) void k_mcts_select(rc_mcts_t m, double c, u
     __shared__ u8 s_act[kMaxPath];
     __shared__ int s_head[kSelHash];        // chains of path levels by node (earlier visits of a state)
     __shared__ u16 s_next[kMaxPath];
-    __shared__ int s_seg[256];              // line following: smallest lane per node bucket of a candidate segment
     __shared__ u32 s_unc[kMaxPath / 32];    // re-validation: levels float32 could not settle
+    __shared__ int s_seg[256];              // line following: lanes per node bucket of a candidate segment
     const u32 t = blockIdx.x, tid = threadIdx.x;
     if (m.status[t] != RC_MCTS_RUNNING) return;
     const unsigned long long t_begin = wall_clock64();
@@ -589,12 +589,12 @@ __global__ __launch_bounds__(kBlock) void k_mcts_select(rc_mcts_t m, double c, u
         s_act[k] = (u8)arg;
         // Line following.  If this node lay on one of the tree's last ring_k descent paths and left it by the same
         // action, the levels that followed it there are the likely continuation: up to 64 of them are checked at
-        // once, one lane per level.  A level passes if its record's decision for the line's arrival edge is the
-        // line's action, it is the node the level above leads to, and the node is new to this descent (no chain
-        // entry, no earlier lane of the segment in its bucket).  Runs of passing levels are appended in one step; a
-        // level that only fails the "new to this descent" test is a revisit and gets the exact evaluation (one row
-        // load), after which the lanes behind it -- already loaded -- carry on.  Per segment of up to 64 levels that is
-        // two memory round trips (line, records) plus one per revisit, instead of one per level.
+        // once, one lane per level, under the premise that the levels above in the segment follow the line too.  A
+        // level passes if its decision for the line's arrival edge is the line's action and it is the node the level
+        // above leads to.  The decision comes from the node's record if the node is new to this descent, else from a
+        // float32 evaluation of its rows in the lane (lane_pick) with the exact loss counts: earlier visits in the
+        // chains plus earlier lanes of the segment at the same node.  The leading run of passing levels is appended
+        // in one step: two or three memory round trips per segment instead of one per level.
         const u32 tag = (u32)__builtin_amdgcn_readfirstlane((int)x.w);
         const u32 tseq = tag >> 16, age = (seq - tseq) & 0xFFFFu;
         int room = max_path - plen - 1;
@@ -608,92 +608,81 @@ __global__ __launch_bounds__(kBlock) void k_mcts_select(rc_mcts_t m, double c, u
             const u32 act_i = in_line ? (u32)m.ring_act[line + li] : kNoAct;
             const u32 arr_i = (lane == 0 || !in_line) ? (u32)arg : (u32)m.ring_act[line + li - 1];
             const u32x4 r = load_rec(tb, node_i);
-            for (int i = lane; i < 256; i += kWave) s_seg[i] = kWave;
+            const bool inner = in_line && act_i != kNoAct;
+            const int nl_i = inner ? m.nbr[(base + node_i) * kA + act_i] : 0;   // where the line's action leads
             const u32 rb0 = r.z & 15u, rb1 = (r.z >> 8) & 15u;
-            const bool rback = (arr_i ^ 1u) == rb0;
-            const u32 d_i = rback ? rb1 : rb0;
-            const int nx_i = (int)(rback ? r.y : r.x);
-            bool vis = false;
+            u32 d_i = (arr_i ^ 1u) == rb0 ? rb1 : rb0;
+            // earlier visits of the lane's node: in the chains (levels <= k) ...
+            u64 cnt5 = 0;
+            bool again = false, unsure = false;
             for (int j = in_line ? s_head[sel_hash(node_i)] : -1; j >= 0;) {
-                vis |= s_node[j] == node_i;
+                if (s_node[j] == node_i) {
+                    again = true;
+                    cnt5_add(cnt5, unsure, (u32)s_act[j]);
+                    if (j > 0) cnt5_add(cnt5, unsure, (u32)(s_act[j - 1] ^ 1));
+                }
                 const u32 nx = s_next[j];
                 j = nx == 0xFFFFu ? -1 : (int)nx;
             }
+            // ... and among the lanes above (they follow the line by premise: departure act_j, arrival rev(arr_j)).  Only
+            // lanes that share a node bucket with another lane can have a partner: usually a handful of the 64.
+            const LaneEval e = lane_prepare(c32, m, (base + node_i) * kA);   // requested with the records: one round trip
+            for (int i = lane; i < 256; i += kWave) s_seg[i] = 0;
             const u32 hb = ((u32)node_i * 0x9E3779B1u) >> 24;
-            if (in_line) atomicMin(&s_seg[hb], (int)lane);
-            const int from = __shfl_up(nx_i, 1);
-            const bool again = vis || s_seg[hb] < (int)lane;   // possibly seen before in this descent (conservative)
-            const bool inner = in_line && act_i != kNoAct && !(r.z & kRecLeaf);
-            const u64 inm = __ballot(in_line);
-            const u64 fastm = __ballot(inner && !again && d_i == act_i);
-            const u64 revm = __ballot(inner && again);
-            const u64 linkm = __ballot((lane == 0 ? next : from) == node_i);
-            ++line_rounds;
-            int p = 0;                         // lanes 0 .. p - 1 are decided
-            u64 linkfix = 0;                   // lanes whose link was checked by hand (behind an exact step)
-            int new_cur = next, new_prev = arg;
-            for (;;) {
-                const u64 rest = ~((fastm & (linkm | linkfix)) >> p);
-                const int run = rest ? __builtin_ctzll(rest) : kWave;
-                if (run > 0) {
-                    if ((int)lane >= p && (int)lane < p + run) {
-                        const int kk = k + 1 + (int)lane;
-                        s_node[kk] = node_i;
-                        s_act[kk] = (u8)act_i;
-                        s_next[kk] = (u16)atomicExch(&s_head[sel_hash(node_i)], kk);
+            if (in_line) atomicAdd(&s_seg[hb], 1);
+            u64 crowd = __ballot(in_line && s_seg[hb] > 1);
+            while (crowd) {
+                const int j = __builtin_ctzll(crowd);
+                crowd &= crowd - 1;
+                const int nj = __builtin_amdgcn_readlane(node_i, j);
+                const u64 hit = __ballot(in_line && nj == node_i) & ~((2ull << j) - 1ull);
+                if (hit) {   // wave-uniform, rare
+                    const u32 aj = (u32)__builtin_amdgcn_readlane((int)act_i, j), rj = (u32)__builtin_amdgcn_readlane((int)arr_i, j) ^ 1u;
+                    if ((hit >> lane) & 1ull) {
+                        again = true;
+                        if (aj != kNoAct) cnt5_add(cnt5, unsure, aj);
+                        cnt5_add(cnt5, unsure, rj);
                     }
-                    new_prev = (int)__builtin_amdgcn_readlane((int)act_i, p + run - 1);
-                    new_cur = __builtin_amdgcn_readlane(nx_i, p + run - 1);
-                    p += run;
                 }
-                if (p >= kWave || !((inm >> p) & 1ull)) break;                 // segment or line exhausted
-                if (!((((linkm | linkfix) & revm) >> p) & 1ull)) break;       // another decision, a leaf, or off the line
-                // lane p: a node this descent has (probably) been at before -- exact decision with its loss counts
-                const int kk = k + 1 + p;
-                const int node_p = __builtin_amdgcn_readlane(node_i, p);
-                u32 cnt_p = ((u32)(new_prev ^ 1) == lane) ? 1u : 0u;
-                const u32 hp = sel_hash(node_p);
-                const int head_p = s_head[hp];
-                for (int j = head_p; j >= 0;) {
-                    if (s_node[j] == node_p) {
-                        cnt_p += (u32)s_act[j] == lane;
-                        if (j > 0) cnt_p += (u32)(s_act[j - 1] ^ 1) == lane;
-                    }
-                    const u32 nx = s_next[j];
-                    j = nx == 0xFFFFu ? -1 : (int)nx;
-                }
-                const NodeRows rr = load_rows(tb, node_p, la);
-                const int a_p = puct_argmax_walk(c, c32, rr.n_a, rr.p_f, rr.w_f, cnt_p, act, (int)lane, slow_levels);
-                const int nxt = __builtin_amdgcn_readlane(rr.nb, a_p);
-                ++revisits;
-                s_node[kk] = node_p;
-                s_act[kk] = (u8)a_p;
-                s_next[kk] = (u16)head_p;
-                s_head[hp] = kk;
-                new_prev = a_p;
-                new_cur = nxt;
-                const int line_act = (int)__builtin_amdgcn_readlane((int)act_i, p);
-                ++p;
-                if (a_p != line_act || p >= kWave || !((inm >> p) & 1ull) || __builtin_amdgcn_readlane(node_i, p & 63) != nxt) break;
-                linkfix |= 1ull << p;
             }
-            if (p > 0) {
-                cur = new_cur;
-                prev_act = new_prev;
-                const bool have = p < kWave && ((__ballot(in_line && node_i == cur) >> p) & 1ull);
+            if (__ballot(inner && again)) {   // some level revisits a node: its decision from its rows, in the lane
+                cnt5_add(cnt5, unsure, arr_i ^ 1u);   // own arrival edge
+                bool sure;
+                const u32 dx = (u32)lane_pick(e, cnt5, sure);
+                if (again) {
+                    d_i = dx;
+                    unsure |= !sure;
+                }
+            }
+            const int from = __shfl_up(nl_i, 1);
+            const bool ok = inner && !(r.z & kRecLeaf) && !(again && unsure) && d_i == act_i && (lane == 0 ? next : from) == node_i;
+            const u64 okm = __ballot(ok);
+            const int q = ~okm ? __builtin_ctzll(~okm) : kWave;
+            ++line_rounds;
+            revisits += __popcll(__ballot(again) & ((q < kWave ? (1ull << q) : 0ull) - 1ull));
+            if (q > 0) {
+                if ((int)lane < q) {
+                    const int kk = k + 1 + (int)lane;
+                    s_node[kk] = node_i;
+                    s_act[kk] = (u8)act_i;
+                    s_next[kk] = (u16)atomicExch(&s_head[sel_hash(node_i)], kk);
+                }
+                cur = __builtin_amdgcn_readlane(nl_i, q - 1);
+                prev_act = (int)__builtin_amdgcn_readlane((int)act_i, q - 1);
+                const bool have = q < kWave && ((__ballot(in_line && node_i == cur) >> q) & 1ull);
                 if (have) {
-                    x.x = (u32)__builtin_amdgcn_readlane((int)r.x, p & 63);
-                    x.y = (u32)__builtin_amdgcn_readlane((int)r.y, p & 63);
-                    x.z = (u32)__builtin_amdgcn_readlane((int)r.z, p & 63);
-                    x.w = (u32)__builtin_amdgcn_readlane((int)r.w, p & 63);
+                    x.x = (u32)__builtin_amdgcn_readlane((int)r.x, q & 63);
+                    x.y = (u32)__builtin_amdgcn_readlane((int)r.y, q & 63);
+                    x.z = (u32)__builtin_amdgcn_readlane((int)r.z, q & 63);
+                    x.w = (u32)__builtin_amdgcn_readlane((int)r.w, q & 63);
                 } else {
                     x = load_rec(tb, cur);
                 }
                 h = sel_hash(cur);
                 head = s_head[h];
-                plen += 1 + p;
-                walked += (u32)p;
-                line_levels += p;
+                plen += 1 + q;
+                walked += (u32)q;
+                line_levels += q;
                 continue;
             }
         }

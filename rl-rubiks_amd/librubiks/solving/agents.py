@@ -251,7 +251,8 @@ class MCTS(DeepAgent):
     """Batched PUCT graph search with virtual loss and max-backup (reference agents.py:415-645)."""
 
     nu = 100
-    refill_level_budget = 64   # see search_batch(slots=...)
+    refill_level_budget = 0    # new levels per descent and iteration while scrambles wait for a slot (0 = no limit)
+    compact_min = 32           # smallest forest that is still compacted when half of its trees have finished
 
     def __init__(self, net, c: float, search_graph: bool, net_dtype=torch.bfloat16, use_graph: bool = True,
                  max_path: int = 4096, sync_every: int = 16, level_budget="auto"):
@@ -307,9 +308,9 @@ class MCTS(DeepAgent):
         slots: run at most this many trees at a time and give the places of finished trees to the scrambles
         still waiting (continuous batching): the GPU stays full until the last games instead of idling on the
         stragglers of every batch.  Per-game results are those of a plain batch (trees are independent).
-        compact: once nobody is waiting and at most half of the trees of a forest of 256 or more are still
-        running, the finished ones are harvested and the forest is compacted to the running trees, so the
-        stragglers continue on small batches instead of paying full-size network calls.
+        compact: once nobody is waiting and at most half of the trees of a forest (of `compact_min` trees or more)
+        are still running, the finished ones are harvested and the forest is compacted to the running trees, so
+        the stragglers continue on small batches instead of paying full-size network calls.
         """
         run = self.start_batch(states, time_limit, max_states, compact=compact, slots=slots)
         assert max_iterations is None or run.S == run.n_games, "max_iterations applies to lock-step batches only"
@@ -361,9 +362,9 @@ class MCTSRun:
     copy into pinned memory) while the GPU works on the current one, so the launch queue never runs dry.
     Finished trees are copied out of the forest (`subset`) and turned into results on a side stream; with
     `slots` < games their places go to the scrambles still waiting, which make their root iteration in a small
-    forest of their own and are then adopted.  While games are waiting, descents are cut at the agent's
-    `refill_level_budget` new levels per iteration, so that the few very deep descents of old trees do not pace
-    the full batch (the budget is lifted for the tail).
+    forest of their own and are then adopted.  While games are waiting, descents may be cut at the agent's
+    `refill_level_budget` new levels per iteration (0 = off, the default since descents follow lines: a budget
+    then costs more iterations than it saves time per iteration).
     """
 
     def __init__(self, agent: "MCTS", roots: DeviceCubes, time_limit: float, max_states: int, compact: bool, slots):
@@ -467,7 +468,7 @@ class MCTSRun:
             del small
             if self.next_game >= self.n_games:
                 forest.level_budget = self.base_budget   # nobody is waiting any more: strict lock step for the tail
-        elif not waiting and self.compact and forest.B >= 256 and n_run <= forest.B // 2:
+        elif not waiting and self.compact and forest.B >= self.agent.compact_min and n_run <= forest.B // 2:
             if len(done):
                 self._harvest(done)
                 owner[done] = -1

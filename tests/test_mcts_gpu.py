@@ -67,7 +67,7 @@ def test_batch_vs_oracle(net_gpu):
     max_states = 700
     for c, graph in ((0.6, True), (4.13, False)):
         agent = MCTS(net_gpu, c=c, search_graph=graph, net_dtype=torch.float32)
-        res = agent.search_batch(states, None, max_states)
+        res = agent.search_batch(states, None, max_states, compact=False)   # the trees stay in agent.forest for inspection
         onet = oa.TorchNet(net_gpu, device="cuda")
         n_solved = 0
         for t, s in enumerate(states):
@@ -98,7 +98,7 @@ def test_level_budget_does_not_change_trees(budget, net_gpu):
     np.random.seed(11)
     states = np.array([oc.scramble(2 + i % 9, True)[0] for i in range(72)])
     agent = MCTS(net_gpu, c=4.13, search_graph=True, net_dtype=torch.float32, level_budget=budget)
-    res = agent.search_batch(states, None, 900)
+    res = agent.search_batch(states, None, 900, compact=False)
     assert agent.forest.level_budget == budget
     onet = oa.TorchNet(net_gpu, device="cuda")
     for t, s in enumerate(states):
