@@ -174,73 +174,76 @@ __device__ __forceinline__ float head_elem(const void *head, size_t i, bool bf16
 // HEAD = true : `probs` is the head GEMM's output (12 logits + value per row, bf16 or float) and the softmax
 //               happens here.
 template <bool HEAD>
-__global__ __launch_bounds__(kWave) void k_mcts_backup(rc_mcts_t m, const void *__restrict__ probs_or_head,
+__global__ __launch_bounds__(kBlock) void k_mcts_backup(rc_mcts_t m, const void *__restrict__ probs_or_head,
                                                       const float *__restrict__ values, size_t ld, bool head_bf16) {
+    __shared__ float s_best;
     const float *probs = reinterpret_cast<const float *>(probs_or_head);
-    const u32 t = blockIdx.x, lane = threadIdx.x;
+    const u32 t = blockIdx.x, tid = threadIdx.x, lane = tid & (kWave - 1);
     if (!m.expanded[t]) return;
     const size_t base = (size_t)t * (m.capacity + 1);
     const int plen = m.path_len[t];
     const int *pnode = m.path_node + (size_t)t * m.max_path;
     const u8 *pact = m.path_act + (size_t)t * m.max_path;
     const int leaf = pnode[plen - 1];
-    const bool act = lane < kA;
-    const u32 newm = m.new_mask[t];
-    const bool is_new = act && ((newm >> lane) & 1u);
-    const int idx = act ? m.child_idx[(size_t)t * kA + lane] : 0;
-    // this child's row in the network output: 12 t + k, or 11 t + (rank among the new children) with packed rows
-    const size_t row = (size_t)t * m.rows_per_tree +
-                       (m.rows_per_tree == (u32)kA ? lane : (u32)__popc(newm & ((1u << lane) - 1u)));
+    if (tid < kWave) {   // the twelve children: lanes 0..11 of the first wave
+        const bool act = lane < kA;
+        const u32 newm = m.new_mask[t];
+        const bool is_new = act && ((newm >> lane) & 1u);
+        const int idx = act ? m.child_idx[(size_t)t * kA + lane] : 0;
+        // this child's row in the network output: 12 t + k, or 11 t + (rank among the new children) with packed rows
+        const size_t row = (size_t)t * m.rows_per_tree +
+                           (m.rows_per_tree == (u32)kA ? lane : (u32)__popc(newm & ((1u << lane) - 1u)));
 
-    float v = 0.f;
-    if (is_new) {
-        float p[kA];
-        if (HEAD) {
-            float mx = -INFINITY, sum = 0.f;
-#pragma unroll
-            for (int a = 0; a < kA; ++a) { p[a] = head_elem(probs_or_head, row * ld + a, head_bf16); mx = fmaxf(mx, p[a]); }
-#pragma unroll
-            for (int a = 0; a < kA; ++a) { p[a] = expf(p[a] - mx); sum += p[a]; }
-#pragma unroll
-            for (int a = 0; a < kA; ++a) p[a] /= sum;   // agents.py:552 softmax(dim=1)
-            v = head_elem(probs_or_head, row * ld + kA, head_bf16);
-        } else {
-#pragma unroll
-            for (int a = 0; a < kA; ++a) p[a] = probs[row * kA + a];
-            v = values[row];
+        float v = 0.f;
+        if (is_new) {
+            float p[kA];
+            if (HEAD) {
+                float mx = -INFINITY, sum = 0.f;
+    #pragma unroll
+                for (int a = 0; a < kA; ++a) { p[a] = head_elem(probs_or_head, row * ld + a, head_bf16); mx = fmaxf(mx, p[a]); }
+    #pragma unroll
+                for (int a = 0; a < kA; ++a) { p[a] = expf(p[a] - mx); sum += p[a]; }
+    #pragma unroll
+                for (int a = 0; a < kA; ++a) p[a] /= sum;   // agents.py:552 softmax(dim=1)
+                v = head_elem(probs_or_head, row * ld + kA, head_bf16);
+            } else {
+    #pragma unroll
+                for (int a = 0; a < kA; ++a) p[a] = probs[row * kA + a];
+                v = values[row];
+            }
+            m.V[base + idx] = v;
+    #pragma unroll
+            for (int a = 0; a < kA; ++a) {
+                m.P[(base + idx) * kA + a] = p[a];
+                m.W[(base + idx) * kA + a] = v;   // W[new] = v for all 12 actions (agents.py:561)
+            }
+        } else if (act) {
+            v = m.V[base + idx];
         }
-        m.V[base + idx] = v;
-#pragma unroll
-        for (int a = 0; a < kA; ++a) {
-            m.P[(base + idx) * kA + a] = p[a];
-            m.W[(base + idx) * kA + a] = v;   // W[new] = v for all 12 actions (agents.py:561)
-        }
-    } else if (act) {
-        v = m.V[base + idx];
+        // best value among the new children (agents.py:559); with no new child the reference raises --
+        // defined here as the best existing neighbour value (oracle/agents.py docstring)
+        const float best = newm ? wave_max12(v, is_new) : wave_max12(v, act);
+        if (act) m.W[(base + leaf) * kA + lane] = v;   // W[leaf] = V[neighbors[leaf]] (agents.py:560)
+        if (lane == 0) s_best = best;
+
     }
-    // best value among the new children (agents.py:559); with no new child the reference raises --
-    // defined here as the best existing neighbour value (oracle/agents.py docstring)
-    const float best = newm ? wave_max12(v, is_new) : wave_max12(v, act);
-    if (act) m.W[(base + leaf) * kA + lane] = v;   // W[leaf] = V[neighbors[leaf]] (agents.py:560)
-
     // path updates.  NumPy's buffered `N[rows, cols] += 1` counts a (node, action) pair that occurs
     // twice on the path only once; a mark bit reproduces that for any path length: first every
     // path edge is marked, then whoever finds the mark replaces it by old + 1.
     const int edges = plen - 1;
     constexpr int kMark = 1 << 30;
-    for (int i = lane; i < edges; i += kWave) m.N[(base + pnode[i]) * kA + pact[i]] |= kMark;
-    wave_store_fence();
-    for (int i0 = 0; i0 < edges; i0 += kWave) {
-        const int i = i0 + lane;
-        if (i < edges) {
-            const size_t e = (base + pnode[i]) * kA + pact[i];
-            const int nv = m.N[e];
-            if (nv & kMark) m.N[e] = (nv & ~kMark) + 1;            // agents.py:568
-            m.W[e] = fmaxf(m.W[e], best);                           // agents.py:562
-            m.L[e] = 0;                                             // agents.py:569
-            m.L[(base + pnode[i + 1]) * kA + (pact[i] ^ 1)] = 0;    // agents.py:570
-        }
-        if (i0 + kWave < edges) wave_store_fence();
+    // All four waves share the path.  Two threads that hold the same (node, action) pair write the same values,
+    // whichever of them runs first, so no ordering is needed inside a pass.
+    for (int i = tid; i < edges; i += kBlock) m.N[(base + pnode[i]) * kA + pact[i]] |= kMark;
+    __syncthreads();
+    const float best = s_best;
+    for (int i = tid; i < edges; i += kBlock) {
+        const size_t e = (base + pnode[i]) * kA + pact[i];
+        const int nv = m.N[e];
+        if (nv & kMark) m.N[e] = (nv & ~kMark) + 1;            // agents.py:568
+        m.W[e] = fmaxf(m.W[e], best);                           // agents.py:562
+        m.L[e] = 0;                                             // agents.py:569
+        m.L[(base + pnode[i + 1]) * kA + (pact[i] ^ 1)] = 0;    // agents.py:570
     }
 }
 
@@ -911,7 +914,7 @@ int rc_mcts_expand(const rc_mcts_t *m, uint32_t max_states, rc_stream_t stream) 
 int rc_mcts_backup(const rc_mcts_t *m, const float *probs, const float *values, rc_stream_t stream) {
     if (int rc = check_mcts(m)) return rc;
     RC_REQUIRE(probs && values, RC_ERR_NULL);
-    hipLaunchKernelGGL(k_mcts_backup<false>, dim3(m->n_trees), dim3(kWave), 0, (hipStream_t)stream, *m, (const void *)probs,
+    hipLaunchKernelGGL(k_mcts_backup<false>, dim3(m->n_trees), dim3(kBlock), 0, (hipStream_t)stream, *m, (const void *)probs,
                        values, (size_t)0, false);
     return launch_status();
 }
@@ -920,7 +923,7 @@ int rc_mcts_backup_head(const rc_mcts_t *m, const void *head, size_t ld, int hea
     if (int rc = check_mcts(m)) return rc;
     RC_REQUIRE(head != nullptr, RC_ERR_NULL);
     RC_REQUIRE(ld >= (size_t)kActions + 1, RC_ERR_RANGE);
-    hipLaunchKernelGGL(k_mcts_backup<true>, dim3(m->n_trees), dim3(kWave), 0, (hipStream_t)stream, *m, head,
+    hipLaunchKernelGGL(k_mcts_backup<true>, dim3(m->n_trees), dim3(kBlock), 0, (hipStream_t)stream, *m, head,
                        (const float *)nullptr, ld, head_is_bf16 != 0);
     return launch_status();
 }
