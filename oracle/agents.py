@@ -16,11 +16,14 @@ Pinned by tests/golden/agents_golden.npz: traces (node count, action queue, neig
 counts, values, A* G/parents) recorded from the imported reference agents driven by a small
 deterministic network (tests/golden/make_golden_agents.py).
 
-Two places define behaviour where the reference raises / hangs (both unreachable in the golden traces):
+Three places define behaviour where the reference raises / hangs / is unbounded (all unreachable in the golden traces):
   * MCTS: a leaf whose 12 children are all known already -> reference raises ValueError on
     `v.max()` of an empty array (agents.py:559); here the best child value falls back to the max
     over the existing neighbours' V.
   * A*: empty open list -> reference would spin forever; here the search stops and returns False.
+  * MCTS: `max_path` (optional) bounds the number of nodes on a PUCT descent path; a descent that reaches it before
+    a leaf ends the search as unsolved with the actions taken so far as the queue (the reference's descent is
+    unbounded; the device kernels stage the path in LDS and stop at 4 096 nodes, RC_MCTS_PATH_OVERFLOW).
 """
 import heapq
 from collections import deque
@@ -145,8 +148,9 @@ class MCTS:
         self.L = np.concatenate([self.L, np.zeros((n, N_ACT))])
 
     # ---- search loop (agents.py:461-494) ---------------------------------------------------------
-    def search(self, state: np.ndarray, max_states: int, max_iterations: int = None) -> bool:
+    def search(self, state: np.ndarray, max_states: int, max_iterations: int = None, max_path: int = None) -> bool:
         self._reset()
+        self.max_path, self.path_overflow = max_path, False
         self.indices[state.tobytes()] = 1
         self.states[1] = state
         if cube.is_solved(state):
@@ -165,6 +169,8 @@ class MCTS:
                     self._shorten_action_queue(solved_idx)
                 return True
             path, actions = self._find_leaf()
+            if self.path_overflow:
+                break
         self.action_queue = deque(actions)   # best guess when the budget runs out (agents.py:492)
         return False
 
@@ -222,6 +228,9 @@ class MCTS:
         cur = 1
         path, actions = [cur], []
         while not self.leaves[cur]:
+            if getattr(self, "max_path", None) and len(path) >= self.max_path:
+                self.path_overflow = True
+                break
             sqrt_n = np.sqrt(self.N[cur].sum())
             u = self.c * self.P[cur] * sqrt_n / (1 + self.N[cur])
             q = self.W[cur] - self.L[cur]
@@ -300,6 +309,7 @@ class AStar:
     # agents.py:221-252
     def search(self, state: np.ndarray, max_states: int, max_iterations: int = None) -> bool:
         self._reset()
+        self.open_empty = False
         if cube.is_solved(state):
             return True
         self.indices[state.tobytes()] = 1
@@ -307,11 +317,17 @@ class AStar:
         self.G[1] = 0
         heapq.heappush(self.open_queue, (0, 1))
         self.iterations = 0
-        while len(self) + self.expansions * N_ACT <= max_states and \
-                (max_iterations is None or self.iterations < max_iterations):
+        return self.resume(max_states, max_iterations)
+
+    def resume(self, max_states: int, max_iterations: int = None) -> bool:
+        """The search loop, from wherever the open list stands (tests call it again after `search(max_iterations=k)`)."""
+        done = 0
+        while len(self) + self.expansions * N_ACT <= max_states and (max_iterations is None or done < max_iterations):
             self.iterations += 1
+            done += 1
             n_pop = min(len(self.open_queue), self.expansions)
             if n_pop == 0:
+                self.open_empty = True
                 return False   # defined here; the reference would spin (module docstring)
             batch = np.array([heapq.heappop(self.open_queue)[1] for _ in range(n_pop)], dtype=int)
             if self._expand_batch(batch):

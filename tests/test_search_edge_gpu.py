@@ -1,0 +1,284 @@
+"""
+GPU parity tests for the behaviours this build DEFINES where the reference raises, hangs or is unbounded
+(DESIGN.md section 4), HIP path vs the oracle's identical definition, plus an exact-tree test of the
+production bf16 path.
+
+1. MCTS leaf whose 12 children are all in the tree already (reference: ValueError on v.max() of an empty array,
+   librubiks/solving/agents.py:548-559): best value = max V over the existing neighbours.  Unreachable in small
+   natural searches (the cube graph has no short cycles besides a a' and commuting faces), so the situation is
+   planted into BOTH trees: the unseen children of the current leaf are appended as leaf nodes.
+2. A PUCT descent longer than max_path: tree ends unsolved, RC_MCTS_PATH_OVERFLOW (reference: unbounded loop).
+3. A* whose open list runs dry (reference: spins in agents.py:236-239): ends unsolved, RC_ASTAR_OPEN_EMPTY.
+4. Searches bounded by time only cap every tree at DEFAULT_NODE_CAP nodes (reference: grows without bound,
+   agents.py:450-459).
+5. Production dtype: the trees the bf16 engine builds (packed 11 rows, fused input layer / head / backup, graph
+   replay, line following) equal node-for-node what the oracle builds from the SAME network outputs, replayed
+   through a table-lookup net recorded from the device trees.
+"""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from oracle import agents as oa  # noqa: E402  (checker only)
+from oracle import cube as oc  # noqa: E402
+
+_M32 = 0xFFFFFFFF
+
+
+def _pack_key(state: np.ndarray) -> np.ndarray:
+    """int8[20] -> uint32[4]: 20 codes of 5 bits, 6 per dword (csrc/rubiks_common.h key_set)."""
+    k = [0, 0, 0, 0]
+    for j, code in enumerate(state):
+        k[j // 6] |= (int(code) & 31) << (5 * (j % 6))
+    return np.array(k, dtype=np.uint32)
+
+
+def _key_hash(k) -> int:
+    """csrc/rubiks_common.h key_hash."""
+    h = (int(k[0]) * 0x9E3779B1) & _M32
+    h ^= h >> 15
+    h = (h + int(k[1]) * 0x85EBCA77) & _M32
+    h ^= h >> 13
+    h = (h + int(k[2]) * 0xC2B2AE3D) & _M32
+    h ^= h >> 16
+    h = (h + int(k[3]) * 0x27D4EB2F) & _M32
+    h ^= h >> 15
+    h = (h * 0x165667B1) & _M32
+    h ^= h >> 16
+    return h
+
+
+def _compare(tree: dict, ref, n: int):
+    assert tree["n"] == n == len(ref)
+    assert np.array_equal(tree["states"][1:n + 1], ref.states[1:n + 1])
+    assert np.array_equal(tree["neighbors"][:n + 1], ref.neighbors[:n + 1])
+    assert np.array_equal(tree["leaves"][1:n + 1], ref.leaves[1:n + 1])
+    assert np.array_equal(tree["N"][:n + 1], ref.N[:n + 1])
+    assert np.array_equal(tree["L"][:n + 1], ref.L[:n + 1])
+    assert np.array_equal(tree["V"][1:n + 1], ref.V[1:n + 1].astype(np.float64))
+    assert np.array_equal(tree["P"][1:n + 1], ref.P[1:n + 1].astype(np.float64))
+    expanded = ~ref.leaves[1:n + 1]   # W of a never-expanded node is v everywhere on both sides; compare all rows
+    assert np.array_equal(tree["W"][1:n + 1], ref.W[1:n + 1]) and expanded.any()
+
+
+@pytest.fixture(scope="module")
+def net_gpu(standin_net):
+    return standin_net.cuda()
+
+
+def test_leaf_with_all_children_known(net_gpu):
+    from librubiks.cube import DeviceCubes
+    from librubiks.model import GenericNet
+    from librubiks.solving.mcts_device import MCTSForest
+    B, C, c, warm = 6, 400, 0.6, 7
+    np.random.seed(21)
+    states = np.array([oc.scramble(15 + i, True)[0] for i in range(B)])
+    onet = oa.TorchNet(net_gpu, device="cuda")
+    forest = MCTSForest(B, C)
+    forest.set_net(GenericNet(net_gpu), torch.float32)
+    forest.reset(DeviceCubes.from_numpy(states))
+    for _ in range(warm):
+        forest.step(c, C, use_graph=False)
+    torch.cuda.synchronize()
+    refs, paths = [], []
+    for t in range(B):
+        ref = oa.MCTS(onet, c=c, search_graph=False)
+        assert not ref.search(states[t], C, max_iterations=warm)
+        actions = list(ref.action_queue)
+        path = [1]
+        for a in actions:
+            path.append(int(ref.neighbors[path[-1], a]))
+        refs.append(ref)
+        paths.append((path, actions))
+        assert forest.path_node[t, :len(path)].cpu().tolist() == path   # same descent on the device
+    # plant the unseen children of every tree's current leaf into both trees, as leaf nodes
+    planted = 0
+    for t, (ref, (path, actions)) in enumerate(zip(refs, paths)):
+        leaf = path[-1]
+        kids = oc.expand12(ref.states[leaf][None])
+        unseen = [k for k in range(12) if kids[k].tobytes() not in ref.indices]
+        assert len(unseen) >= 10
+        p, v = onet(kids[unseen])
+        base, n = t * (C + 1), len(ref)
+        table = forest.hash[t].cpu().numpy()
+        for i, k in enumerate(unseen):
+            idx = n + 1 + i
+            ref.indices[kids[k].tobytes()] = idx
+            ref.states[idx], ref.P[idx], ref.V[idx], ref.W[idx] = kids[k], p[i], v[i], v[i]
+            key = _pack_key(kids[k])
+            slot = _key_hash(key) & (forest.hash_size - 1)
+            while table[slot] != 0:
+                slot = (slot + 1) & (forest.hash_size - 1)
+            table[slot] = idx
+            forest.keys[base + idx] = torch.from_numpy(key.view(np.int32)).cuda()
+            forest.P[base + idx] = torch.from_numpy(p[i].astype(np.float32)).cuda()
+            forest.W[base + idx] = float(v[i])
+            forest.V[base + idx] = float(v[i])
+            forest.leaf[base + idx] = 1
+            forest.rec[base + idx] = torch.tensor([0, 0, 1 << 16, 0], dtype=torch.int32).cuda()
+        forest.hash[t] = torch.from_numpy(table).cuda()
+        forest.n_nodes[t] = n + len(unseen)
+        planted += len(unseen)
+    assert planted >= 10 * B
+    # the next iteration expands a leaf that has NO new child; then a few more on top of the planted nodes
+    for extra in (1, 6):
+        for _ in range(extra):
+            forest.step(c, C, use_graph=False)
+        torch.cuda.synchronize()
+        for t, ref in enumerate(refs):
+            path, actions = paths[t]
+            for _ in range(extra):
+                n_before = len(ref)
+                solved_idx, _ = ref._expand_leaf(path, actions)
+                assert solved_idx == -1
+                if extra == 1:
+                    assert len(ref) == n_before           # nothing new: the defined branch ran
+                path, actions = ref._find_leaf()
+            paths[t] = (path, actions)
+            _compare(forest.tree_arrays(t), ref, len(ref))
+            assert forest.path_node[t, :len(path)].cpu().tolist() == path
+
+
+@pytest.mark.parametrize("use_graph", [False, True])
+def test_path_overflow(net_gpu, use_graph):
+    from librubiks.solving import mcts_device as md
+    from librubiks.solving.agents import MCTS
+    np.random.seed(4)
+    states = np.array([oc.scramble(20, True)[0] for _ in range(48)])
+    max_path, cap = 7, 1500
+    agent = MCTS(net_gpu, c=0.2, search_graph=True, net_dtype=torch.float32, max_path=max_path, use_graph=use_graph)
+    res = agent.search_batch(states, None, cap, compact=False)
+    onet = oa.TorchNet(net_gpu, device="cuda")
+    overflowed = 0
+    for t, s in enumerate(states):
+        ref = oa.MCTS(onet, c=0.2, search_graph=True)
+        ok = ref.search(s, cap, max_path=max_path)
+        assert bool(res.solved[t]) == ok and res.nodes[t] == len(ref), f"tree {t}"
+        assert list(res.queues[t]) == list(ref.action_queue), f"tree {t}"
+        assert (res.status[t] == md.PATH_OVERFLOW) == ref.path_overflow, f"tree {t}"
+        assert res.iterations[t] == ref.iterations
+        overflowed += ref.path_overflow
+        if ref.path_overflow:
+            assert len(ref.action_queue) == max_path - 1 and not ok
+            if overflowed <= 4:
+                _compare(agent.forest.tree_arrays(t), ref, len(ref))
+    assert overflowed >= 8
+
+
+def test_astar_open_list_runs_dry(net_gpu):
+    """Both sides: an iteration that finds nothing on the open list ends the problem as unsolved."""
+    from librubiks.cube import DeviceCubes
+    from librubiks.model import GenericNet
+    from librubiks.solving import astar_device as ad
+    np.random.seed(8)
+    states = np.array([oc.scramble(7, True)[0] for _ in range(5)])
+    N, cap, lam = 3, 2000, 0.2
+    batch = ad.AStarBatch(5, cap, N)
+    batch.set_net(GenericNet(net_gpu), torch.float32)
+    batch.reset(DeviceCubes.from_numpy(states))
+    refs = []
+    onet = oa.TorchNet(net_gpu, device="cuda")
+    for s in states:
+        ref = oa.AStar(onet, lam, N)
+        assert not ref.search(s, cap, max_iterations=2)
+        refs.append(ref)
+    for _ in range(2):
+        batch.iteration(lam, cap)
+    torch.cuda.synchronize()
+    nodes_before = batch.n_nodes.cpu().numpy().copy()
+    assert [len(r) for r in refs] == nodes_before.tolist()
+    # empty the open lists of problems 1 and 3 on both sides
+    for b in (1, 3):
+        batch.heap_size[b] = 0
+        refs[b].open_queue.clear()
+    batch.iteration(lam, cap)
+    torch.cuda.synchronize()
+    status = batch.status.cpu().numpy()
+    for b, ref in enumerate(refs):
+        cont = ref.resume(cap, max_iterations=1)
+        if b in (1, 3):
+            assert status[b] == ad.OPEN_EMPTY and cont is False and ref.open_empty
+            assert batch.n_nodes[b].item() == nodes_before[b] == len(ref)
+        else:
+            assert (status[b] == ad.SOLVED) == bool(cont) and status[b] in (ad.RUNNING, ad.SOLVED) and not ref.open_empty
+            assert batch.n_nodes[b].item() == len(ref) > nodes_before[b]
+
+
+def test_time_limit_only_caps_the_tree(net_gpu, monkeypatch):
+    from librubiks.solving import agents as pa
+    from librubiks.solving import mcts_device as md
+    np.random.seed(6)
+    states = np.array([oc.scramble(20, True)[0] for _ in range(12)])
+    monkeypatch.setattr(pa, "DEFAULT_NODE_CAP", 700)
+    agent = pa.MCTS(net_gpu, c=0.6, search_graph=True, net_dtype=torch.float32)
+    res = agent.search_batch(states, time_limit=120.0)
+    assert res.seconds < 60
+    onet = oa.TorchNet(net_gpu, device="cuda")
+    for t, s in enumerate(states):
+        ref = oa.MCTS(onet, c=0.6, search_graph=True)
+        ok = ref.search(s, 700)
+        assert bool(res.solved[t]) == ok and res.nodes[t] == len(ref) and list(res.queues[t]) == list(ref.action_queue)
+        if not ok:
+            assert res.status[t] == md.EXHAUSTED and res.nodes[t] + 12 > 700
+
+
+def test_time_limit_only_real_cap(net_gpu):
+    """One tree at the real cap of 2^18 nodes: it stops there instead of growing without bound."""
+    from librubiks.solving import agents as pa
+    from librubiks.solving import mcts_device as md
+    assert pa.DEFAULT_NODE_CAP == 1 << 18
+    np.random.seed(2)
+    state = oc.scramble(30, True)[0]
+    agent = pa.MCTS(net_gpu, c=0.6, search_graph=False, net_dtype=torch.float32)
+    res = agent.search_batch(state[None], time_limit=300.0)
+    if not res.solved[0]:
+        assert res.status[0] == md.EXHAUSTED and (1 << 18) - 12 < res.nodes[0] <= 1 << 18
+    assert res.seconds < 120
+
+
+class _TableNet:
+    """The oracle's network interface answered from a record {state bytes: (P row, V)}."""
+
+    def __init__(self, table):
+        self.table = table
+
+    def __call__(self, states):
+        if len(states) == 0:
+            return np.zeros((0, 12), dtype=np.float32), np.zeros(0, dtype=np.float32)
+        rows = [self.table[s.tobytes()] for s in states]
+        return np.stack([r[0] for r in rows]), np.array([r[1] for r in rows], dtype=np.float32)
+
+
+def test_production_bf16_trees_equal_oracle_on_recorded_outputs():
+    import os
+    from conftest import ROOT
+    from librubiks.model import Model, ModelConfig
+    from librubiks.solving.agents import MCTS
+    torch.manual_seed(0)
+    wdir = os.path.join(ROOT, "weights", "fc_small_r1")
+    net = Model.load(wdir).eval() if os.path.isdir(wdir) else Model.create(ModelConfig()).eval()
+    np.random.seed(17)
+    B, cap = 96, 900
+    states = np.array([oc.scramble(8 + i % 13, True)[0] for i in range(B)])
+    for graph_search in (True, False):
+        agent = MCTS(net, c=0.6, search_graph=graph_search)          # defaults: bf16 engine, HIP graph
+        assert agent.net_dtype == torch.bfloat16 and agent.use_graph
+        res = agent.search_batch(states, None, cap, compact=False)    # the trees stay in agent.forest
+        assert agent.forest._fused and agent.forest.rows_per_tree == 11
+        n_solved = deep = 0
+        for t in range(B):
+            tree = agent.forest.tree_arrays(t)
+            n = tree["n"]
+            table = {tree["states"][i].tobytes(): (tree["P"][i].astype(np.float32), np.float32(tree["V"][i]))
+                     for i in range(1, n + 1)}
+            ref = oa.MCTS(_TableNet(table), c=0.6, search_graph=graph_search)
+            ok = ref.search(states[t], cap)
+            assert bool(res.solved[t]) == ok and res.nodes[t] == len(ref) == n, f"tree {t}"
+            assert list(res.queues[t]) == list(ref.action_queue), f"tree {t}"
+            assert res.iterations[t] == ref.iterations
+            _compare(tree, ref, n)
+            n_solved += ok
+            deep += ref.iterations > 40
+        assert n_solved >= 10 and deep >= 10
