@@ -448,6 +448,9 @@ def main():
                          "auto = the agent's default: a budget while scrambles are waiting for a slot, none for the tail)")
     ap.add_argument("--first-layer-table", default="auto", choices=["auto", "f16", "f16pair", "bf16", "mfma", "mfma16", "onehot"],
                     help="bf16 engine's input layer: fused gather-sum with an f16 / bf16 table, or the one-hot GEMM")
+    ap.add_argument("--as-rank", default=None, metavar="R/W",
+                    help="single process, no process group: take rank R's share of a W-rank run's scrambles (tests compare "
+                         "the ranks of a distributed run with these)")
     args = ap.parse_args()
     if args.level_budget != "auto":
         args.level_budget = int(args.level_budget)
@@ -477,13 +480,14 @@ def main():
     # games 0 .. trees*world - 1 are BASELINE configs[1]'s scrambles (rank r: its `trees`), the pool continues the stream
     np.random.seed(0)
     per_rank = args.trees * args.pool_factor
-    all_cubes, _, _ = cube.scramble_batch(per_rank * world, args.depth, True)
-    lo, hi = shard_range(args.trees * world, rank, world)
+    slice_rank, slice_world = (rank, world) if not args.as_rank else tuple(int(x) for x in args.as_rank.split("/"))
+    all_cubes, _, _ = cube.scramble_batch(per_rank * slice_world, args.depth, True)
+    lo, hi = shard_range(args.trees * slice_world, slice_rank, slice_world)
     config_roots = DeviceCubes.empty(hi - lo)
     config_roots.soa[:, :hi - lo] = all_cubes.soa[:, lo:hi]
     pool_roots = DeviceCubes.empty(per_rank)
     pool_roots.soa[:, :hi - lo] = config_roots.soa[:, :hi - lo]           # the pool starts with the rank's config scrambles ...
-    rest_lo = args.trees * world + rank * (per_rank - args.trees)        # ... and continues with its slice of the rest
+    rest_lo = args.trees * slice_world + slice_rank * (per_rank - args.trees)   # ... and continues with its slice of the rest
     pool_roots.soa[:, hi - lo:per_rank] = all_cubes.soa[:, rest_lo:rest_lo + per_rank - (hi - lo)]
     del all_cubes
 

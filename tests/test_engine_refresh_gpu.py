@@ -74,13 +74,13 @@ def test_astar_engine_follows_the_module():
     net_b = Model.create(ModelConfig()).eval()
     agent = AStar(net_a, lambda_=0.2, expansions=10)
     ra = agent.search_batch(states, None, 3000, max_iterations=6)
-    cost_a = np.array(agent.batch.heap_cost[:8].cpu())
+    cost_a = agent.batch.heap_cost[:8].cpu().numpy()
     agent.net = net_b
     rb = agent.search_batch(states, None, 3000, max_iterations=6)
-    cost_b = np.array(agent.batch.heap_cost[:8].cpu())
+    cost_b = agent.batch.heap_cost[:8].cpu().numpy()
     fresh = AStar(net_b, lambda_=0.2, expansions=10)
     rf = fresh.search_batch(states, None, 3000, max_iterations=6)
-    assert np.array_equal(cost_b, np.array(fresh.batch.heap_cost[:8].cpu())) and np.array_equal(rb.nodes, rf.nodes)
+    assert np.array_equal(cost_b, fresh.batch.heap_cost[:8].cpu().numpy()) and np.array_equal(rb.nodes, rf.nodes)
     assert not np.array_equal(cost_a, cost_b)
     with torch.no_grad():
         for p in net_b.parameters():
@@ -88,6 +88,6 @@ def test_astar_engine_follows_the_module():
     rc = agent.search_batch(states, None, 3000, max_iterations=6)
     fresh = AStar(net_b, lambda_=0.2, expansions=10)
     rf = fresh.search_batch(states, None, 3000, max_iterations=6)
-    assert np.array_equal(np.array(agent.batch.heap_cost[:8].cpu()), np.array(fresh.batch.heap_cost[:8].cpu()))
+    assert np.array_equal(agent.batch.heap_cost[:8].cpu().numpy(), fresh.batch.heap_cost[:8].cpu().numpy())
     assert np.array_equal(rc.nodes, rf.nodes)
-    assert not np.array_equal(np.array(agent.batch.heap_cost[:8].cpu()), cost_b)
+    assert not np.array_equal(agent.batch.heap_cost[:8].cpu().numpy(), cost_b)

@@ -74,3 +74,45 @@ def test_mcts_default_budget():
     assert agent.forest.C >= 175_000
     if trained:
         assert res.solved.sum() >= 6
+
+
+def _bench_line(args, env_extra, launcher=()):
+    import json
+    import subprocess
+    import sys
+    env = dict(os.environ, **env_extra)
+    cmd = [sys.executable, *launcher, os.path.join(ROOT, "bench.py"), *args]
+    out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, out.stdout[-2000:]
+    return json.loads(lines[0])
+
+
+def test_bench_two_ranks_aggregate_their_shares():
+    """
+    bench.py as the driver launches it for N = 2 (torch.distributed.run, one process per rank; here both ranks on
+    this one GPU with the gloo backend): rank r searches its slice of the scrambles and the line aggregates them.
+    Each rank's share is also run alone (`--as-rank r/2`: same slice, same forest sizes, hence the same bf16 GEMM
+    shapes and bit-identical trees): the distributed line must report exactly the sum of the two.
+    """
+    import socket
+    common = ["--steps", "6", "--warmup", "2", "--trees", "48", "--pool-factor", "2", "--legs", "bf16", "--solve-max-states",
+              "1500", "--phase-reps", "0", "--no-cpu-baseline", "--no-env-roofline", "--prep-cap", "40"]
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    two = _bench_line(["--gpus", "2", *common], {"RUBIKS_DIST_BACKEND": "gloo"},
+                      launcher=("-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                                "--master-port", str(port)))
+    shares = [_bench_line(["--gpus", "1", "--as-rank", f"{r}/2", *common], {}) for r in range(2)]
+    assert two["n_gpus"] == 2 and two["scaling"] == "weak" and two["dtype"] == "bf16"
+    a = two["legs"]["bf16"]["run_to_completion"]
+    parts = [x["legs"]["bf16"]["run_to_completion"] for x in shares]
+    assert a["games"] == 96 and [p["games"] for p in parts] == [48, 48]
+    assert a["nodes"] == parts[0]["nodes"] + parts[1]["nodes"]
+    assert abs(a["solve_rate"] - (parts[0]["solve_rate"] + parts[1]["solve_rate"]) / 2) < 1e-12
+    pool = two["legs"]["bf16"]["pool_run"]
+    assert pool["games"] == 2 * 96 and pool["nodes"] == sum(x["legs"]["bf16"]["pool_run"]["nodes"] for x in shares)
+    assert two["legs"]["bf16"]["steps_timed"] == 6 and two["value"] > 0
+    assert two["config"]["parallelism"] == "scramble-sharded x2"

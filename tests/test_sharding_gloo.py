@@ -127,3 +127,61 @@ def test_sharded_search_batch_two_ranks():
     for _, full in got:
         for k in ("solved", "lengths", "nodes"):
             assert full[k] == whole[k].tolist()
+
+
+def _bucket_worker(rank, world, port, q):
+    import torch
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from librubiks.train import GradBuckets
+    torch.manual_seed(0)
+    net = torch.nn.Sequential(torch.nn.Linear(6, 40), torch.nn.ReLU(), torch.nn.Linear(40, 30), torch.nn.ReLU(),
+                              torch.nn.Linear(30, 2))
+    buckets = GradBuckets(net, bucket_bytes=200)      # three buckets, one per Linear layer (last layer first)
+    out = []
+    for step in range(2):                             # a second step: zero() really resets, hooks fire again
+        buckets.zero()
+        x = torch.full((3, 6), float(rank + 1 + step))
+        net(x).sum().backward()
+        launched = len(buckets.works)
+        local = [p.grad.clone() for p in net.parameters()]   # (already reduced where a bucket has finished: compare on rank sums)
+        buckets.wait()
+        out.append((launched, [p.grad.tolist() for p in net.parameters()]))
+    views = all(p.grad.data_ptr() >= f.data_ptr() and p.grad.data_ptr() < f.data_ptr() + f.numel() * 4
+                for p in net.parameters() for f in [buckets.flats[buckets.bucket_of[p]]])
+    q.put((rank, len(buckets.flats), views, out))
+    buckets.close()
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_bucketed_async_gradient_average():
+    """GradBuckets: gradients live in flat buckets, every bucket is all-reduced during backward, result = mean over ranks."""
+    import torch
+    world = 2
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_bucket_worker, args=(r, world, port, q)) for r in range(world)]
+    [p.start() for p in procs]
+    got = sorted(q.get(timeout=120) for _ in range(world))
+    [p.join(60) for p in procs]
+    assert all(p.exitcode == 0 for p in procs)
+    assert got[0][1] == got[1][1] >= 3 and got[0][2] and got[1][2]
+    for step in range(2):
+        # reference: the same two local backward passes in this process, averaged by hand
+        grads = []
+        for rank in range(world):
+            torch.manual_seed(0)
+            net = torch.nn.Sequential(torch.nn.Linear(6, 40), torch.nn.ReLU(), torch.nn.Linear(40, 30), torch.nn.ReLU(),
+                                      torch.nn.Linear(30, 2))
+            net(torch.full((3, 6), float(rank + 1 + step))).sum().backward()
+            grads.append([p.grad.numpy().copy() for p in net.parameters()])
+        mean = [np.mean([grads[r][i] for r in range(world)], axis=0) for i in range(len(grads[0]))]
+        for r in range(world):
+            launched, reduced = got[r][3][step]
+            assert launched == got[r][1]                      # every bucket's all_reduce was started inside backward
+            for i, m in enumerate(mean):
+                assert np.allclose(np.array(reduced[i]), m, rtol=1e-6, atol=1e-7)

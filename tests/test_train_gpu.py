@@ -139,6 +139,81 @@ def test_data_parallel_training_two_ranks():
     assert draw0 == draw1                                  # the global stream stays common: evaluation scrambles are shared
 
 
+def _train_eval_rank(rank, world, port, q, out_dir):
+    import os
+    import sys
+    import torch.distributed as dist
+    here = os.path.dirname(os.path.abspath(__file__))
+    sys.path[:0] = [here, os.path.dirname(here), os.path.join(os.path.dirname(here), "rl-rubiks_amd")]
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from librubiks.model import Model, ModelConfig
+    from librubiks.solving.agents import MCTS
+    from librubiks.solving.evaluation import Evaluator
+    from librubiks.train import Train
+    torch.manual_seed(0)
+    np.random.seed(0)
+    net = Model.create(ModelConfig())
+    evaluator = Evaluator(10, [2, 4], None, 150)
+    seen = []
+    plain_eval = evaluator.eval
+
+    def recording_eval(agent):      # what the common np.random stream was before the evaluation, and what came out
+        state = np.random.get_state()
+        out = plain_eval(agent)
+        seen.append((state, out[0].copy(), out[1].copy()))
+        return out
+
+    evaluator.eval = recording_eval
+    tr = Train(rollouts=2, batch_size=24, rollout_games=16, rollout_depth=6, optim_fn=torch.optim.Adam, alpha_update=0,
+               lr=1e-4, gamma=1, update_interval=0, agent=MCTS(net, c=0.6, search_graph=True, net_dtype=torch.float32),
+               evaluator=evaluator, evaluation_interval=1, tau=1, reward_method="lapanfix")
+    net, _ = tr.train(net)
+    wait = tr.tt.profiles["Gradient all-reduce wait"]
+    loop = tr.tt.profiles["Training loop"]
+    if rank == 0:
+        net.save(out_dir)
+        np.save(os.path.join(out_dir, "rng_keys.npy"), np.stack([s[0][1] for s in seen]))
+        np.save(os.path.join(out_dir, "rng_pos.npy"), np.array([s[0][2] for s in seen]))
+    q.put((rank, [s[1].tolist() for s in seen], [s[2].tolist() for s in seen], tr.sol_percents, len(wait), wait.sum() / loop.sum()))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_data_parallel_training_evaluates_one_common_scramble_set(tmp_path):
+    """
+    Two ranks train data-parallel (private ADI streams, bucketed gradient averaging) and evaluate inside the loop:
+    the Evaluator shards ONE scramble set over the ranks, so both ranks report the same (depths x games) results, and
+    those are what a single process gets for the final weights from the same position of the common np.random stream.
+    """
+    import socket
+    import torch.multiprocessing as mp
+    from librubiks.model import Model
+    from librubiks.solving.agents import MCTS
+    from librubiks.solving.evaluation import Evaluator
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_train_eval_rank, args=(r, 2, port, q, str(tmp_path))) for r in range(2)]
+    [p.start() for p in procs]
+    got = sorted(q.get(timeout=600) for _ in range(2))
+    [p.join(120) for p in procs]
+    assert all(p.exitcode == 0 for p in procs)
+    (_, res0, st0, sol0, n_wait0, share0), (_, res1, st1, sol1, n_wait1, share1) = got
+    assert res0 == res1 and st0 == st1 and sol0 == sol1 and len(res0) == 2          # two evaluations, identical on both ranks
+    assert n_wait0 == n_wait1 == 4                                                   # 2 rollouts x 2 optimizer steps
+    print(f"gradient all-reduce wait = {share0:.1%} / {share1:.1%} of the training loop (two gloo ranks on one GPU)")
+    assert 0 < share0 < 1
+    # single process, final weights, the stream position of the LAST evaluation
+    keys, pos = np.load(tmp_path / "rng_keys.npy"), np.load(tmp_path / "rng_pos.npy")
+    np.random.set_state(("MT19937", keys[-1], int(pos[-1]), 0, 0.0))
+    net = Model.load(str(tmp_path)).eval()
+    res, states, _ = Evaluator(10, [2, 4], None, 150).eval(MCTS(net, c=0.6, search_graph=True, net_dtype=torch.float32))
+    assert res.tolist() == res0[-1] and states.tolist() == st0[-1]
+
+
 def test_reference_train_test_restated():
     """tests/test_train.py:13-24 of the reference (its arguments, minus the analysis / plot that are out of scope)."""
     from librubiks.model import Model, ModelConfig
