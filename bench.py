@@ -226,7 +226,7 @@ def cpu_baseline(model, depth, budget_s=14.0, max_states=5000):
             "sample": f"{games} depth-{depth} scrambles x max_states={max_states}, single-tree MCTS c=0.6 "
                       f"(oracle/agents.py on NumPy + torch CPU fp32, {best[1]} torch threads picked by calibration), "
                       f"{dt:.1f} s",
-            "env_ops": cpu_env_ops(), "bfs_config1": cpu_bfs_config1()}
+            "env_ops": cpu_env_ops(), "bfs_config1": cpu_bfs_config1(), "boundary_calls": boundary_calls()}
 
 
 def cpu_env_ops(sizes=(10_000, 196_608), warm=5, reps=20):
@@ -254,6 +254,45 @@ def cpu_env_ops(sizes=(10_000, 196_608), warm=5, reps=20):
                 ts.append(time.perf_counter() - t)
             row[name] = round(n / float(np.median(ts)) / 1e6, 2)
         out[str(n)] = row
+    return out
+
+
+def boundary_calls(reps=300):
+    """
+    The stateless drop-in functions at the sizes the reference's own callers use (agents.py:109,513: n = 1 and 12;
+    ADI-sized 1 200), NumPy in / NumPy (or device tensor) out: microseconds per call, product (one HIP launch through
+    pinned host memory + one stream synchronisation) next to the restated NumPy expression on one host core.
+    """
+    from librubiks import cube
+    from oracle import cube as oc
+    rng = np.random.RandomState(1)
+    out = {"unit": "us per call (median)", "reps": reps}
+
+    def med(fn):
+        for _ in range(10):
+            fn()
+        ts = []
+        for _ in range(reps):
+            t = time.perf_counter()
+            fn()
+            ts.append(time.perf_counter() - t)
+        return round(float(np.median(ts)) * 1e6, 1)
+
+    for n in (1, 12, 1200):
+        states = np.tile(oc.get_solved(), (n, 1))
+        for _ in range(20):
+            states = oc.multi_rotate_actions(states, rng.randint(0, 12, n))
+        acts = rng.randint(0, 12, n)
+        faces, dirs = acts // 2, 1 - acts % 2
+        row = {"multi_rotate": {"hip": med(lambda: cube.multi_rotate(states, faces, dirs)),
+                                "numpy": med(lambda: oc.multi_rotate(states, faces, dirs))},
+               "multi_is_solved": {"hip": med(lambda: cube.multi_is_solved(states)), "numpy": med(lambda: oc.multi_is_solved(states))},
+               "as_oh": {"hip_to_device_tensor": med(lambda: cube.as_oh(states)),
+                         "numpy_plus_copy_to_device": med(lambda: torch.from_numpy(oc.as_oh(states)).cuda())}}
+        if n == 1:
+            row["rotate"] = {"hip": med(lambda: cube.rotate(states[0], int(faces[0]), int(dirs[0]))),
+                             "numpy": med(lambda: oc.rotate(states[0], int(faces[0]), int(dirs[0])))}
+        out[f"n={n}"] = row
     return out
 
 

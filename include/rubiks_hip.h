@@ -66,6 +66,18 @@ int rc_get_solved(int8_t *out20);
 int rc_aos_to_soa(const int8_t *aos, int8_t *soa, size_t n, size_t stride, rc_stream_t stream);
 int rc_soa_to_aos(const int8_t *soa, int8_t *aos, size_t n, size_t stride, rc_stream_t stream);
 
+/* ---- small calls on the reference's own layout ------------------------------------------------
+ * The same three operations on (n,20) row-major int8 states, for the sizes at which the reference's callers use the
+ * stateless functions (n = 1 .. a few thousand: librubiks/solving/agents.py:109,513).  One launch each, no SoA
+ * staging; every pointer may be device memory OR pinned host memory mapped into the device (hipHostMalloc), so a
+ * NumPy caller pays one launch and one stream synchronisation per call.  No alignment requirement.
+ *   rc_multi_rotate_aos  out[i] = move actions[i] on in[i]      (librubiks/cube/cube.py:49-52,256-263)
+ *   rc_is_solved_aos     flags[i] = in[i] == solved             (librubiks/cube/cube.py:85-89)
+ *   rc_as_oh_aos_f32     out[i, 24 j + in[i, j]] = 1, else 0    (librubiks/cube/cube.py:130-133,265-277) */
+int rc_multi_rotate_aos(const int8_t *in_aos, const uint8_t *actions, int8_t *out_aos, size_t n, rc_stream_t stream);
+int rc_is_solved_aos(const int8_t *in_aos, uint8_t *flags, size_t n, rc_stream_t stream);
+int rc_as_oh_aos_f32(const int8_t *in_aos, float *out, size_t n, rc_stream_t stream);
+
 /* ---- cube environment ------------------------------------------------------------------------ */
 
 /* out[i] = move actions[i] applied to in[i].  Replaces _Cube2024.multi_rotate

@@ -378,6 +378,44 @@ __global__ __launch_bounds__(kBlock) void k_soa_to_aos(const u32 *__restrict__ s
     }
 }
 
+
+// ---- small calls on the reference's own (n,20) row-major layout -----------------------------------------------
+// The drop-in functions cube.rotate / multi_rotate / multi_is_solved / as_oh are called by the reference with
+// n = 1 .. a few thousand (agents.py:109,513).  At those sizes the work is nothing and the cost is the number of
+// launches and copies, so these kernels read and write the caller's row-major bytes directly -- the pointers may be
+// pinned host memory mapped into the device (one launch, no staging copy, no transposition).
+__global__ __launch_bounds__(kBlock) void k_multi_rotate_aos(const u8 *__restrict__ in, const u8 *__restrict__ actions,
+                                                             u8 *__restrict__ out, size_t n) {
+    __shared__ u32 s_lut[sizeof(kTables.lut) / 4];
+    stage_to_lds(s_lut, c_tables.lut, sizeof(kTables.lut));
+    __syncthreads();
+    const u8 *lut = reinterpret_cast<const u8 *>(s_lut);
+    for (size_t idx = (size_t)blockIdx.x * kBlock + threadIdx.x; idx < n * kPlanes; idx += (size_t)gridDim.x * kBlock) {
+        const size_t i = idx / kPlanes;
+        const u32 j = (u32)(idx - i * kPlanes);
+        const u32 a = actions[i] & (kActionPad - 1);
+        out[idx] = lut[a * (2 * kCodePad) + (j >= (u32)kCorners ? kCodePad : 0) + (in[idx] & 31u)];
+    }
+}
+
+__global__ __launch_bounds__(kBlock) void k_is_solved_aos(const u8 *__restrict__ in, u8 *__restrict__ flags, size_t n) {
+    for (size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += (size_t)gridDim.x * kBlock) {
+        bool ok = true;
+#pragma unroll
+        for (int j = 0; j < kPlanes; ++j) ok &= in[i * kPlanes + j] == (u8)kTables.solved[j];
+        flags[i] = ok ? 1 : 0;
+    }
+}
+
+template <typename T>
+__global__ __launch_bounds__(kBlock) void k_as_oh_aos(const u8 *__restrict__ in, T *__restrict__ out, size_t n, T one) {
+    for (size_t idx = (size_t)blockIdx.x * kBlock + threadIdx.x; idx < n * (kPlanes * kCodes); idx += (size_t)gridDim.x * kBlock) {
+        const size_t i = idx / (kPlanes * kCodes);
+        const u32 c = (u32)(idx - i * (kPlanes * kCodes));
+        out[idx] = in[i * kPlanes + c / kCodes] == (u8)(c % kCodes) ? one : (T)0;
+    }
+}
+
 }  // namespace rubiks
 
 // =================================================================================================
@@ -516,6 +554,29 @@ int rc_soa_to_aos(const int8_t *soa, int8_t *aos, size_t n, size_t stride, rc_st
     RC_REQUIRE(aligned16(aos), RC_ERR_ALIGN);
     hipLaunchKernelGGL(k_soa_to_aos, dim3((unsigned)ceil_div(n, kTB)), dim3(kBlock), 0, (hipStream_t)stream,
                        (const u32 *)soa, (u8 *)aos, n, stride / 4);
+    return launch_status();
+}
+
+int rc_multi_rotate_aos(const int8_t *in_aos, const uint8_t *actions, int8_t *out_aos, size_t n, rc_stream_t stream) {
+    if (n == 0) return RC_OK;
+    RC_REQUIRE(in_aos && actions && out_aos, RC_ERR_NULL);
+    hipLaunchKernelGGL(k_multi_rotate_aos, dim3(grid_for(n * kPlanes)), dim3(kBlock), 0, (hipStream_t)stream, (const u8 *)in_aos,
+                       actions, (u8 *)out_aos, n);
+    return launch_status();
+}
+
+int rc_is_solved_aos(const int8_t *in_aos, uint8_t *flags, size_t n, rc_stream_t stream) {
+    if (n == 0) return RC_OK;
+    RC_REQUIRE(in_aos && flags, RC_ERR_NULL);
+    hipLaunchKernelGGL(k_is_solved_aos, dim3(grid_for(n)), dim3(kBlock), 0, (hipStream_t)stream, (const u8 *)in_aos, flags, n);
+    return launch_status();
+}
+
+int rc_as_oh_aos_f32(const int8_t *in_aos, float *out, size_t n, rc_stream_t stream) {
+    if (n == 0) return RC_OK;
+    RC_REQUIRE(in_aos && out, RC_ERR_NULL);
+    hipLaunchKernelGGL(k_as_oh_aos<float>, dim3(grid_for(n * (kPlanes * kCodes))), dim3(kBlock), 0, (hipStream_t)stream, (const u8 *)in_aos, out,
+                       n, 1.0f);
     return launch_status();
 }
 

@@ -25,6 +25,9 @@ SIGNATURES = {
     "rc_get_solved": [P],
     "rc_aos_to_soa": [P, P, SZ, SZ, P],
     "rc_soa_to_aos": [P, P, SZ, SZ, P],
+    "rc_multi_rotate_aos": [P, P, P, SZ, P],
+    "rc_is_solved_aos": [P, P, SZ, P],
+    "rc_as_oh_aos_f32": [P, P, SZ, P],
     "rc_multi_rotate": [P, P, P, SZ, SZ, SZ, P],
     "rc_expand12": [P, P, SZ, SZ, SZ, P],
     "rc_is_solved": [P, P, P, P, SZ, SZ, P],

@@ -34,6 +34,35 @@ def _actions_of(faces, directions) -> np.ndarray:
     return (2 * faces + 1 - directions).astype(np.uint8)
 
 
+SMALL_CALL = 1 << 15   # largest n served by the one-launch row-major kernels; beyond it the SoA path is faster
+
+
+class _Staging:
+    """
+    Pinned host buffers for the small calls of the stateless API (rotate / multi_rotate / multi_is_solved / as_oh
+    with a handful of states, as the reference's agents call them): the kernel reads the (n,20) bytes and writes its
+    result straight through the mapping of pinned host memory into the device, so a call is one memcpy into the
+    staging buffer, one launch and one stream synchronisation -- no allocation, no transposition, no DMA copies.
+    """
+
+    def __init__(self):
+        self.cap = 0
+
+    def get(self, n: int):
+        if n > self.cap:
+            self.cap = max(1024, 1 << int(np.ceil(np.log2(n))))
+            self.states = torch.empty((self.cap, N_PLANES), dtype=torch.int8, pin_memory=True)
+            self.out = torch.empty((self.cap, N_PLANES), dtype=torch.int8, pin_memory=True)
+            self.actions = torch.empty(self.cap, dtype=torch.uint8, pin_memory=True)
+            self.flags = torch.empty(self.cap, dtype=torch.uint8, pin_memory=True)
+            self.np_states, self.np_out = self.states.numpy(), self.out.numpy()
+            self.np_actions, self.np_flags = self.actions.numpy(), self.flags.numpy()
+        return self
+
+
+_staging = _Staging()
+
+
 def _padded_actions(actions: np.ndarray, n: int) -> torch.Tensor:
     buf = np.zeros((n + 15) // 16 * 16, dtype=np.uint8)
     buf[:n] = actions
@@ -44,7 +73,7 @@ def _padded_actions(actions: np.ndarray, n: int) -> torch.Tensor:
 # Rotate logic #   reference cube.py:41-52,244-263
 ################
 def rotate(state: np.ndarray, face: int, direction: int) -> np.ndarray:
-    """One move on one state; runs the batched kernel with n = 1."""
+    """One move on one state; runs the row-major kernel with n = 1."""
     return multi_rotate(np.asarray(state)[None], np.array([face]), np.array([direction]))[0]
 
 
@@ -56,6 +85,15 @@ def multi_rotate(states: np.ndarray, faces: np.ndarray, directions: np.ndarray) 
         _hip.lib()
         return np.empty((0, N_PLANES), dtype=dtype)
     assert len(faces) == n and len(directions) == n
+    if n <= SMALL_CALL:
+        lib, st = _hip.lib(), _staging.get(n)
+        st.np_states[:n] = states
+        st.np_actions[:n] = _actions_of(faces, directions)
+        stream = torch.cuda.current_stream()
+        _hip.check(lib.rc_multi_rotate_aos(st.states.data_ptr(), st.actions.data_ptr(), st.out.data_ptr(), n, stream.cuda_stream),
+                   "rc_multi_rotate_aos")
+        stream.synchronize()
+        return st.np_out[:n].copy()
     cubes = DeviceCubes.from_numpy(states)
     return cubes.multi_rotate(_padded_actions(_actions_of(faces, directions), n)).numpy()
 
@@ -84,9 +122,17 @@ def is_solved(state: np.ndarray) -> bool:
 
 def multi_is_solved(states: np.ndarray) -> np.ndarray:
     states = np.asarray(states)
-    if len(states) == 0:
+    n = len(states)
+    if n == 0:
         _hip.lib()
         return np.zeros(0, dtype=bool)
+    if n <= SMALL_CALL:
+        lib, st = _hip.lib(), _staging.get(n)
+        st.np_states[:n] = states
+        stream = torch.cuda.current_stream()
+        _hip.check(lib.rc_is_solved_aos(st.states.data_ptr(), st.flags.data_ptr(), n, stream.cuda_stream), "rc_is_solved_aos")
+        stream.synchronize()
+        return st.np_flags[:n].astype(bool)
     return DeviceCubes.from_numpy(states).is_solved().cpu().numpy()
 
 
@@ -141,9 +187,18 @@ def as_oh(states: np.ndarray) -> torch.Tensor:
     states = np.asarray(states)
     if states.ndim == 1:
         states = states[None]
-    if len(states) == 0:
+    n = len(states)
+    if n == 0:
         _hip.lib()
         return torch.zeros((0, OH_WIDTH), device=gpu)
+    if n <= SMALL_CALL:   # one launch: the kernel reads the states from pinned host memory and writes every output element
+        lib, st = _hip.lib(), _staging.get(n)
+        st.np_states[:n] = states
+        out = torch.empty((n, OH_WIDTH), dtype=torch.float32, device=gpu)
+        stream = torch.cuda.current_stream()
+        _hip.check(lib.rc_as_oh_aos_f32(st.states.data_ptr(), out.data_ptr(), n, stream.cuda_stream), "rc_as_oh_aos_f32")
+        stream.synchronize()   # the staging buffer is free for the next call once the kernel has read it
+        return out
     return DeviceCubes.from_numpy(states).as_oh(torch.float32)
 
 

@@ -303,3 +303,30 @@ def test_c_abi_argument_errors():
     assert lib.rc_expand12(p, p, 100, 256, 256, None) == -3                    # children need 1200 columns
     assert lib.rc_init(99) == -4                                               # RC_ERR_RANGE
     assert b"aligned" in ctypes.c_char_p(lib.rc_error_string(-2)).value
+
+
+@pytest.mark.parametrize("n", [1, 2, 12, 13, 1200, 4097])
+def test_small_call_row_major_kernels(n):
+    """The one-launch row-major path of the stateless API (pinned host memory in and out) against the oracle."""
+    from librubiks import cube
+    from librubiks.cube import cube as cube_mod
+    assert n <= cube_mod.SMALL_CALL
+    rng = np.random.RandomState(n)
+    states = np.tile(oc.get_solved(), (n, 1))
+    for _ in range(25):
+        states = oc.multi_rotate_actions(states, rng.randint(0, 12, n))
+    states[n // 2] = oc.get_solved()
+    acts = rng.randint(0, 12, n)
+    faces, dirs = acts // 2, 1 - acts % 2
+    before = states.copy()
+    out = cube.multi_rotate(states, faces, dirs)
+    assert out.dtype == np.int8 and out.shape == (n, 20) and np.array_equal(out, oc.multi_rotate(states, faces, dirs))
+    out2 = cube.multi_rotate(out, faces, 1 - dirs)       # a second call reuses the staging buffers: `out` must be a copy
+    assert np.array_equal(out2, states) and np.array_equal(out, oc.multi_rotate(states, faces, dirs))
+    solved = cube.multi_is_solved(states)
+    assert solved.dtype == bool and np.array_equal(solved, oc.multi_is_solved(states)) and solved[n // 2]
+    oh = cube.as_oh(states)
+    assert oh.shape == (n, 480) and oh.dtype == torch.float32 and oh.is_cuda
+    assert np.array_equal(oh.cpu().numpy(), oc.as_oh(states))
+    assert np.array_equal(states, before)                 # inputs are never mutated
+    assert np.array_equal(cube.rotate(states[0], int(faces[0]), int(dirs[0])), oc.rotate(states[0], int(faces[0]), int(dirs[0])))
