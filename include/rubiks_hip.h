@@ -148,6 +148,20 @@ int rc_first_layer_mfma_bf16(const int8_t *soa, size_t n, size_t stride, const u
  * two library GEMMs (model.py:150-157: Linear -> activation), 16 bytes per lane.  4 B of HBM traffic per element. */
 int rc_act_bf16_inplace(uint16_t *x, size_t n, int activation, float alpha, rc_stream_t stream);
 
+/* ---- fp32-accurate network on the f16 matrix cores (f16x3 split) -------------------------------------------------
+ * A float x travels as two IEEE halves, x = hi + lo * 2^-11 with hi = half(x), lo = half((x - hi) * 2^11); a layer is
+ *   y = act(hi_x W_hi^T + 2^-11 (hi_x W_lo^T + lo_x W_hi^T) + b)      (fp32 accumulation on MFMA, library GEMMs)
+ * which is closer to the float64 result than an fp32 GEMM (librubiks/model.py::SplitF32Net; replaces the fp32 forward
+ * of librubiks/model.py:131-141).  These two kernels build the GEMM operands:
+ *   rc_oh_split_f16   out[r] = [onehot(r), onehot(r) * 2^-11] as IEEE half, row pitch 960 (the one-hot is exact in half:
+ *                     its product with [W_hi | W_lo] IS the input layer)                      (cube.py:265-277)
+ *   rc_split_act_f16  y = act(c + corr_scale * c_corr + bias) per element of the fp32 GEMM outputs c, c_corr
+ *                     [n_rows][n_cols] (c_corr may be NULL); writes out_hi_lo[r] = [hi(y row), lo(y row)] (row pitch
+ *                     2 n_cols, may be NULL) and / or y itself to out_f32 (may be NULL).  n_cols % 8 == 0; ELU uses expm1f. */
+int rc_oh_split_f16(const int8_t *soa, size_t n, size_t stride, uint16_t *out, rc_stream_t stream);
+int rc_split_act_f16(const float *c, const float *c_corr, float corr_scale, size_t n_rows, size_t n_cols, const float *bias,
+                     int activation, float alpha, uint16_t *out_hi_lo, float *out_f32, rc_stream_t stream);
+
 /* ---- network head: last activation + skinny output layer in one pass -----------------------------------------
  * out[i][o] = bias[o] + sum_k w[o][k] * act(x[i][k])   for o < n_out <= 16   (float out, row pitch 16)
  * Replaces the final activation pass and the 1024 -> 13 GEMM of the merged policy/value heads

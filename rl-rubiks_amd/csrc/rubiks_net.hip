@@ -475,6 +475,112 @@ extern "C" int rc_act_bf16_inplace(uint16_t *x, size_t n, int activation, float 
     return launch_status();
 }
 
+// =================================================================================================
+// fp32-accurate network on the f16 matrix cores ("f16x3 split", librubiks/model.py::SplitF32Net)
+// =================================================================================================
+// A float x is carried as two halves:  x = hi + lo * 2^-11,  hi = f16(x),  lo = f16((x - hi) * 2^11)  (22 significant
+// bits; the 2^11 keeps lo out of f16's subnormal range).  A product of two such numbers is
+//   hi_a hi_b + 2^-11 (hi_a lo_b + lo_a hi_b) + O(2^-22),
+// three f16 MFMA products accumulated in fp32 (each f16 x f16 product is exact in fp32).  Measured against float64 on
+// the hidden layer's shape, the result is CLOSER than the fp32 MFMA GEMM (mean |error| 4.0e-7 vs 1.1e-6 at |y| ~ 1)
+// at 2.8 x its speed (tools/split_gemm_probe.py).  The two kernels here produce the operands: the split one-hot
+// input and the bias + activation + re-split between two layers.
+constexpr float kSplitScale = 2048.0f;        // 2^11
+constexpr u32 kHalfOne = 0x3C00u, kHalfScaleInv = 0x1000u;   // 1.0 and 2^-11 as IEEE half
+
+__device__ __forceinline__ u32 pack_half2(float lo, float hi) {
+    typedef __attribute__((ext_vector_type(2))) float float2_;
+    typedef __attribute__((ext_vector_type(2))) _Float16 half2_;
+    float2_ v = {lo, hi};
+    half2_ r = __builtin_convertvector(v, half2_);   // round to nearest even
+    return __builtin_bit_cast(u32, r);
+}
+__device__ __forceinline__ float round_to_half_f32(float x) { return (float)(_Float16)x; }
+
+// out[r][c] = onehot(r)[c] for c < 480 and onehot(r)[c - 480] * 2^-11 for c >= 480 (IEEE half, row pitch 960): the A operand
+// whose product with [W_hi | W_lo] is the input layer in one GEMM.  One 16-byte chunk per thread, inside one cubie's block.
+__global__ __launch_bounds__(kBlock) void k_oh_split_f16(const u8 *__restrict__ soa, size_t n, size_t stride, uint4 *__restrict__ out) {
+    constexpr int kChunks = 2 * kOH / 8;   // 120 chunks of 8 halves per row
+    for (size_t idx = (size_t)blockIdx.x * kBlock + threadIdx.x; idx < n * kChunks; idx += (size_t)gridDim.x * kBlock) {
+        const size_t r = idx / kChunks;
+        const u32 ch = (u32)(idx - r * kChunks);
+        const u32 c = (ch * 8) % kOH;                      // column inside the 480-wide one-hot
+        const u32 one = ch * 8 >= (u32)kOH ? kHalfScaleInv : kHalfOne;
+        const u32 code = soa[(size_t)(c / 24) * stride + r];
+        const u32 off = code - (c % 24);                   // position of the 1 inside this chunk, if < 8
+        u32 w[4] = {0, 0, 0, 0};
+        if (off < 8) w[off >> 1] = one << (16 * (off & 1));
+        out[idx] = make_uint4(w[0], w[1], w[2], w[3]);
+    }
+}
+
+// y = act(c + corr_scale * c_corr + bias); hi/lo halves to out_hl[r][col] / out_hl[r][n_cols + col] (row pitch 2 n_cols), or
+// y itself to out_f32.  The small correction product is added to the main one here, in fp32.
+template <int ACT>
+__global__ __launch_bounds__(kBlock) void k_split_act(const float4 *__restrict__ c, const float4 *__restrict__ c_corr, float corr_scale,
+                                                      size_t n_rows, size_t n_cols, const float4 *__restrict__ bias, float alpha,
+                                                      uint4 *__restrict__ out_hl, float4 *__restrict__ out_f32) {
+    const size_t chunks = n_cols / 8;
+    for (size_t idx = (size_t)blockIdx.x * kBlock + threadIdx.x; idx < n_rows * chunks; idx += (size_t)gridDim.x * kBlock) {
+        const size_t r = idx / chunks, ch = idx - r * chunks;
+        float4 a0 = c[idx * 2], a1 = c[idx * 2 + 1];
+        const float4 b0 = bias[ch * 2], b1 = bias[ch * 2 + 1];
+        if (c_corr) {
+            const float4 k0 = c_corr[idx * 2], k1 = c_corr[idx * 2 + 1];
+            a0 = make_float4(a0.x + corr_scale * k0.x, a0.y + corr_scale * k0.y, a0.z + corr_scale * k0.z, a0.w + corr_scale * k0.w);
+            a1 = make_float4(a1.x + corr_scale * k1.x, a1.y + corr_scale * k1.y, a1.z + corr_scale * k1.z, a1.w + corr_scale * k1.w);
+        }
+        float y[8] = {a0.x + b0.x, a0.y + b0.y, a0.z + b0.z, a0.w + b0.w, a1.x + b1.x, a1.y + b1.y, a1.z + b1.z, a1.w + b1.w};
+#pragma unroll
+        for (int e = 0; e < 8; ++e)
+            y[e] = ACT == RC_ACT_RELU ? fmaxf(y[e], 0.f) : ACT == RC_ACT_ELU ? (y[e] > 0.f ? y[e] : alpha * expm1f(y[e])) : y[e];
+        if (out_f32) {
+            out_f32[idx * 2] = make_float4(y[0], y[1], y[2], y[3]);
+            out_f32[idx * 2 + 1] = make_float4(y[4], y[5], y[6], y[7]);
+        }
+        if (out_hl) {
+            float hi[8], lo[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                hi[e] = round_to_half_f32(y[e]);
+                lo[e] = (y[e] - hi[e]) * kSplitScale;
+            }
+            uint4 *row = out_hl + r * (2 * chunks);
+            row[ch] = make_uint4(pack_half2(hi[0], hi[1]), pack_half2(hi[2], hi[3]), pack_half2(hi[4], hi[5]), pack_half2(hi[6], hi[7]));
+            row[chunks + ch] = make_uint4(pack_half2(lo[0], lo[1]), pack_half2(lo[2], lo[3]), pack_half2(lo[4], lo[5]), pack_half2(lo[6], lo[7]));
+        }
+    }
+}
+
+extern "C" int rc_oh_split_f16(const int8_t *soa, size_t n, size_t stride, uint16_t *out, rc_stream_t stream) {
+    if (n == 0) return RC_OK;
+    RC_CHECK_SOA(soa, n, stride);
+    RC_REQUIRE(out != nullptr, RC_ERR_NULL);
+    RC_REQUIRE(aligned16(out), RC_ERR_ALIGN);
+    hipLaunchKernelGGL(k_oh_split_f16, dim3(grid_for(n * (2 * kOH / 8), kBlock, 256 * 16)), dim3(kBlock), 0, (hipStream_t)stream,
+                       (const u8 *)soa, n, stride, (uint4 *)out);
+    return launch_status();
+}
+
+extern "C" int rc_split_act_f16(const float *c, const float *c_corr, float corr_scale, size_t n_rows, size_t n_cols, const float *bias,
+                                int activation, float alpha, uint16_t *out_hi_lo, float *out_f32, rc_stream_t stream) {
+    if (n_rows == 0 || n_cols == 0) return RC_OK;
+    RC_REQUIRE(c && bias && (out_hi_lo || out_f32), RC_ERR_NULL);
+    RC_REQUIRE(aligned16(c) && aligned16(c_corr) && aligned16(bias) && aligned16(out_hi_lo) && aligned16(out_f32) && n_cols % 8 == 0, RC_ERR_ALIGN);
+    RC_REQUIRE(activation >= RC_ACT_NONE && activation <= RC_ACT_ELU, RC_ERR_RANGE);
+    const dim3 grid(grid_for(n_rows * (n_cols / 8), kBlock, 256 * 16)), block(kBlock);
+    hipStream_t s = (hipStream_t)stream;
+#define RC_LAUNCH_SPLIT(ACT)                                                                                                  \
+    hipLaunchKernelGGL(k_split_act<ACT>, grid, block, 0, s, (const float4 *)c, (const float4 *)c_corr, corr_scale, n_rows, n_cols, \
+                       (const float4 *)bias, alpha,                                                                            \
+                       (uint4 *)out_hi_lo, (float4 *)out_f32)
+    if (activation == RC_ACT_ELU) RC_LAUNCH_SPLIT(RC_ACT_ELU);
+    else if (activation == RC_ACT_RELU) RC_LAUNCH_SPLIT(RC_ACT_RELU);
+    else RC_LAUNCH_SPLIT(RC_ACT_NONE);
+#undef RC_LAUNCH_SPLIT
+    return launch_status();
+}
+
 extern "C" int rc_adi_targets(const float *values, const uint8_t *child_solved, const uint8_t *state_solved, size_t n,
                               size_t depth, float win_reward, int fix_mode, int64_t *policy_target, float *value_target,
                               rc_stream_t stream) {

@@ -275,6 +275,12 @@ class InferenceNet:
     def supports_cubes(self) -> bool:
         return self._fused_first is not None
 
+    def workspace(self, rows: int):
+        """Buffer for the fused input layer's output (`x1` of the *_cubes methods), or None."""
+        if self._fused_first is None:
+            return None
+        return torch.empty((rows, self._fused_first[4]), dtype=torch.bfloat16, device=self.device)
+
     @torch.no_grad()
     def first_layer(self, cubes, out: torch.Tensor = None, lo: int = 0, n: int = None) -> torch.Tensor:
         """act(Linear(as_oh(cubes[lo:lo+n]))) as one HIP kernel: bf16 [n, H] without a one-hot matrix (lo % 16 == 0)."""
@@ -355,6 +361,129 @@ class InferenceNet:
         return self._run(self.value_layers, oh).float().reshape(-1)
 
 
+SPLIT_SCALE = 2.0 ** 11
+F32_SPLIT = "f32_split"   # `net_dtype` value selecting SplitF32Net
+
+
+class SplitF32Net:
+    """
+    The eval-mode forward of an fc_* `Model` at fp32 accuracy on the f16 matrix cores (MI355X has no TF32 and its fp32
+    MFMA runs at 1/16 of the f16 rate).  Every float travels as two IEEE halves, x = hi + lo * 2^-11 (22 significant
+    bits), and a layer is three f16 MFMA products with fp32 accumulation,
+        y = act(hi_x W_hi^T + 2^-11 (hi_x W_lo^T + lo_x W_hi^T) + b),
+    i.e. two library GEMMs per layer (K and 2K deep) and one HIP kernel (bias + activation + re-split).  BatchNorm is
+    folded in float64 as in InferenceNet, the two heads are merged, the 13-wide output layer runs in plain fp32.
+    Against the float64 forward the error is BELOW that of the fp32 GEMM chain (tests/test_net_gpu.py), at ~2.5x its
+    speed; it is the reference-precision engine of bench.py.  Same interface as InferenceNet.
+    """
+    dtype = F32_SPLIT
+    input_dtype = torch.float32
+    supports_cubes = True
+
+    def __init__(self, model: Model, device=None):
+        ref = InferenceNet(model, dtype=torch.float64, device=device, first_layer_table="onehot")
+        self.device = ref.device
+        self.layers, self.value_layers = self._split(ref.layers), self._split(ref.value_layers)
+        self.flops_per_state = ref.flops_per_state
+        self.n_out = ref.layers[-1][0].shape[0]
+
+    @staticmethod
+    def _split(layers):
+        out = []
+        for i, (W, b, act) in enumerate(layers):
+            W, b = W.double(), b.double()
+            if i == len(layers) - 1:
+                assert act is None
+                out.append(("f32", W.float().contiguous(), b.float().contiguous()))
+                continue
+            assert bool(torch.isfinite(W).all()) and float(W.abs().max()) < 3.0e4, "weights outside IEEE half range"
+            assert W.shape[0] % 8 == 0
+            hi = W.half()
+            lo = ((W - hi.double()) * SPLIT_SCALE).half()
+            code = 0 if act is None else 1 if isinstance(act, nn.ReLU) else 2
+            alpha = float(getattr(act, "alpha", 1.0))
+            if i == 0:    # one-hot input: x_lo = 0, so y = oh W_hi^T + 2^-11 oh W_lo^T = [oh, oh 2^-11] [W_hi | W_lo]^T
+                out.append(("in", torch.cat([hi, lo], 1).contiguous(), b.float().contiguous(), code, alpha))
+            else:
+                out.append(("hid", hi.contiguous(), torch.cat([lo, hi], 1).contiguous(), b.float().contiguous(), code, alpha))
+        return out
+
+    def workspace(self, rows: int):
+        return None
+
+    # ---- operands ---------------------------------------------------------------------------------------------
+    def _input_from_cubes(self, cubes, lo: int = 0, n: int = None) -> torch.Tensor:
+        from librubiks import _hip
+        if lo or n is not None:
+            n = cubes.n - lo if n is None else n
+            assert lo % 16 == 0 and 0 <= lo and lo + n <= cubes.n
+            cubes = _CubeWindow(cubes.soa.data_ptr() + lo, n, cubes.stride)
+        a = torch.empty((cubes.n, 2 * OH_WIDTH), dtype=torch.float16, device=self.device)
+        _hip.check(_hip.lib().rc_oh_split_f16(_soa_ptr(cubes), cubes.n, cubes.stride, a.data_ptr(), _hip.stream_ptr()),
+                   "rc_oh_split_f16")
+        return a
+
+    @staticmethod
+    def _input_from_oh(oh: torch.Tensor) -> torch.Tensor:
+        oh = oh.float()
+        return torch.cat([oh, oh * (1.0 / SPLIT_SCALE)], 1).half()   # exact: entries are 0, 1 and 2^-11
+
+    @staticmethod
+    def _act(c: torch.Tensor, corr, bias: torch.Tensor, code: int, alpha: float, split: bool) -> torch.Tensor:
+        """act(c + 2^-11 corr + bias) as [hi | lo] halves (split) or as fp32."""
+        from librubiks import _hip
+        n, w = c.shape
+        out = torch.empty((n, 2 * w), dtype=torch.float16, device=c.device) if split else torch.empty_like(c)
+        _hip.check(_hip.lib().rc_split_act_f16(c.data_ptr(), None if corr is None else corr.data_ptr(), 1.0 / SPLIT_SCALE, n, w,
+                                               bias.data_ptr(), code, alpha, out.data_ptr() if split else None,
+                                               None if split else out.data_ptr(), _hip.stream_ptr()), "rc_split_act_f16")
+        return out
+
+    @torch.no_grad()
+    def _forward(self, a: torch.Tensor, layers) -> torch.Tensor:
+        """a: [n, 960] half operand of the input layer -> fp32 [n, n_out]."""
+        for i, layer in enumerate(layers):
+            last_hidden = i == len(layers) - 2
+            corr = None
+            if layer[0] == "in":
+                _, B, b, code, alpha = layer
+                c = torch.mm(a, B.t(), out_dtype=torch.float32)
+            elif layer[0] == "hid":
+                _, Wh, B2, b, code, alpha = layer
+                K = Wh.shape[1]
+                c = torch.mm(a[:, :K], Wh.t(), out_dtype=torch.float32)   # hi x hi
+                corr = torch.mm(a, B2.t(), out_dtype=torch.float32)       # hi x lo + lo x hi, scaled by 2^11; added in the kernel below
+            else:
+                _, W, b = layer
+                return torch.addmm(b, a, W.t())
+            a = self._act(c, corr, b, code, alpha, split=not last_hidden)   # the output layer takes plain fp32 activations
+        return a
+
+    # ---- InferenceNet's interface --------------------------------------------------------------------------------
+    @torch.no_grad()
+    def __call__(self, oh: torch.Tensor):
+        out = self._forward(self._input_from_oh(oh), self.layers)
+        return out[:, :N_ACTIONS], out[:, N_ACTIONS]
+
+    @torch.no_grad()
+    def value(self, oh: torch.Tensor) -> torch.Tensor:
+        return self._forward(self._input_from_oh(oh), self.value_layers).reshape(-1)
+
+    @torch.no_grad()
+    def head_cubes(self, cubes, x1=None) -> torch.Tensor:
+        """[n, 13] float32: 12 policy logits, then the value (the layout rc_mcts_backup_head reads)."""
+        return self._forward(self._input_from_cubes(cubes), self.layers)
+
+    @torch.no_grad()
+    def forward_cubes(self, cubes, x1=None):
+        out = self.head_cubes(cubes)
+        return out[:, :N_ACTIONS], out[:, N_ACTIONS]
+
+    @torch.no_grad()
+    def value_cubes(self, cubes, x1=None, lo: int = 0, n: int = None) -> torch.Tensor:
+        return self._forward(self._input_from_cubes(cubes, lo, n), self.value_layers).reshape(-1)
+
+
 class _CubeWindow:
     """Rows lo .. lo + n of a DeviceCubes batch as (base pointer, n, stride) for the fused input layer."""
     __slots__ = ("ptr", "n", "stride")
@@ -404,7 +533,7 @@ def net_fingerprint(net, dtype=None):
     `load_state_dict` and `.data` swaps all change it).  Engines (`InferenceNet`, `GenericNet`) are frozen or call
     their module live, so their identity is enough.  Search engines are rebuilt whenever this changes.
     """
-    if isinstance(net, (InferenceNet, GenericNet)):
+    if isinstance(net, (InferenceNet, SplitF32Net, GenericNet)):
         return (id(net),)
     if isinstance(net, Model) and net.config.architecture.startswith("fc"):
         tensors = list(net.parameters()) + list(net.buffers())
@@ -414,8 +543,8 @@ def net_fingerprint(net, dtype=None):
 
 def make_inference_net(net, dtype=torch.bfloat16):
     """The fastest engine that preserves `net`'s eval-mode function."""
-    if isinstance(net, (InferenceNet, GenericNet)):
+    if isinstance(net, (InferenceNet, SplitF32Net, GenericNet)):
         return net
     if isinstance(net, Model) and net.config.architecture.startswith("fc"):
-        return InferenceNet(net, dtype=dtype)
+        return SplitF32Net(net) if dtype == F32_SPLIT else InferenceNet(net, dtype=dtype)
     return GenericNet(net)

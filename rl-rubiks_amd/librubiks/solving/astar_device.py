@@ -89,7 +89,7 @@ class AStarBatch:
         rows = min(NET_CHUNK, self.B * self.N * N_ACT)
         if getattr(self.engine, "supports_cubes", False):
             self._oh = None
-            self._x1 = torch.empty((rows, self.engine._fused_first[4]), dtype=torch.bfloat16, device=self.device)
+            self._x1 = self.engine.workspace(rows)
         else:
             self._oh = torch.empty((rows, 480), dtype=self.engine.input_dtype, device=self.device)
 
@@ -107,7 +107,7 @@ class AStarBatch:
         if getattr(self.engine, "supports_cubes", False):   # input layer fused with the one-hot encoding: no (n, 480) matrix
             for lo in range(0, total, NET_CHUNK):
                 n = min(NET_CHUNK, total - lo)
-                self.values[lo:lo + n] = self.engine.value_cubes(self.new_states, self._x1[:n], lo, n)
+                self.values[lo:lo + n] = self.engine.value_cubes(self.new_states, None if self._x1 is None else self._x1[:n], lo, n)
             return
         for lo in range(0, total, NET_CHUNK):
             n = min(NET_CHUNK, total - lo)

@@ -173,7 +173,7 @@ class MCTSForest:
         self._fused = bool(getattr(self.engine, "supports_cubes", False))
         if self._fused:   # the input layer reads the child SoA directly: no one-hot matrix
             self._oh = None
-            self._x1 = torch.empty((N_ACT * self.B, self.engine._fused_first[4]), dtype=torch.bfloat16, device=self.device)
+            self._x1 = self.engine.workspace(N_ACT * self.B)
         else:
             self._oh = torch.empty((N_ACT * self.B, 480), dtype=self.engine.input_dtype, device=self.device)
         self._graph = None
@@ -191,7 +191,7 @@ class MCTSForest:
         """child_soa -> one-hot (HIP kernel) -> network -> softmax -> static probs / values buffers."""
         cubes, rows = self._net_input()
         if self._fused:
-            logits, values = self.engine.forward_cubes(cubes, self._x1[:rows])
+            logits, values = self.engine.forward_cubes(cubes, None if self._x1 is None else self._x1[:rows])
         else:
             cubes.as_oh(out=self._oh[:rows])
             logits, values = self.engine(self._oh[:rows])
@@ -220,7 +220,7 @@ class MCTSForest:
         _hip.check(self.lib.rc_mcts_expand(m, max_states, st), "rc_mcts_expand")
         if self._fused:   # head GEMM output (12 logits + value per row) goes straight into the backup kernel
             cubes, rows = self._net_input()
-            head = self.engine.head_cubes(cubes, self._x1[:rows])
+            head = self.engine.head_cubes(cubes, None if self._x1 is None else self._x1[:rows])
             _hip.check(self.lib.rc_mcts_backup_head(m, head.data_ptr(), head.stride(0), int(head.dtype == torch.bfloat16), st),
                        "rc_mcts_backup_head")
         else:

@@ -138,3 +138,77 @@ def test_inplace_activation_kernel(n):
         assert float((y == want).float().mean()) > 0.99
     assert _hip.lib().rc_act_bf16_inplace(x.data_ptr(), 12, 2, 1.0, None) == -2      # n % 8 != 0
     assert _hip.lib().rc_act_bf16_inplace(x.data_ptr(), 8, 7, 1.0, None) == -4       # unknown activation
+
+
+def test_split_f32_engine_is_at_least_as_accurate_as_fp32():
+    """
+    SplitF32Net (three f16 MFMA products per layer, fp32 accumulation) against the float64 forward of the module,
+    next to the fp32 forward the reference runs (librubiks/model.py:131-141): the split engine must not be further
+    from float64 than fp32 itself is.  Tolerance stated: its max |error| <= 1.25 x that of the fp32 module, and
+    < 2e-5 absolute on outputs of magnitude ~10.
+    """
+    import copy
+    import os
+    from conftest import ROOT
+    from librubiks import cube
+    from librubiks.model import F32_SPLIT, InferenceNet, Model, ModelConfig, SplitF32Net, make_inference_net
+    torch.manual_seed(0)
+    np.random.seed(0)
+    wdir = os.path.join(ROOT, "weights", "fc_small_r1")
+    nets = [Model.create(ModelConfig()).eval()]
+    if os.path.isdir(wdir):
+        nets.append(Model.load(wdir).eval())
+    cubes, _, _ = cube.scramble_batch(4096, 30, True)
+    oh = cubes.as_oh(torch.float32)
+    for net in nets:
+        eng = make_inference_net(net, F32_SPLIT)
+        assert isinstance(eng, SplitF32Net) and eng.supports_cubes
+        ref64 = copy.deepcopy(net).double()
+        with torch.no_grad():
+            p64, v64 = ref64(oh.double())
+            p32, v32 = net(oh)
+        ps, vs = eng.forward_cubes(cubes)
+        pe, ve = eng(oh)                                  # the one-hot entry point gives the same numbers
+        assert torch.equal(ps, pe) and torch.equal(vs, ve)
+        pi, vi = InferenceNet(net, torch.float32)(oh)     # BN-folded fp32 engine, for reference
+        err = lambda a, b: float((a.double() - b).abs().max())   # noqa: E731
+        e_split = max(err(ps, p64), err(vs, v64.reshape(-1)))
+        e_f32 = max(err(p32, p64), err(v32.reshape(-1), v64.reshape(-1)))
+        e_fold = max(err(pi, p64), err(vi, v64.reshape(-1)))
+        scale = float(p64.abs().max())
+        print(f"|out| <= {scale:.2f}: max |err| vs float64: split {e_split:.3e}, fp32 module {e_f32:.3e}, fp32 folded engine {e_fold:.3e}")
+        assert e_split <= 1.25 * e_f32 + 1e-7 and e_split < 2e-5 * max(1.0, scale / 10)
+        # value head alone (A*'s cost) and a column window of the SoA
+        assert err(eng.value_cubes(cubes), v64.reshape(-1)) <= 1.25 * e_f32 + 1e-7
+        assert torch.equal(eng.value_cubes(cubes, None, 1024, 512), eng.value_cubes(cubes)[1024:1536])
+
+
+def test_split_f32_engine_drives_the_search():
+    """MCTS and A* on the split engine: same solve decisions as the fp32 engine on easy scrambles, trees exact vs oracle replay."""
+    import os
+    from conftest import ROOT
+    from librubiks.model import F32_SPLIT, Model, ModelConfig
+    from librubiks.solving.agents import AStar, MCTS
+    from oracle import cube as oc
+    torch.manual_seed(0)
+    np.random.seed(1)
+    wdir = os.path.join(ROOT, "weights", "fc_small_r1")
+    net = Model.load(wdir).eval() if os.path.isdir(wdir) else Model.create(ModelConfig()).eval()
+    states = np.array([oc.scramble(6 + i % 6, True)[0] for i in range(48)])
+    for use_graph in (False, True):
+        agent = MCTS(net, c=0.6, search_graph=True, net_dtype=F32_SPLIT, use_graph=use_graph)
+        res = agent.search_batch(states, None, 6000, compact=False)
+        assert agent.forest._fused and agent.forest.rows_per_tree == 11
+        for t in range(48):
+            if res.solved[t]:
+                x = states[t]
+                for a in res.queues[t]:
+                    x = oc.rotate(x, *oc.ACTION_SPACE[a])
+                assert oc.is_solved(x)
+        if os.path.isdir(wdir):
+            assert res.solved.mean() > 0.8
+    ra = AStar(net, lambda_=0.2, expansions=20, net_dtype=F32_SPLIT).search_batch(states, None, 4000)
+    rb = AStar(net, lambda_=0.2, expansions=20, net_dtype=torch.float32).search_batch(states, None, 4000)
+    assert np.array_equal(ra.solved, rb.solved)
+    if os.path.isdir(wdir):
+        assert ra.solved.mean() > 0.9 and abs(ra.lengths[ra.solved].mean() - rb.lengths[rb.solved].mean()) < 0.5
