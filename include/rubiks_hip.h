@@ -277,6 +277,12 @@ int rc_mcts_backup_head(const rc_mcts_t *m, const void *head, size_t ld, int hea
  * Each tree still performs exactly the reference's sequence of iterations; only their timing changes, so the
  * slowest descent of the batch no longer sets the pace of every iteration. */
 int rc_mcts_select(const rc_mcts_t *m, double c, uint32_t level_budget, rc_stream_t stream);
+/* rc_mcts_backup (or rc_mcts_backup_head) followed by rc_mcts_select as ONE kernel with the same results: the path part of
+ * the backup is applied by the lanes that re-decide the path's levels, to the rows they hold in registers anyway. */
+int rc_mcts_backup_select(const rc_mcts_t *m, const float *probs, const float *values, double c, uint32_t level_budget,
+                          rc_stream_t stream);
+int rc_mcts_backup_select_head(const rc_mcts_t *m, const void *head, size_t ld, int head_is_bf16, double c, uint32_t level_budget,
+                               rc_stream_t stream);
 /* _complete_graph (agents.py:597-611) for every tree with status RC_MCTS_SOLVED: each leaf is linked, both
  * ways, to those of its 12 children that already exist in the tree (looked up in the tree's hash table). */
 int rc_mcts_complete_graph(const rc_mcts_t *m, rc_stream_t stream);

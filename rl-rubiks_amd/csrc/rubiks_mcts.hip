@@ -173,70 +173,62 @@ __device__ __forceinline__ float head_elem(const void *head, size_t i, bool bf16
 // HEAD = false: probs / values are separate float arrays (generic path, softmax done by the caller).
 // HEAD = true : `probs` is the head GEMM's output (12 logits + value per row, bf16 or float) and the softmax
 //               happens here.
+// The children's part of the backup, by lanes 0..11 of one wave: P, V, W of the new children, W[leaf] = V[neighbors]
+// (agents.py:555-561).  Returns the value that is backed up along the path (every lane).
 template <bool HEAD>
-__global__ __launch_bounds__(kBlock) void k_mcts_backup(rc_mcts_t m, const void *__restrict__ probs_or_head,
-                                                      const float *__restrict__ values, size_t ld, bool head_bf16) {
-    __shared__ float s_best;
+__device__ __forceinline__ float backup_children(const rc_mcts_t &m, u32 t, u32 lane, size_t base, int leaf, const void *probs_or_head,
+                                                 const float *values, size_t ld, bool head_bf16) {
     const float *probs = reinterpret_cast<const float *>(probs_or_head);
-    const u32 t = blockIdx.x, tid = threadIdx.x, lane = tid & (kWave - 1);
-    if (!m.expanded[t]) return;
-    const size_t base = (size_t)t * (m.capacity + 1);
-    const int plen = m.path_len[t];
-    const int *pnode = m.path_node + (size_t)t * m.max_path;
-    const u8 *pact = m.path_act + (size_t)t * m.max_path;
-    const int leaf = pnode[plen - 1];
-    if (tid < kWave) {   // the twelve children: lanes 0..11 of the first wave
-        const bool act = lane < kA;
-        const u32 newm = m.new_mask[t];
-        const bool is_new = act && ((newm >> lane) & 1u);
-        const int idx = act ? m.child_idx[(size_t)t * kA + lane] : 0;
-        // this child's row in the network output: 12 t + k, or 11 t + (rank among the new children) with packed rows
-        const size_t row = (size_t)t * m.rows_per_tree +
-                           (m.rows_per_tree == (u32)kA ? lane : (u32)__popc(newm & ((1u << lane) - 1u)));
-
-        float v = 0.f;
-        if (is_new) {
-            float p[kA];
-            if (HEAD) {
-                float mx = -INFINITY, sum = 0.f;
-    #pragma unroll
-                for (int a = 0; a < kA; ++a) { p[a] = head_elem(probs_or_head, row * ld + a, head_bf16); mx = fmaxf(mx, p[a]); }
-    #pragma unroll
-                for (int a = 0; a < kA; ++a) { p[a] = expf(p[a] - mx); sum += p[a]; }
-    #pragma unroll
-                for (int a = 0; a < kA; ++a) p[a] /= sum;   // agents.py:552 softmax(dim=1)
-                v = head_elem(probs_or_head, row * ld + kA, head_bf16);
-            } else {
-    #pragma unroll
-                for (int a = 0; a < kA; ++a) p[a] = probs[row * kA + a];
-                v = values[row];
-            }
-            m.V[base + idx] = v;
-    #pragma unroll
-            for (int a = 0; a < kA; ++a) {
-                m.P[(base + idx) * kA + a] = p[a];
-                m.W[(base + idx) * kA + a] = v;   // W[new] = v for all 12 actions (agents.py:561)
-            }
-        } else if (act) {
-            v = m.V[base + idx];
+    const bool act = lane < kA;
+    const u32 newm = m.new_mask[t];
+    const bool is_new = act && ((newm >> lane) & 1u);
+    const int idx = act ? m.child_idx[(size_t)t * kA + lane] : 0;
+    // this child's row in the network output: 12 t + k, or 11 t + (rank among the new children) with packed rows
+    const size_t row = (size_t)t * m.rows_per_tree +
+                       (m.rows_per_tree == (u32)kA ? lane : (u32)__popc(newm & ((1u << lane) - 1u)));
+    float v = 0.f;
+    if (is_new) {
+        float p[kA];
+        if (HEAD) {
+            float mx = -INFINITY, sum = 0.f;
+#pragma unroll
+            for (int a = 0; a < kA; ++a) { p[a] = head_elem(probs_or_head, row * ld + a, head_bf16); mx = fmaxf(mx, p[a]); }
+#pragma unroll
+            for (int a = 0; a < kA; ++a) { p[a] = expf(p[a] - mx); sum += p[a]; }
+#pragma unroll
+            for (int a = 0; a < kA; ++a) p[a] /= sum;   // agents.py:552 softmax(dim=1)
+            v = head_elem(probs_or_head, row * ld + kA, head_bf16);
+        } else {
+#pragma unroll
+            for (int a = 0; a < kA; ++a) p[a] = probs[row * kA + a];
+            v = values[row];
         }
-        // best value among the new children (agents.py:559); with no new child the reference raises --
-        // defined here as the best existing neighbour value (oracle/agents.py docstring)
-        const float best = newm ? wave_max12(v, is_new) : wave_max12(v, act);
-        if (act) m.W[(base + leaf) * kA + lane] = v;   // W[leaf] = V[neighbors[leaf]] (agents.py:560)
-        if (lane == 0) s_best = best;
-
+        m.V[base + idx] = v;
+#pragma unroll
+        for (int a = 0; a < kA; ++a) {
+            m.P[(base + idx) * kA + a] = p[a];
+            m.W[(base + idx) * kA + a] = v;   // W[new] = v for all 12 actions (agents.py:561)
+        }
+    } else if (act) {
+        v = m.V[base + idx];
     }
-    // path updates.  NumPy's buffered `N[rows, cols] += 1` counts a (node, action) pair that occurs
-    // twice on the path only once; a mark bit reproduces that for any path length: first every
-    // path edge is marked, then whoever finds the mark replaces it by old + 1.
+    // best value among the new children (agents.py:559); with no new child the reference raises --
+    // defined here as the best existing neighbour value (oracle/agents.py docstring)
+    const float best = newm ? wave_max12(v, is_new) : wave_max12(v, act);
+    if (act) m.W[(base + leaf) * kA + lane] = v;   // W[leaf] = V[neighbors[leaf]] (agents.py:560)
+    return best;
+}
+
+// Path updates of the backup (agents.py:562-570) by a whole workgroup.  NumPy's buffered `N[rows, cols] += 1` counts a
+// (node, action) pair that occurs twice on the path only once; a mark bit reproduces that for any path length: first
+// every path edge is marked, then whoever finds the mark replaces it by old + 1.  Two threads that hold the same pair
+// write the same values, whichever of them runs first, so no ordering is needed inside a pass.
+__device__ __forceinline__ void backup_path(const rc_mcts_t &m, u32 tid, size_t base, const int *pnode, const u8 *pact, int plen,
+                                            float best) {
     const int edges = plen - 1;
     constexpr int kMark = 1 << 30;
-    // All four waves share the path.  Two threads that hold the same (node, action) pair write the same values,
-    // whichever of them runs first, so no ordering is needed inside a pass.
     for (int i = tid; i < edges; i += kBlock) m.N[(base + pnode[i]) * kA + pact[i]] |= kMark;
     __syncthreads();
-    const float best = s_best;
     for (int i = tid; i < edges; i += kBlock) {
         const size_t e = (base + pnode[i]) * kA + pact[i];
         const int nv = m.N[e];
@@ -245,6 +237,24 @@ __global__ __launch_bounds__(kBlock) void k_mcts_backup(rc_mcts_t m, const void 
         m.L[e] = 0;                                             // agents.py:569
         m.L[(base + pnode[i + 1]) * kA + (pact[i] ^ 1)] = 0;    // agents.py:570
     }
+}
+
+template <bool HEAD>
+__global__ __launch_bounds__(kBlock) void k_mcts_backup(rc_mcts_t m, const void *__restrict__ probs_or_head,
+                                                      const float *__restrict__ values, size_t ld, bool head_bf16) {
+    __shared__ float s_best;
+    const u32 t = blockIdx.x, tid = threadIdx.x;
+    if (!m.expanded[t]) return;
+    const size_t base = (size_t)t * (m.capacity + 1);
+    const int plen = m.path_len[t];
+    const int *pnode = m.path_node + (size_t)t * m.max_path;
+    const u8 *pact = m.path_act + (size_t)t * m.max_path;
+    if (tid < kWave) {
+        const float best = backup_children<HEAD>(m, t, tid, base, pnode[plen - 1], probs_or_head, values, ld, head_bf16);
+        if (tid == 0) s_best = best;
+    }
+    __syncthreads();
+    backup_path(m, tid, base, pnode, pact, plen, s_best);
 }
 
 // ---- select: PUCT descent with virtual loss (agents.py:575-595) ---------------------------------
@@ -301,11 +311,12 @@ __device__ __forceinline__ void load_row12(const void *base, size_t row, u32 (&o
         out[4 * i] = v.x, out[4 * i + 1] = v.y, out[4 * i + 2] = v.z, out[4 * i + 3] = v.w;
     }
 }
-__device__ __forceinline__ LaneEval lane_prepare(float c32, const rc_mcts_t &m, size_t row) {
-    u32 n[kA], p[kA], w[kA];
-    load_row12(m.N, row, n);
-    load_row12(m.P, row, p);
-    load_row12(m.W, row, w);
+__device__ __forceinline__ void store_row12(void *base, size_t row, const u32 (&v)[kA]) {
+    uint4 *p = reinterpret_cast<uint4 *>(reinterpret_cast<u32 *>(base) + row);
+#pragma unroll
+    for (int i = 0; i < 3; ++i) p[i] = make_uint4(v[4 * i], v[4 * i + 1], v[4 * i + 2], v[4 * i + 3]);
+}
+__device__ __forceinline__ LaneEval lane_eval(float c32, const u32 (&n)[kA], const u32 (&p)[kA], const u32 (&w)[kA]) {
     int sum = 0;
 #pragma unroll
     for (int a = 0; a < kA; ++a) sum += (int)n[a];
@@ -317,6 +328,13 @@ __device__ __forceinline__ LaneEval lane_prepare(float c32, const rc_mcts_t &m, 
         e.w[a] = __uint_as_float(w[a]);
     }
     return e;
+}
+__device__ __forceinline__ LaneEval lane_prepare(float c32, const rc_mcts_t &m, size_t row) {
+    u32 n[kA], p[kA], w[kA];
+    load_row12(m.N, row, n);
+    load_row12(m.P, row, p);
+    load_row12(m.W, row, w);
+    return lane_eval(c32, n, p, w);
 }
 // cnt5: virtual-loss count of action a in bits 5a .. 5a+4
 __device__ __forceinline__ int lane_pick(const LaneEval &e, u64 cnt5, bool &certain) {
@@ -408,16 +426,30 @@ __device__ __forceinline__ u32 sel_hash(int node) { return ((u32)node * 0x9E3779
 // by node in an LDS hash table.  The sequential walk is therefore one 16-byte load per level (the next record,
 // requested before the revisit test of the current level is done) and no stores; path and virtual losses go
 // to memory once, after the loop.
-__global__ __launch_bounds__(kBlock) void k_mcts_select(rc_mcts_t m, double c, u32 level_budget) {
+//
+// MODE 1 / 2 (rc_mcts_backup_select*): the kernel also IS the backup of the iteration (MODE 2: from the network's head
+// output, softmax inside).  The children's part runs first on one wave; the path part needs no pass of its own: the lane
+// that re-decides level k holds the node's N / P / W rows in registers anyway, applies the visit and the max-backup of
+// EVERY level of the path at that node to them (the chain of the node lists those levels; a repeated (node, action) pair
+// counts once, as NumPy's buffered += does), evaluates the updated rows and -- if it is the node's first level -- writes
+// them back.  One kernel, one pass over the path and one memory round trip less per iteration.
+template <int MODE>
+__global__ __launch_bounds__(kBlock) void k_mcts_select(rc_mcts_t m, double c, u32 level_budget, const void *__restrict__ probs_or_head,
+                                                      const float *__restrict__ values, size_t ld, bool head_bf16) {
+    __shared__ float s_best;                // MODE > 0: the value backed up along the path
     __shared__ int s_first;                 // first level that has to be walked sequentially
     __shared__ int s_node[kMaxPath];        // the path: old levels, then the walked ones
     __shared__ u8 s_act[kMaxPath];
     __shared__ int s_head[kSelHash];        // chains of path levels by node (earlier visits of a state)
     __shared__ u16 s_next[kMaxPath];
     __shared__ u32 s_unc[kMaxPath / 32];    // re-validation: levels float32 could not settle
-    __shared__ int s_seg[256];              // line following: lanes per node bucket of a candidate segment
+    __shared__ u32 s_late[kMaxPath / 32];   // MODE > 0: later levels of nodes the path visits more than once
+    __shared__ int s_seg[256];              // line following: last lane per node bucket of a candidate segment ...
+    __shared__ uint2 s_segent[kWave];       // ... and per lane {node, previous lane of the bucket | action << 8 | rev(arrival) << 12}
     const u32 t = blockIdx.x, tid = threadIdx.x;
-    if (m.status[t] != RC_MCTS_RUNNING) return;
+    const bool running = m.status[t] == RC_MCTS_RUNNING;
+    const bool backup = MODE > 0 && m.expanded[t];   // uniform over the workgroup
+    if (!running && !backup) return;
     const unsigned long long t_begin = wall_clock64();
     const u32 seq = (u32)m.iterations[t] & 0xFFFFu;   // number of the path this call builds (its expansion count)
     const size_t base = (size_t)t * (m.capacity + 1);
@@ -425,6 +457,17 @@ __global__ __launch_bounds__(kBlock) void k_mcts_select(rc_mcts_t m, double c, u
     u8 *pact = m.path_act + (size_t)t * m.max_path;
     uint4 *rec = reinterpret_cast<uint4 *>(m.rec) + base;
     const int plen_old = m.path_len[t];
+    if (MODE > 0 && backup) {
+        if (tid < kWave) {
+            const float best = backup_children<MODE == 2>(m, t, tid, base, pnode[plen_old - 1], probs_or_head, values, ld, head_bf16);
+            if (tid == 0) s_best = best;
+        }
+        if (!running) {   // the expansion ended the tree (a solved child): its backup is all that is left to do
+            __syncthreads();
+            backup_path(m, tid, base, pnode, pact, plen_old, s_best);
+            return;
+        }
+    }
     const int nlev = plen_old - 1;     // levels 0 .. nlev - 1 carry an action; level nlev is the old leaf
     const u32 row = tid >> 4, rl = tid & 15;
     const bool ract = rl < kA;
@@ -442,25 +485,58 @@ __global__ __launch_bounds__(kBlock) void k_mcts_select(rc_mcts_t m, double c, u
     if (!resume) {
         // Pass A: one lane per level, float32 with the acceptance rule of lane_pick.  Levels it cannot settle (near
         // ties, NaNs, loss counts beyond 5 bits) are flagged for pass B.
-        for (int i = tid; i < kMaxPath / 32; i += kBlock) s_unc[i] = 0;
+        for (int i = tid; i < kMaxPath / 32; i += kBlock) s_unc[i] = s_late[i] = 0;
         __syncthreads();
         const float c32v = (float)c;
-        for (int k = tid; k <= nlev; k += kBlock) {
+        const float best_up = MODE > 0 ? s_best : 0.f;
+        // late = false: every level (MODE 0), or the FIRST level of every node (MODE > 0), which also applies the backup
+        //               to the node's rows and writes them back;
+        // late = true : (MODE > 0) the later levels of nodes the path visits more than once, after a barrier: they must
+        //               read the rows as the first level left them.
+        auto decide = [&](int k, bool late) {
             const int node = s_node[k];
             const int arr = k > 0 ? (int)(s_act[k - 1] ^ 1) : -1;   // own arrival edge
             u64 cnt5 = 0;
             bool dup = false, ovf = false;
+            u32 taken = 0;      // MODE > 0: actions the path takes at this node, over all its levels
+            int first_lvl = k;  // ... and the first of those levels
             for (int j = s_head[sel_hash(node)]; j >= 0;) {
-                if (j < k && s_node[j] == node) {
-                    dup = true;
-                    cnt5_add(cnt5, ovf, (u32)s_act[j]);
-                    if (j > 0) cnt5_add(cnt5, ovf, (u32)(s_act[j - 1] ^ 1));
+                if (s_node[j] == node) {
+                    taken |= 1u << s_act[j];
+                    first_lvl = min(first_lvl, j);
+                    if (j < k) {
+                        dup = true;
+                        cnt5_add(cnt5, ovf, (u32)s_act[j]);
+                        if (j > 0) cnt5_add(cnt5, ovf, (u32)(s_act[j - 1] ^ 1));
+                    }
                 }
                 const u32 nx = s_next[j];
                 j = nx == 0xFFFFu ? -1 : (int)nx;
             }
+            if (MODE > 0 && backup && !late && k != first_lvl) {
+                atomicOr(&s_late[k >> 5], 1u << (k & 31));
+                return;
+            }
             const size_t r = (base + node) * kA;
-            const LaneEval e = lane_prepare(c32v, m, r);
+            u32 n[kA], p[kA], w[kA];
+            load_row12(m.N, r, n);
+            load_row12(m.P, r, p);
+            load_row12(m.W, r, w);
+            if (MODE > 0 && backup && !late && taken) {   // N[path, a] += 1 (once per pair), W[path, a] = max(W, best)  (agents.py:562,568)
+#pragma unroll
+                for (int a = 0; a < kA; ++a)
+                    if ((taken >> a) & 1u) {
+                        n[a] += 1u;
+                        w[a] = __float_as_uint(fmaxf(__uint_as_float(w[a]), best_up));
+                    }
+                store_row12(m.N, r, n);
+                store_row12(m.W, r, w);
+            }
+            if (MODE > 0 && backup && k < nlev) {   // L[path, a] = 0, L[path[1:], rev a] = 0  (agents.py:569-570)
+                m.L[r + s_act[k]] = 0;
+                m.L[(base + s_node[k + 1]) * kA + (s_act[k] ^ 1)] = 0;
+            }
+            const LaneEval e = lane_eval(c32v, n, p, w);
             bool c0, c1, c2 = true;
             const int b0 = lane_pick(e, 0, c0);
             const int b1 = lane_pick(e, 1ull << (5 * b0), c1);
@@ -476,6 +552,12 @@ __global__ __launch_bounds__(kBlock) void k_mcts_select(rc_mcts_t m, double c, u
             } else {
                 atomicOr(&s_unc[k >> 5], 1u << (k & 31));
             }
+        };
+        for (int k = tid; k <= nlev; k += kBlock) decide(k, false);
+        if (MODE > 0 && backup) {
+            __syncthreads();
+            for (int k0 = 32 * (int)(tid >> 5); k0 <= nlev; k0 += 32 * (kBlock / 32))   // each group of 32 lanes takes a word of flags
+                if ((s_late[k0 >> 5] >> (tid & 31)) & 1u) decide(k0 + (int)(tid & 31), true);
         }
         __syncthreads();
         // Pass B: the flagged levels in float64, NumPy's evaluation order, one 16-lane row per level.
@@ -598,6 +680,8 @@ __global__ __launch_bounds__(kBlock) void k_mcts_select(rc_mcts_t m, double c, u
         // float32 evaluation of its rows in the lane (lane_pick) with the exact loss counts: earlier visits in the
         // chains plus earlier lanes of the segment at the same node.  The leading run of passing levels is appended
         // in one step: two or three memory round trips per segment instead of one per level.
+        // Consecutive segments of one line are chained without returning to the sequential step, and the line's nodes of
+        // the NEXT segment are requested while this one is being checked.
         const u32 tag = (u32)__builtin_amdgcn_readfirstlane((int)x.w);
         const u32 tseq = tag >> 16, age = (seq - tseq) & 0xFFFFu;
         int room = max_path - plen - 1;
@@ -605,87 +689,112 @@ __global__ __launch_bounds__(kBlock) void k_mcts_select(rc_mcts_t m, double c, u
         if (!visited && tseq != 0 && age >= 1 && age <= ring_k && (tag & 15u) == (u32)arg && room > 0) {
             const size_t line = ((size_t)t * ring_k + (tseq & (ring_k - 1))) * (size_t)max_path;
             const int llen = m.ring_len[(size_t)t * ring_k + (tseq & (ring_k - 1))];
-            const int li = (int)((tag >> 4) & 0xFFFu) + 1 + (int)lane;     // lane i checks level k + 1 + i
-            const bool in_line = li < llen && (int)lane < room;
-            const int node_i = in_line ? m.ring_node[line + li] : 0;
-            const u32 act_i = in_line ? (u32)m.ring_act[line + li] : kNoAct;
-            const u32 arr_i = (lane == 0 || !in_line) ? (u32)arg : (u32)m.ring_act[line + li - 1];
-            const u32x4 r = load_rec(tb, node_i);
-            const bool inner = in_line && act_i != kNoAct;
-            const int nl_i = inner ? m.nbr[(base + node_i) * kA + act_i] : 0;   // where the line's action leads
-            const u32 rb0 = r.z & 15u, rb1 = (r.z >> 8) & 15u;
-            u32 d_i = (arr_i ^ 1u) == rb0 ? rb1 : rb0;
-            // earlier visits of the lane's node: in the chains (levels <= k) ...
-            u64 cnt5 = 0;
-            bool again = false, unsure = false;
-            for (int j = in_line ? s_head[sel_hash(node_i)] : -1; j >= 0;) {
-                if (s_node[j] == node_i) {
-                    again = true;
-                    cnt5_add(cnt5, unsure, (u32)s_act[j]);
-                    if (j > 0) cnt5_add(cnt5, unsure, (u32)(s_act[j - 1] ^ 1));
-                }
-                const u32 nx = s_next[j];
-                j = nx == 0xFFFFu ? -1 : (int)nx;
-            }
-            // ... and among the lanes above (they follow the line by premise: departure act_j, arrival rev(arr_j)).  Only
-            // lanes that share a node bucket with another lane can have a partner: usually a handful of the 64.
-            const LaneEval e = lane_prepare(c32, m, (base + node_i) * kA);   // requested with the records: one round trip
-            for (int i = lane; i < 256; i += kWave) s_seg[i] = 0;
-            const u32 hb = ((u32)node_i * 0x9E3779B1u) >> 24;
-            if (in_line) atomicAdd(&s_seg[hb], 1);
-            u64 crowd = __ballot(in_line && s_seg[hb] > 1);
-            while (crowd) {
-                const int j = __builtin_ctzll(crowd);
-                crowd &= crowd - 1;
-                const int nj = __builtin_amdgcn_readlane(node_i, j);
-                const u64 hit = __ballot(in_line && nj == node_i) & ~((2ull << j) - 1ull);
-                if (hit) {   // wave-uniform, rare
-                    const u32 aj = (u32)__builtin_amdgcn_readlane((int)act_i, j), rj = (u32)__builtin_amdgcn_readlane((int)arr_i, j) ^ 1u;
-                    if ((hit >> lane) & 1ull) {
+            int lpos = (int)((tag >> 4) & 0xFFFu) + 1;   // line position that lane 0 checks
+            int kb = k;                                   // lane i checks level kb + 1 + i
+            int want = next;                              // the node lane 0 must be at
+            int arr0 = arg;                               // the action that leads to it
+            int total = 0;
+            bool in_line = lpos + (int)lane < llen && (int)lane < room;
+            int node_i = in_line ? m.ring_node[line + lpos + lane] : 0;
+            u32 act_i = in_line ? (u32)m.ring_act[line + lpos + lane] : kNoAct;
+            u32 arr_i = (lane == 0 || !in_line) ? (u32)arr0 : (u32)m.ring_act[line + lpos + lane - 1];
+            bool have = false;
+            for (;;) {
+                const u32x4 r = load_rec(tb, node_i);
+                const bool inner = in_line && act_i != kNoAct;
+                const int nl_i = inner ? m.nbr[(base + node_i) * kA + act_i] : 0;   // where the line's action leads
+                const LaneEval e = lane_prepare(c32, m, (base + node_i) * kA);      // requested with the records: one round trip
+                // the next segment of the line, in flight while this one is checked
+                const int li2 = lpos + kWave + (int)lane;
+                const bool in2 = li2 < llen && kWave + (int)lane < room;
+                const int node2 = in2 ? m.ring_node[line + li2] : 0;
+                const u32 act2 = in2 ? (u32)m.ring_act[line + li2] : kNoAct;
+                const u32 arr2 = in2 ? (u32)m.ring_act[line + li2 - 1] : 0u;
+                const u32 rb0 = r.z & 15u, rb1 = (r.z >> 8) & 15u;
+                u32 d_i = (arr_i ^ 1u) == rb0 ? rb1 : rb0;
+                // earlier visits of the lane's node: in the chains (levels <= kb) ...
+                u64 cnt5 = 0;
+                bool again = false, unsure = false;
+                for (int j = in_line ? s_head[sel_hash(node_i)] : -1; j >= 0;) {
+                    if (s_node[j] == node_i) {
                         again = true;
-                        if (aj != kNoAct) cnt5_add(cnt5, unsure, aj);
-                        cnt5_add(cnt5, unsure, rj);
+                        cnt5_add(cnt5, unsure, (u32)s_act[j]);
+                        if (j > 0) cnt5_add(cnt5, unsure, (u32)(s_act[j - 1] ^ 1));
+                    }
+                    const u32 nx = s_next[j];
+                    j = nx == 0xFFFFu ? -1 : (int)nx;
+                }
+                // ... and among the lanes above (they follow the line by premise: departure act_j, arrival rev(arr_j)): the lanes
+                // of the segment are chained by node bucket in LDS, and every lane walks its bucket's (short) list.
+                for (int i = lane; i < 256; i += kWave) s_seg[i] = 0xFF;
+                const u32 hb = ((u32)node_i * 0x9E3779B1u) >> 24;
+                if (in_line) {
+                    const u32 prev_lane = (u32)atomicExch(&s_seg[hb], (int)lane);
+                    s_segent[lane] = make_uint2((u32)node_i, prev_lane | (act_i << 8) | ((arr_i ^ 1u) << 12));
+                    for (u32 j = (u32)s_seg[hb]; j != 0xFFu;) {
+                        const uint2 en = s_segent[j];
+                        if (j < lane && (int)en.x == node_i) {
+                            again = true;
+                            if (((en.y >> 8) & 15u) != kNoAct) cnt5_add(cnt5, unsure, (en.y >> 8) & 15u);
+                            cnt5_add(cnt5, unsure, (en.y >> 12) & 15u);
+                        }
+                        j = en.y & 0xFFu;
                     }
                 }
-            }
-            if (__ballot(inner && again)) {   // some level revisits a node: its decision from its rows, in the lane
-                cnt5_add(cnt5, unsure, arr_i ^ 1u);   // own arrival edge
-                bool sure;
-                const u32 dx = (u32)lane_pick(e, cnt5, sure);
-                if (again) {
-                    d_i = dx;
-                    unsure |= !sure;
+                if (__ballot(inner && again)) {   // some level revisits a node: its decision from its rows, in the lane
+                    cnt5_add(cnt5, unsure, arr_i ^ 1u);   // own arrival edge
+                    bool sure;
+                    const u32 dx = (u32)lane_pick(e, cnt5, sure);
+                    if (again) {
+                        d_i = dx;
+                        unsure |= !sure;
+                    }
                 }
-            }
-            const int from = __shfl_up(nl_i, 1);
-            const bool ok = inner && !(r.z & kRecLeaf) && !(again && unsure) && d_i == act_i && (lane == 0 ? next : from) == node_i;
-            const u64 okm = __ballot(ok);
-            const int q = ~okm ? __builtin_ctzll(~okm) : kWave;
-            ++line_rounds;
-            revisits += __popcll(__ballot(again) & ((q < kWave ? (1ull << q) : 0ull) - 1ull));
-            if (q > 0) {
+                const int from = __shfl_up(nl_i, 1);
+                const bool ok = inner && !(r.z & kRecLeaf) && !(again && unsure) && d_i == act_i && (lane == 0 ? want : from) == node_i;
+                const u64 okm = __ballot(ok);
+                const int q = ~okm ? __builtin_ctzll(~okm) : kWave;
+                ++line_rounds;
+                revisits += __popcll(__ballot(again) & ((q < kWave ? (1ull << q) : 0ull) - 1ull));
                 if ((int)lane < q) {
-                    const int kk = k + 1 + (int)lane;
+                    const int kk = kb + 1 + (int)lane;
                     s_node[kk] = node_i;
                     s_act[kk] = (u8)act_i;
                     s_next[kk] = (u16)atomicExch(&s_head[sel_hash(node_i)], kk);
                 }
-                cur = __builtin_amdgcn_readlane(nl_i, q - 1);
-                prev_act = (int)__builtin_amdgcn_readlane((int)act_i, q - 1);
-                const bool have = q < kWave && ((__ballot(in_line && node_i == cur) >> q) & 1ull);
-                if (have) {
-                    x.x = (u32)__builtin_amdgcn_readlane((int)r.x, q & 63);
-                    x.y = (u32)__builtin_amdgcn_readlane((int)r.y, q & 63);
-                    x.z = (u32)__builtin_amdgcn_readlane((int)r.z, q & 63);
-                    x.w = (u32)__builtin_amdgcn_readlane((int)r.w, q & 63);
-                } else {
-                    x = load_rec(tb, cur);
+                total += q;
+                if (q > 0) {
+                    want = __builtin_amdgcn_readlane(nl_i, q - 1);
+                    arr0 = (int)__builtin_amdgcn_readlane((int)act_i, q - 1);
                 }
+                if (q < kWave) {   // the run ends inside this segment: lane q's record, if it is the node we are at, is at hand
+                    have = (__ballot(in_line && node_i == want) >> q) & 1ull;
+                    if (have) {
+                        x.x = (u32)__builtin_amdgcn_readlane((int)r.x, q);
+                        x.y = (u32)__builtin_amdgcn_readlane((int)r.y, q);
+                        x.z = (u32)__builtin_amdgcn_readlane((int)r.z, q);
+                        x.w = (u32)__builtin_amdgcn_readlane((int)r.w, q);
+                    }
+                    break;
+                }
+                kb += kWave;
+                lpos += kWave;
+                room -= kWave;
+                in_line = in2;
+                node_i = node2;
+                act_i = act2;
+                arr_i = arr2;
+                if (!__ballot(in_line)) break;   // line or room exhausted
+            }
+            if (total > 0) {
+                cur = want;
+                prev_act = arr0;
+                if (!have) x = load_rec(tb, cur);
                 h = sel_hash(cur);
                 head = s_head[h];
-                plen += 1 + q;
-                walked += (u32)q;
-                line_levels += q;
+                plen += 1 + total;
+                walked += (u32)total;
+                line_levels += total;
                 continue;
             }
         }
@@ -943,7 +1052,27 @@ int rc_mcts_shorten(const rc_mcts_t *m, rc_stream_t stream) {
 
 int rc_mcts_select(const rc_mcts_t *m, double c, uint32_t level_budget, rc_stream_t stream) {
     if (int rc = check_mcts(m)) return rc;
-    hipLaunchKernelGGL(k_mcts_select, dim3(m->n_trees), dim3(kBlock), 0, (hipStream_t)stream, *m, c, level_budget);
+    hipLaunchKernelGGL(k_mcts_select<0>, dim3(m->n_trees), dim3(kBlock), 0, (hipStream_t)stream, *m, c, level_budget,
+                       (const void *)nullptr, (const float *)nullptr, (size_t)0, false);
+    return launch_status();
+}
+
+int rc_mcts_backup_select(const rc_mcts_t *m, const float *probs, const float *values, double c, uint32_t level_budget,
+                          rc_stream_t stream) {
+    if (int rc = check_mcts(m)) return rc;
+    RC_REQUIRE(probs && values, RC_ERR_NULL);
+    hipLaunchKernelGGL(k_mcts_select<1>, dim3(m->n_trees), dim3(kBlock), 0, (hipStream_t)stream, *m, c, level_budget,
+                       (const void *)probs, values, (size_t)0, false);
+    return launch_status();
+}
+
+int rc_mcts_backup_select_head(const rc_mcts_t *m, const void *head, size_t ld, int head_is_bf16, double c, uint32_t level_budget,
+                               rc_stream_t stream) {
+    if (int rc = check_mcts(m)) return rc;
+    RC_REQUIRE(head != nullptr, RC_ERR_NULL);
+    RC_REQUIRE(ld >= (size_t)kActions + 1, RC_ERR_RANGE);
+    hipLaunchKernelGGL(k_mcts_select<2>, dim3(m->n_trees), dim3(kBlock), 0, (hipStream_t)stream, *m, c, level_budget, head,
+                       (const float *)nullptr, ld, head_is_bf16 != 0);
     return launch_status();
 }
 

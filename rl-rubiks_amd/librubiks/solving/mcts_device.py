@@ -42,6 +42,8 @@ _hip.register({
     "rc_mcts_backup": [POINTER(_McStruct), c_void_p, c_void_p, c_void_p],
     "rc_mcts_backup_head": [POINTER(_McStruct), c_void_p, c_size_t, c_int, c_void_p],
     "rc_mcts_select": [POINTER(_McStruct), c_double, c_uint32, c_void_p],
+    "rc_mcts_backup_select": [POINTER(_McStruct), c_void_p, c_void_p, c_double, c_uint32, c_void_p],
+    "rc_mcts_backup_select_head": [POINTER(_McStruct), c_void_p, c_size_t, c_int, c_double, c_uint32, c_void_p],
     "rc_mcts_complete_graph": [POINTER(_McStruct), c_void_p],
     "rc_mcts_shorten": [POINTER(_McStruct), c_void_p],
 })
@@ -221,15 +223,15 @@ class MCTSForest:
         if self._fused:   # head GEMM output (12 logits + value per row) goes straight into the backup kernel
             cubes, rows = self._net_input()
             head = self.engine.head_cubes(cubes, None if self._x1 is None else self._x1[:rows])
-            _hip.check(self.lib.rc_mcts_backup_head(m, head.data_ptr(), head.stride(0), int(head.dtype == torch.bfloat16), st),
-                       "rc_mcts_backup_head")
+            _hip.check(self.lib.rc_mcts_backup_select_head(m, head.data_ptr(), head.stride(0), int(head.dtype == torch.bfloat16),
+                                                           c, self.level_budget, st), "rc_mcts_backup_select_head")
         else:
             self._evaluate_children()
-            _hip.check(self.lib.rc_mcts_backup(m, self.probs.data_ptr(), self.values.data_ptr(), st), "rc_mcts_backup")
-        _hip.check(self.lib.rc_mcts_select(m, c, self.level_budget, st), "rc_mcts_select")
+            _hip.check(self.lib.rc_mcts_backup_select(m, self.probs.data_ptr(), self.values.data_ptr(), c, self.level_budget, st),
+                       "rc_mcts_backup_select")
 
     def step(self, c: float, max_states: int, use_graph: bool = True):
-        """One lock-step iteration of every running tree: expand -> network -> backup -> select."""
+        """One lock-step iteration of every running tree: expand -> network -> backup + select (one kernel)."""
         if self._root_phase:   # the roots' own expansion: 12 new children per tree, run once, eagerly
             self._iteration(c, max_states)
             self._root_phase = False
