@@ -442,10 +442,16 @@ __global__ __launch_bounds__(kBlock) void k_mcts_select(rc_mcts_t m, double c, u
     __shared__ u8 s_act[kMaxPath];
     __shared__ int s_head[kSelHash];        // chains of path levels by node (earlier visits of a state)
     __shared__ u16 s_next[kMaxPath];
-    __shared__ u32 s_unc[kMaxPath / 32];    // re-validation: levels float32 could not settle
-    __shared__ u32 s_late[kMaxPath / 32];   // MODE > 0: later levels of nodes the path visits more than once
-    __shared__ int s_seg[256];              // line following: last lane per node bucket of a candidate segment ...
-    __shared__ uint2 s_segent[kWave];       // ... and per lane {node, previous lane of the bucket | action << 8 | rev(arrival) << 12}
+    __shared__ u32 s_unc[kMaxPath / 32];    // re-validation: levels float32 could not settle (bitmap: the complete set)
+    __shared__ u32 s_late[kMaxPath / 32];   // MODE > 0: later levels of nodes the path visits more than once (bitmap)
+    // 1.5 KiB used twice.  Re-validation: the same two sets as dense lists (so that their passes use every lane), as long
+    // as they fit -- what does not fit is found through the bitmaps.  Walk: the lane lists of a line segment.
+    __shared__ u32 s_scratch[384];
+    __shared__ int s_nlate, s_nunc;
+    constexpr int kLateCap = 640, kUncCap = 128;
+    u16 *s_latelist = reinterpret_cast<u16 *>(s_scratch), *s_unclist = s_latelist + kLateCap;
+    int *s_seg = reinterpret_cast<int *>(s_scratch);               // [256] last lane per node bucket of a candidate segment ...
+    uint2 *s_segent = reinterpret_cast<uint2 *>(s_scratch + 256);   // [64] ... and per lane {node, previous lane | action << 8 | rev(arrival) << 12}
     const u32 t = blockIdx.x, tid = threadIdx.x;
     const bool running = m.status[t] == RC_MCTS_RUNNING;
     const bool backup = MODE > 0 && m.expanded[t];   // uniform over the workgroup
@@ -486,6 +492,7 @@ __global__ __launch_bounds__(kBlock) void k_mcts_select(rc_mcts_t m, double c, u
         // Pass A: one lane per level, float32 with the acceptance rule of lane_pick.  Levels it cannot settle (near
         // ties, NaNs, loss counts beyond 5 bits) are flagged for pass B.
         for (int i = tid; i < kMaxPath / 32; i += kBlock) s_unc[i] = s_late[i] = 0;
+        if (tid == 0) s_nlate = s_nunc = 0;
         __syncthreads();
         const float c32v = (float)c;
         const float best_up = MODE > 0 ? s_best : 0.f;
@@ -514,7 +521,9 @@ __global__ __launch_bounds__(kBlock) void k_mcts_select(rc_mcts_t m, double c, u
                 j = nx == 0xFFFFu ? -1 : (int)nx;
             }
             if (MODE > 0 && backup && !late && k != first_lvl) {
-                atomicOr(&s_late[k >> 5], 1u << (k & 31));
+                const int pos = atomicAdd(&s_nlate, 1);
+                if (pos < kLateCap) s_latelist[pos] = (u16)k;
+                else atomicOr(&s_late[k >> 5], 1u << (k & 31));
                 return;
             }
             const size_t r = (base + node) * kA;
@@ -550,20 +559,28 @@ __global__ __launch_bounds__(kBlock) void k_mcts_select(rc_mcts_t m, double c, u
                                        line_tag((seq - 1) & 0xFFFFu, k, k < nlev ? (u32)s_act[k] : kNoAct));
                 if (k < nlev && d != (int)s_act[k]) atomicMin(&s_first, k);
             } else {
+                const int pos = atomicAdd(&s_nunc, 1);
+                if (pos < kUncCap) s_unclist[pos] = (u16)k;
                 atomicOr(&s_unc[k >> 5], 1u << (k & 31));
             }
         };
         for (int k = tid; k <= nlev; k += kBlock) decide(k, false);
         if (MODE > 0 && backup) {
             __syncthreads();
-            for (int k0 = 32 * (int)(tid >> 5); k0 <= nlev; k0 += 32 * (kBlock / 32))   // each group of 32 lanes takes a word of flags
-                if ((s_late[k0 >> 5] >> (tid & 31)) & 1u) decide(k0 + (int)(tid & 31), true);
+            const int nlate = s_nlate;
+            for (int i = tid; i < min(nlate, kLateCap); i += kBlock) decide((int)s_latelist[i], true);
+            if (nlate > kLateCap)   // the overflow, by the bitmap: each group of 32 lanes takes a word of flags
+                for (int k0 = 32 * (int)(tid >> 5); k0 <= nlev; k0 += 32 * (kBlock / 32))
+                    if ((s_late[k0 >> 5] >> (tid & 31)) & 1u) decide(k0 + (int)(tid & 31), true);
         }
         __syncthreads();
         // Pass B: the flagged levels in float64, NumPy's evaluation order, one 16-lane row per level.
-        for (int k0 = 0; k0 <= nlev; k0 += kBlock / 16) {
-            if (((s_unc[k0 >> 5] >> (k0 & 31)) & 0xFFFFu) == 0) continue;   // uniform over the workgroup
-            const int k = k0 + (int)row;
+        const int nunc = s_nunc;
+        const bool by_list = nunc <= kUncCap;   // else: scan the bitmap, 16 levels per step
+        for (int i0 = 0; i0 < (by_list ? nunc : nlev + 1); i0 += kBlock / 16) {
+            if (!by_list && ((s_unc[i0 >> 5] >> (i0 & 31)) & 0xFFFFu) == 0) continue;   // uniform over the workgroup
+            const int i = i0 + (int)row;
+            const int k = by_list ? (i < nunc ? (int)s_unclist[i] : nlev + 1) : i;
             const bool live = k <= nlev && ((s_unc[k >> 5] >> (k & 31)) & 1u);
             const int node = live ? s_node[k] : 0;
             u32 cnt = (live && k > 0 && (u32)(s_act[k - 1] ^ 1) == rl) ? 1u : 0u;   // own arrival edge
