@@ -185,10 +185,10 @@ int rc_adi_targets(const float *values, const uint8_t *child_solved, const uint8
  *
  * Replaces the per-tree Python loop of librubiks/solving/agents.py:415-645 (class MCTS) for B
  * trees at once.  One iteration of every running tree =
- *     rc_mcts_expand  ->  [network on the 12 B child rows]  ->  rc_mcts_backup  ->  rc_mcts_select
+ *     rc_mcts_expand  ->  [network on the 11 B child rows]  ->  rc_mcts_backup  ->  rc_mcts_select
  * Node indices are 1-based per tree, 0 = "no neighbour" (agents.py:419-421); node arrays are
  * tree-major with capacity + 1 rows per tree.  All pointers are device pointers owned by the
- * caller (zero-initialised before rc_mcts_init); the struct itself lives in host memory.
+ * caller (zero-initialised once, before the first rc_mcts_plant); the struct itself lives in host memory.
  */
 #define RC_MCTS_RUNNING 0
 #define RC_MCTS_SOLVED 1        /* a child of the expanded leaf is the solved cube (agents.py:540-543) */
@@ -201,7 +201,7 @@ typedef struct rc_mcts {
     uint32_t capacity;   /* largest node index per tree */
     uint32_t hash_size;  /* slots per tree, power of two, >= 2 * (capacity + 1) */
     uint32_t max_path;   /* descent buffer length per tree (2 .. 4096) */
-    uint32_t rows_per_tree; /* network rows reserved per tree and iteration: 12, or 11 with packed rows (below) */
+    uint32_t rows_per_tree; /* network rows reserved per tree and iteration: 11 (see child_soa) */
     /* per node, [B][capacity + 1] (x12 where noted) */
     void *keys;          /* uint32[4]: the 20 codes packed 5 bits each (6 codes per dword) */
     int32_t *nbr;        /* x12  neighbors   (agents.py:421) */
@@ -223,10 +223,9 @@ typedef struct rc_mcts {
     int32_t *path_node;  /* [B][max_path] indices_visited (agents.py:581,592) */
     uint8_t *path_act;   /* [B][max_path] actions_taken   (agents.py:582,593) */
     /* per iteration staging */
-    int8_t *child_soa;   /* [20][child_stride]: network input.  rows_per_tree = 12: child k of tree t at column 12 t + k.
-                          * rows_per_tree = 11: only the NEW children, packed in child order at columns 11 t + rank.  A
-                          * non-root leaf always has a known child (its parent), so 11 rows suffice for every
-                          * iteration but the root's own expansion, which must run with 12 */
+    int8_t *child_soa;   /* [20][child_stride]: network input: the NEW children of tree t's leaf, packed in child order at
+                          * columns 11 t + rank.  A non-root leaf always has a known child (its parent), so 11 rows
+                          * suffice; a root's iteration takes two steps (phase): [root, children 0..9], then [children 10, 11] */
     size_t child_stride;
     int32_t *child_idx;  /* [B][12] node index of every child of the expanded leaf */
     uint32_t *new_mask;  /* [B] bit k set iff child k was not in the tree before */
@@ -252,18 +251,23 @@ typedef struct rc_mcts {
     int32_t *ring_node;  /* [B][ring_k][max_path] */
     uint8_t *ring_act;   /* [B][ring_k][max_path] action taken at each level, 15 at the path's leaf */
     int32_t *ring_len;   /* [B][ring_k] */
+    /* per tree, [B]: 0 = ordinary iterations; 1 / 2 = first / second step of a planted root's own iteration (| 16: that
+     * expansion found a solved child, reported as RC_MCTS_SOLVED when the second step has completed the tree) */
+    int32_t *phase;
 } rc_mcts_t;
 
-/* Inserts the B root states (SoA) as node 1 of each tree; a solved root gets RC_MCTS_ROOT_SOLVED.
- * Also writes the roots to child_soa columns 12 t so that the caller can evaluate them. */
-int rc_mcts_init(const rc_mcts_t *m, const int8_t *roots_soa, size_t stride, rc_stream_t stream);
-/* P[1], V[1] of every tree from row 12 t of probs[12 B][12] / values[12 B] (agents.py:470-473). */
-int rc_mcts_root_eval(const rc_mcts_t *m, const float *probs, const float *values, rc_stream_t stream);
+/* (Re)starts trees: for i < n_slots, tree slots[i] (or tree i if slots is NULL) is emptied -- its hash table is cleared,
+ * nothing else needs to be -- and gets roots_soa column first_col + i as node 1; a solved root gets RC_MCTS_ROOT_SOLVED.
+ * The root is evaluated and expanded (agents.py:466-473 and the first expand_leaf) inside the next two ordinary
+ * iterations, on the tree's own 11 network rows: see `phase`.  Other trees of the forest are not touched, so finished
+ * trees of a running batch can hand their slots to waiting scrambles between two iterations. */
+int rc_mcts_plant(const rc_mcts_t *m, const int32_t *slots, uint32_t n_slots, const int8_t *roots_soa, size_t stride,
+                  size_t first_col, rc_stream_t stream);
 /* expand_leaf part 1 (agents.py:505-544): 12 children of the path's leaf, dedup against the tree,
  * new indices in child order, links both ways, first solved child. */
 int rc_mcts_expand(const rc_mcts_t *m, uint32_t max_states, rc_stream_t stream);
 /* expand_leaf part 2 (agents.py:555-571): P, V of new children, W/N/L updates along the path.
- * probs = softmax(policy logits) rows, values = value head, both for the 12 B child rows. */
+ * probs = softmax(policy logits) rows, values = value head, both for the 11 B child rows. */
 int rc_mcts_backup(const rc_mcts_t *m, const float *probs, const float *values, rc_stream_t stream);
 /* Same as rc_mcts_backup, but straight from the network's head output: row r of `head` (bf16 when
  * head_is_bf16 != 0, else float; `ld` elements per row) holds the 12 policy logits followed by the value.

@@ -27,20 +27,31 @@ constexpr int kMaxPath = 4096;  // longest PUCT descent the kernels stage in LDS
 // only ever selects CANDIDATES for parallel validation, so a stale or aliased tag costs time, never correctness.
 constexpr u32 kRecLeaf = 1u << 16;
 constexpr u32 kNoAct = 15;
+
+// Life of a tree slot.  A planted root is evaluated and expanded inside the ordinary lock-step iterations, on the 11 network
+// rows every tree owns, in two steps (the root's expansion creates 12 new children, one more than the rows of a step):
+//   ROOT_A  expand the root (children = nodes 2..13); rows: the root itself, then children 0..9
+//   ROOT_B  rows: children 10, 11; then the root's backup (agents.py:555-561) and the first descent
+// A solved child found by the root's expansion is only reported (status) when ROOT_B has completed the tree.
+constexpr int kPhaseNormal = 0, kPhaseRootA = 1, kPhaseRootB = 2, kPhaseMask = 15, kPhaseSolved = 16;
 __device__ __forceinline__ u32 line_tag(u32 seq, int level, u32 act) { return (seq << 16) | ((u32)level << 4) | act; }
 
-// ---- init: root = node 1 ------------------------------------------------------------------------
-__global__ __launch_bounds__(kBlock) void k_mcts_init(rc_mcts_t m, const u8 *__restrict__ roots, size_t stride) {
-    const u32 t = blockIdx.x * kBlock + threadIdx.x;
-    if (t >= m.n_trees) return;
+// ---- plant: (re)start trees.  One workgroup per listed slot: hash table cleared, root = node 1, phase ROOT_A ------
+__global__ __launch_bounds__(kBlock) void k_mcts_plant(rc_mcts_t m, const int *__restrict__ slots, const u8 *__restrict__ roots,
+                                                     size_t stride, size_t first_col) {
+    const u32 t = slots ? (u32)slots[blockIdx.x] : blockIdx.x;
+    const size_t col = first_col + blockIdx.x;
+    uint4 *tab4 = reinterpret_cast<uint4 *>(m.hash + (size_t)t * m.hash_size);
+    for (u32 i = threadIdx.x; i < m.hash_size / 4; i += kBlock) tab4[i] = make_uint4(0, 0, 0, 0);
+    __syncthreads();
+    if (threadIdx.x != 0) return;
     u32 w[4] = {0, 0, 0, 0};
     bool solved = true;
 #pragma unroll
     for (int j = 0; j < kPlanes; ++j) {
-        const u32 code = roots[(size_t)j * stride + t] & 31u;
+        const u32 code = roots[(size_t)j * stride + col] & 31u;
         key_set(w, j, code);
         solved &= code == (u32)(u8)kTables.solved[j];
-        m.child_soa[(size_t)j * m.child_stride + (size_t)m.rows_per_tree * t] = (int8_t)code;
     }
     const uint4 key = make_uint4(w[0], w[1], w[2], w[3]);
     const size_t base = (size_t)t * (m.capacity + 1);
@@ -50,6 +61,11 @@ __global__ __launch_bounds__(kBlock) void k_mcts_init(rc_mcts_t m, const u8 *__r
     m.leaf[base] = 1;   // row 0 is never expanded; the reference's leaves[0] stays True as well
     reinterpret_cast<uint4 *>(m.rec)[base] = make_uint4(0, 0, kRecLeaf, 0);
     reinterpret_cast<uint4 *>(m.rec)[base + 1] = make_uint4(0, 0, kRecLeaf, 0);
+    for (int a = 0; a < kA; ++a) {   // rows of the sentinel and of the root (children get theirs when they are created)
+        m.N[base * kA + a] = m.N[(base + 1) * kA + a] = 0;
+        m.nbr[base * kA + a] = m.nbr[(base + 1) * kA + a] = 0;
+        m.L[base * kA + a] = m.L[(base + 1) * kA + a] = 0;
+    }
     m.n_nodes[t] = 1;
     m.status[t] = solved ? RC_MCTS_ROOT_SOLVED : RC_MCTS_RUNNING;
     m.solved_idx[t] = solved ? 1 : -1;
@@ -60,16 +76,8 @@ __global__ __launch_bounds__(kBlock) void k_mcts_init(rc_mcts_t m, const u8 *__r
     m.path_node[(size_t)t * m.max_path] = 1;
     m.expanded[t] = 0;
     m.new_mask[t] = 0;
-}
-
-__global__ __launch_bounds__(kBlock) void k_mcts_root_eval(rc_mcts_t m, const float *__restrict__ probs,
-                                                          const float *__restrict__ values) {
-    const u32 i = blockIdx.x * kBlock + threadIdx.x;   // (tree, action)
-    if (i >= m.n_trees * kA) return;
-    const u32 t = i / kA, a = i - t * kA;
-    const size_t node = (size_t)t * (m.capacity + 1) + 1;
-    m.P[node * kA + a] = probs[(size_t)t * m.rows_per_tree * kA + a];
-    if (a == 0) m.V[node] = values[(size_t)t * m.rows_per_tree];
+    m.phase[t] = kPhaseRootA;
+    for (u32 i = 0; i < m.ring_k; ++i) m.ring_len[(size_t)t * m.ring_k + i] = 0;   // the previous tenant's lines are void
 }
 
 // ---- expand: one wave per tree, lane k < 12 owns child k ----------------------------------------
@@ -81,13 +89,25 @@ __global__ __launch_bounds__(kWave) void k_mcts_expand(rc_mcts_t m, u32 max_stat
     const u32 t = blockIdx.x, lane = threadIdx.x;
     if (lane == 0) m.expanded[t] = 0;
     if (m.status[t] != RC_MCTS_RUNNING || m.pending[t]) return;   // a suspended descent has no leaf yet
+    const int ph = m.phase[t] & kPhaseMask;
+    const size_t base = (size_t)t * (m.capacity + 1);
+    uint4 *keys = reinterpret_cast<uint4 *>(m.keys) + base;
+    const size_t col0 = (size_t)m.rows_per_tree * t;
+    if (ph == kPhaseRootB) {   // second half of the root's iteration: children 10 and 11 (nodes 12, 13) are evaluated now
+        if (lane < 2) {
+            const uint4 ck = keys[2 + 10 + lane];
+#pragma unroll
+            for (int j = 0; j < kPlanes; ++j) m.child_soa[(size_t)j * m.child_stride + col0 + lane] = (int8_t)key_code(ck, j);
+        }
+        if (lane == 0) m.expanded[t] = 1;
+        return;
+    }
+    const bool root = ph == kPhaseRootA;
     const int n = m.n_nodes[t];
     if ((u32)n + kA > max_states || (u32)n + kA > m.capacity) {   // agents.py:476
         if (lane == 0) m.status[t] = RC_MCTS_EXHAUSTED;
         return;
     }
-    const size_t base = (size_t)t * (m.capacity + 1);
-    uint4 *keys = reinterpret_cast<uint4 *>(m.keys) + base;
     int *tab = m.hash + (size_t)t * m.hash_size;
     const u32 mask = m.hash_size - 1;
     const int plen = m.path_len[t];
@@ -122,12 +142,16 @@ __global__ __launch_bounds__(kWave) void k_mcts_expand(rc_mcts_t m, u32 max_stat
     const u64 newm = __ballot(act && found == 0);
     const int rank = __popcll(newm & ((1ull << lane) - 1ull));
     const int idx = found ? found : n + 1 + rank;
-    // network input: all 12 children at 12 t + k, or only the new ones packed at 11 t + rank
-    const bool packed = m.rows_per_tree != (u32)kA;
-    if (act && (!packed || (!found && rank < 11))) {   // (rank < 11 always holds for a non-root leaf: its parent is known)
-        const size_t col = (size_t)m.rows_per_tree * t + (packed ? (u32)rank : lane);
+    // network input: the new children, packed in child order at columns 11 t + rank (a non-root leaf has at most 11: its
+    // parent is known); the root's step evaluates the root itself first, then children 0..9
+    if (act && !found && rank < (root ? 10 : 11)) {
+        const size_t col = col0 + (u32)rank + (root ? 1u : 0u);
 #pragma unroll
         for (int j = 0; j < kPlanes; ++j) m.child_soa[(size_t)j * m.child_stride + col] = (int8_t)key_code(ck, j);
+    }
+    if (root && lane == kA) {
+#pragma unroll
+        for (int j = 0; j < kPlanes; ++j) m.child_soa[(size_t)j * m.child_stride + col0] = (int8_t)key_code(pk, j);
     }
     if (act && !found) {
         keys[idx] = ck;
@@ -137,10 +161,22 @@ __global__ __launch_bounds__(kWave) void k_mcts_expand(rc_mcts_t m, u32 max_stat
         }
         m.leaf[base + idx] = 1;
         reinterpret_cast<uint4 *>(m.rec)[base + idx] = make_uint4(0, 0, kRecLeaf, 0);
+        // a node's rows start here (no array is ever cleared wholesale): N = 0, L = 0, neighbors = 0 but the way back
+        uint4 *nrow = reinterpret_cast<uint4 *>(m.N + (base + idx) * kA), *brow = reinterpret_cast<uint4 *>(m.nbr + (base + idx) * kA);
+        unsigned long long *lrow = reinterpret_cast<unsigned long long *>(m.L + (base + idx) * kA);
+        u32 back[kA];
+#pragma unroll
+        for (int e = 0; e < kA; ++e) back[e] = (u32)e == (lane ^ 1u) ? (u32)leaf : 0u;
+#pragma unroll
+        for (int e = 0; e < 3; ++e) {
+            nrow[e] = make_uint4(0, 0, 0, 0);
+            brow[e] = make_uint4(back[4 * e], back[4 * e + 1], back[4 * e + 2], back[4 * e + 3]);
+            lrow[e] = 0ull;
+        }
     }
     if (act) {   // links both ways, for seen children too (agents.py:533-535)
         m.nbr[(base + leaf) * kA + lane] = idx;
-        m.nbr[(base + idx) * kA + (lane ^ 1)] = leaf;
+        if (found) m.nbr[(base + idx) * kA + (lane ^ 1)] = leaf;
         m.child_idx[(size_t)t * kA + lane] = idx;
     }
     const u64 solm = __ballot(solved);
@@ -154,7 +190,8 @@ __global__ __launch_bounds__(kWave) void k_mcts_expand(rc_mcts_t m, u32 max_stat
     if (solm) {   // first solved child wins (agents.py:540-543)
         const int first = __ffsll((unsigned long long)solm) - 1;
         if ((int)lane == first) {
-            m.status[t] = RC_MCTS_SOLVED;
+            if (root) m.phase[t] = kPhaseRootA | kPhaseSolved;   // reported once ROOT_B has completed the tree
+            else m.status[t] = RC_MCTS_SOLVED;
             m.solved_idx[t] = idx;
             m.solved_action[t] = first;
         }
@@ -176,47 +213,73 @@ __device__ __forceinline__ float head_elem(const void *head, size_t i, bool bf16
 // The children's part of the backup, by lanes 0..11 of one wave: P, V, W of the new children, W[leaf] = V[neighbors]
 // (agents.py:555-561).  Returns the value that is backed up along the path (every lane).
 template <bool HEAD>
-__device__ __forceinline__ float backup_children(const rc_mcts_t &m, u32 t, u32 lane, size_t base, int leaf, const void *probs_or_head,
-                                                 const float *values, size_t ld, bool head_bf16) {
+__device__ __forceinline__ float net_row(const void *probs_or_head, const float *values, size_t row, size_t ld, bool head_bf16,
+                                         float (&p)[kA]) {
+    if (HEAD) {
+        float mx = -INFINITY, sum = 0.f;
+#pragma unroll
+        for (int a = 0; a < kA; ++a) { p[a] = head_elem(probs_or_head, row * ld + a, head_bf16); mx = fmaxf(mx, p[a]); }
+#pragma unroll
+        for (int a = 0; a < kA; ++a) { p[a] = expf(p[a] - mx); sum += p[a]; }
+#pragma unroll
+        for (int a = 0; a < kA; ++a) p[a] /= sum;   // agents.py:552 softmax(dim=1)
+        return head_elem(probs_or_head, row * ld + kA, head_bf16);
+    }
     const float *probs = reinterpret_cast<const float *>(probs_or_head);
+#pragma unroll
+    for (int a = 0; a < kA; ++a) p[a] = probs[row * kA + a];
+    return values[row];
+}
+
+template <bool HEAD>
+__device__ __forceinline__ float backup_children(const rc_mcts_t &m, u32 t, u32 lane, size_t base, int leaf, int ph,
+                                                 const void *probs_or_head, const float *values, size_t ld, bool head_bf16) {
     const bool act = lane < kA;
     const u32 newm = m.new_mask[t];
-    const bool is_new = act && ((newm >> lane) & 1u);
     const int idx = act ? m.child_idx[(size_t)t * kA + lane] : 0;
-    // this child's row in the network output: 12 t + k, or 11 t + (rank among the new children) with packed rows
-    const size_t row = (size_t)t * m.rows_per_tree +
-                       (m.rows_per_tree == (u32)kA ? lane : (u32)__popc(newm & ((1u << lane) - 1u)));
+    const size_t row0 = (size_t)t * m.rows_per_tree;
+    // which children this step's rows hold: the new ones in child order -- or, for a root (all 12 new), 0..9 behind the
+    // root's own row in ROOT_A and 10, 11 in ROOT_B
+    const bool in_rows = ph == kPhaseRootA ? lane < 10 : ph == kPhaseRootB ? (act && lane >= 10) : (act && ((newm >> lane) & 1u));
+    const size_t row = row0 + (ph == kPhaseRootA ? lane + 1 : ph == kPhaseRootB ? lane - 10 : (u32)__popc(newm & ((1u << lane) - 1u)));
     float v = 0.f;
-    if (is_new) {
+    if (in_rows || (ph == kPhaseRootA && lane == kA)) {
         float p[kA];
-        if (HEAD) {
-            float mx = -INFINITY, sum = 0.f;
-#pragma unroll
-            for (int a = 0; a < kA; ++a) { p[a] = head_elem(probs_or_head, row * ld + a, head_bf16); mx = fmaxf(mx, p[a]); }
-#pragma unroll
-            for (int a = 0; a < kA; ++a) { p[a] = expf(p[a] - mx); sum += p[a]; }
-#pragma unroll
-            for (int a = 0; a < kA; ++a) p[a] /= sum;   // agents.py:552 softmax(dim=1)
-            v = head_elem(probs_or_head, row * ld + kA, head_bf16);
-        } else {
-#pragma unroll
-            for (int a = 0; a < kA; ++a) p[a] = probs[row * kA + a];
-            v = values[row];
-        }
-        m.V[base + idx] = v;
+        const bool is_root = !in_rows;
+        v = net_row<HEAD>(probs_or_head, values, is_root ? row0 : row, ld, head_bf16, p);
+        const size_t node = base + (is_root ? 1 : idx);
+        m.V[node] = v;
 #pragma unroll
         for (int a = 0; a < kA; ++a) {
-            m.P[(base + idx) * kA + a] = p[a];
-            m.W[(base + idx) * kA + a] = v;   // W[new] = v for all 12 actions (agents.py:561)
+            m.P[node * kA + a] = p[a];
+            if (!is_root) m.W[node * kA + a] = v;   // W[new] = v for all 12 actions (agents.py:561)
         }
     } else if (act) {
         v = m.V[base + idx];
     }
+    if (ph == kPhaseRootA) return 0.f;   // the root's own backup follows in ROOT_B, when all its children have values
     // best value among the new children (agents.py:559); with no new child the reference raises --
     // defined here as the best existing neighbour value (oracle/agents.py docstring)
-    const float best = newm ? wave_max12(v, is_new) : wave_max12(v, act);
+    const float best = newm ? wave_max12(v, act && ((newm >> lane) & 1u)) : wave_max12(v, act);
     if (act) m.W[(base + leaf) * kA + lane] = v;   // W[leaf] = V[neighbors[leaf]] (agents.py:560)
     return best;
+}
+
+// Phase bookkeeping after the children's part; returns true if the tree is done with this iteration (no path, no descent).
+__device__ __forceinline__ bool backup_phase_done(const rc_mcts_t &m, u32 t, u32 tid, int phase) {
+    const int ph = phase & kPhaseMask;
+    if (ph == kPhaseRootA) {
+        if (tid == 0) m.phase[t] = kPhaseRootB | (phase & kPhaseSolved);
+        return true;
+    }
+    if (ph == kPhaseRootB) {
+        if (tid == 0) {
+            m.phase[t] = kPhaseNormal;
+            if (phase & kPhaseSolved) m.status[t] = RC_MCTS_SOLVED;
+        }
+        return (phase & kPhaseSolved) != 0;
+    }
+    return false;
 }
 
 // Path updates of the backup (agents.py:562-570) by a whole workgroup.  NumPy's buffered `N[rows, cols] += 1` counts a
@@ -249,11 +312,13 @@ __global__ __launch_bounds__(kBlock) void k_mcts_backup(rc_mcts_t m, const void 
     const int plen = m.path_len[t];
     const int *pnode = m.path_node + (size_t)t * m.max_path;
     const u8 *pact = m.path_act + (size_t)t * m.max_path;
+    const int phase = m.phase[t];
     if (tid < kWave) {
-        const float best = backup_children<HEAD>(m, t, tid, base, pnode[plen - 1], probs_or_head, values, ld, head_bf16);
+        const float best = backup_children<HEAD>(m, t, tid, base, pnode[plen - 1], phase & kPhaseMask, probs_or_head, values, ld, head_bf16);
         if (tid == 0) s_best = best;
     }
     __syncthreads();
+    if (backup_phase_done(m, t, tid, phase)) return;
     backup_path(m, tid, base, pnode, pact, plen, s_best);
 }
 
@@ -463,16 +528,25 @@ __global__ __launch_bounds__(kBlock) void k_mcts_select(rc_mcts_t m, double c, u
     u8 *pact = m.path_act + (size_t)t * m.max_path;
     uint4 *rec = reinterpret_cast<uint4 *>(m.rec) + base;
     const int plen_old = m.path_len[t];
+    const int phase = m.phase[t];
+    if (MODE == 0 && (phase & kPhaseMask) != kPhaseNormal) return;   // a root's first descent follows its backup in ROOT_B
     if (MODE > 0 && backup) {
         if (tid < kWave) {
-            const float best = backup_children<MODE == 2>(m, t, tid, base, pnode[plen_old - 1], probs_or_head, values, ld, head_bf16);
+            const float best = backup_children<MODE == 2>(m, t, tid, base, pnode[plen_old - 1], phase & kPhaseMask, probs_or_head, values,
+                                                           ld, head_bf16);
             if (tid == 0) s_best = best;
+        }
+        if ((phase & kPhaseMask) != kPhaseNormal) {   // uniform over the workgroup
+            __syncthreads();
+            if (backup_phase_done(m, t, tid, phase)) return;
         }
         if (!running) {   // the expansion ended the tree (a solved child): its backup is all that is left to do
             __syncthreads();
             backup_path(m, tid, base, pnode, pact, plen_old, s_best);
             return;
         }
+    } else if (MODE > 0 && (phase & kPhaseMask) != kPhaseNormal) {
+        return;
     }
     const int nlev = plen_old - 1;     // levels 0 .. nlev - 1 carry an action; level nlev is the old leaf
     const u32 row = tid >> 4, rl = tid & 15;
@@ -1002,12 +1076,12 @@ static int check_mcts(const rc_mcts_t *m) {
     RC_REQUIRE(m->keys && m->nbr && m->P && m->W && m->N && m->L && m->V && m->leaf && m->hash && m->n_nodes &&
                    m->status && m->solved_idx && m->solved_action && m->iterations && m->path_len && m->path_node &&
                    m->pending && m->path_act && m->child_soa && m->child_idx && m->new_mask && m->expanded && m->rec && m->ring_node && m->ring_act &&
-                   m->ring_len,
+                   m->ring_len && m->phase,
                RC_ERR_NULL);
     RC_REQUIRE(m->n_trees > 0 && m->capacity >= 13 && m->max_path >= 2 && m->max_path <= (uint32_t)kMaxPath, RC_ERR_RANGE);
     RC_REQUIRE((m->hash_size & (m->hash_size - 1)) == 0 && m->hash_size >= 2 * (m->capacity + 1), RC_ERR_RANGE);
     RC_REQUIRE(aligned16(m->keys) && aligned16(m->rec) && aligned16(m->child_soa) && (m->child_stride & 15u) == 0, RC_ERR_ALIGN);
-    RC_REQUIRE(m->rows_per_tree == 11 || m->rows_per_tree == 12, RC_ERR_RANGE);
+    RC_REQUIRE(m->rows_per_tree == 11, RC_ERR_RANGE);
     RC_REQUIRE(m->ring_k >= 1 && m->ring_k <= 64 && (m->ring_k & (m->ring_k - 1)) == 0, RC_ERR_RANGE);
     RC_REQUIRE(m->child_stride >= round_up((size_t)m->n_trees * m->rows_per_tree, 16), RC_ERR_STRIDE);
     return RC_OK;
@@ -1015,19 +1089,15 @@ static int check_mcts(const rc_mcts_t *m) {
 
 extern "C" {
 
-int rc_mcts_init(const rc_mcts_t *m, const int8_t *roots_soa, size_t stride, rc_stream_t stream) {
+int rc_mcts_plant(const rc_mcts_t *m, const int32_t *slots, uint32_t n_slots, const int8_t *roots_soa, size_t stride, size_t first_col,
+                  rc_stream_t stream) {
     if (int rc = check_mcts(m)) return rc;
-    RC_CHECK_SOA(roots_soa, m->n_trees, stride);
-    hipLaunchKernelGGL(k_mcts_init, dim3(grid_for(m->n_trees, kBlock, 1 << 30)), dim3(kBlock), 0, (hipStream_t)stream, *m,
-                       (const u8 *)roots_soa, stride);
-    return launch_status();
-}
-
-int rc_mcts_root_eval(const rc_mcts_t *m, const float *probs, const float *values, rc_stream_t stream) {
-    if (int rc = check_mcts(m)) return rc;
-    RC_REQUIRE(probs && values, RC_ERR_NULL);
-    hipLaunchKernelGGL(k_mcts_root_eval, dim3(grid_for((size_t)m->n_trees * kActions, kBlock, 1 << 30)), dim3(kBlock), 0,
-                       (hipStream_t)stream, *m, probs, values);
+    if (n_slots == 0) return RC_OK;
+    RC_REQUIRE(roots_soa != nullptr, RC_ERR_NULL);
+    RC_REQUIRE(aligned16(roots_soa) && (stride & 15u) == 0, RC_ERR_ALIGN);
+    RC_REQUIRE(n_slots <= m->n_trees && stride >= first_col + n_slots && (m->hash_size & 3u) == 0, RC_ERR_RANGE);
+    hipLaunchKernelGGL(k_mcts_plant, dim3(n_slots), dim3(kBlock), 0, (hipStream_t)stream, *m, (const int *)slots, (const u8 *)roots_soa,
+                       stride, first_col);
     return launch_status();
 }
 

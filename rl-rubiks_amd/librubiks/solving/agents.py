@@ -304,7 +304,8 @@ class MCTS(DeepAgent):
         """
         One MCTS tree per row of `states` ((G,20) int8 NumPy array or DeviceCubes).  `max_states` is the
         reference's per-tree cap (stop when len + 12 > max_states); `time_limit` bounds the wall time of the
-        whole batch.  See `MCTSRun` for how the batch is driven.
+        whole batch; `max_iterations` bounds every tree's number of expansions (lock-step batches only).
+        See `MCTSRun` for how the batch is driven.
         slots: run at most this many trees at a time and give the places of finished trees to the scrambles
         still waiting (continuous batching): the GPU stays full until the last games instead of idling on the
         stragglers of every batch.  Per-game results are those of a plain batch (trees are independent).
@@ -314,8 +315,10 @@ class MCTS(DeepAgent):
         """
         run = self.start_batch(states, time_limit, max_states, compact=compact, slots=slots)
         assert max_iterations is None or run.S == run.n_games, "max_iterations applies to lock-step batches only"
-        while not run.done and (max_iterations is None or run.it < max_iterations):
-            run.round(None if max_iterations is None else max_iterations - run.it)
+        # a tree's first expansion (its root's) takes two lock-step iterations, every later one a single iteration
+        steps = None if max_iterations is None else max_iterations + 1
+        while not run.done and (steps is None or run.it < steps):
+            run.round(None if steps is None else steps - run.it)
         return run.finish()
 
     @no_grad
@@ -361,8 +364,9 @@ class MCTSRun:
     never waits for the round it has just queued: it reads the tree states of the PREVIOUS round (an asynchronous
     copy into pinned memory) while the GPU works on the current one, so the launch queue never runs dry.
     Finished trees are copied out of the forest (`subset`) and turned into results on a side stream; with
-    `slots` < games their places go to the scrambles still waiting, which make their root iteration in a small
-    forest of their own and are then adopted.  While games are waiting, descents may be cut at the agent's
+    `slots` < games their places go to the scrambles still waiting (`plant`: one launch clears the slots' hash tables
+    and writes the new roots, which the next two iterations evaluate and expand in step with everybody else).  While
+    games are waiting, descents may be cut at the agent's
     `refill_level_budget` new levels per iteration (0 = off, the default since descents follow lines: a budget
     then costs more iterations than it saves time per iteration).
     """
@@ -374,12 +378,7 @@ class MCTSRun:
         S = self.S = self.n_games if slots is None else max(1, min(int(slots), self.n_games))
         forest = self.forest = agent._forest_for(S, max(self.cap_states, 16))
         agent.tt.tick()
-        if S == self.n_games:
-            forest.reset(roots)
-        else:
-            first = DeviceCubes.empty(S)
-            first.soa[:, :S] = roots.soa[:, :S]
-            forest.reset(first)
+        forest.plant(None, roots, 0)       # the first S scrambles; the others move in as trees finish
         self.owner = np.arange(S)          # game index of every slot; -1 once its result has been taken and nobody moved in
         self.stale_until = np.full(S, -1)  # snapshots up to this index predate the tree that now lives in the slot
         self.next_game = S
@@ -451,21 +450,13 @@ class MCTSRun:
         if waiting and len(done) and (len(done) >= self.min_refill or n_run == 0):
             self._harvest(done)
             k = min(len(done), self.n_games - self.next_game)
-            idx = torch.from_numpy(done[:k]).to(forest.status.device)
-            fresh_roots = DeviceCubes.empty(k)
-            fresh_roots.soa[:, :k] = self.roots.soa[:, self.next_game:self.next_game + k]
-            small = md.MCTSForest(k, forest.C, forest.max_path)   # the waiting scrambles make their root iteration apart
-            small.set_net(forest.engine, agent.net_dtype)
-            small.level_budget = forest.level_budget
-            small.reset(fresh_roots)
-            small.step(agent.c, self.cap_states, False)
-            forest.adopt(small, idx)
+            idx = torch.from_numpy(done[:k].astype(np.int32)).to(forest.status.device)
+            forest.plant(idx, self.roots, self.next_game)   # the waiting scrambles move in: roots evaluated by the next two iterations
             owner[done] = -1
             owner[done[:k]] = np.arange(self.next_game, self.next_game + k)
             self.stale_until[done[:k]] = self.q - 1     # every snapshot queued so far predates the adoption
             self.next_game += k
             self.stats["refills"] += 1
-            del small
             if self.next_game >= self.n_games:
                 forest.level_budget = self.base_budget   # nobody is waiting any more: strict lock step for the tail
         elif not waiting and self.compact and forest.B >= self.agent.compact_min and n_run <= forest.B // 2:

@@ -32,12 +32,11 @@ class _McStruct(Structure):   # mirrors rc_mcts_t (include/rubiks_hip.h)
                [("child_stride", c_size_t)] + \
                [(name, c_void_p) for name in ("child_idx", "new_mask", "expanded", "select_stats", "bfs", "short_act",
                                               "short_len", "rec")] + \
-               [("ring_k", c_uint32)] + [(name, c_void_p) for name in ("ring_node", "ring_act", "ring_len")]
+               [("ring_k", c_uint32)] + [(name, c_void_p) for name in ("ring_node", "ring_act", "ring_len", "phase")]
 
 
 _hip.register({
-    "rc_mcts_init": [POINTER(_McStruct), c_void_p, c_size_t, c_void_p],
-    "rc_mcts_root_eval": [POINTER(_McStruct), c_void_p, c_void_p, c_void_p],
+    "rc_mcts_plant": [POINTER(_McStruct), c_void_p, c_uint32, c_void_p, c_size_t, c_size_t, c_void_p],
     "rc_mcts_expand": [POINTER(_McStruct), c_uint32, c_void_p],
     "rc_mcts_backup": [POINTER(_McStruct), c_void_p, c_void_p, c_void_p],
     "rc_mcts_backup_head": [POINTER(_McStruct), c_void_p, c_size_t, c_int, c_void_p],
@@ -60,8 +59,9 @@ def unpack_keys(keys: np.ndarray) -> np.ndarray:
 
 _PER_NODE = ("keys", "nbr", "P", "W", "N", "L", "V", "leaf", "rec")
 _PER_TREE = ("n_nodes", "status", "solved_idx", "solved_action", "iterations", "path_len", "pending", "path_node", "path_act",
-             "ring_node", "ring_act", "ring_len")
+             "ring_node", "ring_act", "ring_len", "phase")
 RING_K = 8   # descent paths kept per tree for line following (rc_mcts_t::ring_k)
+ROWS = 11    # network rows per tree and iteration (rc_mcts_t::rows_per_tree)
 
 
 class MCTSForest:
@@ -82,7 +82,7 @@ class MCTSForest:
             "solved_action": ((B,), torch.int32), "iterations": ((B,), torch.int32), "path_len": ((B,), torch.int32),
             "pending": ((B,), torch.int32), "path_node": ((B, max_path), torch.int32), "path_act": ((B, max_path), torch.uint8),
             "ring_node": ((B, RING_K, max_path), torch.int32), "ring_act": ((B, RING_K, max_path), torch.uint8),
-            "ring_len": ((B, RING_K), torch.int32),
+            "ring_len": ((B, RING_K), torch.int32), "phase": ((B,), torch.int32),
         }
         for name, (shape, dt) in layout.items():
             if _state is not None:
@@ -91,24 +91,21 @@ class MCTSForest:
             else:
                 t = z(shape, dt)
             setattr(self, name, t)
-        self.children = DeviceCubes.empty(N_ACT * B, dev)
+        # Network rows per tree: only the NEW children of the expanded leaf are evaluated, and a non-root leaf has at most
+        # 11 of them (its parent is known): 11 row slots per tree.  A planted root takes two iterations (rc_mcts_t::phase).
+        self.children = DeviceCubes.empty(ROWS * B, dev)
         self.child_idx = z((B, N_ACT), torch.int32)
         self.new_mask = z((B,), torch.int32)
         self.expanded = z((B,), torch.uint8)
-        self.probs = z((N_ACT * B, N_ACT), torch.float32)     # static network outputs (graph capture)
-        self.values = z((N_ACT * B,), torch.float32)
+        self.probs = z((ROWS * B, N_ACT), torch.float32)     # static network outputs (graph capture)
+        self.values = z((ROWS * B,), torch.float32)
         s = _McStruct()
         s.n_trees, s.capacity, s.hash_size, s.max_path = B, C, self.hash_size, max_path
-        s.rows_per_tree = N_ACT if _state is None else 11
+        s.rows_per_tree = ROWS
         s.ring_k = RING_K
-        # Network rows per tree: the root's expansion creates 12 new children, every later leaf at most 11 (its
-        # parent is a known child), so after the first iteration only the new children are evaluated, packed
-        # into 11 row slots per tree (-8.3 % network work).  `subset` forests start in the packed regime.
-        self._root_phase = _state is None
-        self.children11 = DeviceCubes(self.children.soa, 11 * B)   # the same buffer seen as 11 B columns
         for name in ("keys", "nbr", "P", "W", "N", "L", "V", "leaf", "rec", "hash", "n_nodes", "status", "solved_idx",
                      "solved_action", "iterations", "path_len", "pending", "path_node", "path_act", "child_idx", "new_mask",
-                     "expanded", "ring_node", "ring_act", "ring_len"):
+                     "expanded", "ring_node", "ring_act", "ring_len", "phase"):
             setattr(s, name, getattr(self, name).data_ptr())
         s.child_soa, s.child_stride = self.children.soa.data_ptr(), self.children.stride
         self.select_stats = z((B, 8), torch.int32)   # diagnostics: where each descent became sequential, its length, ticks
@@ -138,27 +135,10 @@ class MCTSForest:
         state["hash"] = self.hash[keep].contiguous()
         for name in _PER_TREE:
             state[name] = getattr(self, name)[keep].contiguous()
-        assert not self._root_phase, "compact only after the first iteration"
         sub = MCTSForest(len(keep), self.C, self.max_path, self.device, _state=state)
         sub.level_budget = self.level_budget
         sub.set_net(self.engine, self.engine.dtype if hasattr(self.engine, "dtype") else torch.bfloat16)
         return sub
-
-    def adopt(self, small: "MCTSForest", slots: torch.Tensor):
-        """
-        Overwrites the trees `slots` (int64 indices) with the trees of `small` -- complete search state, copied on
-        the device.  The inverse of `subset`: lets new scrambles, which have made their first (12-row) iteration
-        in a small forest of their own, take the places of finished trees of a running batch.
-        """
-        assert small.C == self.C and small.max_path == self.max_path and len(slots) == small.B
-        assert not small._root_phase and not self._root_phase
-        B, C1 = self.B, self.C + 1
-        for name in _PER_NODE:
-            dst, src = getattr(self, name), getattr(small, name)
-            dst.view(B, C1, *dst.shape[1:])[slots] = src.view(small.B, C1, *src.shape[1:])
-        self.hash[slots] = small.hash
-        for name in _PER_TREE:
-            getattr(self, name)[slots] = getattr(small, name)
 
     def bytes_allocated(self) -> int:
         return sum(t.numel() * t.element_size() for t in (self.keys, self.nbr, self.P, self.W, self.N, self.L, self.V,
@@ -175,19 +155,16 @@ class MCTSForest:
         self._fused = bool(getattr(self.engine, "supports_cubes", False))
         if self._fused:   # the input layer reads the child SoA directly: no one-hot matrix
             self._oh = None
-            self._x1 = self.engine.workspace(N_ACT * self.B)
+            self._x1 = self.engine.workspace(ROWS * self.B)
         else:
-            self._oh = torch.empty((N_ACT * self.B, 480), dtype=self.engine.input_dtype, device=self.device)
+            self._oh = torch.empty((ROWS * self.B, 480), dtype=self.engine.input_dtype, device=self.device)
         self._graph = None
 
-    @property
-    def rows_per_tree(self) -> int:
-        return int(self.struct.rows_per_tree)
+    rows_per_tree = ROWS
 
     def _net_input(self):
         """(device cubes holding this iteration's network input, number of rows)."""
-        R = self.rows_per_tree
-        return (self.children if R == N_ACT else self.children11), R * self.B
+        return self.children, ROWS * self.B
 
     def _evaluate_children(self):
         """child_soa -> one-hot (HIP kernel) -> network -> softmax -> static probs / values buffers."""
@@ -202,17 +179,20 @@ class MCTSForest:
 
     # ---- search phases ---------------------------------------------------------------------------
     def reset(self, roots: DeviceCubes):
-        """Empties every tree and plants root t = roots[t] as node 1; evaluates the roots (agents.py:466-473)."""
+        """Empties every tree and plants root t = roots[t] as node 1 (agents.py:466-469); the roots are evaluated and
+        expanded by the first two iterations (rc_mcts_t::phase)."""
         assert roots.n == self.B and self.engine is not None
-        for t in (self.nbr, self.N, self.L, self.hash, self.leaf):
-            t.zero_()
-        self.struct.rows_per_tree = N_ACT
-        self._root_phase = True
-        st = _hip.stream_ptr()
-        _hip.check(self.lib.rc_mcts_init(ctypes.byref(self.struct), roots.soa.data_ptr(), roots.stride, st), "rc_mcts_init")
-        self._evaluate_children()   # row 12 t holds root t (the other 11 rows are ignored)
-        _hip.check(self.lib.rc_mcts_root_eval(ctypes.byref(self.struct), self.probs.data_ptr(), self.values.data_ptr(), st),
-                   "rc_mcts_root_eval")
+        self.plant(None, roots, 0)
+
+    def plant(self, slots, roots: DeviceCubes, first: int = 0):
+        """Trees `slots` (int32 device tensor, or None for all) restart from roots[first], roots[first + 1], ...: their
+        hash tables are cleared by the kernel, nothing else needs clearing (a node's rows are initialised when it is
+        created).  Safe between two iterations of a running forest: other trees are not touched."""
+        n = self.B if slots is None else int(slots.numel())
+        assert slots is None or (slots.dtype == torch.int32 and slots.is_cuda and slots.is_contiguous())
+        assert 0 <= first and first + n <= roots.n
+        _hip.check(self.lib.rc_mcts_plant(ctypes.byref(self.struct), None if slots is None else slots.data_ptr(), n,
+                                          roots.soa.data_ptr(), roots.stride, first, _hip.stream_ptr()), "rc_mcts_plant")
 
     level_budget = 0   # new levels a tree may descend per iteration (0 = unlimited, strict lock step)
 
@@ -231,13 +211,8 @@ class MCTSForest:
                        "rc_mcts_backup_select")
 
     def step(self, c: float, max_states: int, use_graph: bool = True):
-        """One lock-step iteration of every running tree: expand -> network -> backup + select (one kernel)."""
-        if self._root_phase:   # the roots' own expansion: 12 new children per tree, run once, eagerly
-            self._iteration(c, max_states)
-            self._root_phase = False
-            self.struct.rows_per_tree = 11
-            self._graph = None
-            return
+        """One lock-step iteration of every running tree: expand -> network -> backup + select (one kernel).
+        A freshly planted tree spends its first two steps on its root (evaluation + expansion, then backup + first descent)."""
         if not use_graph:
             return self._iteration(c, max_states)
         key = (float(c), int(max_states), int(self.level_budget))

@@ -188,8 +188,9 @@ def test_time_limit_only():
 
 def test_fused_head_backup_matches_generic_path():
     """
-    rc_mcts_backup_head (softmax inside the kernel, bf16 head output) vs the generic path (torch softmax):
-    after ONE iteration from the same roots the stored P agree to 1e-6 and V / W / N exactly.
+    rc_mcts_backup_select_head (one kernel: softmax inside, bf16 head output, path backup fused into the re-validation)
+    vs the generic three-kernel path (torch softmax, rc_mcts_backup, rc_mcts_select): after three iterations from the
+    same roots the stored P agree to 1e-6 and V / W / N / paths exactly.
     """
     import ctypes
     from librubiks import _hip, cube
@@ -204,13 +205,14 @@ def test_fused_head_backup_matches_generic_path():
     for f in (a, b):
         f.set_net(eng)
         f.reset(cubes)
-    a._iteration(0.6, 64)                      # fused: head -> backup_head
     st, m = _hip.stream_ptr(), ctypes.byref(b.struct)
-    _hip.check(b.lib.rc_mcts_expand(m, 64, st))
-    head = eng.head_cubes(b.children, b._x1).float()
-    probs, values = torch.softmax(head[:, :12], dim=1).contiguous(), head[:, 12].contiguous()
-    _hip.check(b.lib.rc_mcts_backup(m, probs.data_ptr(), values.data_ptr(), st))
-    _hip.check(b.lib.rc_mcts_select(m, 0.6, 0, st))
+    for _ in range(3):                             # the root's two steps, then an ordinary iteration
+        a._iteration(0.6, 64)                      # fused: head -> backup + select in one kernel
+        _hip.check(b.lib.rc_mcts_expand(m, 64, st))
+        head = eng.head_cubes(b.children, b._x1).float()
+        probs, values = torch.softmax(head[:, :12], dim=1).contiguous(), head[:, 12].contiguous()
+        _hip.check(b.lib.rc_mcts_backup(m, probs.data_ptr(), values.data_ptr(), st))
+        _hip.check(b.lib.rc_mcts_select(m, 0.6, 0, st))
     torch.cuda.synchronize()
     assert torch.equal(a.n_nodes, b.n_nodes) and torch.equal(a.nbr, b.nbr)
     assert torch.equal(a.V, b.V) and torch.equal(a.W, b.W) and torch.equal(a.N, b.N)
@@ -226,7 +228,7 @@ def test_compaction_is_invisible(net_gpu):
     res = {}
     for compact in (False, True):
         agent = MCTS(net_gpu, c=0.6, search_graph=True, net_dtype=torch.float32, sync_every=4)
-        res[compact] = agent.search_batch(states, None, 600, compact=compact)
+        res[compact] = agent.search_batch(states, None, 1800, compact=compact)
         if compact:
             assert agent._last_forest.B < 600      # the batch really was compacted
     a, b = res[False], res[True]

@@ -79,7 +79,7 @@ def test_leaf_with_all_children_known(net_gpu):
     forest = MCTSForest(B, C)
     forest.set_net(GenericNet(net_gpu), torch.float32)
     forest.reset(DeviceCubes.from_numpy(states))
-    for _ in range(warm):
+    for _ in range(warm + 1):       # a tree's first iteration (its root's) takes two steps
         forest.step(c, C, use_graph=False)
     torch.cuda.synchronize()
     refs, paths = [], []
