@@ -11,6 +11,7 @@ semantics; the network runs through librubiks.model.InferenceNet (bf16 MFMA by d
 `net_dtype=torch.float32` for parity runs).
 """
 from collections import deque
+from time import perf_counter
 
 import numpy as np
 import torch
@@ -201,9 +202,13 @@ class _Harvest:
 
     @classmethod
     def _host_like(cls, t: torch.Tensor) -> torch.Tensor:
-        key = (tuple(t.shape), t.dtype)
+        """Pinned host tensor shaped like t, from a pool keyed by the row count rounded up to a power of two (harvests
+        come in all sizes; a fresh hipHostMalloc per harvest would cost more than the harvest)."""
+        rows = 1 << max(4, int(np.ceil(np.log2(max(1, t.shape[0])))))
+        key = (rows, tuple(t.shape[1:]), t.dtype)
         free = cls._pinned.setdefault(key, [])
-        return free.pop() if free else torch.empty(t.shape, dtype=t.dtype, pin_memory=True)
+        buf = free.pop() if free else torch.empty((rows,) + tuple(t.shape[1:]), dtype=t.dtype, pin_memory=True)
+        return buf
 
     def __init__(self, agent, forest: md.MCTSForest, games: np.ndarray):
         self.games, self.graph = games, agent.search_graph
@@ -213,10 +218,10 @@ class _Harvest:
             forest.complete_graphs()       # _complete_graph of all solved trees in one launch
             forest.shorten_launch()        # ... and their BFS shortening in another
             src["slen"], src["sact"] = forest.short_len, forest.short_act
-        self.host = {}
+        self.host, self.n = {}, forest.B
         for name, t in src.items():
             self.host[name] = self._host_like(t)
-            self.host[name].copy_(t, non_blocking=True)
+            self.host[name][:self.n].copy_(t, non_blocking=True)
         self.event = torch.cuda.Event()
         self.event.record()
         self.forest = forest   # keeps the buffers alive until the copies have landed
@@ -226,7 +231,7 @@ class _Harvest:
 
     def result(self) -> BatchResult:
         self.event.synchronize()
-        h = {k: v.numpy() for k, v in self.host.items()}
+        h = {k: v.numpy()[:self.n] for k, v in self.host.items()}
         status, plen = h["status"].astype(np.int64), h["plen"].astype(np.int64)
         acts = h["pact"].copy()
         lens = plen - 1                                   # the actions taken: the best guess of an unsolved tree (agents.py:492)
@@ -242,7 +247,7 @@ class _Harvest:
         out = BatchResult(solved, np.where(solved, lens, -1), h["nodes"].astype(np.int64), QueueTable(acts, lens), 0.0,
                           h["iterations"].astype(np.int64), status)
         for name, t in self.host.items():
-            self._pinned[(tuple(t.shape), t.dtype)].append(t)
+            self._pinned[(t.shape[0], tuple(t.shape[1:]), t.dtype)].append(t)
         self.host, self.forest = None, None
         return out
 
@@ -357,6 +362,12 @@ class MCTS(DeepAgent):
         return {s.tobytes(): i for i, s in enumerate(tree["states"][1:tree["n"] + 1], start=1)}
 
 
+def _to_device_async(arr: np.ndarray, device) -> torch.Tensor:
+    """Host array -> device tensor without blocking the host: a copy from pageable memory makes the caller wait until the
+    GPU has reached that point of the stream, i.e. until everything queued ahead of it has run."""
+    return torch.from_numpy(np.ascontiguousarray(arr)).pin_memory().to(device, non_blocking=True)
+
+
 class MCTSRun:
     """
     A batched MCTS search in progress: `round()` queues the next lock-step iterations, `finish()` returns the
@@ -386,7 +397,8 @@ class MCTSRun:
         if self.next_game < self.n_games and agent.level_budget == "auto":
             forest.level_budget = agent.refill_level_budget
         self.min_refill = max(8, S // 32)
-        self.stats = agent.refill_stats = {"iterations": 0, "harvests": 0, "refills": 0, "compactions": 0}
+        self.stats = agent.refill_stats = {"iterations": 0, "harvests": 0, "refills": 0, "compactions": 0,
+                                           "host_enqueue_s": 0.0, "host_wait_s": 0.0, "host_process_s": 0.0}
         self.side = torch.cuda.Stream()
         self.harvests = []                 # _Harvest objects in flight
         self.parts = []                    # (game ids, BatchResult)
@@ -404,15 +416,16 @@ class MCTSRun:
         """Copies the finished trees `idx_np` out of the forest (their slots are needed or dropped) and starts
         turning them into results on the side stream."""
         forest, agent = self.forest, self.agent
-        idx = torch.from_numpy(idx_np).to(forest.status.device)
-        sub = forest.subset(idx)
+        idx = _to_device_async(idx_np, forest.status.device)
+        games = self.owner[idx_np].copy()
+        keep_tree = agent._tree_src is None and (games == 0).any()   # game 0's tree stays inspectable (the reference's attributes)
+        sub = forest.subset(idx, results_only=not keep_tree)
         ev = torch.cuda.Event()
         ev.record()
-        games = self.owner[idx_np].copy()
         with torch.cuda.stream(self.side):
             self.side.wait_event(ev)
             self.harvests.append(_Harvest(agent, sub, games))
-        if agent._tree_src is None and (games == 0).any():
+        if keep_tree:
             agent._tree_src = (sub, int(np.flatnonzero(games == 0)[0]))
         self.stats["harvests"] += 1
 
@@ -422,16 +435,29 @@ class MCTSRun:
         n_steps = min(agent.sync_every, max(1, self.it))   # short first rounds: a batch that is solved at once ends at once
         if max_steps is not None:
             n_steps = min(n_steps, max_steps)
+        t0 = perf_counter()
         for _ in range(n_steps):
             forest.step(agent.c, self.cap_states, agent.use_graph)
         self.it += n_steps
         self.stats["iterations"] = self.it
         self.snapshots.append((self.q, forest, *forest.status_snapshot()))
         self.q += 1
+        t1 = perf_counter()
+        self.stats["host_enqueue_s"] += t1 - t0
         if len(self.snapshots) < 2 and self.it > 1:
             return            # look at round r - 1 while round r runs
         qi, f_snap, ev, st_host = self.snapshots.popleft()
         ev.synchronize()
+        t2 = perf_counter()
+        self.stats["host_wait_s"] += t2 - t1   # time the host had to spare: it waited for the GPU, not the other way round
+        try:
+            self._act_on(qi, f_snap, st_host)
+        finally:
+            self.stats["host_process_s"] += perf_counter() - t2
+
+    def _act_on(self, qi: int, f_snap, st_host):
+        """Harvest / refill / compaction decisions from the tree states of round qi."""
+        agent, forest = self.agent, self.forest
         if f_snap is not forest:
             return            # taken before a compaction
         status = st_host.numpy()
@@ -450,7 +476,7 @@ class MCTSRun:
         if waiting and len(done) and (len(done) >= self.min_refill or n_run == 0):
             self._harvest(done)
             k = min(len(done), self.n_games - self.next_game)
-            idx = torch.from_numpy(done[:k].astype(np.int32)).to(forest.status.device)
+            idx = _to_device_async(done[:k].astype(np.int32), forest.status.device)
             forest.plant(idx, self.roots, self.next_game)   # the waiting scrambles move in: roots evaluated by the next two iterations
             owner[done] = -1
             owner[done[:k]] = np.arange(self.next_game, self.next_game + k)
@@ -464,7 +490,7 @@ class MCTSRun:
                 self._harvest(done)
                 owner[done] = -1
             keep_np = np.flatnonzero(owner >= 0)
-            keep = torch.from_numpy(keep_np).to(forest.status.device)
+            keep = _to_device_async(keep_np, forest.status.device)
             small = forest.subset(keep)
             if forest is agent.forest:   # keep the full-size forest's buffers for the next search, drop its graph
                 forest._graph = None

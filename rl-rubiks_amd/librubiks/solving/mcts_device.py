@@ -60,12 +60,15 @@ def unpack_keys(keys: np.ndarray) -> np.ndarray:
 _PER_NODE = ("keys", "nbr", "P", "W", "N", "L", "V", "leaf", "rec")
 _PER_TREE = ("n_nodes", "status", "solved_idx", "solved_action", "iterations", "path_len", "pending", "path_node", "path_act",
              "ring_node", "ring_act", "ring_len", "phase")
+_RESULT_NODE = ("keys", "nbr", "leaf")          # what rc_mcts_complete_graph / rc_mcts_shorten read of a tree
+_RESULT_TREE = ("n_nodes", "status", "solved_idx", "solved_action", "iterations", "path_len", "pending", "path_act", "phase")
 RING_K = 8   # descent paths kept per tree for line following (rc_mcts_t::ring_k)
 ROWS = 11    # network rows per tree and iteration (rc_mcts_t::rows_per_tree)
 
 
 class MCTSForest:
-    def __init__(self, n_trees: int, capacity: int, max_path: int = 4096, device=None, _state: dict = None):
+    def __init__(self, n_trees: int, capacity: int, max_path: int = 4096, device=None, _state: dict = None,
+                 _results_only: bool = False):
         self.lib = _hip.lib()
         dev = device or torch.device("cuda", torch.cuda.current_device())
         B, C = int(n_trees), int(capacity)
@@ -85,12 +88,15 @@ class MCTSForest:
             "ring_len": ((B, RING_K), torch.int32), "phase": ((B,), torch.int32),
         }
         for name, (shape, dt) in layout.items():
-            if _state is not None:
+            if _state is not None and name in _state:
                 t = _state[name]
                 assert tuple(t.shape) == shape and t.dtype == dt and t.is_contiguous(), name
+            elif _results_only:   # arrays that turning finished trees into results never touches: one row, so that pointers are valid
+                t = z((1,) + shape[1:], dt)
             else:
                 t = z(shape, dt)
             setattr(self, name, t)
+        self.results_only = _results_only
         # Network rows per tree: only the NEW children of the expanded leaf are evaluated, and a non-root leaf has at most
         # 11 of them (its parent is known): 11 row slots per tree.  A planted root takes two iterations (rc_mcts_t::phase).
         self.children = DeviceCubes.empty(ROWS * B, dev)
@@ -121,21 +127,24 @@ class MCTSForest:
         self._graph = None
         self._graph_key = None
 
-    def subset(self, keep: torch.Tensor) -> "MCTSForest":
+    def subset(self, keep: torch.Tensor, results_only: bool = False) -> "MCTSForest":
         """
-        A new, smaller forest holding only the trees `keep` (int64 indices), with their complete search state
-        copied on the device.  Used to drop finished trees from a batch: the survivors continue exactly where
-        they were, on GEMMs of len(keep) x 12 rows instead of B x 12.
+        A new, smaller forest holding only the trees `keep` (int64 indices), with their search state copied on the
+        device.  Used to drop finished trees from a batch: the survivors continue exactly where they were, on GEMMs
+        of len(keep) x 11 rows instead of B x 11.
+        results_only: the trees are finished and only wait to be turned into results (graph completion, BFS
+        shortening, paths): just the arrays those steps read are copied (65 of ~285 bytes per node), the forest
+        cannot be stepped or inspected.
         """
         B, C1 = self.B, self.C + 1
         state = {}
-        for name in _PER_NODE:
+        for name in (_RESULT_NODE if results_only else _PER_NODE):
             t = getattr(self, name)
             state[name] = t.view(B, C1, *t.shape[1:])[keep].reshape(len(keep) * C1, *t.shape[1:]).contiguous()
         state["hash"] = self.hash[keep].contiguous()
-        for name in _PER_TREE:
+        for name in (_RESULT_TREE if results_only else _PER_TREE):
             state[name] = getattr(self, name)[keep].contiguous()
-        sub = MCTSForest(len(keep), self.C, self.max_path, self.device, _state=state)
+        sub = MCTSForest(len(keep), self.C, self.max_path, self.device, _state=state, _results_only=results_only)
         sub.level_budget = self.level_budget
         sub.set_net(self.engine, self.engine.dtype if hasattr(self.engine, "dtype") else torch.bfloat16)
         return sub
@@ -213,6 +222,7 @@ class MCTSForest:
     def step(self, c: float, max_states: int, use_graph: bool = True):
         """One lock-step iteration of every running tree: expand -> network -> backup + select (one kernel).
         A freshly planted tree spends its first two steps on its root (evaluation + expansion, then backup + first descent)."""
+        assert not self.results_only
         if not use_graph:
             return self._iteration(c, max_states)
         key = (float(c), int(max_states), int(self.level_budget))
@@ -234,6 +244,7 @@ class MCTSForest:
     # ---- results ---------------------------------------------------------------------------------
     def tree_arrays(self, t: int) -> dict:
         """Host copies of tree t's node arrays, shaped like the reference agent's attributes."""
+        assert not self.results_only, "this forest only holds what turning finished trees into results needs"
         n = int(self.n_nodes[t].item())
         lo, hi = t * (self.C + 1), t * (self.C + 1) + n + 1
         keys = self.keys[lo:hi].cpu().numpy().view(np.uint32)
