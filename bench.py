@@ -215,11 +215,17 @@ def phase_times_split(forest, c, max_states, reps):
         for i, k in enumerate(names):
             acc[k] += ev[i].elapsed_time(ev[i + 1])
     out = {k: round(v / reps, 4) for k, v in acc.items()}
-    _, Wh, B2, b, code, alpha = eng.layers[1]
     cubes, rows = forest._net_input()
-    a = torch.randn((rows, 2 * Wh.shape[1]), device=Wh.device).half()
-    f = lambda: (torch.mm(a[:, :Wh.shape[1]], Wh.t(), out_dtype=torch.float32), torch.mm(a, B2.t(), out_dtype=torch.float32))   # noqa: E731
-    out["gemm_hidden1"] = round(event_ms(f, reps)[0], 4)
+    hid = {}
+    for li in (1, 2):   # the two hidden layers behind the input layer: one hi x hi GEMM (K) and one correction GEMM (2 K) each
+        _, Wh, B2, b, code, alpha = eng.layers[li]
+        K = Wh.shape[1]
+        a = torch.randn((rows, 2 * K), device=Wh.device).half()
+        hid[f"gemm_hidden{li}_main"] = round(event_ms(lambda: torch.mm(a[:, :K], Wh.t(), out_dtype=torch.float32), reps)[0], 4)
+        hid[f"gemm_hidden{li}_corr"] = round(event_ms(lambda: torch.mm(a, B2.t(), out_dtype=torch.float32), reps)[0], 4)
+    out.update(hid)
+    out["gemm_hidden1"] = round(hid["gemm_hidden1_main"] + hid["gemm_hidden1_corr"], 4)
+    Wh = eng.layers[1][1]
     out["gemm_hidden1_weight"] = (int(Wh.shape[0]), int(Wh.shape[1]))
     return out
 
@@ -482,7 +488,10 @@ def step_rooflines(engine, agent, roots, args, name):
                     "ms_per_launch": phases["gemm_hidden1"], "fp32_equivalent_tflops": round(f32_equiv / t / 1e12, 1),
                     "fp32_mfma_peak_tflops": MFMA_F32_PEAK_TFLOPS,
                     "note": "f16 MFMA flops executed (3 per fp32-equivalent flop) against the dense f16 peak; the same layer as an "
-                            "fp32 MFMA GEMM is bounded by 157.3 TFLOP/s"}
+                            "fp32 MFMA GEMM is bounded by 157.3 TFLOP/s.  Both launches are the library kernel "
+                            "Cijk_Alik_Bljk_HSS_BH_..._MT256x192x64 (236 workgroups, stream-K), as are the two of the next layer: "
+                            "phases_ms.gemm_hidden{1,2}_{main,corr} are the four durations whose mean is that kernel's average in "
+                            "profiles/r2_bench_kernel_stats.csv"}
         flops_net = eng.flops_per_state * rows
         group = {"kernel": f"whole split-engine forward on {rows} child rows (operand kernels + 5 f16 GEMMs + fp32 output layer)", "bound": "mfma",
                  "achieved": round(3 * flops_net / (phases["net_forward"] * 1e-3) / 1e12, 1), "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s",
