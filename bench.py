@@ -423,6 +423,7 @@ def run_leg(name, model, pool_roots, config_roots, args, world, coll_device):
     if not args.window_only:
         agent.forest = None
         torch.cuda.empty_cache()
+        agent.search_batch(config_roots, None, cap, max_iterations=30)   # untimed warm-up: forest allocated, step graph captured
         barrier()
         t1 = time.perf_counter()
         full = agent.search_batch(config_roots, None, cap)

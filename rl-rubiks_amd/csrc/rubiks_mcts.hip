@@ -956,7 +956,9 @@ __global__ __launch_bounds__(kBlock) void k_mcts_complete_graph(rc_mcts_t m) {
     const int *tab = m.hash + (size_t)t * m.hash_size;
     const u32 mask = m.hash_size - 1;
     const u32 n = (u32)m.n_nodes[t];
-    for (u32 w = threadIdx.x; w < n * kA; w += kBlock) {
+    // gridDim.y workgroups share a tree: the (leaf, action) pairs are independent, and a tree finished at 50 000 nodes
+    // would otherwise keep one CU busy for milliseconds next to the lock-step iterations of the running trees
+    for (u32 w = blockIdx.y * kBlock + threadIdx.x; w < n * kA; w += kBlock * gridDim.y) {
         const u32 node = 1 + w / kA, a = w % kA;
         if (!m.leaf[base + node]) continue;
         const uint4 pk = keys[node];
@@ -1126,7 +1128,8 @@ int rc_mcts_backup_head(const rc_mcts_t *m, const void *head, size_t ld, int hea
 
 int rc_mcts_complete_graph(const rc_mcts_t *m, rc_stream_t stream) {
     if (int rc = check_mcts(m)) return rc;
-    hipLaunchKernelGGL(k_mcts_complete_graph, dim3(m->n_trees), dim3(kBlock), 0, (hipStream_t)stream, *m);
+    const unsigned split = m->n_trees >= 512 ? 1 : m->n_trees >= 64 ? 8 : 32;
+    hipLaunchKernelGGL(k_mcts_complete_graph, dim3(m->n_trees, split), dim3(kBlock), 0, (hipStream_t)stream, *m);
     return launch_status();
 }
 
