@@ -73,6 +73,8 @@ def make_agents():
         fx[pre + "V"] = agent.V[:n + 1].astype(np.float32)
         assert np.array_equal(fx[pre + "P"][1:].astype(np.float64), agent.P[1:n + 1])   # values are f32-exact
         fx[pre + "L"] = agent.L[:n + 1].astype(np.int32)
+        for k in ("states", "P", "V"):      # row 0 of these is np.empty memory in the reference (agents.py:440-444): zeroed,
+            fx[pre + k][0] = 0              # so that the fixture is reproducible byte for byte
         print(f"MCTS {name}: solved={solved} n={n} queue={list(agent.action_queue)[:12]}")
 
     for name, seed, depth, lam, nexp, max_states in ASTAR_CASES:
@@ -89,6 +91,8 @@ def make_agents():
         fx[pre + "G"] = agent.G[:n + 1].copy()
         fx[pre + "parents"] = agent.parents[:n + 1].astype(np.int32)
         fx[pre + "parent_actions"] = agent.parent_actions[:n + 1].astype(np.int8)
+        fx[pre + "states"][0], fx[pre + "G"][0] = 0, 0        # np.empty rows of the reference (agents.py:390-393) ...
+        fx[pre + "parents"][:2] = 0                            # ... incl. the root's parent, which it never sets
         oq = sorted((float(c), int(i)) for c, i in agent.open_queue)
         fx[pre + "open_cost"] = np.array([c for c, _ in oq])
         fx[pre + "open_idx"] = np.array([i for _, i in oq], dtype=np.int32)
