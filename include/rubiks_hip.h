@@ -159,6 +159,12 @@ int rc_act_bf16_inplace(uint16_t *x, size_t n, int activation, float alpha, rc_s
  *                     [n_rows][n_cols] (c_corr may be NULL); writes out_hi_lo[r] = [hi(y row), lo(y row)] (row pitch
  *                     2 n_cols, may be NULL) and / or y itself to out_f32 (may be NULL).  n_cols % 8 == 0; ELU uses expm1f. */
 int rc_oh_split_f16(const int8_t *soa, size_t n, size_t stride, uint16_t *out, rc_stream_t stream);
+/* The whole input layer of that network in one kernel on the matrix cores, straight from the cube states:
+ *   out_hi_lo[r] = [hi(y), lo(y)],  y = act(onehot(r) w_hi^T + 2^-11 onehot(r) w_lo^T + bias)      (row pitch 2 H halves)
+ * w_hi, w_lo: IEEE half [H][480] row-major (the nn.Linear weight split as above), H % 64 == 0.  Replaces rc_oh_split_f16 +
+ * the K = 960 GEMM + rc_split_act_f16 for the first layer (cube.py:265-277 + model.py:123-127,150-157 at fp32 accuracy). */
+int rc_first_layer_split_f16(const int8_t *soa, size_t n, size_t stride, const uint16_t *w_hi, const uint16_t *w_lo,
+                             const float *bias, uint16_t *out_hi_lo, size_t H, int activation, float alpha, rc_stream_t stream);
 int rc_split_act_f16(const float *c, const float *c_corr, float corr_scale, size_t n_rows, size_t n_cols, const float *bias,
                      int activation, float alpha, uint16_t *out_hi_lo, float *out_f32, rc_stream_t stream);
 

@@ -2,6 +2,8 @@
 // the one-hot encoding.  as_oh(states) @ W1^T is a 20-row gather-sum because a one-hot row has
 // exactly 20 ones; doing it from an LDS-resident slice of W1^T removes the (n x 480) one-hot matrix,
 // the K = 480 GEMM and the separate bias + activation pass.
+#include <atomic>
+
 #include "rubiks_common.h"
 
 namespace rubiks {
@@ -392,12 +394,15 @@ extern "C" int rc_first_layer_mfma_bf16(const int8_t *soa, size_t n, size_t stri
     hipStream_t s = (hipStream_t)stream;
 #define RC_LAUNCH_MF(ACT, F16)                                                                                     \
     do {                                                                                                           \
-        static bool attr_set = false;                                                                              \
-        if (!attr_set) {                                                                                           \
+        /* per device and thread-safe: the attribute belongs to the function ON A DEVICE (one process may drive several) */ \
+        static std::atomic<unsigned long long> attr_set{0};                                                        \
+        int dev_ = 0;                                                                                              \
+        (void)hipGetDevice(&dev_);                                                                                 \
+        if (!((attr_set.load(std::memory_order_acquire) >> (dev_ & 63)) & 1ull)) {                                  \
             hipError_t e = hipFuncSetAttribute((const void *)k_first_layer_mfma<ACT, F16>,                          \
                                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);        \
             if (e != hipSuccess) return hip_rc(e);                                                                 \
-            attr_set = true;                                                                                       \
+            attr_set.fetch_or(1ull << (dev_ & 63), std::memory_order_release);                                     \
         }                                                                                                          \
         hipLaunchKernelGGL((k_first_layer_mfma<ACT, F16>), grid, block, lds_bytes, s, (const u8 *)soa, n, stride,   \
                            (const uint4 *)w1, bias, (uint4 *)out, (u32)H, rows_per_block, alpha);                  \
@@ -552,6 +557,165 @@ __global__ __launch_bounds__(kBlock) void k_split_act(const float4 *__restrict__
     }
 }
 
+// =================================================================================================
+// Input layer of the fp32-accurate split network on the matrix cores (SplitF32Net, below):
+//   y = act(onehot W_hi^T + 2^-11 onehot W_lo^T + b),  written as the two halves [hi(y) | lo(y)] the next layer's GEMMs read.
+// Same structure as k_first_layer_mfma -- one-hot A fragments generated from the cube codes, the W1 slice in LDS, a lane's
+// accumulators are adjacent output columns -- with three differences: (1) 60 k-steps instead of 30: the second 30 multiply the
+// one-hot scaled by 2^-11 (exact in half) with the W_lo table, into the same fp32 accumulators; (2) a workgroup owns 64 columns
+// (hi + lo slices = 122 KiB of LDS) and a wave holds TWO 32-state tiles, so every B fragment read from LDS feeds two MFMAs
+// (the 128-column kernel is bound by its LDS reads, not by the matrix cores); (3) the epilogue re-splits into halves.
+// It replaces rc_oh_split_f16 + the K = 960 library GEMM + rc_split_act_f16 of the input layer.
+// =================================================================================================
+constexpr int kSpCols = 64;
+constexpr int kSpSub = 2;
+
+// expm1(x) for x <= 0 to ~1e-7 absolute (what ELU's negative branch needs next to fp32 activations of order 1) without
+// libm's register appetite: the Taylor polynomial near zero (x^9 / 9! < 3e-10 at |x| = 0.35), exp(x) - 1 beyond.
+__device__ __forceinline__ float expm1_neg(float x) {
+    float p = 1.0f / 40320.0f;
+    p = fmaf(p, x, 1.0f / 5040.0f);
+    p = fmaf(p, x, 1.0f / 720.0f);
+    p = fmaf(p, x, 1.0f / 120.0f);
+    p = fmaf(p, x, 1.0f / 24.0f);
+    p = fmaf(p, x, 1.0f / 6.0f);
+    p = fmaf(p, x, 0.5f);
+    p = fmaf(p, x, 1.0f);
+    return x < -0.35f ? __expf(x) - 1.0f : p * x;
+}
+
+template <int ACT>
+__global__ __launch_bounds__(kMfWaves * kWave) void k_first_layer_split(const u8 *__restrict__ soa, size_t n, size_t stride,
+                                                                      const uint4 *__restrict__ w_hi, const uint4 *__restrict__ w_lo,
+                                                                      const float *__restrict__ bias, u32 *__restrict__ out, u32 H,
+                                                                      u32 rows_per_block, float alpha) {
+    extern __shared__ __attribute__((aligned(256))) unsigned char lds[];
+    unsigned char *wslice = lds;                                                       // [2 tables][64 slots][976 B]
+    const u32 tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    uint4 *onehot = reinterpret_cast<uint4 *>(lds + 2 * kSpCols * kMfPitch);           // [2][9] A fragments: 1.0 / 2^-11 at position p
+    const u32 col_tiles = H / kSpCols;
+    const u32 ct = blockIdx.x % col_tiles, rg = blockIdx.x / col_tiles;
+    const size_t row_lo = (size_t)rg * rows_per_block;
+    if (row_lo >= n) return;
+    const size_t row_hi = (row_lo + rows_per_block < n) ? row_lo + rows_per_block : n;
+    {   // 2 x 64 columns x 60 chunks of 16 B = 7 680 chunks / 512 threads = 15 per thread.  Column g of the slice goes to slot
+        // (g % 2) * 32 + g / 2: MFMA column tile c, lane r owns column 2 r + c.
+        constexpr int kPer = 2 * kSpCols * 60 / (kMfWaves * kWave), kBatch = 5;
+#pragma unroll
+        for (int b0 = 0; b0 < kPer; b0 += kBatch) {
+            uint4 tmp[kBatch];
+#pragma unroll
+            for (int t = 0; t < kBatch; ++t) {
+                const u32 i = tid + (b0 + t) * (kMfWaves * kWave), tbl = i / (kSpCols * 60), j = i % (kSpCols * 60);
+                tmp[t] = (tbl ? w_lo : w_hi)[(size_t)(ct * kSpCols + j / 60) * 60 + j % 60];
+            }
+#pragma unroll
+            for (int t = 0; t < kBatch; ++t) {
+                const u32 i = tid + (b0 + t) * (kMfWaves * kWave), tbl = i / (kSpCols * 60), j = i % (kSpCols * 60);
+                const u32 g = j / 60, slot = (g & 1) * 32 + (g >> 1);
+                *reinterpret_cast<uint4 *>(wslice + (tbl * kSpCols + slot) * kMfPitch + (j % 60) * 16) = tmp[t];
+            }
+        }
+    }
+    if (tid < 18) {
+        u32 w[4] = {0, 0, 0, 0};
+        const u32 p = tid % 9, one = tid < 9 ? kHalfOne : kHalfScaleInv;
+        if (p < 8) w[p >> 1] = (p & 1) ? one << 16 : one;
+        onehot[tid] = make_uint4(w[0], w[1], w[2], w[3]);
+    }
+    const u32 r = lane & 31, h = lane >> 5;
+    float b[2];
+#pragma unroll
+    for (int c = 0; c < 2; ++c) b[c] = bias[ct * kSpCols + 2 * r + c];
+    __syncthreads();
+
+    const u32 off_a = h ? 8u : 0u, off_c = h ? 16u : 8u;
+    constexpr size_t kStep = (size_t)kMfWaves * kSpSub * kMfTile;
+    for (size_t t0 = row_lo + (size_t)wave * kSpSub * kMfTile; t0 < row_hi; t0 += kStep) {
+        u32 pk[kSpSub][5];
+#pragma unroll
+        for (int u = 0; u < kSpSub; ++u) {
+            const size_t row = t0 + (size_t)u * kMfTile + r;
+            const u8 *p = soa + (row < n ? row : n - 1);
+            u32 raw[kPlanes];
+#pragma unroll
+            for (int j = 0; j < kPlanes; ++j) raw[j] = p[(size_t)j * stride];
+#pragma unroll
+            for (int q = 0; q < 5; ++q)
+                pk[u][q] = (raw[4 * q] & 31u) | (raw[4 * q + 1] & 31u) << 8 | (raw[4 * q + 2] & 31u) << 16 | (raw[4 * q + 3] & 31u) << 24;
+        }
+        auto code = [&](int u, int j) -> u32 { return (pk[u][j >> 2] >> (8 * (j & 3))) & 0xffu; };
+        f32x16 acc[kSpSub][2];
+#pragma unroll
+        for (int u = 0; u < kSpSub; ++u)
+#pragma unroll
+            for (int c = 0; c < 2; ++c)
+#pragma unroll
+                for (int i = 0; i < 16; ++i) acc[u][c][i] = b[c];
+        // two passes of 30 k-steps: table 0 = W_hi with one-hot 1.0, table 1 = W_lo with one-hot 2^-11 (the pass loop is
+        // NOT unrolled: unrolling all 60 steps overflows the 256 registers a wave has at two waves per SIMD)
+#pragma unroll 1
+        for (int tbl = 0; tbl < 2; ++tbl) {
+            const uint4 *frag = onehot + 9 * tbl;
+            const unsigned char *bbase = wslice + ((size_t)tbl * kSpCols + r) * kMfPitch + 16 * h;   // + c * 32 * pitch + 32 * ks
+            auto a_frag = [&](int u, int ks) -> uint4 {
+                const int m2 = ks / 3, ph = ks % 3;
+                const u32 pos = ph == 0 ? code(u, 2 * m2) - off_a : ph == 1 ? (h ? code(u, 2 * m2 + 1) : code(u, 2 * m2) - 16u)
+                                                                             : code(u, 2 * m2 + 1) - off_c;
+                return frag[min(pos, 8u)];
+            };
+            uint4 a_cur[kSpSub], b_cur[2];
+#pragma unroll
+            for (int u = 0; u < kSpSub; ++u) a_cur[u] = a_frag(u, 0);
+#pragma unroll
+            for (int c = 0; c < 2; ++c) b_cur[c] = *reinterpret_cast<const uint4 *>(bbase + c * 32 * kMfPitch);
+#pragma unroll
+            for (int ks = 0; ks < 30; ++ks) {
+                uint4 a_nxt[kSpSub] = {a_cur[0], a_cur[1]}, b_nxt[2] = {b_cur[0], b_cur[1]};
+                if (ks + 1 < 30) {
+#pragma unroll
+                    for (int c = 0; c < 2; ++c) b_nxt[c] = *reinterpret_cast<const uint4 *>(bbase + c * 32 * kMfPitch + 32 * (ks + 1));
+#pragma unroll
+                    for (int u = 0; u < kSpSub; ++u) a_nxt[u] = a_frag(u, ks + 1);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int c = 0; c < 2; ++c)
+#pragma unroll
+                    for (int u = 0; u < kSpSub; ++u)
+                        acc[u][c] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a_cur[u]),
+                                                                           __builtin_bit_cast(f16x8, b_cur[c]), acc[u][c], 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int u = 0; u < kSpSub; ++u) a_cur[u] = a_nxt[u];
+#pragma unroll
+                for (int c = 0; c < 2; ++c) b_cur[c] = b_nxt[c];
+            }
+        }
+        // epilogue: activation, then the two halves of the lane's columns 2 r, 2 r + 1: one 4-byte store each into the
+        // [hi | lo] row of the state (row pitch 2 H halves)
+#pragma unroll
+        for (int u = 0; u < kSpSub; ++u)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                const size_t row = t0 + (size_t)u * kMfTile + (i & 3) + 8 * (i >> 2) + 4 * h;
+                float y[2], hi[2], lo[2];
+#pragma unroll
+                for (int c = 0; c < 2; ++c) {
+                    const float x = acc[u][c][i];
+                    y[c] = ACT == RC_ACT_RELU ? fmaxf(x, 0.f) : ACT == RC_ACT_ELU ? (x > 0.f ? x : alpha * expm1_neg(x)) : x;
+                    hi[c] = round_to_half_f32(y[c]);
+                    lo[c] = (y[c] - hi[c]) * kSplitScale;
+                }
+                if (row < n) {
+                    u32 *orow = out + row * H;   // 2 H halves = H dwords per row
+                    orow[(ct * kSpCols) / 2 + r] = pack_half2(hi[0], hi[1]);
+                    orow[H / 2 + (ct * kSpCols) / 2 + r] = pack_half2(lo[0], lo[1]);
+                }
+            }
+    }
+}
+
 extern "C" int rc_oh_split_f16(const int8_t *soa, size_t n, size_t stride, uint16_t *out, rc_stream_t stream) {
     if (n == 0) return RC_OK;
     RC_CHECK_SOA(soa, n, stride);
@@ -578,6 +742,43 @@ extern "C" int rc_split_act_f16(const float *c, const float *c_corr, float corr_
     else if (activation == RC_ACT_RELU) RC_LAUNCH_SPLIT(RC_ACT_RELU);
     else RC_LAUNCH_SPLIT(RC_ACT_NONE);
 #undef RC_LAUNCH_SPLIT
+    return launch_status();
+}
+
+extern "C" int rc_first_layer_split_f16(const int8_t *soa, size_t n, size_t stride, const uint16_t *w_hi, const uint16_t *w_lo,
+                                        const float *bias, uint16_t *out_hi_lo, size_t H, int activation, float alpha,
+                                        rc_stream_t stream) {
+    if (n == 0) return RC_OK;
+    RC_CHECK_SOA(soa, n, stride);
+    RC_REQUIRE(w_hi && w_lo && bias && out_hi_lo, RC_ERR_NULL);
+    RC_REQUIRE(aligned16(w_hi) && aligned16(w_lo) && aligned16(out_hi_lo), RC_ERR_ALIGN);
+    RC_REQUIRE(H >= (size_t)kSpCols && H % kSpCols == 0 && activation >= RC_ACT_NONE && activation <= RC_ACT_ELU, RC_ERR_RANGE);
+    const u32 col_tiles = (u32)(H / kSpCols);
+    u32 row_groups = (256 + col_tiles - 1) / col_tiles;   // ~one workgroup per CU (the LDS slice allows no more)
+    constexpr u32 kRowsPerPass = kMfWaves * kSpSub * kMfTile;
+    u32 rows_per_block = (u32)round_up(ceil_div(n, row_groups), kRowsPerPass);
+    row_groups = (u32)ceil_div(n, rows_per_block);
+    const size_t lds_bytes = (size_t)2 * kSpCols * kMfPitch + 2 * 9 * 16;
+    const dim3 grid(col_tiles * row_groups), block(kMfWaves * kWave);
+    hipStream_t s = (hipStream_t)stream;
+#define RC_LAUNCH_SP(ACT)                                                                                             \
+    do {                                                                                                              \
+        static std::atomic<unsigned long long> attr_set{0};                                                           \
+        int dev_ = 0;                                                                                                 \
+        (void)hipGetDevice(&dev_);                                                                                    \
+        if (!((attr_set.load(std::memory_order_acquire) >> (dev_ & 63)) & 1ull)) {                                     \
+            hipError_t e = hipFuncSetAttribute((const void *)k_first_layer_split<ACT>, hipFuncAttributeMaxDynamicSharedMemorySize, \
+                                               (int)lds_bytes);                                                       \
+            if (e != hipSuccess) return hip_rc(e);                                                                    \
+            attr_set.fetch_or(1ull << (dev_ & 63), std::memory_order_release);                                        \
+        }                                                                                                             \
+        hipLaunchKernelGGL((k_first_layer_split<ACT>), grid, block, lds_bytes, s, (const u8 *)soa, n, stride, (const uint4 *)w_hi, \
+                           (const uint4 *)w_lo, bias, (u32 *)out_hi_lo, (u32)H, rows_per_block, alpha);               \
+    } while (0)
+    if (activation == RC_ACT_ELU) RC_LAUNCH_SP(RC_ACT_ELU);
+    else if (activation == RC_ACT_RELU) RC_LAUNCH_SP(RC_ACT_RELU);
+    else RC_LAUNCH_SP(RC_ACT_NONE);
+#undef RC_LAUNCH_SP
     return launch_status();
 }
 
@@ -616,12 +817,15 @@ extern "C" int rc_first_layer_bf16(const int8_t *soa, size_t n, size_t stride, c
     uint4 *o = (uint4 *)out;
 #define RC_LAUNCH_FL(ACT, F16)                                                                                     \
     do {                                                                                                           \
-        static bool attr_set = false;                                                                              \
-        if (!attr_set) {                                                                                           \
+        /* per device and thread-safe: the attribute belongs to the function ON A DEVICE (one process may drive several) */ \
+        static std::atomic<unsigned long long> attr_set{0};                                                        \
+        int dev_ = 0;                                                                                              \
+        (void)hipGetDevice(&dev_);                                                                                 \
+        if (!((attr_set.load(std::memory_order_acquire) >> (dev_ & 63)) & 1ull)) {                                  \
             hipError_t e = hipFuncSetAttribute((const void *)k_first_layer<ACT, F16>,                               \
                                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);        \
             if (e != hipSuccess) return hip_rc(e);                                                                 \
-            attr_set = true;                                                                                       \
+            attr_set.fetch_or(1ull << (dev_ & 63), std::memory_order_release);                                     \
         }                                                                                                          \
         hipLaunchKernelGGL((k_first_layer<ACT, F16>), grid, block, lds_bytes, s, in, n, stride, w, bias, o, (u32)H, \
                            rows_per_block, alpha);                                                                 \

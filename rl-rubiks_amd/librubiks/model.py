@@ -403,7 +403,7 @@ class SplitF32Net:
             code = 0 if act is None else 1 if isinstance(act, nn.ReLU) else 2
             alpha = float(getattr(act, "alpha", 1.0))
             if i == 0:    # one-hot input: x_lo = 0, so y = oh W_hi^T + 2^-11 oh W_lo^T = [oh, oh 2^-11] [W_hi | W_lo]^T
-                out.append(("in", torch.cat([hi, lo], 1).contiguous(), b.float().contiguous(), code, alpha))
+                out.append(("in", torch.cat([hi, lo], 1).contiguous(), b.float().contiguous(), code, alpha, hi.contiguous(), lo.contiguous()))
             else:
                 out.append(("hid", hi.contiguous(), torch.cat([lo, hi], 1).contiguous(), b.float().contiguous(), code, alpha))
         return out
@@ -439,14 +439,40 @@ class SplitF32Net:
                                                None if split else out.data_ptr(), _hip.stream_ptr()), "rc_split_act_f16")
         return out
 
+    fused_input = True   # the input layer as one MFMA kernel from the cube states (rc_first_layer_split_f16) when shapes allow
+
+    def _first_from_cubes(self, cubes, layers, lo: int = 0, n: int = None):
+        """[hi | lo] activations of the input layer straight from device cubes, or None if the fused kernel does not apply."""
+        from librubiks import _hip
+        _, B, b, code, alpha, Wh, Wl = layers[0]
+        H = Wh.shape[0]
+        if not self.fused_input or H % 64 or len(layers) < 3:
+            return None
+        if lo or n is not None:
+            n = cubes.n - lo if n is None else n
+            assert lo % 16 == 0 and 0 <= lo and lo + n <= cubes.n
+            cubes = _CubeWindow(cubes.soa.data_ptr() + lo, n, cubes.stride)
+        out = torch.empty((cubes.n, 2 * H), dtype=torch.float16, device=self.device)
+        _hip.check(_hip.lib().rc_first_layer_split_f16(_soa_ptr(cubes), cubes.n, cubes.stride, Wh.data_ptr(), Wl.data_ptr(), b.data_ptr(),
+                                                       out.data_ptr(), H, code, alpha, _hip.stream_ptr()), "rc_first_layer_split_f16")
+        return out
+
+    def _forward_cubes(self, cubes, layers, lo: int = 0, n: int = None) -> torch.Tensor:
+        a = self._first_from_cubes(cubes, layers, lo, n)
+        if a is None:
+            return self._forward(self._input_from_cubes(cubes, lo, n), layers)
+        return self._forward(a, layers, first=1)
+
     @torch.no_grad()
-    def _forward(self, a: torch.Tensor, layers) -> torch.Tensor:
-        """a: [n, 960] half operand of the input layer -> fp32 [n, n_out]."""
+    def _forward(self, a: torch.Tensor, layers, first: int = 0) -> torch.Tensor:
+        """a: [n, 960] half operand of the input layer (or, with first = 1, its [hi | lo] output) -> fp32 [n, n_out]."""
         for i, layer in enumerate(layers):
+            if i < first:
+                continue
             last_hidden = i == len(layers) - 2
             corr = None
             if layer[0] == "in":
-                _, B, b, code, alpha = layer
+                _, B, b, code, alpha = layer[:5]
                 c = torch.mm(a, B.t(), out_dtype=torch.float32)
             elif layer[0] == "hid":
                 _, Wh, B2, b, code, alpha = layer
@@ -472,7 +498,7 @@ class SplitF32Net:
     @torch.no_grad()
     def head_cubes(self, cubes, x1=None) -> torch.Tensor:
         """[n, 13] float32: 12 policy logits, then the value (the layout rc_mcts_backup_head reads)."""
-        return self._forward(self._input_from_cubes(cubes), self.layers)
+        return self._forward_cubes(cubes, self.layers)
 
     @torch.no_grad()
     def forward_cubes(self, cubes, x1=None):
@@ -481,7 +507,7 @@ class SplitF32Net:
 
     @torch.no_grad()
     def value_cubes(self, cubes, x1=None, lo: int = 0, n: int = None) -> torch.Tensor:
-        return self._forward(self._input_from_cubes(cubes, lo, n), self.value_layers).reshape(-1)
+        return self._forward_cubes(cubes, self.value_layers, lo, n).reshape(-1)
 
 
 class _CubeWindow:
