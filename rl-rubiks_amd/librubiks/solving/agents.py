@@ -210,7 +210,8 @@ class _Harvest:
         buf = free.pop() if free else torch.empty((rows,) + tuple(t.shape[1:]), dtype=t.dtype, pin_memory=True)
         return buf
 
-    def __init__(self, agent, forest: md.MCTSForest, games: np.ndarray):
+    def __init__(self, agent, forest: md.MCTSForest, games: np.ndarray, n: int = None):
+        """n: only the first n trees of the forest are real (a partly filled results forest)."""
         self.games, self.graph = games, agent.search_graph
         src = {"status": forest.status, "nodes": forest.n_nodes, "iterations": forest.iterations,
                "plen": forest.path_len, "sol": forest.solved_action, "pact": forest.path_act}
@@ -218,10 +219,10 @@ class _Harvest:
             forest.complete_graphs()       # _complete_graph of all solved trees in one launch
             forest.shorten_launch()        # ... and their BFS shortening in another
             src["slen"], src["sact"] = forest.short_len, forest.short_act
-        self.host, self.n = {}, forest.B
+        self.host, self.n = {}, forest.B if n is None else n
         for name, t in src.items():
-            self.host[name] = self._host_like(t)
-            self.host[name][:self.n].copy_(t, non_blocking=True)
+            self.host[name] = self._host_like(t[:self.n])
+            self.host[name][:self.n].copy_(t[:self.n], non_blocking=True)
         self.event = torch.cuda.Event()
         self.event.record()
         self.forest = forest   # keeps the buffers alive until the copies have landed
@@ -401,6 +402,7 @@ class MCTSRun:
                                            "host_enqueue_s": 0.0, "host_wait_s": 0.0, "host_process_s": 0.0}
         self.side = torch.cuda.Stream()
         self.harvests = []                 # _Harvest objects in flight
+        self.grave, self.grave_fill, self.grave_event, self.grave_games = None, 0, None, None
         self.parts = []                    # (game ids, BatchResult)
         agent._tree, agent._tree_src = None, None
         self.snapshots = deque()           # (index, forest, event, pinned status) of rounds nobody has looked at yet
@@ -412,13 +414,45 @@ class MCTSRun:
                 self.parts.append((h.games, h.result()))
                 self.harvests.remove(h)
 
+    GRAVE = 256   # finished trees collected before their graph completion / BFS shortening is launched
+
+    def _flush_grave(self):
+        """Result extraction for the trees collected so far: ONE launch sequence over up to GRAVE trees on the side stream.
+        Post-processing the ~30 trees of every refill by themselves keeps ~30 CUs busy for milliseconds each time, and the
+        library GEMMs of the running forest (one workgroup per CU) then take two rounds instead of one."""
+        if self.grave is None or self.grave_fill == 0:
+            return
+        g, n = self.grave, self.grave_fill
+        g.status[n:] = md.RUNNING          # slots beyond the fill are not trees
+        ev = torch.cuda.Event()
+        ev.record()
+        with torch.cuda.stream(self.side):
+            self.side.wait_event(ev)
+            h = _Harvest(self.agent, g, self.grave_games[:n].copy(), n=n)
+        self.harvests.append(h)
+        self.grave_event, self.grave_fill = h.event, 0
+
     def _harvest(self, idx_np: np.ndarray):
-        """Copies the finished trees `idx_np` out of the forest (their slots are needed or dropped) and starts
-        turning them into results on the side stream."""
+        """Copies the finished trees `idx_np` out of the forest (their slots are needed or dropped): what result extraction
+        reads of them goes into the results forest, which is processed GRAVE trees at a time on the side stream."""
         forest, agent = self.forest, self.agent
         idx = _to_device_async(idx_np, forest.status.device)
         games = self.owner[idx_np].copy()
         keep_tree = agent._tree_src is None and (games == 0).any()   # game 0's tree stays inspectable (the reference's attributes)
+        if not keep_tree and len(idx_np) < self.GRAVE // 2:
+            if self.grave is None:
+                self.grave = md.MCTSForest(self.GRAVE, forest.C, forest.max_path, forest.device, _results_only=True)
+                self.grave_games = np.zeros(self.GRAVE, dtype=np.int64)
+            if self.grave_fill + len(idx_np) > self.GRAVE:
+                self._flush_grave()
+            if self.grave_event is not None:     # the previous batch must have been read before its slots are overwritten
+                torch.cuda.current_stream().wait_event(self.grave_event)
+                self.grave_event = None
+            self.grave.bury(self.grave_fill, forest, idx)
+            self.grave_games[self.grave_fill:self.grave_fill + len(idx_np)] = games
+            self.grave_fill += len(idx_np)
+            self.stats["harvests"] += 1
+            return
         sub = forest.subset(idx, results_only=not keep_tree)
         ev = torch.cuda.Event()
         ev.record()
@@ -501,7 +535,8 @@ class MCTSRun:
         """Nodes in the trees currently in the forest plus those of the trees already harvested (synchronises)."""
         self._drain(True)
         live = torch.from_numpy(self.owner >= 0).to(self.forest.n_nodes.device)
-        return int(self.forest.n_nodes[live].sum().item()) + sum(int(r.nodes.sum()) for _, r in self.parts)
+        buried = int(self.grave.n_nodes[:self.grave_fill].sum().item()) if self.grave_fill else 0
+        return int(self.forest.n_nodes[live].sum().item()) + buried + sum(int(r.nodes.sum()) for _, r in self.parts)
 
     def finish(self) -> BatchResult:
         agent, forest, owner = self.agent, self.forest, self.owner
@@ -514,6 +549,7 @@ class MCTSRun:
                 agent._tree_src = (forest, int(np.flatnonzero(owner == 0)[0]))
         elif len(left):
             self._harvest(left)
+        self._flush_grave()
         self._drain(True)
         result = BatchResult.merge(self.n_games, self.parts, seconds)
         if self.next_game < self.n_games:   # games that never got a slot before the time limit: unsolved, nothing explored

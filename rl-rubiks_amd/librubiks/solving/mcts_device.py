@@ -91,8 +91,8 @@ class MCTSForest:
             if _state is not None and name in _state:
                 t = _state[name]
                 assert tuple(t.shape) == shape and t.dtype == dt and t.is_contiguous(), name
-            elif _results_only:   # arrays that turning finished trees into results never touches: one row, so that pointers are valid
-                t = z((1,) + shape[1:], dt)
+            elif _results_only and name not in _RESULT_NODE + _RESULT_TREE + ("hash",):
+                t = z((1,) + shape[1:], dt)   # arrays that turning finished trees into results never touches: one row, so that pointers are valid
             else:
                 t = z(shape, dt)
             setattr(self, name, t)
@@ -148,6 +148,18 @@ class MCTSForest:
         sub.level_budget = self.level_budget
         sub.set_net(self.engine, self.engine.dtype if hasattr(self.engine, "dtype") else torch.bfloat16)
         return sub
+
+    def bury(self, pos: int, other: "MCTSForest", idx: torch.Tensor):
+        """Copies what result extraction reads of the (finished) trees `idx` of `other` into this results-only forest's slots
+        pos .. pos + len(idx) - 1."""
+        assert self.results_only and other.C == self.C and other.max_path == self.max_path and pos + len(idx) <= self.B
+        k, C1 = len(idx), self.C + 1
+        for name in _RESULT_NODE:
+            dst, src = getattr(self, name), getattr(other, name)
+            dst.view(self.B, C1, *dst.shape[1:])[pos:pos + k] = src.view(other.B, C1, *src.shape[1:])[idx]
+        self.hash[pos:pos + k] = other.hash[idx]
+        for name in _RESULT_TREE:
+            getattr(self, name)[pos:pos + k] = getattr(other, name)[idx]
 
     def bytes_allocated(self) -> int:
         return sum(t.numel() * t.element_size() for t in (self.keys, self.nbr, self.P, self.W, self.N, self.L, self.V,
