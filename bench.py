@@ -523,13 +523,13 @@ def step_rooflines(engine, agent, roots, args, name):
     if fused:
         H = eng._fused_first[4]
         mode = eng._fused_first[5]
-        mfma = mode in (2, 4)
-        kname = ("rc_first_layer_mfma_bf16 (one-hot x W1 on the matrix cores, one-hot fragments generated from the cube codes, "
+        mfma = mode in (2, 4, 5)
+        kname = ("rc_first_layer_mfma2_bf16" if mode == 5 else "rc_first_layer_mfma_bf16") + (" (one-hot x W1 on the matrix cores, one-hot fragments generated from the cube codes, "
                  "W1 slice in LDS, + bias + ELU)") if mfma else "rc_first_layer_bf16 (one-hot x W1 as 20-row gather-sum from LDS + bias + ELU)"
         f_in = 2 * 480 * H * rows
         tf_in = f_in / (phases["input_layer"] * 1e-3) / 1e12
         nbytes = (20 + 2 * H) * rows
-        roofline_input = {"kernel": kname, "table": {0: "bf16", 1: "f16", 2: "bf16", 3: "f16 pairs", 4: "f16"}[mode],
+        roofline_input = {"kernel": kname, "table": {0: "bf16", 1: "f16", 2: "bf16", 3: "f16 pairs", 4: "f16", 5: "f16, two tiles per wave"}[mode],
                           "bound": "mfma" if mfma else "lds", "achieved": round(tf_in, 1), "peak": MFMA_BF16_PEAK_TFLOPS,
                           "unit": "TFLOP/s", "frac": round(tf_in / MFMA_BF16_PEAK_TFLOPS, 4), "flops_per_launch": f_in,
                           "traffic": None, "ms_per_launch": phases["input_layer"], "algorithmic_bytes": nbytes,
@@ -563,7 +563,7 @@ def main():
     ap.add_argument("--level-budget", default="auto",
                     help="new tree levels a PUCT descent may walk per step before it is suspended (0 = strict lock step; "
                          "auto = the agent's default: a budget while scrambles are waiting for a slot, none for the tail)")
-    ap.add_argument("--first-layer-table", default="auto", choices=["auto", "f16", "f16pair", "bf16", "mfma", "mfma16", "onehot"],
+    ap.add_argument("--first-layer-table", default="auto", choices=["auto", "f16", "f16pair", "bf16", "mfma", "mfma16", "mfma16x2", "onehot"],
                     help="bf16 engine's input layer: fused gather-sum with an f16 / bf16 table, or the one-hot GEMM")
     ap.add_argument("--as-rank", default=None, metavar="R/W",
                     help="single process, no process group: take rank R's share of a W-rank run's scrambles (tests compare "

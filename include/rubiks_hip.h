@@ -144,6 +144,13 @@ int rc_first_layer_bf16(const int8_t *soa, size_t n, size_t stride, const uint16
 int rc_first_layer_mfma_bf16(const int8_t *soa, size_t n, size_t stride, const uint16_t *w1, const float *bias,
                              uint16_t *out, size_t H, int activation, float alpha, int table_is_f16, rc_stream_t stream);
 
+/* The same layer with 64 output columns per workgroup and two 32-state tiles per wave sharing every W1 fragment read from
+ * LDS (the structure of rc_first_layer_split_f16 with one table).  Measured 55.7 us against 50.5 us for the kernel above
+ * at 11 264 x 4096, so the bf16 engine keeps the kernel above; selectable as first_layer_table="mfma16x2".
+ * w1_half: IEEE half [H][480] row-major, H % 64 == 0 (61 KiB of LDS: no attribute call needed). */
+int rc_first_layer_mfma2_bf16(const int8_t *soa, size_t n, size_t stride, const uint16_t *w1_half, const float *bias,
+                              uint16_t *out, size_t H, int activation, float alpha, rc_stream_t stream);
+
 /* In-place ReLU / ELU(alpha) of a contiguous bf16 tensor of n elements (n % 8 == 0): the activation pass between
  * two library GEMMs (model.py:150-157: Linear -> activation), 16 bytes per lane.  4 B of HBM traffic per element. */
 int rc_act_bf16_inplace(uint16_t *x, size_t n, int activation, float alpha, rc_stream_t stream);

@@ -584,15 +584,17 @@ __device__ __forceinline__ float expm1_neg(float x) {
     return x < -0.35f ? __expf(x) - 1.0f : p * x;
 }
 
-template <int ACT>
+// SPLIT = false: the same kernel as the bf16 engine's input layer (one table, W1 in IEEE half; bf16 output [n][H]).
+template <int ACT, bool SPLIT>
 __global__ __launch_bounds__(kMfWaves * kWave) void k_first_layer_split(const u8 *__restrict__ soa, size_t n, size_t stride,
                                                                       const uint4 *__restrict__ w_hi, const uint4 *__restrict__ w_lo,
                                                                       const float *__restrict__ bias, u32 *__restrict__ out, u32 H,
                                                                       u32 rows_per_block, float alpha) {
     extern __shared__ __attribute__((aligned(256))) unsigned char lds[];
-    unsigned char *wslice = lds;                                                       // [2 tables][64 slots][976 B]
+    constexpr int kTables = SPLIT ? 2 : 1;
+    unsigned char *wslice = lds;                                                       // [kTables][64 slots][976 B]
     const u32 tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
-    uint4 *onehot = reinterpret_cast<uint4 *>(lds + 2 * kSpCols * kMfPitch);           // [2][9] A fragments: 1.0 / 2^-11 at position p
+    uint4 *onehot = reinterpret_cast<uint4 *>(lds + kTables * kSpCols * kMfPitch);     // [kTables][9] A fragments: 1.0 / 2^-11 at position p
     const u32 col_tiles = H / kSpCols;
     const u32 ct = blockIdx.x % col_tiles, rg = blockIdx.x / col_tiles;
     const size_t row_lo = (size_t)rg * rows_per_block;
@@ -600,7 +602,7 @@ __global__ __launch_bounds__(kMfWaves * kWave) void k_first_layer_split(const u8
     const size_t row_hi = (row_lo + rows_per_block < n) ? row_lo + rows_per_block : n;
     {   // 2 x 64 columns x 60 chunks of 16 B = 7 680 chunks / 512 threads = 15 per thread.  Column g of the slice goes to slot
         // (g % 2) * 32 + g / 2: MFMA column tile c, lane r owns column 2 r + c.
-        constexpr int kPer = 2 * kSpCols * 60 / (kMfWaves * kWave), kBatch = 5;
+        constexpr int kBatch = 5, kPer = kTables * kSpCols * 60 / (kMfWaves * kWave) / kBatch * kBatch;   // 15 or 5 (+ a tail of 2.5)
 #pragma unroll
         for (int b0 = 0; b0 < kPer; b0 += kBatch) {
             uint4 tmp[kBatch];
@@ -616,8 +618,13 @@ __global__ __launch_bounds__(kMfWaves * kWave) void k_first_layer_split(const u8
                 *reinterpret_cast<uint4 *>(wslice + (tbl * kSpCols + slot) * kMfPitch + (j % 60) * 16) = tmp[t];
             }
         }
+        for (u32 i = tid + kPer * (kMfWaves * kWave); i < (u32)(kTables * kSpCols * 60); i += kMfWaves * kWave) {   // what kBatch left over
+            const u32 tbl = i / (kSpCols * 60), j = i % (kSpCols * 60), g = j / 60, slot = (g & 1) * 32 + (g >> 1);
+            *reinterpret_cast<uint4 *>(wslice + (tbl * kSpCols + slot) * kMfPitch + (j % 60) * 16) =
+                (tbl ? w_lo : w_hi)[(size_t)(ct * kSpCols + j / 60) * 60 + j % 60];
+        }
     }
-    if (tid < 18) {
+    if (tid < 9 * kTables) {
         u32 w[4] = {0, 0, 0, 0};
         const u32 p = tid % 9, one = tid < 9 ? kHalfOne : kHalfScaleInv;
         if (p < 8) w[p >> 1] = (p & 1) ? one << 16 : one;
@@ -655,8 +662,8 @@ __global__ __launch_bounds__(kMfWaves * kWave) void k_first_layer_split(const u8
         // two passes of 30 k-steps: table 0 = W_hi with one-hot 1.0, table 1 = W_lo with one-hot 2^-11 (the pass loop is
         // NOT unrolled: unrolling all 60 steps overflows the 256 registers a wave has at two waves per SIMD)
 #pragma unroll 1
-        for (int tbl = 0; tbl < 2; ++tbl) {
-            const uint4 *frag = onehot + 9 * tbl;
+        for (int tbl = 0; tbl < kTables; ++tbl) {
+            const uint4 *frag = onehot + 9 * tbl;   // (building the fragment in registers instead was measured: 43 % slower)
             const unsigned char *bbase = wslice + ((size_t)tbl * kSpCols + r) * kMfPitch + 16 * h;   // + c * 32 * pitch + 32 * ks
             auto a_frag = [&](int u, int ks) -> uint4 {
                 const int m2 = ks / 3, ph = ks % 3;
@@ -692,8 +699,8 @@ __global__ __launch_bounds__(kMfWaves * kWave) void k_first_layer_split(const u8
                 for (int c = 0; c < 2; ++c) b_cur[c] = b_nxt[c];
             }
         }
-        // epilogue: activation, then the two halves of the lane's columns 2 r, 2 r + 1: one 4-byte store each into the
-        // [hi | lo] row of the state (row pitch 2 H halves)
+        // epilogue: activation, then the lane's columns 2 r, 2 r + 1 of one state as one 4-byte store: bf16 pair, or -- split --
+        // the pair of hi halves and the pair of lo halves into the [hi | lo] row of the state (row pitch 2 H halves)
 #pragma unroll
         for (int u = 0; u < kSpSub; ++u)
 #pragma unroll
@@ -703,14 +710,22 @@ __global__ __launch_bounds__(kMfWaves * kWave) void k_first_layer_split(const u8
 #pragma unroll
                 for (int c = 0; c < 2; ++c) {
                     const float x = acc[u][c][i];
-                    y[c] = ACT == RC_ACT_RELU ? fmaxf(x, 0.f) : ACT == RC_ACT_ELU ? (x > 0.f ? x : alpha * expm1_neg(x)) : x;
-                    hi[c] = round_to_half_f32(y[c]);
-                    lo[c] = (y[c] - hi[c]) * kSplitScale;
+                    if (SPLIT) {
+                        y[c] = ACT == RC_ACT_RELU ? fmaxf(x, 0.f) : ACT == RC_ACT_ELU ? (x > 0.f ? x : alpha * expm1_neg(x)) : x;
+                        hi[c] = round_to_half_f32(y[c]);
+                        lo[c] = (y[c] - hi[c]) * kSplitScale;
+                    } else {
+                        y[c] = act_apply(x, ACT, alpha);
+                    }
                 }
                 if (row < n) {
-                    u32 *orow = out + row * H;   // 2 H halves = H dwords per row
-                    orow[(ct * kSpCols) / 2 + r] = pack_half2(hi[0], hi[1]);
-                    orow[H / 2 + (ct * kSpCols) / 2 + r] = pack_half2(lo[0], lo[1]);
+                    if (SPLIT) {
+                        u32 *orow = out + row * H;   // 2 H halves = H dwords per row
+                        orow[(ct * kSpCols) / 2 + r] = pack_half2(hi[0], hi[1]);
+                        orow[H / 2 + (ct * kSpCols) / 2 + r] = pack_half2(lo[0], lo[1]);
+                    } else {
+                        out[row * (H / 2) + (ct * kSpCols) / 2 + r] = pack_bf16(y[0], y[1]);
+                    }
                 }
             }
     }
@@ -767,18 +782,43 @@ extern "C" int rc_first_layer_split_f16(const int8_t *soa, size_t n, size_t stri
         int dev_ = 0;                                                                                                 \
         (void)hipGetDevice(&dev_);                                                                                    \
         if (!((attr_set.load(std::memory_order_acquire) >> (dev_ & 63)) & 1ull)) {                                     \
-            hipError_t e = hipFuncSetAttribute((const void *)k_first_layer_split<ACT>, hipFuncAttributeMaxDynamicSharedMemorySize, \
+            hipError_t e = hipFuncSetAttribute((const void *)k_first_layer_split<ACT, true>, hipFuncAttributeMaxDynamicSharedMemorySize, \
                                                (int)lds_bytes);                                                       \
             if (e != hipSuccess) return hip_rc(e);                                                                    \
             attr_set.fetch_or(1ull << (dev_ & 63), std::memory_order_release);                                        \
         }                                                                                                             \
-        hipLaunchKernelGGL((k_first_layer_split<ACT>), grid, block, lds_bytes, s, (const u8 *)soa, n, stride, (const uint4 *)w_hi, \
+        hipLaunchKernelGGL((k_first_layer_split<ACT, true>), grid, block, lds_bytes, s, (const u8 *)soa, n, stride, (const uint4 *)w_hi, \
                            (const uint4 *)w_lo, bias, (u32 *)out_hi_lo, (u32)H, rows_per_block, alpha);               \
     } while (0)
     if (activation == RC_ACT_ELU) RC_LAUNCH_SP(RC_ACT_ELU);
     else if (activation == RC_ACT_RELU) RC_LAUNCH_SP(RC_ACT_RELU);
     else RC_LAUNCH_SP(RC_ACT_NONE);
 #undef RC_LAUNCH_SP
+    return launch_status();
+}
+
+extern "C" int rc_first_layer_mfma2_bf16(const int8_t *soa, size_t n, size_t stride, const uint16_t *w1_half, const float *bias,
+                                         uint16_t *out, size_t H, int activation, float alpha, rc_stream_t stream) {
+    if (n == 0) return RC_OK;
+    RC_CHECK_SOA(soa, n, stride);
+    RC_REQUIRE(w1_half && bias && out, RC_ERR_NULL);
+    RC_REQUIRE(aligned16(w1_half) && aligned16(out), RC_ERR_ALIGN);
+    RC_REQUIRE(H >= (size_t)kSpCols && H % kSpCols == 0 && activation >= RC_ACT_NONE && activation <= RC_ACT_ELU, RC_ERR_RANGE);
+    const u32 col_tiles = (u32)(H / kSpCols);
+    u32 row_groups = (256 + col_tiles - 1) / col_tiles;
+    constexpr u32 kRowsPerPass = kMfWaves * kSpSub * kMfTile;
+    u32 rows_per_block = (u32)round_up(ceil_div(n, row_groups), kRowsPerPass);
+    row_groups = (u32)ceil_div(n, rows_per_block);
+    const size_t lds_bytes = (size_t)kSpCols * kMfPitch + 9 * 16;
+    const dim3 grid(col_tiles * row_groups), block(kMfWaves * kWave);
+    hipStream_t s = (hipStream_t)stream;
+#define RC_LAUNCH_M2(ACT)                                                                                             \
+    hipLaunchKernelGGL((k_first_layer_split<ACT, false>), grid, block, lds_bytes, s, (const u8 *)soa, n, stride,     \
+                       (const uint4 *)w1_half, (const uint4 *)w1_half, bias, (u32 *)out, (u32)H, rows_per_block, alpha)
+    if (activation == RC_ACT_ELU) RC_LAUNCH_M2(RC_ACT_ELU);
+    else if (activation == RC_ACT_RELU) RC_LAUNCH_M2(RC_ACT_RELU);
+    else RC_LAUNCH_M2(RC_ACT_NONE);
+#undef RC_LAUNCH_M2
     return launch_status();
 }
 

@@ -43,6 +43,7 @@ SIGNATURES = {
     "rc_adi_targets": [P, P, P, SZ, SZ, ctypes.c_float, I, P, P, P],
     "rc_first_layer_bf16": [P, SZ, SZ, P, P, P, SZ, I, ctypes.c_float, I, P],
     "rc_first_layer_mfma_bf16": [P, SZ, SZ, P, P, P, SZ, I, ctypes.c_float, I, P],
+    "rc_first_layer_mfma2_bf16": [P, SZ, SZ, P, P, P, SZ, I, ctypes.c_float, P],
 }
 _RESTYPES = {"rc_error_string": c_char_p}
 

@@ -247,9 +247,12 @@ class InferenceNet:
             half_ok = bool(torch.isfinite(W1_full).all()) and float(W1_full.abs().max()) < 3.0e4
             # mode: 0 / 1 gather-sum with a bf16 / f16 table, 3 f16 table with pairs of rows added in f16 first,
             #       2 / 4 matrix-core variant with the Linear weight as stored in bf16 / f16
-            if first_layer_table in ("mfma", "mfma16") or (first_layer_table == "auto" and half_ok):
+            #       5 matrix-core variant with 64 columns per workgroup and two tiles per wave sharing the W1 fragments (f16
+            #         weights; "mfma16x2"): measured 55.7 us against 50.5 us for mode 4 at 11 264 rows, so not the default
+            if first_layer_table in ("mfma", "mfma16", "mfma16x2") or (first_layer_table == "auto" and half_ok):
                 use_f16 = first_layer_table != "mfma" and half_ok
-                table, mode = W1_full.to(torch.float16 if use_f16 else torch.bfloat16).contiguous(), 4 if use_f16 else 2
+                two_tiles = use_f16 and first_layer_table == "mfma16x2" and W1.shape[0] % 64 == 0
+                table, mode = W1_full.to(torch.float16 if use_f16 else torch.bfloat16).contiguous(), 5 if two_tiles else 4 if use_f16 else 2
             else:
                 use_f16 = first_layer_table in ("f16", "f16pair") and half_ok
                 table = W1_full.t().to(torch.float16 if use_f16 else torch.bfloat16).contiguous()
@@ -292,6 +295,10 @@ class InferenceNet:
             cubes = _CubeWindow(cubes.soa.data_ptr() + lo, n, cubes.stride)
         if out is None:
             out = torch.empty((cubes.n, H), dtype=torch.bfloat16, device=w1t.device)
+        if is_f16 == 5:
+            _hip.check(_hip.lib().rc_first_layer_mfma2_bf16(_soa_ptr(cubes), cubes.n, cubes.stride, w1t.data_ptr(), b1.data_ptr(),
+                                                            out.data_ptr(), H, code, alpha, _hip.stream_ptr()), "rc_first_layer_mfma2_bf16")
+            return out
         if is_f16 in (2, 4):
             _hip.check(_hip.lib().rc_first_layer_mfma_bf16(_soa_ptr(cubes), cubes.n, cubes.stride, w1t.data_ptr(),
                                                            b1.data_ptr(), out.data_ptr(), H, code, alpha, int(is_f16 == 4),
