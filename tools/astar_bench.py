@@ -22,6 +22,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--weights", default=os.path.join(ROOT, "weights", "fc_small_r1"))
     ap.add_argument("--solve-max-states", type=int, default=0)
+    ap.add_argument("--dtype", default="bf16", choices=["bf16", "f32", "f32s"], help="network engine inside the agent")
     args = ap.parse_args()
     from librubiks import cube
     from librubiks.model import Model, ModelConfig
@@ -30,7 +31,8 @@ def main():
     torch.manual_seed(0)
     cubes, _, _ = cube.scramble_batch(args.problems, args.depth, True)
     model = Model.load(args.weights).eval() if os.path.isdir(args.weights) else Model.create(ModelConfig()).eval()
-    agent = AStar(model, args.lambda_, args.expansions)
+    from librubiks.model import F32_SPLIT
+    agent = AStar(model, args.lambda_, args.expansions, net_dtype={"bf16": torch.bfloat16, "f32": torch.float32, "f32s": F32_SPLIT}[args.dtype])
     cap = 12 * args.expansions * (args.steps + args.warmup + 2) + 16
     batch = agent._batch_for(cubes.n, cap)
     batch.reset(cubes)
@@ -51,7 +53,7 @@ def main():
            "ms_per_iteration": dt / args.steps * 1e3, "new_states_per_iteration": nodes / args.steps,
            "child_rows_per_iteration": args.problems * args.expansions * 12,
            "config": {"workload": f"{args.problems} depth-{args.depth} scrambles, AStar lambda={args.lambda_} N={args.expansions}, fc_small",
-                      "weights": args.weights if os.path.isdir(args.weights) else "random-init"},
+                      "weights": args.weights if os.path.isdir(args.weights) else "random-init", "net": args.dtype},
            "solved_so_far": int((batch.status == 1).sum().item())}
     if args.solve_max_states:
         t = time.perf_counter()
