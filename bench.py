@@ -217,14 +217,24 @@ def phase_times_split(forest, c, max_states, reps):
     out = {k: round(v / reps, 4) for k, v in acc.items()}
     cubes, rows = forest._net_input()
     hid = {}
-    for li in (1, 2):   # the two hidden layers behind the input layer: one hi x hi GEMM (K) and one correction GEMM (2 K) each
-        _, Wh, B2, b, code, alpha = eng.layers[li]
-        K = Wh.shape[1]
+    for li in (1, 2):   # the two hidden layers behind the input layer, as the engine runs them
+        _, Wh, B2, b, code, alpha, W3 = eng.layers[li]
+        K, N = Wh.shape[1], Wh.shape[0]
         a = torch.randn((rows, 2 * K), device=Wh.device).half()
-        hid[f"gemm_hidden{li}_main"] = round(event_ms(lambda: torch.mm(a[:, :K], Wh.t(), out_dtype=torch.float32), reps)[0], 4)
-        hid[f"gemm_hidden{li}_corr"] = round(event_ms(lambda: torch.mm(a, B2.t(), out_dtype=torch.float32), reps)[0], 4)
+        tile = eng._fused_tile(rows, N, K) if eng.fused_hidden else 0
+        last = li == len(eng.layers) - 2
+        if tile:   # one kernel: three f16 products + bias + activation + re-split (csrc/rubiks_gemm.hip)
+            o = torch.empty((rows, N if last else 2 * N), dtype=torch.float32 if last else torch.float16, device=Wh.device)
+            hid[f"gemm_hidden{li}"] = round(event_ms(lambda: _hip.check(lib.rc_split_gemm_f16(
+                a.data_ptr(), W3.data_ptr(), b.data_ptr(), rows, N, K, code, alpha, None if last else o.data_ptr(),
+                o.data_ptr() if last else None, tile, _hip.stream_ptr()), "rc_split_gemm_f16"), reps)[0], 4)
+            hid[f"gemm_hidden{li}_kernel"] = "rc_split_gemm_f16"
+        else:      # hi x hi GEMM (K deep) + correction GEMM (2 K deep) through the library, + rc_split_act_f16
+            hid[f"gemm_hidden{li}_main"] = round(event_ms(lambda: torch.mm(a[:, :K], Wh.t(), out_dtype=torch.float32), reps)[0], 4)
+            hid[f"gemm_hidden{li}_corr"] = round(event_ms(lambda: torch.mm(a, B2.t(), out_dtype=torch.float32), reps)[0], 4)
+            hid[f"gemm_hidden{li}"] = round(hid[f"gemm_hidden{li}_main"] + hid[f"gemm_hidden{li}_corr"], 4)
+            hid[f"gemm_hidden{li}_kernel"] = "hipBLASLt x2"
     out.update(hid)
-    out["gemm_hidden1"] = round(hid["gemm_hidden1_main"] + hid["gemm_hidden1_corr"], 4)
     Wh = eng.layers[1][1]
     out["gemm_hidden1_weight"] = (int(Wh.shape[0]), int(Wh.shape[1]))
     return out
@@ -482,17 +492,19 @@ def step_rooflines(engine, agent, roots, args, name):
         f32_equiv = 2 * W1[0] * W1[1] * rows                      # the layer as an fp32 GEMM
         executed = 3 * f32_equiv                                    # three f16 products per element pair
         t = phases["gemm_hidden1"] * 1e-3
-        roofline = {"kernel": f"first hidden layer of the split engine: f16 GEMMs [{rows} x {W1[1]}] x [{W1[1]} x {W1[0]}] (hi x hi) and "
-                              f"[{rows} x {2 * W1[1]}] x [{2 * W1[1]} x {W1[0]}] (hi x lo + lo x hi), fp32 out, via hipBLASLt: the dominant kernels of a step",
+        own = phases.get("gemm_hidden1_kernel") == "rc_split_gemm_f16"
+        roofline = {"kernel": (f"rc_split_gemm_f16 (own MFMA kernel, 352 x 256 tiles): first hidden layer of the split engine, "
+                               f"[{rows} x {3 * W1[1]}] x [{3 * W1[1]} x {W1[0]}] f16 products (hi x lo, lo x hi, hi x hi) in one fp32 "
+                               f"accumulator + bias + ELU + re-split to halves: the dominant kernel of a step") if own else
+                              (f"first hidden layer of the split engine: f16 GEMMs [{rows} x {W1[1]}] x [{W1[1]} x {W1[0]}] (hi x hi) and "
+                               f"[{rows} x {2 * W1[1]}] x [{2 * W1[1]} x {W1[0]}] (hi x lo + lo x hi), fp32 out, via hipBLASLt: the dominant kernels of a step"),
                     "bound": "mfma", "achieved": round(executed / t / 1e12, 1), "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s",
                     "frac": round(executed / t / 1e12 / MFMA_BF16_PEAK_TFLOPS, 4), "traffic": None, "flops_per_launch": executed,
                     "ms_per_launch": phases["gemm_hidden1"], "fp32_equivalent_tflops": round(f32_equiv / t / 1e12, 1),
                     "fp32_mfma_peak_tflops": MFMA_F32_PEAK_TFLOPS,
                     "note": "f16 MFMA flops executed (3 per fp32-equivalent flop) against the dense f16 peak; the same layer as an "
-                            "fp32 MFMA GEMM is bounded by 157.3 TFLOP/s.  Both launches are the library kernel "
-                            "Cijk_Alik_Bljk_HSS_BH_..._MT256x192x64 (236 workgroups, stream-K), as are the two of the next layer: "
-                            "phases_ms.gemm_hidden{1,2}_{main,corr} are the four durations whose mean is that kernel's average in "
-                            "profiles/r2_bench_kernel_stats.csv"}
+                            "fp32 MFMA GEMM is bounded by 157.3 TFLOP/s.  ms_per_launch is measured live with HIP events on the "
+                            "launch stream (phases_ms.gemm_hidden1); the rocprofv3 average of the same kernel is in profiles/"}
         flops_net = eng.flops_per_state * rows
         group = {"kernel": f"whole split-engine forward on {rows} child rows (operand kernels + 5 f16 GEMMs + fp32 output layer)", "bound": "mfma",
                  "achieved": round(3 * flops_net / (phases["net_forward"] * 1e-3) / 1e12, 1), "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s",

@@ -34,7 +34,7 @@
 extern "C" {
 #endif
 
-#define RC_ABI_VERSION 2
+#define RC_ABI_VERSION 3
 
 #define RC_OK 0
 #define RC_ERR_NULL (-1)      /* required pointer is NULL */
@@ -175,6 +175,16 @@ int rc_first_layer_split_f16(const int8_t *soa, size_t n, size_t stride, const u
 int rc_split_act_f16(const float *c, const float *c_corr, float corr_scale, size_t n_rows, size_t n_cols, const float *bias,
                      int activation, float alpha, uint16_t *out_hi_lo, float *out_f32, rc_stream_t stream);
 
+/* One hidden layer of that network as ONE kernel (own MFMA GEMM, fused epilogue; csrc/rubiks_gemm.hip):
+ *   y = act(hi_x W_hi^T + 2^-11 (hi_x W_lo^T + lo_x W_hi^T) + bias)          (model.py:123-127,150-157 at fp32 accuracy)
+ * a_hi_lo: [n_rows][2 k] halves (hi | lo), as the kernels above write it;  w_lo_hi_hi: [n_out][3 k] halves, the layer's
+ * weight split and laid out [W_lo | W_hi | W_hi] (the order the K loop walks: both correction products, a 2^-11 scaling of
+ * the accumulator, the main product);  exactly one of out_hi_lo ([n_rows][2 n_out] halves) and out_f32 ([n_rows][n_out])
+ * is non-NULL.  k % 64 == 0;  tile: 0 = choose, 1 = 352 x 256 (n_out % 256 == 0), 2 = 176 x 128 (n_out % 128 == 0).
+ * Replaces two library GEMMs + rc_split_act_f16; the fp32 partial matrices never reach HBM. */
+int rc_split_gemm_f16(const uint16_t *a_hi_lo, const uint16_t *w_lo_hi_hi, const float *bias, size_t n_rows, size_t n_out,
+                      size_t k, int activation, float alpha, uint16_t *out_hi_lo, float *out_f32, int tile, rc_stream_t stream);
+
 /* ---- network head: last activation + skinny output layer in one pass -----------------------------------------
  * out[i][o] = bias[o] + sum_k w[o][k] * act(x[i][k])   for o < n_out <= 16   (float out, row pitch 16)
  * Replaces the final activation pass and the 1024 -> 13 GEMM of the merged policy/value heads
@@ -203,6 +213,7 @@ int rc_adi_targets(const float *values, const uint8_t *child_solved, const uint8
  * tree-major with capacity + 1 rows per tree.  All pointers are device pointers owned by the
  * caller (zero-initialised once, before the first rc_mcts_plant); the struct itself lives in host memory.
  */
+#define RC_MCTS_NODE_WORDS 64   /* 32-bit words per node record (see rc_mcts_t) */
 #define RC_MCTS_RUNNING 0
 #define RC_MCTS_SOLVED 1        /* a child of the expanded leaf is the solved cube (agents.py:540-543) */
 #define RC_MCTS_EXHAUSTED 2     /* len + 12 > max_states (agents.py:476) or node capacity reached */
@@ -215,13 +226,22 @@ typedef struct rc_mcts {
     uint32_t hash_size;  /* slots per tree, power of two, >= 2 * (capacity + 1) */
     uint32_t max_path;   /* descent buffer length per tree (2 .. 4096) */
     uint32_t rows_per_tree; /* network rows reserved per tree and iteration: 11 (see child_soa) */
-    /* per node, [B][capacity + 1] (x12 where noted) */
+    /* per node, [B][capacity + 1] */
     void *keys;          /* uint32[4]: the 20 codes packed 5 bits each (6 codes per dword) */
+    /* The per-action arrays of a node (the reference's agents.py:421-426 attributes) are the fields of ONE record of
+     * RC_MCTS_NODE_WORDS 32-bit words = 256 bytes = two cache lines, [B][capacity + 1][64], 256-byte aligned:
+     *   line 0: words 0-11 N | 12-23 W | 24-27 walk record (rec, below) | 28-31 spare       (what backup / re-validation write)
+     *   line 1: words 32-43 P | 44-55 nbr | 56-63 spare                                      (read-only once the children exist)
+     * Each pointer below addresses its field of node 0 of tree 0: entry a of node n is X[n * RC_MCTS_NODE_WORDS + a].
+     * Re-deciding a level of the previous descent path reads one record and dirties one line of it.
+     * The reference's L (virtual losses, agents.py:427) is NOT stored: every backup clears exactly the entries the descent
+     * before it raised (agents.py:569-570, 589-591), so between iterations L == nu x (how often the pending descent path
+     * path_node / path_act leaves a node by an action or arrives by its reverse), and zero once a tree is solved.  The
+     * kernels take their loss counts from the path; MCTSForest.tree_arrays() reports L from it. */
     int32_t *nbr;        /* x12  neighbors   (agents.py:421) */
     float *P;            /* x12  policy      (agents.py:423); values are float32-exact in the reference too */
     float *W;            /* x12  max value   (agents.py:426) */
     int32_t *N;          /* x12  visit count (agents.py:425) */
-    uint16_t *L;         /* x12  virtual-loss COUNT; reference L = 100 * count (agents.py:427,433,589-591) */
     float *V;            /*      value       (agents.py:424) */
     uint8_t *leaf;       /*      is leaf     (agents.py:422) */
     int32_t *hash;       /* [B][hash_size] open addressing, slot = node index or 0; full-key compare via keys */
@@ -251,7 +271,7 @@ typedef struct rc_mcts {
     int32_t *bfs;        /* [B][capacity + 1][2] scratch: {claim, parent << 4 | action} */
     uint8_t *short_act;  /* [B][max_path] shortened action queue of every solved tree */
     int32_t *short_len;  /* [B] its length, -1 where no shortened queue was produced */
-    /* per node, [B][capacity + 1]: 16-byte walk record, owned by the kernels (16-byte aligned):
+    /* per node: the 16-byte walk record, owned by the kernels (words 24-27 of the node record):
      *   uint32 {neighbour through best0, neighbour through best1, best0 | best1 << 8 | leaf << 16, 0}
      * best0 = the action a PUCT descent takes at the node while no virtual loss is pending there, best1 = the same
      * with one loss on best0 (the descent arrived through rev(best0)).  rc_mcts_init / rc_mcts_expand write leaf

@@ -1,0 +1,423 @@
+// Hidden layers of the fp32-accurate split network (librubiks/model.py::SplitF32Net) as ONE kernel per layer:
+//   y = act(hi_x W_hi^T + 2^-11 (hi_x W_lo^T + lo_x W_hi^T) + b),  written as the [hi(y) | lo(y)] halves the next layer reads
+// (or as fp32 for the layer in front of the output layer).  It replaces two library GEMMs (K and 2K deep, fp32 out) and
+// rc_split_act_f16: the three f16 products run through one fp32 accumulator -- the two correction products first, scaled by
+// 2^-11 (exact), the main product on top -- so the fp32 partial matrices never reach HBM.
+//
+// Shape of the problem (BASELINE config #2: 11 264 = 32 x 352 child rows per step, 4096 -> 2048 -> 512): the tile is
+// 352 x 256 (8 waves, 2 x 4, 176 x 64 outputs per wave), so the 4096 -> 2048 layer is exactly 256 workgroups = one per CU
+// with no tail, and 176 x 128 (4 waves) for the 512-wide layer, again 256 workgroups.
+//
+// Data movement: both operands are K-contiguous ([rows][K] halves), staged global -> LDS by global_load_lds_dwordx4 in
+// 64-deep K-steps (128-byte LDS rows, two stages).  LDS-DMA writes lane-linear, so the bank swizzle is applied to the
+// SOURCE chunk: 16-byte chunk c of row r is stored at slot c ^ ((r >> 1) & 7), which makes the ds_read_b128 fragment reads
+// of v_mfma_f32_16x16x32_f16 (16 rows x 2 chunks per 16-lane group) conflict-free.  The weights are the MFMA's A operand
+// and the activations its B operand, so a lane's four accumulator registers are four ADJACENT output columns of one row:
+// the epilogue stores 8 bytes of hi halves and 8 bytes of lo halves per fragment.
+#include <atomic>
+
+#include "rubiks_common.h"
+#include "rubiks_netmath.h"
+
+namespace rubiks {
+
+typedef __attribute__((ext_vector_type(8))) _Float16 f16x8;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+typedef __attribute__((address_space(3))) void lds_void;
+typedef const __attribute__((address_space(1))) void glb_void;
+
+constexpr int kGemmRowBytes = 128;   // one K-step: 64 halves per row
+
+struct GemmArgs {
+    const unsigned char *a;      // activations [M][2K] halves: hi | lo
+    const unsigned char *w;      // weights [N][3K] halves: lo | hi | hi   (the order the K loop walks them)
+    const float *bias;
+    void *out;                   // [M][2N] halves (hi | lo) or [M][N] fp32
+    u32 M, N, K;
+    float alpha;
+};
+
+template <int WM, int WN, int MR, int NR> struct GemmTile {
+    static constexpr int BM = WM * MR * 16, BN = WN * NR * 16, WAVES = WM * WN, THREADS = WAVES * 64;
+    static constexpr int A_BYTES = BM * kGemmRowBytes, B_BYTES = BN * kGemmRowBytes, STAGE = A_BYTES + B_BYTES;
+    static constexpr int PIECES = STAGE / 1024;                  // wave-level LDS-DMA instructions per stage (8 rows each)
+    static constexpr int PPW = (PIECES + WAVES - 1) / WAVES;     // per wave
+    static constexpr int LDS_BYTES = 2 * STAGE;
+};
+
+template <int WM, int WN, int MR, int NR, int ACT, bool OUT_SPLIT>
+__global__ __launch_bounds__(WM *WN * 64) void k_split_gemm(GemmArgs g) {
+    using T = GemmTile<WM, WN, MR, NR>;
+    extern __shared__ __attribute__((aligned(1024))) unsigned char lds[];
+    const u32 tid = threadIdx.x, lane = tid & 63;
+    const u32 wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const u32 wr = wave / WN, wc = wave % WN;
+
+    // workgroups that share an XCD (blockIdx % 8) take consecutive tiles: column tiles fastest, so an XCD's L2 sees few
+    // distinct activation rows and every weight column once
+    const u32 nwg = gridDim.x, nn = g.N / T::BN;
+    const u32 xcd = blockIdx.x % 8, q = nwg / 8, r8 = nwg % 8;
+    const u32 wg = (xcd < r8 ? xcd * (q + 1) : r8 * (q + 1) + (xcd - r8) * q) + blockIdx.x / 8;
+    const u32 tm = wg / nn, tn = wg % nn;
+    const size_t row0 = (size_t)tm * T::BM;
+    const u32 col0 = tn * T::BN;
+    const u32 K = g.K, lda = 2 * K * 2, ldw = 3 * K * 2;   // bytes
+    const u32 last_row = (u32)(g.M - 1 - row0);            // rows past M re-read the last row; their outputs are not stored
+
+    u32 src_off[T::PPW];
+#pragma unroll
+    for (int i = 0; i < T::PPW; ++i) {
+        const u32 p = i * T::WAVES + wave, R = p * 8 + (lane >> 3), chunk = (lane & 7) ^ ((R >> 1) & 7);
+        if (p < (u32)(T::BM / 8)) src_off[i] = min(R, last_row) * lda + chunk * 16;
+        else src_off[i] = (R - T::BM) * ldw + chunk * 16;
+    }
+    const unsigned char *a_tile = g.a + row0 * lda;
+    const unsigned char *w_tile = g.w + (size_t)col0 * ldw;
+
+    auto stage = [&](u32 ks, u32 buf) {
+        const u32 kk = ks * 64, a_col = kk < 2 * K ? kk : kk - 2 * K;
+        const unsigned char *ab = a_tile + a_col * 2, *wb = w_tile + kk * 2;
+        unsigned char *dst = lds + buf * T::STAGE;
+#pragma unroll
+        for (int i = 0; i < T::PPW; ++i) {
+            const u32 p = i * T::WAVES + wave;
+            if (p < (u32)T::PIECES) {
+                const unsigned char *src = (p < (u32)(T::BM / 8) ? ab : wb) + src_off[i];
+                __builtin_amdgcn_global_load_lds((glb_void *)src, (lds_void *)(dst + p * 1024), 16, 0, 0);
+            }
+        }
+    };
+
+    // fragment addresses inside a stage: row (lane & 15) of a 16-row block, chunk ((lane >> 4) + 4 kh) ^ swizzle(row)
+    const u32 fr = lane & 15, fq = lane >> 4, swz = fr >> 1;
+    u32 x_off[2], w_off[2];
+#pragma unroll
+    for (int kh = 0; kh < 2; ++kh) {
+        const u32 c = ((fq + 4 * kh) ^ swz) * 16;
+        x_off[kh] = (wr * MR * 16 + fr) * kGemmRowBytes + c;
+        w_off[kh] = T::A_BYTES + (wc * NR * 16 + fr) * kGemmRowBytes + c;
+    }
+
+    f32x4 acc[MR][NR];
+#pragma unroll
+    for (int m = 0; m < MR; ++m)
+#pragma unroll
+        for (int n = 0; n < NR; ++n) acc[m][n] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    const u32 nk = 3 * K / 64, scale_step = 2 * K / 64;
+    stage(0, 0);
+    for (u32 ks = 0; ks < nk; ++ks) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (ks + 1 < nk) stage(ks + 1, (ks + 1) & 1);
+        if (ks == scale_step) {
+#pragma unroll
+            for (int m = 0; m < MR; ++m)
+#pragma unroll
+                for (int n = 0; n < NR; ++n) acc[m][n] *= (1.0f / kSplitScale);
+        }
+        const unsigned char *s = lds + (ks & 1) * T::STAGE;
+        f16x8 wf[NR][2];
+#pragma unroll
+        for (int n = 0; n < NR; ++n)
+#pragma unroll
+            for (int kh = 0; kh < 2; ++kh) wf[n][kh] = *reinterpret_cast<const f16x8 *>(s + w_off[kh] + n * 16 * kGemmRowBytes);
+#pragma unroll
+        for (int m = 0; m < MR; ++m) {
+            f16x8 xf[2];
+#pragma unroll
+            for (int kh = 0; kh < 2; ++kh) xf[kh] = *reinterpret_cast<const f16x8 *>(s + x_off[kh] + m * 16 * kGemmRowBytes);
+#pragma unroll
+            for (int kh = 0; kh < 2; ++kh)
+#pragma unroll
+                for (int n = 0; n < NR; ++n) acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[n][kh], xf[kh], acc[m][n], 0, 0, 0);
+        }
+    }
+
+    // epilogue: lane holds columns cbase + 16 n + 4 fq + {0..3} of row rbase + 16 m + fr
+    const u32 cbase = col0 + wc * NR * 16 + 4 * fq;
+    float4 b4[NR];
+#pragma unroll
+    for (int n = 0; n < NR; ++n) b4[n] = *reinterpret_cast<const float4 *>(g.bias + cbase + 16 * n);
+#pragma unroll
+    for (int m = 0; m < MR; ++m) {
+        const size_t row = row0 + wr * MR * 16 + m * 16 + fr;
+        if (row >= g.M) continue;
+#pragma unroll
+        for (int n = 0; n < NR; ++n) {
+            float y[4] = {acc[m][n][0] + b4[n].x, acc[m][n][1] + b4[n].y, acc[m][n][2] + b4[n].z, acc[m][n][3] + b4[n].w};
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                if (ACT == RC_ACT_RELU) y[e] = fmaxf(y[e], 0.f);
+                if (ACT == RC_ACT_ELU) y[e] = y[e] > 0.f ? y[e] : g.alpha * expm1_neg(y[e]);
+            }
+            const u32 col = cbase + 16 * n;
+            if (OUT_SPLIT) {
+                float hi[4], lo[4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    hi[e] = round_to_half_f32(y[e]);
+                    lo[e] = (y[e] - hi[e]) * kSplitScale;
+                }
+                unsigned char *orow = reinterpret_cast<unsigned char *>(g.out) + row * ((size_t)g.N * 4);
+                *reinterpret_cast<uint2 *>(orow + col * 2) = make_uint2(pack_half2(hi[0], hi[1]), pack_half2(hi[2], hi[3]));
+                *reinterpret_cast<uint2 *>(orow + ((size_t)g.N + col) * 2) = make_uint2(pack_half2(lo[0], lo[1]), pack_half2(lo[2], lo[3]));
+            } else {
+                float *orow = reinterpret_cast<float *>(g.out) + row * (size_t)g.N;
+                *reinterpret_cast<float4 *>(orow + col) = make_float4(y[0], y[1], y[2], y[3]);
+            }
+        }
+    }
+}
+
+// The same tile with the two wave rows (waves 0-3 / 4-7: one of each per SIMD) running half a phase apart: a K-step is four
+// phases, one per block of three 16-row fragments, each {LDS reads + LDS-DMA issue | barrier | MFMAs | barrier}; the second
+// wave row enters the loop one barrier late, so on every SIMD one wave issues MFMAs while the other reads its next
+// fragments and stages the next K-step.  2 x 4 waves only.
+//   global barrier index (row 0 counts 8 per K-step s, row 1 is one behind):
+//     row 0: R_p in (8s+2p-1, 8s+2p), MFMA_p in (8s+2p, 8s+2p+1);   row 1: R_p in (8s+2p, 8s+2p+1), MFMA_p in (8s+2p+1, 8s+2p+2)
+//   stage s+1 goes into the buffer last read in step s-1: row 1's reads R_3(s-1) retire after barrier 8s-1, so row 0 issues its
+//   LDS-DMA in R_1, R_2 (after 8s+1) and row 1 in R_0, R_1 (after 8s); both wait vmcnt(0) before barrier 8s+7, which every
+//   wave passes before its first read of stage s+1.
+template <int MR, int NR, int ACT, bool OUT_SPLIT>
+__global__ __launch_bounds__(512) void k_split_gemm_pp(GemmArgs g) {
+    constexpr int WM = 2, WN = 4;
+    using T = GemmTile<WM, WN, MR, NR>;
+    constexpr int kBlk = 3, kPhases = (MR + kBlk - 1) / kBlk;
+    static_assert(kPhases == 4, "four phases per K-step");
+    extern __shared__ __attribute__((aligned(1024))) unsigned char lds[];
+    const u32 tid = threadIdx.x, lane = tid & 63;
+    const u32 wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const u32 wr = wave / WN, wc = wave % WN;
+
+    const u32 nwg = gridDim.x, nn = g.N / T::BN;
+    const u32 xcd = blockIdx.x % 8, q = nwg / 8, r8 = nwg % 8;
+    const u32 wg = (xcd < r8 ? xcd * (q + 1) : r8 * (q + 1) + (xcd - r8) * q) + blockIdx.x / 8;
+    const u32 tm = wg / nn, tn = wg % nn;
+    const size_t row0 = (size_t)tm * T::BM;
+    const u32 col0 = tn * T::BN;
+    const u32 K = g.K, lda = 2 * K * 2, ldw = 3 * K * 2;
+    const u32 last_row = (u32)(g.M - 1 - row0);
+
+    // LDS-DMA piece p = i * 8 + wave covers stage rows 8 p .. 8 p + 7 (activation rows first, then weight rows); lane l moves
+    // the 16-byte chunk (l & 7) ^ swizzle(row) of row 8 p + (l >> 3).  64 | rows per i, so the swizzle does not depend on i.
+    const u32 r_lane = wave * 8 + (lane >> 3), c_lane = ((lane & 7) ^ ((r_lane >> 1) & 7)) * 16;
+    const unsigned char *a_tile = g.a + row0 * lda;
+    const unsigned char *w_tile = g.w + (size_t)col0 * ldw;
+
+    constexpr int kHalf = (T::PPW + 1) / 2;
+    auto stage_part = [&](u32 ks, u32 buf, int lo, int hi) {   // this wave's pieces lo .. hi - 1 of stage ks
+        const u32 kk = ks * 64, a_col = kk < 2 * K ? kk : kk - 2 * K;
+        const unsigned char *ab = a_tile + a_col * 2, *wb = w_tile + kk * 2;
+        unsigned char *dst = lds + buf * T::STAGE;
+        u32 rl = r_lane, cl = c_lane;
+        asm volatile("" : "+v"(rl), "+v"(cl));   // keeps the per-piece addresses out of registers between K-steps (hoisted, they spill)
+#pragma unroll
+        for (int i = 0; i < T::PPW; ++i) {
+            if (i < lo || i >= hi) continue;
+            const u32 p = i * T::WAVES + wave;
+            if (p < (u32)T::PIECES) {
+                const u32 R = i * 64 + rl;
+                const unsigned char *src = p < (u32)(T::BM / 8) ? ab + (min(R, last_row) * lda + cl) : wb + ((R - T::BM) * ldw + cl);
+                __builtin_amdgcn_global_load_lds((glb_void *)src, (lds_void *)(dst + p * 1024), 16, 0, 0);
+            }
+        }
+    };
+
+    const u32 fr = lane & 15, fq = lane >> 4, swz = fr >> 1;
+    u32 x_off[2], w_off[2];
+#pragma unroll
+    for (int kh = 0; kh < 2; ++kh) {
+        const u32 c = ((fq + 4 * kh) ^ swz) * 16;
+        x_off[kh] = (wr * MR * 16 + fr) * kGemmRowBytes + c;
+        w_off[kh] = T::A_BYTES + (wc * NR * 16 + fr) * kGemmRowBytes + c;
+    }
+
+    f32x4 acc[MR][NR];
+#pragma unroll
+    for (int m = 0; m < MR; ++m)
+#pragma unroll
+        for (int n = 0; n < NR; ++n) acc[m][n] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    const u32 nk = 3 * K / 64, scale_step = 2 * K / 64;
+    stage_part(0, 0, 0, T::PPW);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    if (wr == 1) __builtin_amdgcn_s_barrier();   // the half-phase stagger
+
+    f16x8 wf[NR][2], xf[kBlk][2];
+    for (u32 ks = 0; ks < nk; ++ks) {
+        const unsigned char *s = lds + (ks & 1) * T::STAGE;
+        const bool more = ks + 1 < nk;
+        const u32 nbuf = (ks + 1) & 1;
+#pragma unroll
+        for (int ph = 0; ph < kPhases; ++ph) {
+            // ---- R_ph: fragments of this phase, and this wave's share of the next stage
+            if (ph == 0) {
+#pragma unroll
+                for (int n = 0; n < NR; ++n)
+#pragma unroll
+                    for (int kh = 0; kh < 2; ++kh) wf[n][kh] = *reinterpret_cast<const f16x8 *>(s + w_off[kh] + n * 16 * kGemmRowBytes);
+            }
+#pragma unroll
+            for (int j = 0; j < kBlk; ++j)
+                if (ph * kBlk + j < MR) {
+#pragma unroll
+                    for (int kh = 0; kh < 2; ++kh)
+                        xf[j][kh] = *reinterpret_cast<const f16x8 *>(s + x_off[kh] + (ph * kBlk + j) * 16 * kGemmRowBytes);
+                }
+            if (more) {
+                if (wr == 1) {
+                    if (ph == 0) stage_part(ks + 1, nbuf, 0, kHalf);
+                    if (ph == 1) stage_part(ks + 1, nbuf, kHalf, T::PPW);
+                } else {
+                    if (ph == 1) stage_part(ks + 1, nbuf, 0, kHalf);
+                    if (ph == 2) stage_part(ks + 1, nbuf, kHalf, T::PPW);
+                }
+            }
+            if (ph == kPhases - 1 && wr == 1) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __builtin_amdgcn_sched_barrier(0);
+            __builtin_amdgcn_s_barrier();
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_sched_barrier(0);
+            // ---- MFMA_ph
+            if (ph == 0 && ks == scale_step) {
+#pragma unroll
+                for (int m = 0; m < MR; ++m)
+#pragma unroll
+                    for (int n = 0; n < NR; ++n) acc[m][n] *= (1.0f / kSplitScale);
+            }
+            __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+            for (int j = 0; j < kBlk; ++j)
+                if (ph * kBlk + j < MR) {
+#pragma unroll
+                    for (int kh = 0; kh < 2; ++kh)
+#pragma unroll
+                        for (int n = 0; n < NR; ++n)
+                            acc[ph * kBlk + j][n] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[n][kh], xf[j][kh], acc[ph * kBlk + j][n], 0, 0, 0);
+                }
+            __builtin_amdgcn_s_setprio(0);
+            if (ph == kPhases - 1 && wr == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __builtin_amdgcn_sched_barrier(0);
+            __builtin_amdgcn_s_barrier();
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    }
+    if (wr == 0) __builtin_amdgcn_s_barrier();
+
+    const u32 cbase = col0 + wc * NR * 16 + 4 * fq;
+    float4 b4[NR];
+#pragma unroll
+    for (int n = 0; n < NR; ++n) b4[n] = *reinterpret_cast<const float4 *>(g.bias + cbase + 16 * n);
+#pragma unroll
+    for (int m = 0; m < MR; ++m) {
+        const size_t row = row0 + wr * MR * 16 + m * 16 + fr;
+        if (row >= g.M) continue;
+#pragma unroll
+        for (int n = 0; n < NR; ++n) {
+            float y[4] = {acc[m][n][0] + b4[n].x, acc[m][n][1] + b4[n].y, acc[m][n][2] + b4[n].z, acc[m][n][3] + b4[n].w};
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                if (ACT == RC_ACT_RELU) y[e] = fmaxf(y[e], 0.f);
+                if (ACT == RC_ACT_ELU) y[e] = y[e] > 0.f ? y[e] : g.alpha * expm1_neg(y[e]);
+            }
+            const u32 col = cbase + 16 * n;
+            if (OUT_SPLIT) {
+                float hi[4], lo[4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    hi[e] = round_to_half_f32(y[e]);
+                    lo[e] = (y[e] - hi[e]) * kSplitScale;
+                }
+                unsigned char *orow = reinterpret_cast<unsigned char *>(g.out) + row * ((size_t)g.N * 4);
+                *reinterpret_cast<uint2 *>(orow + col * 2) = make_uint2(pack_half2(hi[0], hi[1]), pack_half2(hi[2], hi[3]));
+                *reinterpret_cast<uint2 *>(orow + ((size_t)g.N + col) * 2) = make_uint2(pack_half2(lo[0], lo[1]), pack_half2(lo[2], lo[3]));
+            } else {
+                float *orow = reinterpret_cast<float *>(g.out) + row * (size_t)g.N;
+                *reinterpret_cast<float4 *>(orow + col) = make_float4(y[0], y[1], y[2], y[3]);
+            }
+        }
+    }
+}
+
+template <int MR, int NR, int ACT, bool OUT_SPLIT> static int launch_split_gemm_pp(const GemmArgs &g, hipStream_t s) {
+    using T = GemmTile<2, 4, MR, NR>;
+    static std::atomic<unsigned long long> attr_set{0};
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    if (!((attr_set.load(std::memory_order_acquire) >> (dev & 63)) & 1ull)) {
+        hipError_t e = hipFuncSetAttribute((const void *)k_split_gemm_pp<MR, NR, ACT, OUT_SPLIT>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                           T::LDS_BYTES);
+        if (e != hipSuccess) return hip_rc(e);
+        attr_set.fetch_or(1ull << (dev & 63), std::memory_order_release);
+    }
+    const u32 grid = (u32)(ceil_div((size_t)g.M, (size_t)T::BM) * (g.N / T::BN));
+    hipLaunchKernelGGL((k_split_gemm_pp<MR, NR, ACT, OUT_SPLIT>), dim3(grid), dim3(T::THREADS), T::LDS_BYTES, s, g);
+    return launch_status();
+}
+
+template <int MR, int NR> static int dispatch_split_gemm_pp(const GemmArgs &g, int act, bool split, hipStream_t s) {
+#define RC_GEMM_ACT(ACT) (split ? launch_split_gemm_pp<MR, NR, ACT, true>(g, s) : launch_split_gemm_pp<MR, NR, ACT, false>(g, s))
+    if (act == RC_ACT_ELU) return RC_GEMM_ACT(RC_ACT_ELU);
+    if (act == RC_ACT_RELU) return RC_GEMM_ACT(RC_ACT_RELU);
+    return RC_GEMM_ACT(RC_ACT_NONE);
+#undef RC_GEMM_ACT
+}
+
+template <int WM, int WN, int MR, int NR, int ACT, bool OUT_SPLIT> static int launch_split_gemm(const GemmArgs &g, hipStream_t s) {
+    using T = GemmTile<WM, WN, MR, NR>;
+    static std::atomic<unsigned long long> attr_set{0};   // per device: the attribute belongs to the function ON A DEVICE
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    if (!((attr_set.load(std::memory_order_acquire) >> (dev & 63)) & 1ull)) {
+        hipError_t e = hipFuncSetAttribute((const void *)k_split_gemm<WM, WN, MR, NR, ACT, OUT_SPLIT>,
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, T::LDS_BYTES);
+        if (e != hipSuccess) return hip_rc(e);
+        attr_set.fetch_or(1ull << (dev & 63), std::memory_order_release);
+    }
+    const u32 grid = (u32)(ceil_div((size_t)g.M, (size_t)T::BM) * (g.N / T::BN));
+    hipLaunchKernelGGL((k_split_gemm<WM, WN, MR, NR, ACT, OUT_SPLIT>), dim3(grid), dim3(T::THREADS), T::LDS_BYTES, s, g);
+    return launch_status();
+}
+
+template <int WM, int WN, int MR, int NR> static int dispatch_split_gemm(const GemmArgs &g, int act, bool split, hipStream_t s) {
+#define RC_GEMM_ACT(ACT) (split ? launch_split_gemm<WM, WN, MR, NR, ACT, true>(g, s) : launch_split_gemm<WM, WN, MR, NR, ACT, false>(g, s))
+    if (act == RC_ACT_ELU) return RC_GEMM_ACT(RC_ACT_ELU);
+    if (act == RC_ACT_RELU) return RC_GEMM_ACT(RC_ACT_RELU);
+    return RC_GEMM_ACT(RC_ACT_NONE);
+#undef RC_GEMM_ACT
+}
+
+}  // namespace rubiks
+
+using namespace rubiks;
+
+extern "C" int rc_split_gemm_f16(const uint16_t *a_hi_lo, const uint16_t *w_lo_hi_hi, const float *bias, size_t n_rows, size_t n_out,
+                                 size_t k, int activation, float alpha, uint16_t *out_hi_lo, float *out_f32, int tile,
+                                 rc_stream_t stream) {
+    if (n_rows == 0) return RC_OK;
+    RC_REQUIRE(a_hi_lo && w_lo_hi_hi && bias && ((out_hi_lo != nullptr) != (out_f32 != nullptr)), RC_ERR_NULL);
+    RC_REQUIRE(aligned16(a_hi_lo) && aligned16(w_lo_hi_hi) && aligned16(bias) && aligned16(out_hi_lo) && aligned16(out_f32), RC_ERR_ALIGN);
+    RC_REQUIRE(k >= 64 && k % 64 == 0 && k <= (1u << 16) && n_out % 128 == 0 && n_rows < (1ull << 31) && n_out < (1u << 20) &&
+                   activation >= RC_ACT_NONE && activation <= RC_ACT_ELU && tile >= 0 && tile <= 4, RC_ERR_RANGE);
+    GemmArgs g;
+    g.a = (const unsigned char *)a_hi_lo;
+    g.w = (const unsigned char *)w_lo_hi_hi;
+    g.bias = bias;
+    g.out = out_hi_lo ? (void *)out_hi_lo : (void *)out_f32;
+    g.M = (u32)n_rows;
+    g.N = (u32)n_out;
+    g.K = (u32)k;
+    g.alpha = alpha;
+    const bool split = out_hi_lo != nullptr;
+    // tile 0: choose -- the 352 x 256 tile when it fills the chip, else 352 x 128, else 176 x 128
+    const size_t row_tiles = ceil_div(n_rows, (size_t)352);
+    if (tile == 0) tile = (n_out % 256 == 0 && row_tiles * (n_out / 256) >= 192) ? 1 : (row_tiles * (n_out / 128) >= 192) ? 3 : 2;
+    RC_REQUIRE((tile != 1 && tile != 4) || n_out % 256 == 0, RC_ERR_RANGE);
+    hipStream_t s = (hipStream_t)stream;
+    if (tile == 1) return dispatch_split_gemm_pp<11, 4>(g, activation, split, s);      // 352 x 256, staggered wave rows
+    if (tile == 3) return dispatch_split_gemm_pp<11, 2>(g, activation, split, s);      // 352 x 128, staggered wave rows
+    if (tile == 4) return dispatch_split_gemm<2, 4, 11, 4>(g, activation, split, s);   // 352 x 256, one barrier per K-step
+    return dispatch_split_gemm<1, 4, 11, 2>(g, activation, split, s);                  // 176 x 128, one barrier per K-step
+}

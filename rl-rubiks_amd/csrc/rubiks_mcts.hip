@@ -14,6 +14,16 @@
 namespace rubiks {
 
 constexpr int kA = kActions;   // 12
+// A node's per-action rows live in ONE 256-byte record (rc_mcts_t, include/rubiks_hip.h), two cache lines:
+//   line 0: N[12] | W[12] | walk record (16 B) | 16 spare   -- what a backup and a re-validation WRITE
+//   line 1: P[12] | nbr[12] | 32 spare                      -- read-only once the node's children exist
+// The struct's N / W / rec / P / nbr pointers point at their field of node 0, so entry a of node n is X[n * kRow + a] (rec as
+// uint4: n * kRowRec).  Re-deciding a level of the previous path reads two adjacent lines and dirties one.
+// The reference's L array (virtual losses, agents.py:427) is not stored at all: after every backup it is identically zero
+// (the backup clears exactly the entries the descent raised, agents.py:569-570), so between iterations it IS the losses of
+// the pending descent path -- path_node / path_act -- from which the descents here take their counts and from which
+// MCTSForest.tree_arrays() reports it.
+constexpr int kRow = RC_MCTS_NODE_WORDS, kRowRec = kRow / 4;
 constexpr int kMaxPath = 4096;  // longest PUCT descent the kernels stage in LDS (20 KiB per workgroup in select)
 
 // Walk record of a node (16 B, rc_mcts_t::rec): what a PUCT descent does at the node while no virtual loss
@@ -59,12 +69,11 @@ __global__ __launch_bounds__(kBlock) void k_mcts_plant(rc_mcts_t m, const int *_
     m.hash[(size_t)t * m.hash_size + (key_hash(key) & (m.hash_size - 1))] = 1;
     m.leaf[base + 1] = 1;
     m.leaf[base] = 1;   // row 0 is never expanded; the reference's leaves[0] stays True as well
-    reinterpret_cast<uint4 *>(m.rec)[base] = make_uint4(0, 0, kRecLeaf, 0);
-    reinterpret_cast<uint4 *>(m.rec)[base + 1] = make_uint4(0, 0, kRecLeaf, 0);
+    reinterpret_cast<uint4 *>(m.rec)[base * kRowRec] = make_uint4(0, 0, kRecLeaf, 0);
+    reinterpret_cast<uint4 *>(m.rec)[(base + 1) * kRowRec] = make_uint4(0, 0, kRecLeaf, 0);
     for (int a = 0; a < kA; ++a) {   // rows of the sentinel and of the root (children get theirs when they are created)
-        m.N[base * kA + a] = m.N[(base + 1) * kA + a] = 0;
-        m.nbr[base * kA + a] = m.nbr[(base + 1) * kA + a] = 0;
-        m.L[base * kA + a] = m.L[(base + 1) * kA + a] = 0;
+        m.N[base * kRow + a] = m.N[(base + 1) * kRow + a] = 0;
+        m.nbr[base * kRow + a] = m.nbr[(base + 1) * kRow + a] = 0;
     }
     m.n_nodes[t] = 1;
     m.status[t] = solved ? RC_MCTS_ROOT_SOLVED : RC_MCTS_RUNNING;
@@ -160,10 +169,9 @@ __global__ __launch_bounds__(kWave) void k_mcts_expand(rc_mcts_t m, u32 max_stat
             h = (h + 1) & mask;
         }
         m.leaf[base + idx] = 1;
-        reinterpret_cast<uint4 *>(m.rec)[base + idx] = make_uint4(0, 0, kRecLeaf, 0);
-        // a node's rows start here (no array is ever cleared wholesale): N = 0, L = 0, neighbors = 0 but the way back
-        uint4 *nrow = reinterpret_cast<uint4 *>(m.N + (base + idx) * kA), *brow = reinterpret_cast<uint4 *>(m.nbr + (base + idx) * kA);
-        unsigned long long *lrow = reinterpret_cast<unsigned long long *>(m.L + (base + idx) * kA);
+        reinterpret_cast<uint4 *>(m.rec)[(base + idx) * kRowRec] = make_uint4(0, 0, kRecLeaf, 0);
+        // a node's rows start here (no array is ever cleared wholesale): N = 0, neighbors = 0 but the way back
+        uint4 *nrow = reinterpret_cast<uint4 *>(m.N + (base + idx) * kRow), *brow = reinterpret_cast<uint4 *>(m.nbr + (base + idx) * kRow);
         u32 back[kA];
 #pragma unroll
         for (int e = 0; e < kA; ++e) back[e] = (u32)e == (lane ^ 1u) ? (u32)leaf : 0u;
@@ -171,12 +179,11 @@ __global__ __launch_bounds__(kWave) void k_mcts_expand(rc_mcts_t m, u32 max_stat
         for (int e = 0; e < 3; ++e) {
             nrow[e] = make_uint4(0, 0, 0, 0);
             brow[e] = make_uint4(back[4 * e], back[4 * e + 1], back[4 * e + 2], back[4 * e + 3]);
-            lrow[e] = 0ull;
         }
     }
     if (act) {   // links both ways, for seen children too (agents.py:533-535)
-        m.nbr[(base + leaf) * kA + lane] = idx;
-        if (found) m.nbr[(base + idx) * kA + (lane ^ 1)] = leaf;
+        m.nbr[(base + leaf) * kRow + lane] = idx;
+        if (found) m.nbr[(base + idx) * kRow + (lane ^ 1)] = leaf;
         m.child_idx[(size_t)t * kA + lane] = idx;
     }
     const u64 solm = __ballot(solved);
@@ -251,8 +258,8 @@ __device__ __forceinline__ float backup_children(const rc_mcts_t &m, u32 t, u32 
         m.V[node] = v;
 #pragma unroll
         for (int a = 0; a < kA; ++a) {
-            m.P[node * kA + a] = p[a];
-            if (!is_root) m.W[node * kA + a] = v;   // W[new] = v for all 12 actions (agents.py:561)
+            m.P[node * kRow + a] = p[a];
+            if (!is_root) m.W[node * kRow + a] = v;   // W[new] = v for all 12 actions (agents.py:561)
         }
     } else if (act) {
         v = m.V[base + idx];
@@ -261,7 +268,7 @@ __device__ __forceinline__ float backup_children(const rc_mcts_t &m, u32 t, u32 
     // best value among the new children (agents.py:559); with no new child the reference raises --
     // defined here as the best existing neighbour value (oracle/agents.py docstring)
     const float best = newm ? wave_max12(v, act && ((newm >> lane) & 1u)) : wave_max12(v, act);
-    if (act) m.W[(base + leaf) * kA + lane] = v;   // W[leaf] = V[neighbors[leaf]] (agents.py:560)
+    if (act) m.W[(base + leaf) * kRow + lane] = v;   // W[leaf] = V[neighbors[leaf]] (agents.py:560)
     return best;
 }
 
@@ -290,15 +297,13 @@ __device__ __forceinline__ void backup_path(const rc_mcts_t &m, u32 tid, size_t 
                                             float best) {
     const int edges = plen - 1;
     constexpr int kMark = 1 << 30;
-    for (int i = tid; i < edges; i += kBlock) m.N[(base + pnode[i]) * kA + pact[i]] |= kMark;
+    for (int i = tid; i < edges; i += kBlock) m.N[(base + pnode[i]) * kRow + pact[i]] |= kMark;
     __syncthreads();
     for (int i = tid; i < edges; i += kBlock) {
-        const size_t e = (base + pnode[i]) * kA + pact[i];
+        const size_t e = (base + pnode[i]) * kRow + pact[i];
         const int nv = m.N[e];
         if (nv & kMark) m.N[e] = (nv & ~kMark) + 1;            // agents.py:568
         m.W[e] = fmaxf(m.W[e], best);                           // agents.py:562
-        m.L[e] = 0;                                             // agents.py:569
-        m.L[(base + pnode[i + 1]) * kA + (pact[i] ^ 1)] = 0;    // agents.py:570
     }
 }
 
@@ -433,13 +438,13 @@ struct TreeBufs {
     __amdgpu_buffer_rsrc_t N, nbr, P, W, rec;
 };
 __device__ __forceinline__ TreeBufs tree_bufs(const rc_mcts_t &m, size_t base) {
-    const int rows = (int)((m.capacity + 1) * kA);
+    const int rows = (int)((m.capacity + 1) * kRow);
     TreeBufs b;
-    b.N = __builtin_amdgcn_make_buffer_rsrc((void *)(m.N + base * kA), 0, rows * 4, kRsrcFlags);
-    b.nbr = __builtin_amdgcn_make_buffer_rsrc((void *)(m.nbr + base * kA), 0, rows * 4, kRsrcFlags);
-    b.P = __builtin_amdgcn_make_buffer_rsrc((void *)(m.P + base * kA), 0, rows * 4, kRsrcFlags);
-    b.W = __builtin_amdgcn_make_buffer_rsrc((void *)(m.W + base * kA), 0, rows * 4, kRsrcFlags);
-    b.rec = __builtin_amdgcn_make_buffer_rsrc((void *)(reinterpret_cast<uint4 *>(m.rec) + base), 0, (int)(m.capacity + 1) * 16,
+    b.N = __builtin_amdgcn_make_buffer_rsrc((void *)(m.N + base * kRow), 0, rows * 4, kRsrcFlags);
+    b.nbr = __builtin_amdgcn_make_buffer_rsrc((void *)(m.nbr + base * kRow), 0, rows * 4, kRsrcFlags);
+    b.P = __builtin_amdgcn_make_buffer_rsrc((void *)(m.P + base * kRow), 0, rows * 4, kRsrcFlags);
+    b.W = __builtin_amdgcn_make_buffer_rsrc((void *)(m.W + base * kRow), 0, rows * 4, kRsrcFlags);
+    b.rec = __builtin_amdgcn_make_buffer_rsrc((void *)(reinterpret_cast<uint4 *>(m.rec) + base * kRowRec), 0, rows * 4,
                                               kRsrcFlags);
     return b;
 }
@@ -449,7 +454,7 @@ struct NodeRows {
     float p_f, w_f;
 };
 __device__ __forceinline__ NodeRows load_rows(const TreeBufs &tb, int node, u32 la) {
-    const u32 off = ((u32)node * kA + la) * 4u;
+    const u32 off = ((u32)node * kRow + la) * 4u;
     NodeRows x;
     x.n_a = (int)__builtin_amdgcn_raw_buffer_load_b32(tb.N, off, 0, 0);
     x.p_f = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(tb.P, off, 0, 0));
@@ -458,13 +463,9 @@ __device__ __forceinline__ NodeRows load_rows(const TreeBufs &tb, int node, u32 
     return x;
 }
 __device__ __forceinline__ u32x4 load_rec(const TreeBufs &tb, int node) {
-    return __builtin_amdgcn_raw_buffer_load_b128(tb.rec, (u32)node * 16u, 0, 0);
+    return __builtin_amdgcn_raw_buffer_load_b128(tb.rec, (u32)node * (kRow * 4u), 0, 0);
 }
 
-// L holds 16-bit counts; two of them share a dword, which is what the atomic unit adds to.
-__device__ __forceinline__ void l_count_add(u16 *L, size_t e) {
-    atomicAdd(reinterpret_cast<u32 *>(L) + (e >> 1), 1u << (16 * (e & 1)));
-}
 
 constexpr int kSelHash = 2048;   // LDS chain heads of the select kernel
 __device__ __forceinline__ u32 sel_hash(int node) { return ((u32)node * 0x9E3779B1u) >> 21; }
@@ -526,7 +527,7 @@ __global__ __launch_bounds__(kBlock) void k_mcts_select(rc_mcts_t m, double c, u
     const size_t base = (size_t)t * (m.capacity + 1);
     int *pnode = m.path_node + (size_t)t * m.max_path;
     u8 *pact = m.path_act + (size_t)t * m.max_path;
-    uint4 *rec = reinterpret_cast<uint4 *>(m.rec) + base;
+    uint4 *rec = reinterpret_cast<uint4 *>(m.rec) + base * kRowRec;   // record of node n: rec[n * kRowRec]
     const int plen_old = m.path_len[t];
     const int phase = m.phase[t];
     if (MODE == 0 && (phase & kPhaseMask) != kPhaseNormal) return;   // a root's first descent follows its backup in ROOT_B
@@ -549,6 +550,19 @@ __global__ __launch_bounds__(kBlock) void k_mcts_select(rc_mcts_t m, double c, u
         return;
     }
     const int nlev = plen_old - 1;     // levels 0 .. nlev - 1 carry an action; level nlev is the old leaf
+    // The re-validation below is bound by fetching the records of the old path's nodes from HBM (two cache lines per level, a
+    // different node each), and a thread handles levels tid, tid + 256, ... one after the other: a deep tree would pay the
+    // memory latency once per 256 levels while the shallow trees are long done.  So every thread requests the lines of ALL its
+    // levels now (first 1 024 levels); the values are only consumed after the pass, the later rounds of the pass find their
+    // records in L2.
+    u32 pf[8];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int k = (int)tid + i * kBlock;
+        const u32 *rp = reinterpret_cast<const u32 *>(m.N) + (base + (size_t)(k < plen_old ? pnode[k] : 0)) * kRow;
+        pf[2 * i] = rp[0];
+        pf[2 * i + 1] = rp[kRow / 2];
+    }
     const u32 row = tid >> 4, rl = tid & 15;
     const bool ract = rl < kA;
     const u32 rla = ract ? rl : 0;
@@ -600,7 +614,7 @@ __global__ __launch_bounds__(kBlock) void k_mcts_select(rc_mcts_t m, double c, u
                 else atomicOr(&s_late[k >> 5], 1u << (k & 31));
                 return;
             }
-            const size_t r = (base + node) * kA;
+            const size_t r = (base + node) * kRow;
             u32 n[kA], p[kA], w[kA];
             load_row12(m.N, r, n);
             load_row12(m.P, r, p);
@@ -615,10 +629,6 @@ __global__ __launch_bounds__(kBlock) void k_mcts_select(rc_mcts_t m, double c, u
                 store_row12(m.N, r, n);
                 store_row12(m.W, r, w);
             }
-            if (MODE > 0 && backup && k < nlev) {   // L[path, a] = 0, L[path[1:], rev a] = 0  (agents.py:569-570)
-                m.L[r + s_act[k]] = 0;
-                m.L[(base + s_node[k + 1]) * kA + (s_act[k] ^ 1)] = 0;
-            }
             const LaneEval e = lane_eval(c32v, n, p, w);
             bool c0, c1, c2 = true;
             const int b0 = lane_pick(e, 0, c0);
@@ -629,7 +639,7 @@ __global__ __launch_bounds__(kBlock) void k_mcts_select(rc_mcts_t m, double c, u
                 d = lane_pick(e, cnt5, c2);
             }
             if (c0 && c1 && c2 && !ovf) {
-                rec[node] = make_uint4((u32)m.nbr[r + b0], (u32)m.nbr[r + b1], (u32)b0 | ((u32)b1 << 8),   // the old path is line seq - 1
+                rec[(size_t)node * kRowRec] = make_uint4((u32)m.nbr[r + b0], (u32)m.nbr[r + b1], (u32)b0 | ((u32)b1 << 8),   // the old path is line seq - 1
                                        line_tag((seq - 1) & 0xFFFFu, k, k < nlev ? (u32)s_act[k] : kNoAct));
                 if (k < nlev && d != (int)s_act[k]) atomicMin(&s_first, k);
             } else {
@@ -669,7 +679,7 @@ __global__ __launch_bounds__(kBlock) void k_mcts_select(rc_mcts_t m, double c, u
                 const u32 nx = s_next[j];
                 j = nx == 0xFFFFu ? -1 : (int)nx;
             }
-            const size_t r = (base + node) * kA + rla;
+            const size_t r = (base + node) * kRow + rla;
             const int n_a = m.N[r], nb = m.nbr[r];
             const float p_f = m.P[r], w_f = m.W[r];
             const int sum_n = row16_sum(ract ? n_a : 0);
@@ -686,19 +696,15 @@ __global__ __launch_bounds__(kBlock) void k_mcts_select(rc_mcts_t m, double c, u
             const int nb0 = __builtin_amdgcn_ds_bpermute((int)((lane0 + (u32)b0) << 2), nb);
             const int nb1 = __builtin_amdgcn_ds_bpermute((int)((lane0 + (u32)b1) << 2), nb);
             if (live && rl == 0) {
-                rec[node] = make_uint4((u32)nb0, (u32)nb1, (u32)b0 | ((u32)b1 << 8),
+                rec[(size_t)node * kRowRec] = make_uint4((u32)nb0, (u32)nb1, (u32)b0 | ((u32)b1 << 8),
                                        line_tag((seq - 1) & 0xFFFFu, k, k < nlev ? (u32)s_act[k] : kNoAct));
                 if (k < nlev && d != (int)s_act[k]) atomicMin(&s_first, k);
             }
         }
         __syncthreads();
+        if (((pf[0] ^ pf[1] ^ pf[2] ^ pf[3]) + (pf[4] ^ pf[5] ^ pf[6] ^ pf[7])) == 0x5EED1234u && nlev < 0) s_first = 0;   // never true: keeps the requests above alive
         const int first = s_first;
-        // the kept prefix takes its virtual losses: L[n_k, a_k] += nu and L[n_k+1, rev a_k] += nu (agents.py:589-591)
-        for (int k = tid; k < first; k += kBlock) {
-            const int a = s_act[k];
-            l_count_add(m.L, (base + s_node[k]) * kA + a);
-            l_count_add(m.L, (base + s_node[k + 1]) * kA + (a ^ 1));
-        }
+        // (the kept prefix's virtual losses, agents.py:589-591, are implied by the path: see the note on L at the top)
         if (first < nlev) {   // from here on the chains hold the kept levels only; the walk appends its own
             for (int i = tid; i < kSelHash; i += kBlock) s_head[i] = -1;
             __syncthreads();
@@ -793,8 +799,8 @@ __global__ __launch_bounds__(kBlock) void k_mcts_select(rc_mcts_t m, double c, u
             for (;;) {
                 const u32x4 r = load_rec(tb, node_i);
                 const bool inner = in_line && act_i != kNoAct;
-                const int nl_i = inner ? m.nbr[(base + node_i) * kA + act_i] : 0;   // where the line's action leads
-                const LaneEval e = lane_prepare(c32, m, (base + node_i) * kA);      // requested with the records: one round trip
+                const int nl_i = inner ? m.nbr[(base + node_i) * kRow + act_i] : 0;   // where the line's action leads
+                const LaneEval e = lane_prepare(c32, m, (base + node_i) * kRow);      // requested with the records: one round trip
                 // the next segment of the line, in flight while this one is checked
                 const int li2 = lpos + kWave + (int)lane;
                 const bool in2 = li2 < llen && kWave + (int)lane < room;
@@ -905,25 +911,20 @@ __global__ __launch_bounds__(kBlock) void k_mcts_select(rc_mcts_t m, double c, u
     }
     if (stop == 2 && lane == 0) m.status[t] = RC_MCTS_PATH_OVERFLOW;
     const int suspended = stop == 3;   // out of budget at a non-leaf: resume here next call
-    // the walked levels go to memory: path, L[n_k, a_k] += nu (agents.py:589) and L[n_k+1, rev a_k] += nu (agents.py:591)
+    // the walked levels go to memory (the path carries their virtual losses, agents.py:589-591)
     for (int k = start + (int)lane; k < plen; k += kWave) {
         if (k > start) pnode[k] = s_node[k];
-        if (k < plen - 1) {
-            const int a = s_act[k];
-            pact[k] = (u8)a;
-            l_count_add(m.L, (base + s_node[k]) * kA + a);
-            l_count_add(m.L, (base + s_node[k + 1]) * kA + (a ^ 1));
-        }
+        if (k < plen - 1) pact[k] = (u8)s_act[k];
     }
     // the whole path becomes line `seq` of the ring, and every node on it is tagged with its place there
     if (seq != 0) {
         const size_t slot = (size_t)t * ring_k + (seq & (ring_k - 1));
-        u32 *rec_w = reinterpret_cast<u32 *>(m.rec) + base * 4 + 3;
+        u32 *rec_w = reinterpret_cast<u32 *>(m.rec) + base * kRow + 3;
         for (int k = (int)lane; k < plen; k += kWave) {
             const u32 a = k < plen - 1 ? (u32)s_act[k] : kNoAct;
             m.ring_node[slot * max_path + k] = s_node[k];
             m.ring_act[slot * max_path + k] = (u8)a;
-            rec_w[(size_t)s_node[k] * 4] = line_tag(seq, k, a);
+            rec_w[(size_t)s_node[k] * kRow] = line_tag(seq, k, a);
         }
         if (lane == 0) m.ring_len[slot] = plen;
     }
@@ -975,8 +976,8 @@ __global__ __launch_bounds__(kBlock) void k_mcts_complete_graph(rc_mcts_t m) {
             if (key_eq(keys[s], ck)) { found = s; break; }
             h = (h + 1) & mask;
         }
-        m.nbr[(base + node) * kA + a] = found;                        // 0 when the child is not in the tree
-        if (found) m.nbr[(base + found) * kA + (a ^ 1)] = (int)node;  // the only node whose action a^1 leads here
+        m.nbr[(base + node) * kRow + a] = found;                        // 0 when the child is not in the tree
+        if (found) m.nbr[(base + found) * kRow + (a ^ 1)] = (int)node;  // the only node whose action a^1 leads here
     }
 }
 
@@ -994,7 +995,7 @@ __global__ __launch_bounds__(kBlock) void k_mcts_shorten(rc_mcts_t m) {
     if (solved == 1) return;   // agents.py:614: the queue is kept
     const size_t base = (size_t)t * (m.capacity + 1);
     const int n = m.n_nodes[t];
-    const int *nbr = m.nbr + base * kA;
+    const int *nbr = m.nbr + base * kRow;
     int *claim = m.bfs + base * 2;            // [node][0]
     int *frontier_a = m.hash + (size_t)t * m.hash_size, *frontier_b = frontier_a + (m.capacity + 1);
     for (int i = tid; i <= n; i += kBlock) {
@@ -1014,7 +1015,7 @@ __global__ __launch_bounds__(kBlock) void k_mcts_shorten(rc_mcts_t m) {
         const int work = fsize * kA;
         // phase 1: every unvisited neighbour is claimed by the smallest scan index that reaches it
         for (int idx = tid; idx < work; idx += kBlock) {
-            const int c = nbr[(size_t)cur[idx / kA] * kA + idx % kA];
+            const int c = nbr[(size_t)cur[idx / kA] * kRow + idx % kA];
             if (c != 0 && claim[2 * c + 1] == 0) atomicMin(&claim[2 * c], idx);
         }
         // the claims are no-return atomics executed at L2: drain them before the barrier, and read them back
@@ -1029,7 +1030,7 @@ __global__ __launch_bounds__(kBlock) void k_mcts_shorten(rc_mcts_t m) {
             int c = 0, win = 0, p = 0;
             if (idx < work) {
                 p = cur[idx / kA];
-                c = nbr[(size_t)p * kA + idx % kA];
+                c = nbr[(size_t)p * kRow + idx % kA];
                 win = (c != 0 && claim[2 * c + 1] == 0 &&
                        __hip_atomic_load(&claim[2 * c], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == idx) ? 1 : 0;
             }
@@ -1075,7 +1076,7 @@ using namespace rubiks;
 
 static int check_mcts(const rc_mcts_t *m) {
     RC_REQUIRE(m != nullptr, RC_ERR_NULL);
-    RC_REQUIRE(m->keys && m->nbr && m->P && m->W && m->N && m->L && m->V && m->leaf && m->hash && m->n_nodes &&
+    RC_REQUIRE(m->keys && m->nbr && m->P && m->W && m->N && m->V && m->leaf && m->hash && m->n_nodes &&
                    m->status && m->solved_idx && m->solved_action && m->iterations && m->path_len && m->path_node &&
                    m->pending && m->path_act && m->child_soa && m->child_idx && m->new_mask && m->expanded && m->rec && m->ring_node && m->ring_act &&
                    m->ring_len && m->phase,
@@ -1083,6 +1084,11 @@ static int check_mcts(const rc_mcts_t *m) {
     RC_REQUIRE(m->n_trees > 0 && m->capacity >= 13 && m->max_path >= 2 && m->max_path <= (uint32_t)kMaxPath, RC_ERR_RANGE);
     RC_REQUIRE((m->hash_size & (m->hash_size - 1)) == 0 && m->hash_size >= 2 * (m->capacity + 1), RC_ERR_RANGE);
     RC_REQUIRE(aligned16(m->keys) && aligned16(m->rec) && aligned16(m->child_soa) && (m->child_stride & 15u) == 0, RC_ERR_ALIGN);
+    {   // the fields of the node record sit where the kernels' strides assume them (one allocation, 256-byte aligned)
+        const uintptr_t n0 = reinterpret_cast<uintptr_t>(m->N);
+        RC_REQUIRE((n0 & 255u) == 0 && reinterpret_cast<uintptr_t>(m->W) == n0 + 48 && reinterpret_cast<uintptr_t>(m->rec) == n0 + 96 &&
+                       reinterpret_cast<uintptr_t>(m->P) == n0 + 128 && reinterpret_cast<uintptr_t>(m->nbr) == n0 + 176, RC_ERR_ALIGN);
+    }
     RC_REQUIRE(m->rows_per_tree == 11, RC_ERR_RANGE);
     RC_REQUIRE(m->ring_k >= 1 && m->ring_k <= 64 && (m->ring_k & (m->ring_k - 1)) == 0, RC_ERR_RANGE);
     RC_REQUIRE(m->child_stride >= round_up((size_t)m->n_trees * m->rows_per_tree, 16), RC_ERR_STRIDE);

@@ -5,6 +5,7 @@
 #include <atomic>
 
 #include "rubiks_common.h"
+#include "rubiks_netmath.h"
 
 namespace rubiks {
 
@@ -20,13 +21,6 @@ __device__ __forceinline__ float act_apply(float x, int act, float alpha) {
     return x;
 }
 
-__device__ __forceinline__ u32 pack_bf16(float lo, float hi) {
-    typedef __attribute__((ext_vector_type(2))) float float2_;
-    typedef __attribute__((ext_vector_type(2))) __bf16 bf2;
-    float2_ v = {lo, hi};
-    bf2 r = __builtin_convertvector(v, bf2);   // v_cvt_pk_bf16_f32, round to nearest even
-    return __builtin_bit_cast(u32, r);
-}
 
 template <int ACT, int F16>   // F16: 0 bf16 table, 1 f16 table, 2 f16 table with pairs of rows added in f16 first
 __global__ __launch_bounds__(kFLThreads) __attribute__((amdgpu_waves_per_eu(4, 4))) void k_first_layer(const u8 *__restrict__ soa, size_t n, size_t stride,
@@ -490,17 +484,7 @@ extern "C" int rc_act_bf16_inplace(uint16_t *x, size_t n, int activation, float 
 // the hidden layer's shape, the result is CLOSER than the fp32 MFMA GEMM (mean |error| 4.0e-7 vs 1.1e-6 at |y| ~ 1)
 // at 2.8 x its speed (tools/split_gemm_probe.py).  The two kernels here produce the operands: the split one-hot
 // input and the bias + activation + re-split between two layers.
-constexpr float kSplitScale = 2048.0f;        // 2^11
 constexpr u32 kHalfOne = 0x3C00u, kHalfScaleInv = 0x1000u;   // 1.0 and 2^-11 as IEEE half
-
-__device__ __forceinline__ u32 pack_half2(float lo, float hi) {
-    typedef __attribute__((ext_vector_type(2))) float float2_;
-    typedef __attribute__((ext_vector_type(2))) _Float16 half2_;
-    float2_ v = {lo, hi};
-    half2_ r = __builtin_convertvector(v, half2_);   // round to nearest even
-    return __builtin_bit_cast(u32, r);
-}
-__device__ __forceinline__ float round_to_half_f32(float x) { return (float)(_Float16)x; }
 
 // out[r][c] = onehot(r)[c] for c < 480 and onehot(r)[c - 480] * 2^-11 for c >= 480 (IEEE half, row pitch 960): the A operand
 // whose product with [W_hi | W_lo] is the input layer in one GEMM.  One 16-byte chunk per thread, inside one cubie's block.
@@ -570,19 +554,6 @@ __global__ __launch_bounds__(kBlock) void k_split_act(const float4 *__restrict__
 constexpr int kSpCols = 64;
 constexpr int kSpSub = 2;
 
-// expm1(x) for x <= 0 to ~1e-7 absolute (what ELU's negative branch needs next to fp32 activations of order 1) without
-// libm's register appetite: the Taylor polynomial near zero (x^9 / 9! < 3e-10 at |x| = 0.35), exp(x) - 1 beyond.
-__device__ __forceinline__ float expm1_neg(float x) {
-    float p = 1.0f / 40320.0f;
-    p = fmaf(p, x, 1.0f / 5040.0f);
-    p = fmaf(p, x, 1.0f / 720.0f);
-    p = fmaf(p, x, 1.0f / 120.0f);
-    p = fmaf(p, x, 1.0f / 24.0f);
-    p = fmaf(p, x, 1.0f / 6.0f);
-    p = fmaf(p, x, 0.5f);
-    p = fmaf(p, x, 1.0f);
-    return x < -0.35f ? __expf(x) - 1.0f : p * x;
-}
 
 // SPLIT = false: the same kernel as the bf16 engine's input layer (one table, W1 in IEEE half; bf16 output [n][H]).
 template <int ACT, bool SPLIT>

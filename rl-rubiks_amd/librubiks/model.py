@@ -412,8 +412,18 @@ class SplitF32Net:
             if i == 0:    # one-hot input: x_lo = 0, so y = oh W_hi^T + 2^-11 oh W_lo^T = [oh, oh 2^-11] [W_hi | W_lo]^T
                 out.append(("in", torch.cat([hi, lo], 1).contiguous(), b.float().contiguous(), code, alpha, hi.contiguous(), lo.contiguous()))
             else:
-                out.append(("hid", hi.contiguous(), torch.cat([lo, hi], 1).contiguous(), b.float().contiguous(), code, alpha))
+                out.append(("hid", hi.contiguous(), torch.cat([lo, hi], 1).contiguous(), b.float().contiguous(), code, alpha,
+                            torch.cat([lo, hi, hi], 1).contiguous()))   # [W_lo | W_hi | W_hi]: the operand of rc_split_gemm_f16
         return out
+
+    fused_hidden = True   # hidden layers as one kernel each (rc_split_gemm_f16) where its tile fills the chip
+
+    @staticmethod
+    def _fused_tile(rows: int, n_out: int, k: int) -> int:
+        """Tile of rc_split_gemm_f16 for this layer, 0 = keep the two library GEMMs + rc_split_act_f16."""
+        if k % 64 or n_out % 256:
+            return 0
+        return 1 if -(-rows // 352) * (n_out // 256) >= 192 else 0   # 352 x 256 tiles, at least 3/4 of the 256 CUs busy
 
     def workspace(self, rows: int):
         return None
@@ -482,8 +492,18 @@ class SplitF32Net:
                 _, B, b, code, alpha = layer[:5]
                 c = torch.mm(a, B.t(), out_dtype=torch.float32)
             elif layer[0] == "hid":
-                _, Wh, B2, b, code, alpha = layer
+                _, Wh, B2, b, code, alpha, W3 = layer
                 K = Wh.shape[1]
+                tile = self._fused_tile(a.shape[0], Wh.shape[0], K) if self.fused_hidden else 0
+                if tile:
+                    from librubiks import _hip
+                    n, w = a.shape[0], Wh.shape[0]
+                    out = torch.empty((n, w if last_hidden else 2 * w), dtype=torch.float32 if last_hidden else torch.float16, device=a.device)
+                    _hip.check(_hip.lib().rc_split_gemm_f16(a.data_ptr(), W3.data_ptr(), b.data_ptr(), n, w, K, code, alpha,
+                                                            None if last_hidden else out.data_ptr(), out.data_ptr() if last_hidden else None,
+                                                            tile, _hip.stream_ptr()), "rc_split_gemm_f16")
+                    a = out
+                    continue
                 c = torch.mm(a[:, :K], Wh.t(), out_dtype=torch.float32)   # hi x hi
                 corr = torch.mm(a, B2.t(), out_dtype=torch.float32)       # hi x lo + lo x hi, scaled by 2^11; added in the kernel below
             else:

@@ -26,7 +26,7 @@ N_ACT = 12
 class _McStruct(Structure):   # mirrors rc_mcts_t (include/rubiks_hip.h)
     _fields_ = [("n_trees", c_uint32), ("capacity", c_uint32), ("hash_size", c_uint32), ("max_path", c_uint32),
                 ("rows_per_tree", c_uint32)] + \
-               [(name, c_void_p) for name in ("keys", "nbr", "P", "W", "N", "L", "V", "leaf", "hash", "n_nodes",
+               [(name, c_void_p) for name in ("keys", "nbr", "P", "W", "N", "V", "leaf", "hash", "n_nodes",
                                               "status", "solved_idx", "solved_action", "iterations", "path_len", "pending",
                                               "path_node", "path_act", "child_soa")] + \
                [("child_stride", c_size_t)] + \
@@ -57,13 +57,16 @@ def unpack_keys(keys: np.ndarray) -> np.ndarray:
     return out
 
 
-_PER_NODE = ("keys", "nbr", "P", "W", "N", "L", "V", "leaf", "rec")
+_PER_NODE = ("keys", "node", "V", "leaf")
 _PER_TREE = ("n_nodes", "status", "solved_idx", "solved_action", "iterations", "path_len", "pending", "path_node", "path_act",
              "ring_node", "ring_act", "ring_len", "phase")
-_RESULT_NODE = ("keys", "nbr", "leaf")          # what rc_mcts_complete_graph / rc_mcts_shorten read of a tree
+_RESULT_NODE = ("keys", "node", "leaf")         # what rc_mcts_complete_graph / rc_mcts_shorten read of a tree (nbr is a field of node)
 _RESULT_TREE = ("n_nodes", "status", "solved_idx", "solved_action", "iterations", "path_len", "pending", "path_act", "phase")
 RING_K = 8   # descent paths kept per tree for line following (rc_mcts_t::ring_k)
 ROWS = 11    # network rows per tree and iteration (rc_mcts_t::rows_per_tree)
+NODE_WORDS = 64   # 32-bit words per node record (RC_MCTS_NODE_WORDS): line 0 = N | W | walk record, line 1 = P | nbr
+_NODE_FIELDS = {"N": (0, 12, torch.int32), "W": (12, 24, torch.float32), "rec": (24, 28, torch.int32),
+                "P": (32, 44, torch.float32), "nbr": (44, 56, torch.int32)}
 
 
 class MCTSForest:
@@ -78,9 +81,8 @@ class MCTSForest:
         z = lambda shape, dt: torch.zeros(shape, dtype=dt, device=dev)   # noqa: E731
         rows = B * (C + 1)
         layout = {   # search state: zero-initialised, or adopted from another forest (`subset`)
-            "keys": ((rows, 4), torch.int32), "nbr": ((rows, N_ACT), torch.int32), "P": ((rows, N_ACT), torch.float32),
-            "W": ((rows, N_ACT), torch.float32), "N": ((rows, N_ACT), torch.int32), "L": ((rows, N_ACT), torch.int16),
-            "V": ((rows,), torch.float32), "leaf": ((rows,), torch.uint8), "rec": ((rows, 4), torch.int32), "hash": ((B, self.hash_size), torch.int32),
+            "keys": ((rows, 4), torch.int32), "node": ((rows, NODE_WORDS), torch.int32),
+            "V": ((rows,), torch.float32), "leaf": ((rows,), torch.uint8), "hash": ((B, self.hash_size), torch.int32),
             "n_nodes": ((B,), torch.int32), "status": ((B,), torch.int32), "solved_idx": ((B,), torch.int32),
             "solved_action": ((B,), torch.int32), "iterations": ((B,), torch.int32), "path_len": ((B,), torch.int32),
             "pending": ((B,), torch.int32), "path_node": ((B, max_path), torch.int32), "path_act": ((B, max_path), torch.uint8),
@@ -96,6 +98,10 @@ class MCTSForest:
             else:
                 t = z(shape, dt)
             setattr(self, name, t)
+        # the reference's per-action node arrays (agents.py:421-427) are strided views of the 256-byte node records: one or two
+        # adjacent cache lines per node for the kernels, the same [rows, 12] tensors for everything that inspects a tree
+        for name, (lo, hi, dt) in _NODE_FIELDS.items():
+            setattr(self, name, self.node[:, lo:hi].view(dt))
         self.results_only = _results_only
         # Network rows per tree: only the NEW children of the expanded leaf are evaluated, and a non-root leaf has at most
         # 11 of them (its parent is known): 11 row slots per tree.  A planted root takes two iterations (rc_mcts_t::phase).
@@ -109,7 +115,7 @@ class MCTSForest:
         s.n_trees, s.capacity, s.hash_size, s.max_path = B, C, self.hash_size, max_path
         s.rows_per_tree = ROWS
         s.ring_k = RING_K
-        for name in ("keys", "nbr", "P", "W", "N", "L", "V", "leaf", "rec", "hash", "n_nodes", "status", "solved_idx",
+        for name in ("keys", "nbr", "P", "W", "N", "V", "leaf", "rec", "hash", "n_nodes", "status", "solved_idx",
                      "solved_action", "iterations", "path_len", "pending", "path_node", "path_act", "child_idx", "new_mask",
                      "expanded", "ring_node", "ring_act", "ring_len", "phase"):
             setattr(s, name, getattr(self, name).data_ptr())
@@ -133,7 +139,7 @@ class MCTSForest:
         device.  Used to drop finished trees from a batch: the survivors continue exactly where they were, on GEMMs
         of len(keep) x 11 rows instead of B x 11.
         results_only: the trees are finished and only wait to be turned into results (graph completion, BFS
-        shortening, paths): just the arrays those steps read are copied (65 of ~285 bytes per node), the forest
+        shortening, paths): just the arrays those steps read are copied (keys, node records, leaf flags), the forest
         cannot be stepped or inspected.
         """
         B, C1 = self.B, self.C + 1
@@ -162,8 +168,8 @@ class MCTSForest:
             getattr(self, name)[pos:pos + k] = getattr(other, name)[idx]
 
     def bytes_allocated(self) -> int:
-        return sum(t.numel() * t.element_size() for t in (self.keys, self.nbr, self.P, self.W, self.N, self.L, self.V,
-                                                           self.leaf, self.hash, self.path_node, self.path_act))
+        return sum(t.numel() * t.element_size() for t in (self.keys, self.node, self.V, self.leaf, self.hash, self.path_node,
+                                                           self.path_act))
 
     # ---- network ---------------------------------------------------------------------------------
     def set_net(self, net, dtype=torch.bfloat16):
@@ -268,9 +274,24 @@ class MCTSForest:
             "V": self.V[lo:hi].cpu().numpy().astype(np.float64),
             "W": self.W[lo:hi].cpu().numpy().astype(np.float64),
             "N": self.N[lo:hi].cpu().numpy().astype(np.int64),
-            "L": self.L[lo:hi].cpu().numpy().astype(np.float64) * 100.0,
+            "L": self._virtual_losses(t, n),
             "leaves": self.leaf[lo:hi].cpu().numpy().astype(bool),
         }
+
+    def _virtual_losses(self, t: int, n: int) -> np.ndarray:
+        """The reference's L (agents.py:427) of tree t: every backup clears what the descent before it raised (agents.py:569-570),
+        so L is nu times the number of times the PENDING descent path leaves a node by an action (agents.py:589) or arrives at
+        one by its reverse (agents.py:591) -- and zero in a solved tree, whose last descent was backed up (agents.py:478-487)."""
+        L = np.zeros((n + 1, N_ACT))
+        if int(self.status[t].item()) == SOLVED:
+            return L
+        plen = int(self.path_len[t].item())
+        if plen > 1:
+            nodes = self.path_node[t, :plen].cpu().numpy().astype(np.int64)
+            acts = self.path_act[t, :plen - 1].cpu().numpy().astype(np.int64)
+            np.add.at(L, (nodes[:-1], acts), 100.0)
+            np.add.at(L, (nodes[1:], acts ^ 1), 100.0)
+        return L
 
     def complete_graphs(self):
         """_complete_graph of every solved tree, on the device (agents.py:597-611)."""
