@@ -734,15 +734,9 @@ __global__ __launch_bounds__(kBlock) void k_mcts_select(rc_mcts_t m, double c, u
     int head = s_head[h];
     for (;;) {
         const int k = plen - 1;
-        const u32 z = (u32)__builtin_amdgcn_readfirstlane((int)x.z);
-        const int b0 = (int)(z & 15u), b1 = (int)((z >> 8) & 15u);
-        const bool back = prev_act >= 0 && (prev_act ^ 1) == b0;   // arrived through rev(best0): that edge carries a loss
-        const int a_f = back ? b1 : b0;
-        const int next_f = __builtin_amdgcn_readfirstlane((int)(back ? x.y : x.x));
-        // the next record is requested at once; the revisit test of this level runs while it flies
-        u32x4 y = load_rec(tb, next_f);
-        u32 hn = sel_hash(next_f);
-        int headn = s_head[hn];
+        // The revisit test of this level needs the path only, so it runs while the node's record (requested a level ago) is
+        // still in flight; a revisited node needs its rows for a full evaluation, and they are requested here, next to the
+        // record instead of after it: loops through transpositions cost one memory round trip per level, not two.
         s_node[k] = cur;   // every lane stores the same value: no exec-mask detour
         u32 cnt = (prev_act >= 0 && (u32)(prev_act ^ 1) == lane) ? 1u : 0u;   // own arrival: L[cur, rev(a_prev)] += nu (agents.py:591)
         bool visited = false;
@@ -755,13 +749,24 @@ __global__ __launch_bounds__(kBlock) void k_mcts_select(rc_mcts_t m, double c, u
             const u32 nx = s_next[j];
             j = nx == 0xFFFFu ? -1 : (int)nx;
         }
+        NodeRows rows_cur = {0, 0, 0.f, 0.f};
+        if (visited) rows_cur = load_rows(tb, cur, la);   // wave-uniform
+        const u32 z = (u32)__builtin_amdgcn_readfirstlane((int)x.z);
+        const int b0 = (int)(z & 15u), b1 = (int)((z >> 8) & 15u);
+        const bool back = prev_act >= 0 && (prev_act ^ 1) == b0;   // arrived through rev(best0): that edge carries a loss
+        const int a_f = back ? b1 : b0;
+        const int next_f = __builtin_amdgcn_readfirstlane((int)(back ? x.y : x.x));
+        // the next record is requested at once (a revisited node decides otherwise often enough, but not always)
+        u32x4 y = load_rec(tb, next_f);
+        u32 hn = sel_hash(next_f);
+        int headn = s_head[hn];
         // one branch for the three ways a walk ends; which one is sorted out after the loop
         stop = (z & kRecLeaf) ? 1 : plen >= max_path ? 2 : (level_budget && walked >= level_budget) ? 3 : 0;
         if (stop) break;
         ++walked;
         int arg = a_f, next = next_f;
         if (visited) {   // wave-uniform: full evaluation with the exact loss counts
-            const NodeRows r = load_rows(tb, cur, la);
+            const NodeRows r = rows_cur;
             arg = puct_argmax_walk(c, c32, r.n_a, r.p_f, r.w_f, cnt, act, (int)lane, slow_levels);
             next = __builtin_amdgcn_readlane(r.nb, arg);
             ++revisits;

@@ -62,7 +62,7 @@ _PER_TREE = ("n_nodes", "status", "solved_idx", "solved_action", "iterations", "
              "ring_node", "ring_act", "ring_len", "phase")
 _RESULT_NODE = ("keys", "node", "leaf")         # what rc_mcts_complete_graph / rc_mcts_shorten read of a tree (nbr is a field of node)
 _RESULT_TREE = ("n_nodes", "status", "solved_idx", "solved_action", "iterations", "path_len", "pending", "path_act", "phase")
-RING_K = 8   # descent paths kept per tree for line following (rc_mcts_t::ring_k)
+RING_K = 32   # descent paths kept per tree for line following (rc_mcts_t::ring_k)
 ROWS = 11    # network rows per tree and iteration (rc_mcts_t::rows_per_tree)
 NODE_WORDS = 64   # 32-bit words per node record (RC_MCTS_NODE_WORDS): line 0 = N | W | walk record, line 1 = P | nbr
 _NODE_FIELDS = {"N": (0, 12, torch.int32), "W": (12, 24, torch.float32), "rec": (24, 28, torch.int32),

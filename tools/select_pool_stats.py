@@ -29,5 +29,6 @@ for rep in range(6):
     pc = lambda a: [round(float(np.percentile(a, q)) / 100, 1) for q in (50, 90, 99, 100)]
     print(f"trees {live.sum()} plen p50/90/99/max {[int(np.percentile(s[:, 1], q)) for q in (50, 90, 99, 100)]} | us p50/90/99/max: "
           f"backup+stage {pc(s[:, 5])} passA {pc(s[:, 6] - s[:, 5])} passB {pc(s[:, 7] - s[:, 6])} prefix-L {pc(s[:, 2] - s[:, 7])} walk {pc(s[:, 3])} total {pc(tot)}")
+    print(f"   slowest raw: start {s[w, 0]} plen {s[w, 1]} validate {s[w, 2] / 100:.1f} us walk {s[w, 3] / 100:.1f} us cycles {s[w, 4]} f5 {s[w, 5]} f6 {s[w, 6]} f7 {s[w, 7] >> 16}/{s[w, 7] & 0xFFFF}  (unstamped build: f5 = float64 fallbacks, f6 = revisited levels, f7 = line rounds / levels)")
     print(f"   slowest: plen {s[w, 1]} first {s[w, 0]} backup+stage {s[w, 5] / 100:.1f} passA {(s[w, 6] - s[w, 5]) / 100:.1f} passB {(s[w, 7] - s[w, 6]) / 100:.1f} "
           f"prefix-L {(s[w, 2] - s[w, 7]) / 100:.1f} walk {s[w, 3] / 100:.1f} ({s[w, 1] - 1 - s[w, 0]} levels, {s[w, 4] / max(s[w, 1] - 1 - s[w, 0], 1):.0f} cyc/level)", flush=True)
