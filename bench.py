@@ -217,10 +217,12 @@ def phase_times_split(forest, c, max_states, reps):
     out = {k: round(v / reps, 4) for k, v in acc.items()}
     cubes, rows = forest._net_input()
     hid = {}
+    a = eng._first_from_cubes(cubes, eng.layers)   # the REAL activations of this step's children (MFMA time depends on the operand bits)
+    if a is None:
+        a = eng._forward(eng._input_from_cubes(cubes), eng.layers[:1] + eng.layers[-1:])   # not reached with fc_small (fused input layer)
     for li in (1, 2):   # the two hidden layers behind the input layer, as the engine runs them
         _, Wh, B2, b, code, alpha, W3 = eng.layers[li]
         K, N = Wh.shape[1], Wh.shape[0]
-        a = torch.randn((rows, 2 * K), device=Wh.device).half()
         tile = eng._fused_tile(rows, N, K) if eng.fused_hidden else 0
         last = li == len(eng.layers) - 2
         if tile:   # one kernel: three f16 products + bias + activation + re-split (csrc/rubiks_gemm.hip)
@@ -229,11 +231,14 @@ def phase_times_split(forest, c, max_states, reps):
                 a.data_ptr(), W3.data_ptr(), b.data_ptr(), rows, N, K, code, alpha, None if last else o.data_ptr(),
                 o.data_ptr() if last else None, tile, _hip.stream_ptr()), "rc_split_gemm_f16"), reps)[0], 4)
             hid[f"gemm_hidden{li}_kernel"] = "rc_split_gemm_f16"
+            a = o
         else:      # hi x hi GEMM (K deep) + correction GEMM (2 K deep) through the library, + rc_split_act_f16
             hid[f"gemm_hidden{li}_main"] = round(event_ms(lambda: torch.mm(a[:, :K], Wh.t(), out_dtype=torch.float32), reps)[0], 4)
             hid[f"gemm_hidden{li}_corr"] = round(event_ms(lambda: torch.mm(a, B2.t(), out_dtype=torch.float32), reps)[0], 4)
             hid[f"gemm_hidden{li}"] = round(hid[f"gemm_hidden{li}_main"] + hid[f"gemm_hidden{li}_corr"], 4)
             hid[f"gemm_hidden{li}_kernel"] = "hipBLASLt x2"
+            a = eng._act(torch.mm(a[:, :K], Wh.t(), out_dtype=torch.float32), torch.mm(a, B2.t(), out_dtype=torch.float32), b, code, alpha,
+                         split=not last)
     out.update(hid)
     Wh = eng.layers[1][1]
     out["gemm_hidden1_weight"] = (int(Wh.shape[0]), int(Wh.shape[1]))
@@ -391,8 +396,19 @@ def run_leg(name, model, pool_roots, config_roots, args, world, coll_device):
     barrier()
     t_pool = time.perf_counter()
     run = agent.start_batch(pool_roots, None, cap, slots=args.trees)
-    while not run.done and run.next_game < min(2 * args.trees, run.n_games) and run.it < args.prep_cap:
+    # Prep ends half way between two result flushes: finished trees are turned into results (graph completion + BFS) 256 at a
+    # time on a side stream, ~35 ms of kernels that slow the concurrent steps by 10-20 %; a 20-step window sees either all of
+    # one flush or nothing of it, the pool as a whole 1.5 %.  `result_flushes_in_window` says which it was; pool_run has them all.
+    prep_games = 2 * args.trees + type(run).GRAVE // 2
+    while not run.done and run.next_game < min(prep_games, run.n_games) and run.it < args.prep_cap:
         run.round()
+    # Harvested trees are turned into host results lazily; doing that here (tens of ms of host work, the GPU idles and drops its
+    # clocks) instead of inside nodes_now() right in front of the timed window, then two more untimed rounds to bring the clocks
+    # back: the first ~10 steps after such a pause were measured 5-30 % slow (tools/window0_probe.py).
+    run.nodes_now()
+    for _ in range(2):
+        if not run.done:
+            run.round()
     prep_iters = run.it
     left = max(args.warmup, 1)
     while left > 0 and not run.done:
@@ -400,7 +416,7 @@ def run_leg(name, model, pool_roots, config_roots, args, world, coll_device):
         run.round(left)
         left -= run.it - before
     barrier()
-    nodes0, refills0, it0 = run.nodes_now(), run.stats["refills"], run.it
+    nodes0, refills0, it0, flushes0 = run.nodes_now(), run.stats["refills"], run.it, run.stats.get("flushes", 0)
     barrier()
     t0 = time.perf_counter()
     left = args.steps
@@ -417,6 +433,7 @@ def run_leg(name, model, pool_roots, config_roots, args, world, coll_device):
     plen = run.forest.path_len.cpu().numpy()
     mean_path = float(plen[(status == 0) & (run.owner >= 0)].mean()) if running_in_window else 0.0
     refills_in_window = run.stats["refills"] - refills0
+    flushes_in_window = run.stats.get("flushes", 0) - flushes0
     pool = None
     if not args.window_only:
         while not run.done:
@@ -453,7 +470,7 @@ def run_leg(name, model, pool_roots, config_roots, args, world, coll_device):
     else:
         rtc_s, pool_nodes, pool_s = float(stats[3]), int(stats[4]), float(stats[5])
     out = {"dtype": LEG_DTYPE[name], "value": round(nodes / seconds, 1), "ms_per_step": round(seconds / max(steps_done, 1) * 1e3, 4),
-           "nodes_in_window": nodes, "steps_timed": steps_done, "prep_iterations_untimed": prep_iters,
+           "nodes_in_window": nodes, "steps_timed": steps_done, "prep_iterations_untimed": prep_iters, "result_flushes_in_window": flushes_in_window,
            "refills_in_window": refills_in_window, "running_trees_rank0": running_in_window,
            "mean_descent_depth_rank0": round(mean_path, 1)}
     if pool:
@@ -655,7 +672,10 @@ def main():
                    "trees_per_gpu": args.trees, "pool_scrambles_per_gpu": per_rank, "select_level_budget": args.level_budget,
                    "scramble_depth": args.depth, "parallelism": f"scramble-sharded x{world}",
                    "timed_region": "K lock-step iterations of the stationary pool (harvest + refill included), barrier + "
-                                   "synchronize on both sides; prep and warm-up untimed"},
+                                   "synchronize on both sides; prep and warm-up untimed; the window starts half way between two "
+                                   "result flushes (graph completion + BFS of 256 finished trees on a side stream, one per 256 "
+                                   "finished games): legs.*.result_flushes_in_window counts those that fell into it, "
+                                   "value_pool_run includes all of them"},
         "value_note": f"headline = the '{legs[0]}' leg: the reference's network arithmetic is fp32 (librubiks/model.py:131-141); f32s reaches "
                       "fp32 accuracy with three f16 MFMA products per layer (error against float64 not above the fp32 forward's: "
                       "tests/test_net_gpu.py), f32 is the fp32 MFMA GEMM chain as is, bf16 the fast engine; all under `legs`",

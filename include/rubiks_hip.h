@@ -155,6 +155,14 @@ int rc_first_layer_mfma2_bf16(const int8_t *soa, size_t n, size_t stride, const 
  * two library GEMMs (model.py:150-157: Linear -> activation), 16 bytes per lane.  4 B of HBM traffic per element. */
 int rc_act_bf16_inplace(uint16_t *x, size_t n, int activation, float alpha, rc_stream_t stream);
 
+/* A hidden layer of the bf16 engine as ONE kernel: out = act(a w^T + bias) in bf16, fp32 accumulation on MFMA
+ * (model.py:123-127,150-157).  a: bf16 [n_rows][k], w: bf16 [n_out][k] (nn.Linear layout), bias: float[n_out], out: bf16
+ * [n_rows][n_out].  The kernel of rc_split_gemm_f16 (below) with one product instead of three: 352 x 256 tiles (tile 1,
+ * n_out % 256 == 0) or 352 x 128 (tile 3, n_out % 128 == 0), tile 0 = choose; k % 64 == 0.  Replaces the library GEMM +
+ * rc_act_bf16_inplace where it is the faster of the two (librubiks/model.py::InferenceNet decides by shape). */
+int rc_gemm_bias_act_bf16(const uint16_t *a, const uint16_t *w, const float *bias, size_t n_rows, size_t n_out, size_t k,
+                          int activation, float alpha, uint16_t *out, int tile, rc_stream_t stream);
+
 /* ---- fp32-accurate network on the f16 matrix cores (f16x3 split) -------------------------------------------------
  * A float x travels as two IEEE halves, x = hi + lo * 2^-11 with hi = half(x), lo = half((x - hi) * 2^11); a layer is
  *   y = act(hi_x W_hi^T + 2^-11 (hi_x W_lo^T + lo_x W_hi^T) + b)      (fp32 accumulation on MFMA, library GEMMs)
@@ -175,12 +183,20 @@ int rc_first_layer_split_f16(const int8_t *soa, size_t n, size_t stride, const u
 int rc_split_act_f16(const float *c, const float *c_corr, float corr_scale, size_t n_rows, size_t n_cols, const float *bias,
                      int activation, float alpha, uint16_t *out_hi_lo, float *out_f32, rc_stream_t stream);
 
+/* Last hidden activation + output layer of that network in one pass (the fp32 counterpart of rc_head_bf16):
+ *   y = act(c + corr_scale * c_corr + bias_h)  (never written),   out[i][o] = bias_o[o] + sum_k w[o][k] * y[i][k],  o < n_out <= 16
+ * c, c_corr: the fp32 GEMM outputs [n][K] (c_corr may be NULL), K = 512 or 1024;  w: float [n_out][K];  out: float, row pitch 16
+ * (columns >= n_out are written as 0): the layout rc_mcts_backup_head reads.  fp32 FMA chains on the exact fp32 MFMA.
+ * Replaces rc_split_act_f16's fp32 output + the 13-wide fp32 library GEMM (model.py:124-129,150-159 at fp32 accuracy). */
+int rc_head_split_f32(const float *c, const float *c_corr, float corr_scale, size_t n, size_t K, const float *bias_h,
+                      int activation, float alpha, const float *w, const float *bias_o, size_t n_out, float *out, rc_stream_t stream);
 /* One hidden layer of that network as ONE kernel (own MFMA GEMM, fused epilogue; csrc/rubiks_gemm.hip):
  *   y = act(hi_x W_hi^T + 2^-11 (hi_x W_lo^T + lo_x W_hi^T) + bias)          (model.py:123-127,150-157 at fp32 accuracy)
  * a_hi_lo: [n_rows][2 k] halves (hi | lo), as the kernels above write it;  w_lo_hi_hi: [n_out][3 k] halves, the layer's
  * weight split and laid out [W_lo | W_hi | W_hi] (the order the K loop walks: both correction products, a 2^-11 scaling of
  * the accumulator, the main product);  exactly one of out_hi_lo ([n_rows][2 n_out] halves) and out_f32 ([n_rows][n_out])
- * is non-NULL.  k % 64 == 0;  tile: 0 = choose, 1 = 352 x 256 (n_out % 256 == 0), 2 = 176 x 128 (n_out % 128 == 0).
+ * is non-NULL.  k % 64 == 0;  tile: 0 = choose, 1 = 352 x 256 (n_out % 256 == 0), 3 = 352 x 128, 2 = 176 x 128 (n_out % 128 == 0),
+ * 4 = 352 x 256 with one barrier per K-step (the simpler schedule, kept for comparison).
  * Replaces two library GEMMs + rc_split_act_f16; the fp32 partial matrices never reach HBM. */
 int rc_split_gemm_f16(const uint16_t *a_hi_lo, const uint16_t *w_lo_hi_hi, const float *bias, size_t n_rows, size_t n_out,
                       size_t k, int activation, float alpha, uint16_t *out_hi_lo, float *out_f32, int tile, rc_stream_t stream);

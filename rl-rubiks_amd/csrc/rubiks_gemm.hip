@@ -23,6 +23,8 @@ namespace rubiks {
 
 typedef __attribute__((ext_vector_type(8))) _Float16 f16x8;
 typedef __attribute__((ext_vector_type(4))) float f32x4;
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+constexpr int kOutHalves = 0, kOutF32 = 1, kBf16 = 2;   // operand / output kinds of k_split_gemm_pp
 typedef __attribute__((address_space(3))) void lds_void;
 typedef const __attribute__((address_space(1))) void glb_void;
 
@@ -179,7 +181,8 @@ __global__ __launch_bounds__(WM *WN * 64) void k_split_gemm(GemmArgs g) {
 //   stage s+1 goes into the buffer last read in step s-1: row 1's reads R_3(s-1) retire after barrier 8s-1, so row 0 issues its
 //   LDS-DMA in R_1, R_2 (after 8s+1) and row 1 in R_0, R_1 (after 8s); both wait vmcnt(0) before barrier 8s+7, which every
 //   wave passes before its first read of stage s+1.
-template <int MR, int NR, int ACT, bool OUT_SPLIT>
+// KIND: kOutHalves / kOutF32 = the split layer (f16 operands, three products), kBf16 = a plain bf16 layer (one product, bf16 out).
+template <int MR, int NR, int ACT, int KIND>
 __global__ __launch_bounds__(512) void k_split_gemm_pp(GemmArgs g) {
     constexpr int WM = 2, WN = 4;
     using T = GemmTile<WM, WN, MR, NR>;
@@ -196,7 +199,7 @@ __global__ __launch_bounds__(512) void k_split_gemm_pp(GemmArgs g) {
     const u32 tm = wg / nn, tn = wg % nn;
     const size_t row0 = (size_t)tm * T::BM;
     const u32 col0 = tn * T::BN;
-    const u32 K = g.K, lda = 2 * K * 2, ldw = 3 * K * 2;
+    const u32 K = g.K, lda = (KIND == kBf16 ? 1 : 2) * K * 2, ldw = (KIND == kBf16 ? 1 : 3) * K * 2;   // bytes
     const u32 last_row = (u32)(g.M - 1 - row0);
 
     // LDS-DMA piece p = i * 8 + wave covers stage rows 8 p .. 8 p + 7 (activation rows first, then weight rows); lane l moves
@@ -207,7 +210,7 @@ __global__ __launch_bounds__(512) void k_split_gemm_pp(GemmArgs g) {
 
     constexpr int kHalf = (T::PPW + 1) / 2;
     auto stage_part = [&](u32 ks, u32 buf, int lo, int hi) {   // this wave's pieces lo .. hi - 1 of stage ks
-        const u32 kk = ks * 64, a_col = kk < 2 * K ? kk : kk - 2 * K;
+        const u32 kk = ks * 64, a_col = (KIND == kBf16 || kk < 2 * K) ? kk : kk - 2 * K;
         const unsigned char *ab = a_tile + a_col * 2, *wb = w_tile + kk * 2;
         unsigned char *dst = lds + buf * T::STAGE;
         u32 rl = r_lane, cl = c_lane;
@@ -239,7 +242,7 @@ __global__ __launch_bounds__(512) void k_split_gemm_pp(GemmArgs g) {
 #pragma unroll
         for (int n = 0; n < NR; ++n) acc[m][n] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-    const u32 nk = 3 * K / 64, scale_step = 2 * K / 64;
+    const u32 nk = (KIND == kBf16 ? 1 : 3) * K / 64, scale_step = KIND == kBf16 ? 0xFFFFFFFFu : 2 * K / 64;
     stage_part(0, 0, 0, T::PPW);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
@@ -295,7 +298,8 @@ __global__ __launch_bounds__(512) void k_split_gemm_pp(GemmArgs g) {
                     for (int kh = 0; kh < 2; ++kh)
 #pragma unroll
                         for (int n = 0; n < NR; ++n)
-                            acc[ph * kBlk + j][n] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[n][kh], xf[j][kh], acc[ph * kBlk + j][n], 0, 0, 0);
+                            acc[ph * kBlk + j][n] = KIND == kBf16 ? __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, wf[n][kh]), __builtin_bit_cast(bf16x8, xf[j][kh]), acc[ph * kBlk + j][n], 0, 0, 0)
+                                                                  : __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[n][kh], xf[j][kh], acc[ph * kBlk + j][n], 0, 0, 0);
                 }
             __builtin_amdgcn_s_setprio(0);
             if (ph == kPhases - 1 && wr == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -323,7 +327,10 @@ __global__ __launch_bounds__(512) void k_split_gemm_pp(GemmArgs g) {
                 if (ACT == RC_ACT_ELU) y[e] = y[e] > 0.f ? y[e] : g.alpha * expm1_neg(y[e]);
             }
             const u32 col = cbase + 16 * n;
-            if (OUT_SPLIT) {
+            if (KIND == kBf16) {
+                unsigned char *orow = reinterpret_cast<unsigned char *>(g.out) + row * ((size_t)g.N * 2);
+                *reinterpret_cast<uint2 *>(orow + col * 2) = make_uint2(pack_bf16(y[0], y[1]), pack_bf16(y[2], y[3]));
+            } else if (KIND == kOutHalves) {
                 float hi[4], lo[4];
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
@@ -341,24 +348,24 @@ __global__ __launch_bounds__(512) void k_split_gemm_pp(GemmArgs g) {
     }
 }
 
-template <int MR, int NR, int ACT, bool OUT_SPLIT> static int launch_split_gemm_pp(const GemmArgs &g, hipStream_t s) {
+template <int MR, int NR, int ACT, int KIND> static int launch_split_gemm_pp(const GemmArgs &g, hipStream_t s) {
     using T = GemmTile<2, 4, MR, NR>;
     static std::atomic<unsigned long long> attr_set{0};
     int dev = 0;
     (void)hipGetDevice(&dev);
     if (!((attr_set.load(std::memory_order_acquire) >> (dev & 63)) & 1ull)) {
-        hipError_t e = hipFuncSetAttribute((const void *)k_split_gemm_pp<MR, NR, ACT, OUT_SPLIT>, hipFuncAttributeMaxDynamicSharedMemorySize,
+        hipError_t e = hipFuncSetAttribute((const void *)k_split_gemm_pp<MR, NR, ACT, KIND>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                            T::LDS_BYTES);
         if (e != hipSuccess) return hip_rc(e);
         attr_set.fetch_or(1ull << (dev & 63), std::memory_order_release);
     }
     const u32 grid = (u32)(ceil_div((size_t)g.M, (size_t)T::BM) * (g.N / T::BN));
-    hipLaunchKernelGGL((k_split_gemm_pp<MR, NR, ACT, OUT_SPLIT>), dim3(grid), dim3(T::THREADS), T::LDS_BYTES, s, g);
+    hipLaunchKernelGGL((k_split_gemm_pp<MR, NR, ACT, KIND>), dim3(grid), dim3(T::THREADS), T::LDS_BYTES, s, g);
     return launch_status();
 }
 
-template <int MR, int NR> static int dispatch_split_gemm_pp(const GemmArgs &g, int act, bool split, hipStream_t s) {
-#define RC_GEMM_ACT(ACT) (split ? launch_split_gemm_pp<MR, NR, ACT, true>(g, s) : launch_split_gemm_pp<MR, NR, ACT, false>(g, s))
+template <int MR, int NR, int KIND> static int dispatch_split_gemm_pp(const GemmArgs &g, int act, hipStream_t s) {
+#define RC_GEMM_ACT(ACT) launch_split_gemm_pp<MR, NR, ACT, KIND>(g, s)
     if (act == RC_ACT_ELU) return RC_GEMM_ACT(RC_ACT_ELU);
     if (act == RC_ACT_RELU) return RC_GEMM_ACT(RC_ACT_RELU);
     return RC_GEMM_ACT(RC_ACT_NONE);
@@ -416,8 +423,34 @@ extern "C" int rc_split_gemm_f16(const uint16_t *a_hi_lo, const uint16_t *w_lo_h
     if (tile == 0) tile = (n_out % 256 == 0 && row_tiles * (n_out / 256) >= 192) ? 1 : (row_tiles * (n_out / 128) >= 192) ? 3 : 2;
     RC_REQUIRE((tile != 1 && tile != 4) || n_out % 256 == 0, RC_ERR_RANGE);
     hipStream_t s = (hipStream_t)stream;
-    if (tile == 1) return dispatch_split_gemm_pp<11, 4>(g, activation, split, s);      // 352 x 256, staggered wave rows
-    if (tile == 3) return dispatch_split_gemm_pp<11, 2>(g, activation, split, s);      // 352 x 128, staggered wave rows
+    if (tile == 1)   // 352 x 256, staggered wave rows
+        return split ? dispatch_split_gemm_pp<11, 4, kOutHalves>(g, activation, s) : dispatch_split_gemm_pp<11, 4, kOutF32>(g, activation, s);
+    if (tile == 3)   // 352 x 128, staggered wave rows
+        return split ? dispatch_split_gemm_pp<11, 2, kOutHalves>(g, activation, s) : dispatch_split_gemm_pp<11, 2, kOutF32>(g, activation, s);
     if (tile == 4) return dispatch_split_gemm<2, 4, 11, 4>(g, activation, split, s);   // 352 x 256, one barrier per K-step
     return dispatch_split_gemm<1, 4, 11, 2>(g, activation, split, s);                  // 176 x 128, one barrier per K-step
+}
+
+extern "C" int rc_gemm_bias_act_bf16(const uint16_t *a, const uint16_t *w, const float *bias, size_t n_rows, size_t n_out, size_t k,
+                                     int activation, float alpha, uint16_t *out, int tile, rc_stream_t stream) {
+    if (n_rows == 0) return RC_OK;
+    RC_REQUIRE(a && w && bias && out, RC_ERR_NULL);
+    RC_REQUIRE(aligned16(a) && aligned16(w) && aligned16(bias) && aligned16(out), RC_ERR_ALIGN);
+    RC_REQUIRE(k >= 64 && k % 64 == 0 && k <= (1u << 16) && n_out % 128 == 0 && n_rows < (1ull << 31) && n_out < (1u << 20) &&
+                   activation >= RC_ACT_NONE && activation <= RC_ACT_ELU && (tile == 0 || tile == 1 || tile == 3), RC_ERR_RANGE);
+    GemmArgs g;
+    g.a = (const unsigned char *)a;
+    g.w = (const unsigned char *)w;
+    g.bias = bias;
+    g.out = (void *)out;
+    g.M = (u32)n_rows;
+    g.N = (u32)n_out;
+    g.K = (u32)k;
+    g.alpha = alpha;
+    const size_t row_tiles = ceil_div(n_rows, (size_t)352);
+    if (tile == 0) tile = (n_out % 256 == 0 && row_tiles * (n_out / 256) >= 192) ? 1 : 3;
+    RC_REQUIRE(tile != 1 || n_out % 256 == 0, RC_ERR_RANGE);
+    hipStream_t s = (hipStream_t)stream;
+    if (tile == 1) return dispatch_split_gemm_pp<11, 4, kBf16>(g, activation, s);
+    return dispatch_split_gemm_pp<11, 2, kBf16>(g, activation, s);
 }

@@ -541,6 +541,70 @@ __global__ __launch_bounds__(kBlock) void k_split_act(const float4 *__restrict__
     }
 }
 
+// Last hidden activation + output layer of the split network in one pass (the fp32 counterpart of k_head):
+//   y = act(c + corr_scale * c_corr + bias_h)   [n][K] fp32, never written;   out[i][o] = bias_o[o] + sum_k w[o][k] y[i][k]
+// on the exact fp32 MFMA (v_mfma_f32_16x16x4_f32 == an fmaf chain).  One 16-row tile per workgroup pass, K split over the
+// four waves, whose partial 16 x 16 products meet in LDS.  A lane loads 16-byte chunks: chunk (j, g) of a row holds
+// k = 16 j + 4 g .. + 3, and MFMA step s of block j contracts the s-th element of every chunk -- a permutation of k that
+// A (activations) and B (weights) share.  It replaces rc_split_act_f16's fp32 output + the library's 13-wide fp32 GEMM:
+// the [n][K] activation matrix (46 MB at n = 11 264) is neither written nor read back.
+template <int ACT, int KB>
+__global__ __launch_bounds__(kBlock) void k_head_split(const float4 *__restrict__ c, const float4 *__restrict__ c_corr, float corr_scale,
+                                                       size_t n, const float4 *__restrict__ bias_h, float alpha, const float4 *__restrict__ w,
+                                                       const float *__restrict__ bias_o, u32 n_out, float *__restrict__ out) {
+    __shared__ float s_part[kBlock / kWave][16][17];
+    constexpr int K = 64 * KB, K4 = K / 4;          // floats, float4 chunks per row; a wave owns K / 4 consecutive floats = KB blocks of 16
+    const u32 tid = threadIdx.x, wv = tid / kWave, lane = tid & (kWave - 1), r = lane & 15, g = lane >> 4;
+    const u32 chunk0 = wv * (K4 / 4) + g;           // + 4 j: the lane's chunk of block j
+    float4 wf[KB], bh[KB];
+#pragma unroll
+    for (int j = 0; j < KB; ++j) {
+        wf[j] = r < n_out ? w[(size_t)r * K4 + chunk0 + 4 * j] : make_float4(0.f, 0.f, 0.f, 0.f);
+        bh[j] = bias_h[chunk0 + 4 * j];
+    }
+    const size_t n_tiles = ceil_div(n, (size_t)16);
+    for (size_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+        const size_t row = tile * 16 + r;
+        const size_t off = (row < n ? row : n - 1) * K4 + chunk0;   // rows past the end: clamped, never stored
+        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int j0 = 0; j0 < KB; j0 += 4) {
+            float4 a[4], k4[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                a[u] = c[off + 4 * (j0 + u)];
+                k4[u] = c_corr ? c_corr[off + 4 * (j0 + u)] : make_float4(0.f, 0.f, 0.f, 0.f);
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const float4 b = bh[j0 + u];
+                float y[4] = {a[u].x + corr_scale * k4[u].x + b.x, a[u].y + corr_scale * k4[u].y + b.y, a[u].z + corr_scale * k4[u].z + b.z,
+                              a[u].w + corr_scale * k4[u].w + b.w};
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    if (ACT == RC_ACT_RELU) y[e] = fmaxf(y[e], 0.f);
+                    if (ACT == RC_ACT_ELU) y[e] = y[e] > 0.f ? y[e] : alpha * expm1f(y[e]);
+                }
+                const float4 wv4 = wf[j0 + u];
+                acc = __builtin_amdgcn_mfma_f32_16x16x4f32(y[0], wv4.x, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_16x16x4f32(y[1], wv4.y, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_16x16x4f32(y[2], wv4.z, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_16x16x4f32(y[3], wv4.w, acc, 0, 0, 0);
+            }
+        }
+        __syncthreads();   // the previous tile's partial sums have been read
+#pragma unroll
+        for (int i = 0; i < 4; ++i) s_part[wv][g * 4 + i][r] = acc[i];   // D: lane holds output r of rows 4 g .. 4 g + 3
+        __syncthreads();
+        {
+            const u32 orow = tid >> 4, o = tid & 15;
+            const float v = (s_part[0][orow][o] + s_part[1][orow][o]) + (s_part[2][orow][o] + s_part[3][orow][o]);
+            const size_t grow = tile * 16 + orow;
+            if (grow < n) out[grow * kHeadMaxOut + o] = (o < n_out) ? v + bias_o[o] : 0.f;
+        }
+    }
+}
+
 // =================================================================================================
 // Input layer of the fp32-accurate split network on the matrix cores (SplitF32Net, below):
 //   y = act(onehot W_hi^T + 2^-11 onehot W_lo^T + b),  written as the two halves [hi(y) | lo(y)] the next layer's GEMMs read.
@@ -728,6 +792,32 @@ extern "C" int rc_split_act_f16(const float *c, const float *c_corr, float corr_
     else if (activation == RC_ACT_RELU) RC_LAUNCH_SPLIT(RC_ACT_RELU);
     else RC_LAUNCH_SPLIT(RC_ACT_NONE);
 #undef RC_LAUNCH_SPLIT
+    return launch_status();
+}
+
+extern "C" int rc_head_split_f32(const float *c, const float *c_corr, float corr_scale, size_t n, size_t K, const float *bias_h,
+                                 int activation, float alpha, const float *w, const float *bias_o, size_t n_out, float *out,
+                                 rc_stream_t stream) {
+    if (n == 0) return RC_OK;
+    RC_REQUIRE(c && bias_h && w && bias_o && out, RC_ERR_NULL);
+    RC_REQUIRE(aligned16(c) && aligned16(c_corr) && aligned16(bias_h) && aligned16(w), RC_ERR_ALIGN);
+    RC_REQUIRE((K == 512 || K == 1024) && n_out >= 1 && n_out <= (size_t)kHeadMaxOut && activation >= RC_ACT_NONE && activation <= RC_ACT_ELU,
+               RC_ERR_RANGE);
+    const unsigned grid = grid_for(ceil_div(n, (size_t)16) * kBlock, kBlock, 256 * 4);
+    hipStream_t s = (hipStream_t)stream;
+#define RC_LAUNCH_HS(ACT, KB)                                                                                                  \
+    hipLaunchKernelGGL((k_head_split<ACT, KB>), dim3(grid), dim3(kBlock), 0, s, (const float4 *)c, (const float4 *)c_corr, corr_scale, n, \
+                       (const float4 *)bias_h, alpha, (const float4 *)w, bias_o, (u32)n_out, out)
+#define RC_LAUNCH_HS_K(ACT)                   \
+    do {                                      \
+        if (K == 1024) RC_LAUNCH_HS(ACT, 16); \
+        else RC_LAUNCH_HS(ACT, 8);            \
+    } while (0)
+    if (activation == RC_ACT_ELU) RC_LAUNCH_HS_K(RC_ACT_ELU);
+    else if (activation == RC_ACT_RELU) RC_LAUNCH_HS_K(RC_ACT_RELU);
+    else RC_LAUNCH_HS_K(RC_ACT_NONE);
+#undef RC_LAUNCH_HS_K
+#undef RC_LAUNCH_HS
     return launch_status();
 }
 

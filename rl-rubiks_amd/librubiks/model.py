@@ -266,12 +266,7 @@ class InferenceNet:
 
     @torch.no_grad()
     def __call__(self, oh: torch.Tensor):
-        x = oh
-        for W, b, act in self.layers:
-            x = torch.addmm(b, x, W.t())
-            if act is not None:
-                x = _activate_(x, act)
-        out = x.float()
+        out = self._run(self.layers, oh).float()
         return out[:, :N_ACTIONS], out[:, N_ACTIONS]
 
     @property
@@ -354,9 +349,28 @@ class InferenceNet:
         """Value head only, float32[n], straight from device-resident cube states (optionally the window lo..lo+n)."""
         return self._run(self.value_layers[1:], self.first_layer(cubes, x1, lo, n)).float().reshape(-1)
 
+    # bf16 hidden layers with an activation as one kernel (rc_gemm_bias_act_bf16) where its tile fills the chip.  Opt-in: the
+    # kernel beats hipBLASLt + the activation pass (0.186 ms against 0.200 ms at 11 264 x 4096 x 2048, +1.5 % on a steady-state
+    # MCTS step), but only at full batches, and switching kernels with the batch size would make a row's bf16 result depend on
+    # how many other rows share its launch (tests/test_full_size_gpu.py requires the pooled and the one-batch search to agree).
+    fused_hidden = False
+
     @staticmethod
     def _run(layers, x):
         for W, b, act in layers:
+            if (act is not None and InferenceNet.fused_hidden and x.dtype == torch.bfloat16 and x.is_cuda and x.is_contiguous()
+                    and W.shape[1] % 64 == 0 and W.shape[0] % 256 == 0 and -(-x.shape[0] // 352) * (W.shape[0] // 256) >= 192):
+                # 352 x 256 tiles on >= 3/4 of the CUs: measured 0.186 ms against 0.200 ms for hipBLASLt + the activation pass at
+                # 11 264 x 4096 x 2048 (tools/bf16_gemm_fused_probe.py); layers without activation and narrow ones stay with the library
+                from librubiks import _hip
+                if getattr(b, "_f32", None) is None:
+                    b._f32 = b.float().contiguous()
+                out = torch.empty((x.shape[0], W.shape[0]), dtype=torch.bfloat16, device=x.device)
+                _hip.check(_hip.lib().rc_gemm_bias_act_bf16(x.data_ptr(), W.data_ptr(), b._f32.data_ptr(), x.shape[0], W.shape[0], W.shape[1],
+                                                            1 if isinstance(act, nn.ReLU) else 2, float(getattr(act, "alpha", 1.0)),
+                                                            out.data_ptr(), 1, _hip.stream_ptr()), "rc_gemm_bias_act_bf16")
+                x = out
+                continue
             x = torch.addmm(b, x, W.t())
             if act is not None:
                 x = _activate_(x, act)
@@ -417,6 +431,7 @@ class SplitF32Net:
         return out
 
     fused_hidden = True   # hidden layers as one kernel each (rc_split_gemm_f16) where its tile fills the chip
+    fused_head = True     # last activation + output layer in one pass (rc_head_split_f32) behind a library-GEMM hidden layer
 
     @staticmethod
     def _fused_tile(rows: int, n_out: int, k: int) -> int:
@@ -506,6 +521,15 @@ class SplitF32Net:
                     continue
                 c = torch.mm(a[:, :K], Wh.t(), out_dtype=torch.float32)   # hi x hi
                 corr = torch.mm(a, B2.t(), out_dtype=torch.float32)       # hi x lo + lo x hi, scaled by 2^11; added in the kernel below
+                nxt = layers[i + 1]
+                if last_hidden and self.fused_head and nxt[0] == "f32" and nxt[1].shape[0] <= 16 and Wh.shape[0] in (512, 1024):
+                    # activation + the skinny output layer in one pass: the fp32 activations are never written (rc_head_split_f32)
+                    from librubiks import _hip
+                    out = torch.empty((a.shape[0], 16), dtype=torch.float32, device=a.device)
+                    _hip.check(_hip.lib().rc_head_split_f32(c.data_ptr(), corr.data_ptr(), 1.0 / SPLIT_SCALE, a.shape[0], Wh.shape[0],
+                                                            b.data_ptr(), code, alpha, nxt[1].data_ptr(), nxt[2].data_ptr(), nxt[1].shape[0],
+                                                            out.data_ptr(), _hip.stream_ptr()), "rc_head_split_f32")
+                    return out[:, :nxt[1].shape[0]]
             else:
                 _, W, b = layer
                 return torch.addmm(b, a, W.t())

@@ -423,6 +423,7 @@ class MCTSRun:
         if self.grave is None or self.grave_fill == 0:
             return
         g, n = self.grave, self.grave_fill
+        self.stats["flushes"] = self.stats.get("flushes", 0) + 1
         g.status[n:] = md.RUNNING          # slots beyond the fill are not trees
         ev = torch.cuda.Event()
         ev.record()

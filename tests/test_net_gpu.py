@@ -216,3 +216,132 @@ def test_split_f32_engine_drives_the_search():
     assert np.array_equal(ra.solved, rb.solved)
     if os.path.isdir(wdir):
         assert ra.solved.mean() > 0.9 and abs(ra.lengths[ra.solved].mean() - rb.lengths[rb.solved].mean()) < 0.5
+
+
+# ---- own MFMA layer kernels (csrc/rubiks_gemm.hip) ------------------------------------------------------------------
+def _split_halves(x64):
+    hi = x64.half()
+    return hi, ((x64 - hi.double()) * 2048.0).half()
+
+
+@pytest.mark.parametrize("rows,k,n_out", [(11264, 512, 256), (1000, 256, 512), (353, 128, 256), (7, 64, 128)])
+@pytest.mark.parametrize("act", [0, 1, 2])
+def test_split_layer_kernel_matches_the_library_chain(rows, k, n_out, act):
+    """rc_split_gemm_f16 (three f16 products in one accumulator + bias + activation + re-split) against the chain it replaces
+    (two fp32-out library GEMMs + rc_split_act_f16) and against float64: |error| within fp32 rounding of the result's scale.
+    Every tile shape walks K in the same order, so their outputs are bit-identical (a row's result does not depend on the tile
+    or on how many rows share the launch)."""
+    from librubiks import _hip
+    lib = _hip.lib()
+    g = torch.Generator().manual_seed(rows + k + act)
+    x = (torch.randn(rows, k, generator=g, dtype=torch.float64) * 0.7).float().double()
+    W = (torch.randn(n_out, k, generator=g, dtype=torch.float64) / np.sqrt(k)).float().double()
+    b = torch.randn(n_out, generator=g, dtype=torch.float64).float().cuda()
+    (xh, xl), (wh, wl) = _split_halves(x), _split_halves(W)
+    a = torch.cat([xh, xl], 1).contiguous().cuda()
+    W3 = torch.cat([wl, wh, wh], 1).contiguous().cuda()
+    Wh, B2 = wh.contiguous().cuda(), torch.cat([wl, wh], 1).contiguous().cuda()
+    y = (xh.double() + xl.double() / 2048.0) @ (wh.double() + wl.double() / 2048.0).t() + b.cpu().double()
+    ref = torch.where(y > 0, y, torch.expm1(y)) if act == 2 else torch.relu(y) if act == 1 else y
+    scale = max(1.0, float(ref.abs().max()))
+    tiles = [t for t in (1, 2, 3, 4) if t in (2, 3) or n_out % 256 == 0]
+    for split_out in (True, False):
+        c = torch.mm(a[:, :k], Wh.t(), out_dtype=torch.float32)
+        corr = torch.mm(a, B2.t(), out_dtype=torch.float32)
+        chain = torch.empty((rows, 2 * n_out), dtype=torch.float16, device="cuda") if split_out else torch.empty((rows, n_out), device="cuda")
+        _hip.check(lib.rc_split_act_f16(c.data_ptr(), corr.data_ptr(), 1.0 / 2048.0, rows, n_out, b.data_ptr(), act, 1.0,
+                                        chain.data_ptr() if split_out else None, None if split_out else chain.data_ptr(), None), "rc_split_act_f16")
+        outs = []
+        for tile in tiles:
+            o = torch.full((rows + 1, 2 * n_out), float("nan"), dtype=torch.float16, device="cuda") if split_out else \
+                torch.full((rows + 1, n_out), float("nan"), device="cuda")
+            _hip.check(lib.rc_split_gemm_f16(a.data_ptr(), W3.data_ptr(), b.data_ptr(), rows, n_out, k, act, 1.0,
+                                             o.data_ptr() if split_out else None, None if split_out else o.data_ptr(), tile, None), "rc_split_gemm_f16")
+            torch.cuda.synchronize()
+            assert bool(torch.isnan(o[rows]).all()), "wrote past the last row"
+            outs.append(o[:rows])
+        for o in outs[1:]:
+            assert torch.equal(o, outs[0])
+
+        def value(t):
+            t = t.cpu()
+            return t[:, :n_out].double() + t[:, n_out:].double() / 2048.0 if split_out else t.double()
+        assert float((value(outs[0]) - ref).abs().max()) <= 4e-6 * scale       # fp32-level accuracy against float64
+        assert float((value(outs[0]) - value(chain)).abs().max()) <= 4e-6 * scale
+
+
+@pytest.mark.parametrize("rows,k,n_out,act", [(11264, 512, 256, 2), (1000, 256, 512, 1), (353, 128, 256, 0), (7, 64, 128, 2)])
+def test_bf16_layer_kernel_matches_the_library_chain(rows, k, n_out, act):
+    """rc_gemm_bias_act_bf16 against torch.addmm + rc_act_bf16_inplace: both round an fp32 accumulation to bf16 (the library
+    rounds once more before the activation), so they agree within one bf16 step, rtol 2^-7; tiles agree bit for bit."""
+    from librubiks import _hip
+    lib = _hip.lib()
+    g = torch.Generator().manual_seed(rows + k)
+    x = (torch.randn(rows, k, generator=g) * 0.7).bfloat16().cuda()
+    W = (torch.randn(n_out, k, generator=g) / np.sqrt(k)).bfloat16().cuda()
+    b = torch.randn(n_out, generator=g).cuda()
+    chain = torch.addmm(b.bfloat16(), x, W.t())
+    if act:
+        _hip.check(lib.rc_act_bf16_inplace(chain.data_ptr(), chain.numel(), act, 1.0, None), "rc_act_bf16_inplace")
+    outs = []
+    for tile in ([1, 3] if n_out % 256 == 0 else [3]):
+        o = torch.full((rows + 1, n_out), float("nan"), dtype=torch.bfloat16, device="cuda")
+        _hip.check(lib.rc_gemm_bias_act_bf16(x.data_ptr(), W.data_ptr(), b.data_ptr(), rows, n_out, k, act, 1.0, o.data_ptr(), tile, None),
+                   "rc_gemm_bias_act_bf16")
+        torch.cuda.synchronize()
+        assert bool(torch.isnan(o[rows]).all())
+        outs.append(o[:rows])
+    for o in outs[1:]:
+        assert torch.equal(o, outs[0])
+    y = x.double() @ W.double().t() + b.double()
+    ref = torch.where(y > 0, y, torch.expm1(y)) if act == 2 else torch.relu(y) if act == 1 else y
+    assert torch.allclose(outs[0].double(), ref, rtol=2.0 ** -7, atol=2.0 ** -7)
+    assert torch.allclose(outs[0].double(), chain.double(), rtol=2.0 ** -6, atol=2.0 ** -6)
+
+
+def test_layer_kernel_argument_errors():
+    from librubiks import _hip
+    lib = _hip.lib()
+    a = torch.zeros((16, 256), dtype=torch.float16, device="cuda")
+    w = torch.zeros((128, 384), dtype=torch.float16, device="cuda")
+    b = torch.zeros(128, device="cuda")
+    o = torch.zeros((16, 256), dtype=torch.float16, device="cuda")
+    f = torch.zeros((16, 128), device="cuda")
+    ok = lambda **kw: lib.rc_split_gemm_f16(kw.get("a", a.data_ptr()), w.data_ptr(), b.data_ptr(), kw.get("rows", 16), kw.get("n", 128),   # noqa: E731
+                                            kw.get("k", 128), kw.get("act", 2), 1.0, kw.get("o", o.data_ptr()), kw.get("f", None), kw.get("tile", 0), None)
+    assert ok() == 0 and ok(rows=0) == 0
+    assert ok(a=None) == -1 and ok(o=None) == -1 and ok(f=f.data_ptr()) == -1   # exactly one output
+    assert ok(k=96) == -4 and ok(n=192) == -4 and ok(act=3) == -4 and ok(tile=5) == -4
+    assert ok(tile=1) == -4                                  # 352 x 256 tiles need n_out % 256 == 0
+    assert ok(a=a.data_ptr() + 2) == -2
+    bf = lambda **kw: lib.rc_gemm_bias_act_bf16(a.data_ptr(), w.data_ptr(), b.data_ptr(), 16, kw.get("n", 128), kw.get("k", 128), 2, 1.0,   # noqa: E731
+                                                kw.get("o", o.data_ptr()), kw.get("tile", 0), None)
+    assert bf() == 0 and bf(o=None) == -1 and bf(k=32) == -4 and bf(tile=2) == -4
+    assert bf(tile=1) == -4
+
+
+@pytest.mark.parametrize("n,K,n_out,act", [(11264, 1024, 13, 2), (1000, 512, 1, 2), (17, 1024, 16, 1), (1, 512, 13, 0)])
+def test_split_head_kernel_matches_float64(n, K, n_out, act):
+    """rc_head_split_f32: act(c + 2^-11 corr + b) followed by the skinny fp32 output layer, against float64 (fp32 FMA chains:
+    error within a few fp32 roundings of sum |w y|) and against the two-step path it replaces."""
+    from librubiks import _hip
+    g = torch.Generator().manual_seed(n + K)
+    c = torch.randn(n, K, generator=g).cuda()
+    corr = (torch.randn(n, K, generator=g) * 100).cuda()
+    bh = torch.randn(K, generator=g).cuda()
+    w = (torch.randn(n_out, K, generator=g) / np.sqrt(K)).cuda()
+    bo = torch.randn(n_out, generator=g).cuda()
+    out = torch.full((n + 1, 16), float("nan"), device="cuda")
+    _hip.check(_hip.lib().rc_head_split_f32(c.data_ptr(), corr.data_ptr(), 1.0 / 2048.0, n, K, bh.data_ptr(), act, 1.0, w.data_ptr(),
+                                            bo.data_ptr(), n_out, out.data_ptr(), None), "rc_head_split_f32")
+    torch.cuda.synchronize()
+    assert bool(torch.isnan(out[n]).all()) and bool((out[:n, n_out:] == 0).all())
+    y = c.double() + corr.double() / 2048.0 + bh.double()
+    y = torch.where(y > 0, y, torch.expm1(y)) if act == 2 else torch.relu(y) if act == 1 else y
+    ref = y @ w.double().t() + bo.double()
+    bound = 8 * 2.0 ** -24 * ((y.abs() @ w.double().abs().t()) + bo.double().abs()) + 1e-6
+    assert bool(((out[:n, :n_out].double() - ref).abs() <= bound).all())
+    assert _hip.lib().rc_head_split_f32(c.data_ptr(), None, 0.0, n, 768, bh.data_ptr(), act, 1.0, w.data_ptr(), bo.data_ptr(), n_out,
+                                        out.data_ptr(), None) == -4     # K must be 512 or 1024
+    assert _hip.lib().rc_head_split_f32(None, None, 0.0, n, K, bh.data_ptr(), act, 1.0, w.data_ptr(), bo.data_ptr(), n_out,
+                                        out.data_ptr(), None) == -1

@@ -1,4 +1,4 @@
-"""Steady-state pool: consecutive timed windows of K steps (sync on both sides), with the refills that fell into each."""
+"""Where the first timed window after the prep spends its time: GPU time per step (events around every forest.step) and host gaps."""
 import os
 import sys
 import time
@@ -10,29 +10,42 @@ from librubiks import cube  # noqa: E402
 from librubiks.model import F32_SPLIT, Model  # noqa: E402
 from librubiks.solving.agents import MCTS  # noqa: E402
 
-import librubiks.model as _model  # noqa: E402
-if os.environ.get("RUBIKS_FUSED_HIDDEN") == "0":   # A/B: the library GEMM + activation pass instead of the own fused kernels
-    _model.InferenceNet.fused_hidden = False
-    _model.SplitF32Net.fused_hidden = False
 dt = {"bf16": torch.bfloat16, "f32s": F32_SPLIT}[sys.argv[1] if len(sys.argv) > 1 else "bf16"]
-K = int(sys.argv[2]) if len(sys.argv) > 2 else 20
 np.random.seed(0)
 cubes, _, _ = cube.scramble_batch(8192, 20, True)
 agent = MCTS(Model.load(os.path.join(ROOT, "weights", "fc_small_r1")).eval(), c=0.6, search_graph=True, net_dtype=dt)
 run = agent.start_batch(cubes, None, 50000, slots=1024)
 while run.next_game < 2048 + 128:
     run.round()
-for w in range(12):
+f = run.forest
+orig = f.step
+evs, host = [], []
+
+
+def step(*a, **k):
+    e = torch.cuda.Event(enable_timing=True)
+    e.record()
+    evs.append(e)
+    host.append(time.perf_counter())
+    return orig(*a, **k)
+
+
+f.step = step
+for w in range(3):
     torch.cuda.synchronize()
-    r0, n0 = run.stats["refills"], run.nodes_now()
+    n0 = run.nodes_now() if len(sys.argv) > 2 else 0
     torch.cuda.synchronize()
+    evs.clear(); host.clear()
     t = time.perf_counter()
-    left = K
+    left = 20
     while left > 0:
         b = run.it
         run.round(left)
         left -= run.it - b
+    e_end = torch.cuda.Event(enable_timing=True)
+    e_end.record()
     torch.cuda.synchronize()
     dtm = time.perf_counter() - t
-    n1 = run.nodes_now()
-    print(f"window {w}: {dtm / K * 1e3:.4f} ms/step, {(n1 - n0) / dtm / 1e6:.2f} M/s, refills {run.stats['refills'] - r0}", flush=True)
+    gpu = [evs[i].elapsed_time(evs[i + 1]) for i in range(len(evs) - 1)] + [evs[-1].elapsed_time(e_end)]
+    print(f"window {w}: wall {dtm * 1e3:.2f} ms; first launch after {1e3 * (host[0] - t):.3f} ms; host enqueue span {1e3 * (host[-1] - host[0]):.2f} ms")
+    print("   gpu ms per step:", " ".join(f"{g:.2f}" for g in gpu), "| sum", f"{sum(gpu):.2f}", flush=True)
