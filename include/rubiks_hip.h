@@ -242,6 +242,9 @@ typedef struct rc_mcts {
     uint32_t hash_size;  /* slots per tree, power of two, >= 2 * (capacity + 1) */
     uint32_t max_path;   /* descent buffer length per tree (2 .. 4096) */
     uint32_t rows_per_tree; /* network rows reserved per tree and iteration: 11 (see child_soa) */
+    uint32_t node_words;    /* 32-bit words between consecutive nodes in N / W / P / nbr / rec: RC_MCTS_NODE_WORDS.  A forest that
+                             * only waits for rc_mcts_complete_graph / rc_mcts_shorten (finished trees) may instead pass 12 with
+                             * nbr as a plain [B][capacity + 1][12] array; every other entry point rejects that */
     /* per node, [B][capacity + 1] */
     void *keys;          /* uint32[4]: the 20 codes packed 5 bits each (6 codes per dword) */
     /* The per-action arrays of a node (the reference's agents.py:421-426 attributes) are the fields of ONE record of

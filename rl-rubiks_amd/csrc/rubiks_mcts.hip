@@ -981,8 +981,8 @@ __global__ __launch_bounds__(kBlock) void k_mcts_complete_graph(rc_mcts_t m) {
             if (key_eq(keys[s], ck)) { found = s; break; }
             h = (h + 1) & mask;
         }
-        m.nbr[(base + node) * kRow + a] = found;                        // 0 when the child is not in the tree
-        if (found) m.nbr[(base + found) * kRow + (a ^ 1)] = (int)node;  // the only node whose action a^1 leads here
+        m.nbr[(base + node) * m.node_words + a] = found;                // 0 when the child is not in the tree (results-only forests: 12 words per node)
+        if (found) m.nbr[(base + found) * m.node_words + (a ^ 1)] = (int)node;  // the only node whose action a^1 leads here
     }
 }
 
@@ -1000,7 +1000,8 @@ __global__ __launch_bounds__(kBlock) void k_mcts_shorten(rc_mcts_t m) {
     if (solved == 1) return;   // agents.py:614: the queue is kept
     const size_t base = (size_t)t * (m.capacity + 1);
     const int n = m.n_nodes[t];
-    const int *nbr = m.nbr + base * kRow;
+    const u32 rw = m.node_words;   // 64 in a search forest, 12 in a results-only one
+    const int *nbr = m.nbr + base * rw;
     int *claim = m.bfs + base * 2;            // [node][0]
     int *frontier_a = m.hash + (size_t)t * m.hash_size, *frontier_b = frontier_a + (m.capacity + 1);
     for (int i = tid; i <= n; i += kBlock) {
@@ -1020,7 +1021,7 @@ __global__ __launch_bounds__(kBlock) void k_mcts_shorten(rc_mcts_t m) {
         const int work = fsize * kA;
         // phase 1: every unvisited neighbour is claimed by the smallest scan index that reaches it
         for (int idx = tid; idx < work; idx += kBlock) {
-            const int c = nbr[(size_t)cur[idx / kA] * kRow + idx % kA];
+            const int c = nbr[(size_t)cur[idx / kA] * rw + idx % kA];
             if (c != 0 && claim[2 * c + 1] == 0) atomicMin(&claim[2 * c], idx);
         }
         // the claims are no-return atomics executed at L2: drain them before the barrier, and read them back
@@ -1035,7 +1036,7 @@ __global__ __launch_bounds__(kBlock) void k_mcts_shorten(rc_mcts_t m) {
             int c = 0, win = 0, p = 0;
             if (idx < work) {
                 p = cur[idx / kA];
-                c = nbr[(size_t)p * kRow + idx % kA];
+                c = nbr[(size_t)p * rw + idx % kA];
                 win = (c != 0 && claim[2 * c + 1] == 0 &&
                        __hip_atomic_load(&claim[2 * c], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == idx) ? 1 : 0;
             }
@@ -1079,7 +1080,7 @@ __global__ __launch_bounds__(kBlock) void k_mcts_shorten(rc_mcts_t m) {
 
 using namespace rubiks;
 
-static int check_mcts(const rc_mcts_t *m) {
+static int check_mcts(const rc_mcts_t *m, bool results_only_ok = false) {
     RC_REQUIRE(m != nullptr, RC_ERR_NULL);
     RC_REQUIRE(m->keys && m->nbr && m->P && m->W && m->N && m->V && m->leaf && m->hash && m->n_nodes &&
                    m->status && m->solved_idx && m->solved_action && m->iterations && m->path_len && m->path_node &&
@@ -1089,7 +1090,11 @@ static int check_mcts(const rc_mcts_t *m) {
     RC_REQUIRE(m->n_trees > 0 && m->capacity >= 13 && m->max_path >= 2 && m->max_path <= (uint32_t)kMaxPath, RC_ERR_RANGE);
     RC_REQUIRE((m->hash_size & (m->hash_size - 1)) == 0 && m->hash_size >= 2 * (m->capacity + 1), RC_ERR_RANGE);
     RC_REQUIRE(aligned16(m->keys) && aligned16(m->rec) && aligned16(m->child_soa) && (m->child_stride & 15u) == 0, RC_ERR_ALIGN);
-    {   // the fields of the node record sit where the kernels' strides assume them (one allocation, 256-byte aligned)
+    if (results_only_ok && m->node_words == (uint32_t)kA) {
+        // a results-only forest (rc_mcts_complete_graph / rc_mcts_shorten): nbr is a plain [rows][12] array, the other per-action
+        // pointers are not read
+    } else {   // the fields of the node record sit where the kernels' strides assume them (one allocation, 256-byte aligned)
+        RC_REQUIRE(m->node_words == (uint32_t)kRow, RC_ERR_RANGE);
         const uintptr_t n0 = reinterpret_cast<uintptr_t>(m->N);
         RC_REQUIRE((n0 & 255u) == 0 && reinterpret_cast<uintptr_t>(m->W) == n0 + 48 && reinterpret_cast<uintptr_t>(m->rec) == n0 + 96 &&
                        reinterpret_cast<uintptr_t>(m->P) == n0 + 128 && reinterpret_cast<uintptr_t>(m->nbr) == n0 + 176, RC_ERR_ALIGN);
@@ -1138,14 +1143,14 @@ int rc_mcts_backup_head(const rc_mcts_t *m, const void *head, size_t ld, int hea
 }
 
 int rc_mcts_complete_graph(const rc_mcts_t *m, rc_stream_t stream) {
-    if (int rc = check_mcts(m)) return rc;
+    if (int rc = check_mcts(m, true)) return rc;
     const unsigned split = m->n_trees >= 512 ? 1 : m->n_trees >= 64 ? 8 : 32;
     hipLaunchKernelGGL(k_mcts_complete_graph, dim3(m->n_trees, split), dim3(kBlock), 0, (hipStream_t)stream, *m);
     return launch_status();
 }
 
 int rc_mcts_shorten(const rc_mcts_t *m, rc_stream_t stream) {
-    if (int rc = check_mcts(m)) return rc;
+    if (int rc = check_mcts(m, true)) return rc;
     RC_REQUIRE(m->bfs && m->short_act && m->short_len, RC_ERR_NULL);
     hipLaunchKernelGGL(k_mcts_shorten, dim3(m->n_trees), dim3(kBlock), 0, (hipStream_t)stream, *m);
     return launch_status();

@@ -25,7 +25,7 @@ N_ACT = 12
 
 class _McStruct(Structure):   # mirrors rc_mcts_t (include/rubiks_hip.h)
     _fields_ = [("n_trees", c_uint32), ("capacity", c_uint32), ("hash_size", c_uint32), ("max_path", c_uint32),
-                ("rows_per_tree", c_uint32)] + \
+                ("rows_per_tree", c_uint32), ("node_words", c_uint32)] + \
                [(name, c_void_p) for name in ("keys", "nbr", "P", "W", "N", "V", "leaf", "hash", "n_nodes",
                                               "status", "solved_idx", "solved_action", "iterations", "path_len", "pending",
                                               "path_node", "path_act", "child_soa")] + \
@@ -60,7 +60,7 @@ def unpack_keys(keys: np.ndarray) -> np.ndarray:
 _PER_NODE = ("keys", "node", "V", "leaf")
 _PER_TREE = ("n_nodes", "status", "solved_idx", "solved_action", "iterations", "path_len", "pending", "path_node", "path_act",
              "ring_node", "ring_act", "ring_len", "phase")
-_RESULT_NODE = ("keys", "node", "leaf")         # what rc_mcts_complete_graph / rc_mcts_shorten read of a tree (nbr is a field of node)
+_RESULT_NODE = ("keys", "nbr", "leaf")          # what rc_mcts_complete_graph / rc_mcts_shorten read of a tree (65 B per node)
 _RESULT_TREE = ("n_nodes", "status", "solved_idx", "solved_action", "iterations", "path_len", "pending", "path_act", "phase")
 RING_K = 32   # descent paths kept per tree for line following (rc_mcts_t::ring_k)
 ROWS = 11    # network rows per tree and iteration (rc_mcts_t::rows_per_tree)
@@ -81,7 +81,7 @@ class MCTSForest:
         z = lambda shape, dt: torch.zeros(shape, dtype=dt, device=dev)   # noqa: E731
         rows = B * (C + 1)
         layout = {   # search state: zero-initialised, or adopted from another forest (`subset`)
-            "keys": ((rows, 4), torch.int32), "node": ((rows, NODE_WORDS), torch.int32),
+            "keys": ((rows, 4), torch.int32), "node": ((rows, NODE_WORDS), torch.int32), "nbr": ((rows, N_ACT), torch.int32),
             "V": ((rows,), torch.float32), "leaf": ((rows,), torch.uint8), "hash": ((B, self.hash_size), torch.int32),
             "n_nodes": ((B,), torch.int32), "status": ((B,), torch.int32), "solved_idx": ((B,), torch.int32),
             "solved_action": ((B,), torch.int32), "iterations": ((B,), torch.int32), "path_len": ((B,), torch.int32),
@@ -90,6 +90,8 @@ class MCTSForest:
             "ring_len": ((B, RING_K), torch.int32), "phase": ((B,), torch.int32),
         }
         for name, (shape, dt) in layout.items():
+            if name == "nbr" and not _results_only:
+                continue            # a field of the node record (below); a results-only forest keeps it as a plain array instead
             if _state is not None and name in _state:
                 t = _state[name]
                 assert tuple(t.shape) == shape and t.dtype == dt and t.is_contiguous(), name
@@ -101,7 +103,8 @@ class MCTSForest:
         # the reference's per-action node arrays (agents.py:421-427) are strided views of the 256-byte node records: one or two
         # adjacent cache lines per node for the kernels, the same [rows, 12] tensors for everything that inspects a tree
         for name, (lo, hi, dt) in _NODE_FIELDS.items():
-            setattr(self, name, self.node[:, lo:hi].view(dt))
+            if not (name == "nbr" and _results_only):
+                setattr(self, name, self.node[:, lo:hi].view(dt))
         self.results_only = _results_only
         # Network rows per tree: only the NEW children of the expanded leaf are evaluated, and a non-root leaf has at most
         # 11 of them (its parent is known): 11 row slots per tree.  A planted root takes two iterations (rc_mcts_t::phase).
@@ -114,6 +117,7 @@ class MCTSForest:
         s = _McStruct()
         s.n_trees, s.capacity, s.hash_size, s.max_path = B, C, self.hash_size, max_path
         s.rows_per_tree = ROWS
+        s.node_words = N_ACT if _results_only else NODE_WORDS
         s.ring_k = RING_K
         for name in ("keys", "nbr", "P", "W", "N", "V", "leaf", "rec", "hash", "n_nodes", "status", "solved_idx",
                      "solved_action", "iterations", "path_len", "pending", "path_node", "path_act", "child_idx", "new_mask",
@@ -139,13 +143,13 @@ class MCTSForest:
         device.  Used to drop finished trees from a batch: the survivors continue exactly where they were, on GEMMs
         of len(keep) x 11 rows instead of B x 11.
         results_only: the trees are finished and only wait to be turned into results (graph completion, BFS
-        shortening, paths): just the arrays those steps read are copied (keys, node records, leaf flags), the forest
+        shortening, paths): just the arrays those steps read are copied (65 of ~280 bytes per node), the forest
         cannot be stepped or inspected.
         """
         B, C1 = self.B, self.C + 1
         state = {}
         for name in (_RESULT_NODE if results_only else _PER_NODE):
-            t = getattr(self, name)
+            t = getattr(self, name)     # (nbr: a strided view of the node records, gathered into a plain array)
             state[name] = t.view(B, C1, *t.shape[1:])[keep].reshape(len(keep) * C1, *t.shape[1:]).contiguous()
         state["hash"] = self.hash[keep].contiguous()
         for name in (_RESULT_TREE if results_only else _PER_TREE):
