@@ -23,16 +23,17 @@ def main():
     ap.add_argument("--trees", type=int, default=1024)
     ap.add_argument("--max-states", type=int, default=50000)
     ap.add_argument("--no-sizes", action="store_true")
+    ap.add_argument("--dtype", default="bf16", choices=["bf16", "f32s"])
     args = ap.parse_args()
     from librubiks import cube
-    from librubiks.model import Model
+    from librubiks.model import F32_SPLIT, Model
     from librubiks.solving import mcts_device as md
     from librubiks.solving.agents import MCTS
 
     np.random.seed(0)
     cubes, _, _ = cube.scramble_batch(args.trees, 20, True)
     model = Model.load(os.path.join(ROOT, "weights", "fc_small_r1")).eval()
-    agent = MCTS(model, c=0.6, search_graph=True)
+    agent = MCTS(model, c=0.6, search_graph=True, net_dtype=F32_SPLIT if args.dtype == "f32s" else torch.bfloat16)
     out = {}
     # (1) trajectory: patch forest.step to log at the agent's own sync points
     agent.search_batch(cubes, None, 2000)   # warm-up
