@@ -510,13 +510,20 @@ def step_rooflines(engine, agent, roots, args, name):
         executed = 3 * f32_equiv                                    # three f16 products per element pair
         t = phases["gemm_hidden1"] * 1e-3
         own = phases.get("gemm_hidden1_kernel") == "rc_split_gemm_f16"
+        gemm_traffic, gemm_traffic_src = None, None
+        tpath = os.path.join(ROOT, "profiles", "r2f_split_gemm_traffic.json")
+        if own and rows == 11264 and os.path.exists(tpath):   # a stored figure of exactly this launch shape, not measured in this run
+            gemm_traffic = json.load(open(tpath))["traffic_bytes"]
+            gemm_traffic_src = ("stored PMC figure: profiles/r2f_split_gemm_traffic.json (separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE "
+                                "passes of this kernel at this shape, gfx950 corrections applied; algorithmic bytes 310 MB)")
         roofline = {"kernel": (f"rc_split_gemm_f16 (own MFMA kernel, 352 x 256 tiles): first hidden layer of the split engine, "
                                f"[{rows} x {3 * W1[1]}] x [{3 * W1[1]} x {W1[0]}] f16 products (hi x lo, lo x hi, hi x hi) in one fp32 "
                                f"accumulator + bias + ELU + re-split to halves: the dominant kernel of a step") if own else
                               (f"first hidden layer of the split engine: f16 GEMMs [{rows} x {W1[1]}] x [{W1[1]} x {W1[0]}] (hi x hi) and "
                                f"[{rows} x {2 * W1[1]}] x [{2 * W1[1]} x {W1[0]}] (hi x lo + lo x hi), fp32 out, via hipBLASLt: the dominant kernels of a step"),
                     "bound": "mfma", "achieved": round(executed / t / 1e12, 1), "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s",
-                    "frac": round(executed / t / 1e12 / MFMA_BF16_PEAK_TFLOPS, 4), "traffic": None, "flops_per_launch": executed,
+                    "frac": round(executed / t / 1e12 / MFMA_BF16_PEAK_TFLOPS, 4), "traffic": gemm_traffic, "traffic_source": gemm_traffic_src,
+                    "flops_per_launch": executed,
                     "ms_per_launch": phases["gemm_hidden1"], "fp32_equivalent_tflops": round(f32_equiv / t / 1e12, 1),
                     "fp32_mfma_peak_tflops": MFMA_F32_PEAK_TFLOPS,
                     "note": "f16 MFMA flops executed (3 per fp32-equivalent flop) against the dense f16 peak; the same layer as an "
