@@ -44,6 +44,7 @@ def main():
     ap.add_argument("--reps", type=int, default=20)
     ap.add_argument("--tile", type=int, default=0)
     ap.add_argument("--out", default=None)
+    ap.add_argument("--zeros", action="store_true", help="all-zero operands: what the kernel does when it is not limited by power")
     args = ap.parse_args()
     dev = torch.device("cuda:0")
     lib = _hip.lib()
@@ -55,6 +56,8 @@ def main():
         x = (torch.randn(M, K, generator=g, dtype=torch.float64) * 0.7).float().double()   # fp32-representable activations
         W = (torch.randn(N, K, generator=g, dtype=torch.float64) / np.sqrt(K)).float().double()
         b = torch.randn(N, generator=g, dtype=torch.float64).float()
+        if args.zeros:
+            x, W = x * 0, W * 0
         xh, xl = split(x)
         wh, wl = split(W)
         a = torch.cat([xh, xl], 1).contiguous().to(dev)
