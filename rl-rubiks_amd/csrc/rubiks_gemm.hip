@@ -4,9 +4,11 @@
 // rc_split_act_f16: the three f16 products run through one fp32 accumulator -- the two correction products first, scaled by
 // 2^-11 (exact), the main product on top -- so the fp32 partial matrices never reach HBM.
 //
-// Shape of the problem (BASELINE config #2: 11 264 = 32 x 352 child rows per step, 4096 -> 2048 -> 512): the tile is
+// Shape of the problem (BASELINE config #2: 11 264 = 32 x 352 child rows per step, 4096 -> 2048 -> 1024): the tile is
 // 352 x 256 (8 waves, 2 x 4, 176 x 64 outputs per wave), so the 4096 -> 2048 layer is exactly 256 workgroups = one per CU
-// with no tail, and 176 x 128 (4 waves) for the 512-wide layer, again 256 workgroups.
+// with no tail.  352 x 128 and 176 x 128 tiles exist for narrow layers and few rows; at 256 workgroups their K-step is
+// shorter than the operand latency, so the 2048 -> 1024 layer stays with the library.  Every tile
+// walks K in the same order: a row's result does not depend on the tile or on the other rows of the launch.
 //
 // Data movement: both operands are K-contiguous ([rows][K] halves), staged global -> LDS by global_load_lds_dwordx4 in
 // 64-deep K-steps (128-byte LDS rows, two stages).  LDS-DMA writes lane-linear, so the bank swizzle is applied to the

@@ -355,10 +355,9 @@ class InferenceNet:
     # how many other rows share its launch (tests/test_full_size_gpu.py requires the pooled and the one-batch search to agree).
     fused_hidden = False
 
-    @staticmethod
-    def _run(layers, x):
+    def _run(self, layers, x):
         for W, b, act in layers:
-            if (act is not None and InferenceNet.fused_hidden and x.dtype == torch.bfloat16 and x.is_cuda and x.is_contiguous()
+            if (act is not None and self.fused_hidden and x.dtype == torch.bfloat16 and x.is_cuda and x.is_contiguous()
                     and W.shape[1] % 64 == 0 and W.shape[0] % 256 == 0 and -(-x.shape[0] // 352) * (W.shape[0] // 256) >= 192):
                 # 352 x 256 tiles on >= 3/4 of the CUs: measured 0.186 ms against 0.200 ms for hipBLASLt + the activation pass at
                 # 11 264 x 4096 x 2048 (tools/bf16_gemm_fused_probe.py); layers without activation and narrow ones stay with the library

@@ -23,10 +23,16 @@ def main():
     ap.add_argument("--weights", default=os.path.join(ROOT, "weights", "fc_small_r1"))
     ap.add_argument("--solve-max-states", type=int, default=0)
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "f32", "f32s"], help="network engine inside the agent")
+    ap.add_argument("--fused-hidden", type=int, default=None, help="1 / 0: force the own bf16 layer kernel on / off (default: the agent's choice)")
     args = ap.parse_args()
     from librubiks import cube
     from librubiks.model import Model, ModelConfig
     from librubiks.solving.agents import AStar
+    if args.fused_hidden is not None:
+        import librubiks.model as _m
+        import librubiks.solving.astar_device as _ad
+        _m.InferenceNet.fused_hidden = bool(args.fused_hidden)
+        _ad.FUSED_BF16_LAYER = bool(args.fused_hidden)
     np.random.seed(0)
     torch.manual_seed(0)
     cubes, _, _ = cube.scramble_batch(args.problems, args.depth, True)
