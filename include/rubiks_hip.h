@@ -308,6 +308,10 @@ typedef struct rc_mcts {
     int32_t *phase;
 } rc_mcts_t;
 
+/* sizeof(rc_mcts_t) as the library was compiled: a binding that mirrors the struct (ctypes, cgo, JNI) checks its own
+ * layout against it before the first call.  Host-only, needs no device. */
+size_t rc_mcts_struct_bytes(void);
+
 /* (Re)starts trees: for i < n_slots, tree slots[i] (or tree i if slots is NULL) is emptied -- its hash table is cleared,
  * nothing else needs to be -- and gets roots_soa column first_col + i as node 1; a solved root gets RC_MCTS_ROOT_SOLVED.
  * The root is evaluated and expanded (agents.py:466-473 and the first expand_leaf) inside the next two ordinary

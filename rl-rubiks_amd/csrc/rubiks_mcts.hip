@@ -1107,6 +1107,8 @@ static int check_mcts(const rc_mcts_t *m, bool results_only_ok = false) {
 
 extern "C" {
 
+size_t rc_mcts_struct_bytes(void) { return sizeof(rc_mcts_t); }
+
 int rc_mcts_plant(const rc_mcts_t *m, const int32_t *slots, uint32_t n_slots, const int8_t *roots_soa, size_t stride, size_t first_col,
                   rc_stream_t stream) {
     if (int rc = check_mcts(m)) return rc;

@@ -36,6 +36,7 @@ class _McStruct(Structure):   # mirrors rc_mcts_t (include/rubiks_hip.h)
 
 
 _hip.register({
+    "rc_mcts_struct_bytes": [],
     "rc_mcts_plant": [POINTER(_McStruct), c_void_p, c_uint32, c_void_p, c_size_t, c_size_t, c_void_p],
     "rc_mcts_expand": [POINTER(_McStruct), c_uint32, c_void_p],
     "rc_mcts_backup": [POINTER(_McStruct), c_void_p, c_void_p, c_void_p],
@@ -45,7 +46,7 @@ _hip.register({
     "rc_mcts_backup_select_head": [POINTER(_McStruct), c_void_p, c_size_t, c_int, c_double, c_uint32, c_void_p],
     "rc_mcts_complete_graph": [POINTER(_McStruct), c_void_p],
     "rc_mcts_shorten": [POINTER(_McStruct), c_void_p],
-})
+}, restypes={"rc_mcts_struct_bytes": ctypes.c_size_t})
 
 
 def unpack_keys(keys: np.ndarray) -> np.ndarray:
@@ -73,6 +74,9 @@ class MCTSForest:
     def __init__(self, n_trees: int, capacity: int, max_path: int = 4096, device=None, _state: dict = None,
                  _results_only: bool = False):
         self.lib = _hip.lib()
+        if self.lib.rc_mcts_struct_bytes() != ctypes.sizeof(_McStruct):
+            raise _hip.RubiksHipError(f"rc_mcts_t is {self.lib.rc_mcts_struct_bytes()} bytes in librubiks_hip.so but {ctypes.sizeof(_McStruct)} "
+                                      "here: rebuild the library (make -C rl-rubiks_amd)")
         dev = device or torch.device("cuda", torch.cuda.current_device())
         B, C = int(n_trees), int(capacity)
         assert B > 0 and C >= 13 and 2 <= max_path <= 4096

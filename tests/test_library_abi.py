@@ -84,3 +84,11 @@ def test_product_never_imports_oracle():
             if fn.endswith((".py", ".hip", ".h", ".cpp")):
                 text = open(os.path.join(dirpath, fn)).read()
                 assert not re.search(r"^\s*(from|import)\s+oracle\b", text, flags=re.M), f"{fn} imports oracle/"
+
+
+def test_mcts_struct_mirror_has_the_compiled_size():
+    """The ctypes mirror of rc_mcts_t and the struct the kernels were compiled with agree (host-only call, no GPU)."""
+    import ctypes
+    from librubiks import _hip
+    from librubiks.solving import mcts_device as md
+    assert _hip.load().rc_mcts_struct_bytes() == ctypes.sizeof(md._McStruct)
