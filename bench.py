@@ -223,9 +223,16 @@ def phase_times_split(forest, c, max_states, reps):
     for li in (1, 2):   # the two hidden layers behind the input layer, as the engine runs them
         _, Wh, B2, b, code, alpha, W3 = eng.layers[li]
         K, N = Wh.shape[1], Wh.shape[0]
-        tile = eng._fused_tile(rows, N, K) if eng.fused_hidden else 0
+        plan = eng._layer_plan(rows, eng.layers, li)
+        tile = eng._fused_tile(rows, N, K) if plan == "fused" else 0
         last = li == len(eng.layers) - 2
-        if tile:   # one kernel: three f16 products + bias + activation + re-split (csrc/rubiks_gemm.hip)
+        if plan == "partials":   # the own kernel with its K loop cut in two, raw fp32 partials for the fused head
+            part = torch.empty((2, rows, N), dtype=torch.float32, device=Wh.device)
+            hid[f"gemm_hidden{li}"] = round(event_ms(lambda: _hip.check(lib.rc_split_gemm_partials_f16(
+                a.data_ptr(), W3.data_ptr(), rows, N, K, part.data_ptr(), _hip.stream_ptr()), "rc_split_gemm_partials_f16"), reps)[0], 4)
+            hid[f"gemm_hidden{li}_kernel"] = "rc_split_gemm_partials_f16"
+            a = part   # (not consumed: the head follows)
+        elif tile:   # one kernel: three f16 products + bias + activation + re-split (csrc/rubiks_gemm.hip)
             o = torch.empty((rows, N if last else 2 * N), dtype=torch.float32 if last else torch.float16, device=Wh.device)
             hid[f"gemm_hidden{li}"] = round(event_ms(lambda: _hip.check(lib.rc_split_gemm_f16(
                 a.data_ptr(), W3.data_ptr(), b.data_ptr(), rows, N, K, code, alpha, None if last else o.data_ptr(),

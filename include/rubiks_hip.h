@@ -183,6 +183,13 @@ int rc_first_layer_split_f16(const int8_t *soa, size_t n, size_t stride, const u
 int rc_split_act_f16(const float *c, const float *c_corr, float corr_scale, size_t n_rows, size_t n_cols, const float *bias,
                      int activation, float alpha, uint16_t *out_hi_lo, float *out_f32, rc_stream_t stream);
 
+/* The same layer with its K loop cut in two for layers too narrow to fill the chip with 352 x 256 tiles: twice the workgroups,
+ * raw fp32 accumulators out_partials[2][n_rows][n_out] with  y = act(out_partials[1] + 2^-11 * out_partials[0] + bias)  left to
+ * the consumer (rc_head_split_f32 / rc_split_act_f16 take them as c = out_partials[1], c_corr = out_partials[0]).
+ * n_out % 256 == 0, k % 128 == 0. */
+int rc_split_gemm_partials_f16(const uint16_t *a_hi_lo, const uint16_t *w_lo_hi_hi, size_t n_rows, size_t n_out, size_t k,
+                               float *out_partials, rc_stream_t stream);
+
 /* Last hidden activation + output layer of that network in one pass (the fp32 counterpart of rc_head_bf16):
  *   y = act(c + corr_scale * c_corr + bias_h)  (never written),   out[i][o] = bias_o[o] + sum_k w[o][k] * y[i][k],  o < n_out <= 16
  * c, c_corr: the fp32 GEMM outputs [n][K] (c_corr may be NULL), K = 512 or 1024;  w: float [n_out][K];  out: float, row pitch 16

@@ -26,7 +26,7 @@ namespace rubiks {
 typedef __attribute__((ext_vector_type(8))) _Float16 f16x8;
 typedef __attribute__((ext_vector_type(4))) float f32x4;
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
-constexpr int kOutHalves = 0, kOutF32 = 1, kBf16 = 2;   // operand / output kinds of k_split_gemm_pp
+constexpr int kOutHalves = 0, kOutF32 = 1, kBf16 = 2, kPartials = 3;   // operand / output kinds of k_split_gemm_pp
 typedef __attribute__((address_space(3))) void lds_void;
 typedef const __attribute__((address_space(1))) void glb_void;
 
@@ -183,7 +183,12 @@ __global__ __launch_bounds__(WM *WN * 64) void k_split_gemm(GemmArgs g) {
 //   stage s+1 goes into the buffer last read in step s-1: row 1's reads R_3(s-1) retire after barrier 8s-1, so row 0 issues its
 //   LDS-DMA in R_1, R_2 (after 8s+1) and row 1 in R_0, R_1 (after 8s); both wait vmcnt(0) before barrier 8s+7, which every
 //   wave passes before its first read of stage s+1.
-// KIND: kOutHalves / kOutF32 = the split layer (f16 operands, three products), kBf16 = a plain bf16 layer (one product, bf16 out).
+// KIND: kOutHalves / kOutF32 = the split layer (f16 operands, three products), kBf16 = a plain bf16 layer (one product, bf16 out),
+// kPartials = the split layer with its K loop cut in two: twice the workgroups, each walks one half of the 3K / 64 K-steps and
+// stores its raw fp32 accumulators into out[half][M][N] (no bias, no activation).  Half 0 holds correction products only, half
+// 1 the rest of them (scaled by 2^-11 inside, as always) plus the main product, so y = act(out[1] + 2^-11 out[0] + bias) --
+// exactly what rc_head_split_f32 / rc_split_act_f16 compute from (c, c_corr).  For layers too narrow to fill the chip with
+// 352 x 256 tiles (the 2048 -> 1024 layer: 128 tiles).
 template <int MR, int NR, int ACT, int KIND>
 __global__ __launch_bounds__(512) void k_split_gemm_pp(GemmArgs g) {
     constexpr int WM = 2, WN = 4;
@@ -197,7 +202,9 @@ __global__ __launch_bounds__(512) void k_split_gemm_pp(GemmArgs g) {
 
     const u32 nwg = gridDim.x, nn = g.N / T::BN;
     const u32 xcd = blockIdx.x % 8, q = nwg / 8, r8 = nwg % 8;
-    const u32 wg = (xcd < r8 ? xcd * (q + 1) : r8 * (q + 1) + (xcd - r8) * q) + blockIdx.x / 8;
+    const u32 wg_all = (xcd < r8 ? xcd * (q + 1) : r8 * (q + 1) + (xcd - r8) * q) + blockIdx.x / 8;
+    const u32 n_tiles = KIND == kPartials ? nwg / 2 : nwg;
+    const u32 half = wg_all / n_tiles, wg = wg_all % n_tiles;   // kPartials: the first half of the (XCD-ordered) grid walks K-half 0
     const u32 tm = wg / nn, tn = wg % nn;
     const size_t row0 = (size_t)tm * T::BM;
     const u32 col0 = tn * T::BN;
@@ -244,17 +251,18 @@ __global__ __launch_bounds__(512) void k_split_gemm_pp(GemmArgs g) {
 #pragma unroll
         for (int n = 0; n < NR; ++n) acc[m][n] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-    const u32 nk = (KIND == kBf16 ? 1 : 3) * K / 64, scale_step = KIND == kBf16 ? 0xFFFFFFFFu : 2 * K / 64;
-    stage_part(0, 0, 0, T::PPW);
+    const u32 nk_all = (KIND == kBf16 ? 1 : 3) * K / 64, scale_step = KIND == kBf16 ? 0xFFFFFFFFu : 2 * K / 64;
+    const u32 ks0 = KIND == kPartials ? half * (nk_all / 2) : 0u, nk = KIND == kPartials ? ks0 + nk_all / 2 : nk_all;
+    stage_part(ks0, 0, 0, T::PPW);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
     if (wr == 1) __builtin_amdgcn_s_barrier();   // the half-phase stagger
 
     f16x8 wf[NR][2], xf[kBlk][2];
-    for (u32 ks = 0; ks < nk; ++ks) {
-        const unsigned char *s = lds + (ks & 1) * T::STAGE;
+    for (u32 ks = ks0; ks < nk; ++ks) {
+        const unsigned char *s = lds + ((ks - ks0) & 1) * T::STAGE;
         const bool more = ks + 1 < nk;
-        const u32 nbuf = (ks + 1) & 1;
+        const u32 nbuf = (ks + 1 - ks0) & 1;
 #pragma unroll
         for (int ph = 0; ph < kPhases; ++ph) {
             // ---- R_ph: fragments of this phase, and this wave's share of the next stage
@@ -315,7 +323,7 @@ __global__ __launch_bounds__(512) void k_split_gemm_pp(GemmArgs g) {
     const u32 cbase = col0 + wc * NR * 16 + 4 * fq;
     float4 b4[NR];
 #pragma unroll
-    for (int n = 0; n < NR; ++n) b4[n] = *reinterpret_cast<const float4 *>(g.bias + cbase + 16 * n);
+    for (int n = 0; n < NR; ++n) b4[n] = KIND == kPartials ? make_float4(0.f, 0.f, 0.f, 0.f) : *reinterpret_cast<const float4 *>(g.bias + cbase + 16 * n);
 #pragma unroll
     for (int m = 0; m < MR; ++m) {
         const size_t row = row0 + wr * MR * 16 + m * 16 + fr;
@@ -329,7 +337,10 @@ __global__ __launch_bounds__(512) void k_split_gemm_pp(GemmArgs g) {
                 if (ACT == RC_ACT_ELU) y[e] = y[e] > 0.f ? y[e] : g.alpha * expm1_neg(y[e]);
             }
             const u32 col = cbase + 16 * n;
-            if (KIND == kBf16) {
+            if (KIND == kPartials) {
+                float *orow = reinterpret_cast<float *>(g.out) + ((size_t)half * g.M + row) * (size_t)g.N;
+                *reinterpret_cast<float4 *>(orow + col) = make_float4(y[0], y[1], y[2], y[3]);
+            } else if (KIND == kBf16) {
                 unsigned char *orow = reinterpret_cast<unsigned char *>(g.out) + row * ((size_t)g.N * 2);
                 *reinterpret_cast<uint2 *>(orow + col * 2) = make_uint2(pack_bf16(y[0], y[1]), pack_bf16(y[2], y[3]));
             } else if (KIND == kOutHalves) {
@@ -361,7 +372,7 @@ template <int MR, int NR, int ACT, int KIND> static int launch_split_gemm_pp(con
         if (e != hipSuccess) return hip_rc(e);
         attr_set.fetch_or(1ull << (dev & 63), std::memory_order_release);
     }
-    const u32 grid = (u32)(ceil_div((size_t)g.M, (size_t)T::BM) * (g.N / T::BN));
+    const u32 grid = (u32)(ceil_div((size_t)g.M, (size_t)T::BM) * (g.N / T::BN)) * (KIND == kPartials ? 2u : 1u);
     hipLaunchKernelGGL((k_split_gemm_pp<MR, NR, ACT, KIND>), dim3(grid), dim3(T::THREADS), T::LDS_BYTES, s, g);
     return launch_status();
 }
@@ -455,4 +466,22 @@ extern "C" int rc_gemm_bias_act_bf16(const uint16_t *a, const uint16_t *w, const
     hipStream_t s = (hipStream_t)stream;
     if (tile == 1) return dispatch_split_gemm_pp<11, 4, kBf16>(g, activation, s);
     return dispatch_split_gemm_pp<11, 2, kBf16>(g, activation, s);
+}
+
+extern "C" int rc_split_gemm_partials_f16(const uint16_t *a_hi_lo, const uint16_t *w_lo_hi_hi, size_t n_rows, size_t n_out, size_t k,
+                                          float *out_partials, rc_stream_t stream) {
+    if (n_rows == 0) return RC_OK;
+    RC_REQUIRE(a_hi_lo && w_lo_hi_hi && out_partials, RC_ERR_NULL);
+    RC_REQUIRE(aligned16(a_hi_lo) && aligned16(w_lo_hi_hi) && aligned16(out_partials), RC_ERR_ALIGN);
+    RC_REQUIRE(k >= 128 && k % 128 == 0 && k <= (1u << 16) && n_out % 256 == 0 && n_rows < (1ull << 31) && n_out < (1u << 20), RC_ERR_RANGE);
+    GemmArgs g;
+    g.a = (const unsigned char *)a_hi_lo;
+    g.w = (const unsigned char *)w_lo_hi_hi;
+    g.bias = nullptr;
+    g.out = (void *)out_partials;
+    g.M = (u32)n_rows;
+    g.N = (u32)n_out;
+    g.K = (u32)k;
+    g.alpha = 0.f;
+    return launch_split_gemm_pp<11, 4, RC_ACT_NONE, kPartials>(g, (hipStream_t)stream);
 }

@@ -41,6 +41,7 @@ SIGNATURES = {
     "rc_split_act_f16": [P, P, ctypes.c_float, SZ, SZ, P, I, ctypes.c_float, P, P, P],
     "rc_split_gemm_f16": [P, P, P, SZ, SZ, SZ, I, ctypes.c_float, P, P, I, P],
     "rc_gemm_bias_act_bf16": [P, P, P, SZ, SZ, SZ, I, ctypes.c_float, P, I, P],
+    "rc_split_gemm_partials_f16": [P, P, SZ, SZ, SZ, P, P],
     "rc_head_split_f32": [P, P, ctypes.c_float, SZ, SZ, P, I, ctypes.c_float, P, P, SZ, P, P],
     "rc_head_bf16": [P, SZ, SZ, P, P, SZ, P, I, ctypes.c_float, P],
     "rc_adi_targets": [P, P, P, SZ, SZ, ctypes.c_float, I, P, P, P],

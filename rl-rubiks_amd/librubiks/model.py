@@ -432,6 +432,19 @@ class SplitF32Net:
     fused_hidden = True   # hidden layers as one kernel each (rc_split_gemm_f16) where its tile fills the chip
     fused_head = True     # last activation + output layer in one pass (rc_head_split_f32) behind a library-GEMM hidden layer
 
+    def _layer_plan(self, rows: int, layers, i: int) -> str:
+        """How hidden layer i runs on `rows` rows: 'fused' (rc_split_gemm_f16), 'partials' (rc_split_gemm_partials_f16 + the fused
+        head), or 'library' (two hipBLASLt GEMMs + rc_split_act_f16 / the fused head)."""
+        Wh = layers[i][1]
+        N, K = Wh.shape
+        if self.fused_hidden and self._fused_tile(rows, N, K):
+            return "fused"
+        nxt = layers[i + 1]
+        head_ok = i == len(layers) - 2 and self.fused_head and nxt[0] == "f32" and nxt[1].shape[0] <= 16 and N in (512, 1024)
+        if head_ok and self.fused_hidden and N % 256 == 0 and K % 128 == 0 and -(-rows // 352) * (N // 256) * 2 >= 192:
+            return "partials"
+        return "library"
+
     @staticmethod
     def _fused_tile(rows: int, n_out: int, k: int) -> int:
         """Tile of rc_split_gemm_f16 for this layer, 0 = keep the two library GEMMs + rc_split_act_f16."""
@@ -518,10 +531,20 @@ class SplitF32Net:
                                                             tile, _hip.stream_ptr()), "rc_split_gemm_f16")
                     a = out
                     continue
-                c = torch.mm(a[:, :K], Wh.t(), out_dtype=torch.float32)   # hi x hi
-                corr = torch.mm(a, B2.t(), out_dtype=torch.float32)       # hi x lo + lo x hi, scaled by 2^11; added in the kernel below
                 nxt = layers[i + 1]
-                if last_hidden and self.fused_head and nxt[0] == "f32" and nxt[1].shape[0] <= 16 and Wh.shape[0] in (512, 1024):
+                head_ok = last_hidden and self.fused_head and nxt[0] == "f32" and nxt[1].shape[0] <= 16 and Wh.shape[0] in (512, 1024)
+                if self._layer_plan(a.shape[0], layers, i) == "partials":
+                    # too narrow for 352 x 256 tiles to fill the chip: the own kernel with its K loop cut in two (twice the workgroups),
+                    # raw fp32 partials; c = partials[1] (main + the tail of the correction), c_corr = partials[0]
+                    from librubiks import _hip
+                    part = torch.empty((2, a.shape[0], Wh.shape[0]), dtype=torch.float32, device=a.device)
+                    _hip.check(_hip.lib().rc_split_gemm_partials_f16(a.data_ptr(), W3.data_ptr(), a.shape[0], Wh.shape[0], K, part.data_ptr(),
+                                                                     _hip.stream_ptr()), "rc_split_gemm_partials_f16")
+                    c, corr = part[1], part[0]
+                else:
+                    c = torch.mm(a[:, :K], Wh.t(), out_dtype=torch.float32)   # hi x hi
+                    corr = torch.mm(a, B2.t(), out_dtype=torch.float32)       # hi x lo + lo x hi, scaled by 2^11; added in the kernel below
+                if head_ok:
                     # activation + the skinny output layer in one pass: the fp32 activations are never written (rc_head_split_f32)
                     from librubiks import _hip
                     out = torch.empty((a.shape[0], 16), dtype=torch.float32, device=a.device)

@@ -345,3 +345,31 @@ def test_split_head_kernel_matches_float64(n, K, n_out, act):
                                         out.data_ptr(), None) == -4     # K must be 512 or 1024
     assert _hip.lib().rc_head_split_f32(None, None, 0.0, n, K, bh.data_ptr(), act, 1.0, w.data_ptr(), bo.data_ptr(), n_out,
                                         out.data_ptr(), None) == -1
+
+
+@pytest.mark.parametrize("rows,k,n_out", [(11264, 256, 256), (1000, 128, 512), (353, 384, 256)])
+def test_split_layer_partials_sum_to_the_whole_layer(rows, k, n_out):
+    """rc_split_gemm_partials_f16 (the K loop cut in two): partials[1] + 2^-11 partials[0] equals the pre-activation the one-kernel
+    form accumulates, up to the fp32 rounding of one more addition; against float64 within fp32 accuracy."""
+    from librubiks import _hip
+    lib = _hip.lib()
+    g = torch.Generator().manual_seed(rows + k)
+    x = (torch.randn(rows, k, generator=g, dtype=torch.float64) * 0.7).float().double()
+    W = (torch.randn(n_out, k, generator=g, dtype=torch.float64) / np.sqrt(k)).float().double()
+    (xh, xl), (wh, wl) = _split_halves(x), _split_halves(W)
+    a = torch.cat([xh, xl], 1).contiguous().cuda()
+    W3 = torch.cat([wl, wh, wh], 1).contiguous().cuda()
+    part = torch.full((2 * rows + 1, n_out), float("nan"), device="cuda")
+    _hip.check(lib.rc_split_gemm_partials_f16(a.data_ptr(), W3.data_ptr(), rows, n_out, k, part.data_ptr(), None), "rc_split_gemm_partials_f16")
+    torch.cuda.synchronize()
+    assert bool(torch.isnan(part[2 * rows]).all()) and not bool(torch.isnan(part[:2 * rows]).any())
+    y = part[rows:2 * rows].double() + part[:rows].double() / 2048.0
+    ref = (xh.double() + xl.double() / 2048.0) @ (wh.double() + wl.double() / 2048.0).t()
+    assert float((y.cpu() - ref).abs().max()) <= 4e-6 * max(1.0, float(ref.abs().max()))
+    whole = torch.empty((rows, n_out), device="cuda")
+    zero = torch.zeros(n_out, device="cuda")
+    _hip.check(lib.rc_split_gemm_f16(a.data_ptr(), W3.data_ptr(), zero.data_ptr(), rows, n_out, k, 0, 1.0, None, whole.data_ptr(), 1, None),
+               "rc_split_gemm_f16")
+    assert float((y.float() - whole).abs().max()) <= 2e-6 * max(1.0, float(ref.abs().max()))
+    assert lib.rc_split_gemm_partials_f16(a.data_ptr(), W3.data_ptr(), rows, n_out, 64, part.data_ptr(), None) == -4   # k % 128
+    assert lib.rc_split_gemm_partials_f16(a.data_ptr(), W3.data_ptr(), rows, 128, k, part.data_ptr(), None) == -4      # n_out % 256
