@@ -231,7 +231,8 @@ def phase_times_split(forest, c, max_states, reps):
             hid[f"gemm_hidden{li}"] = round(event_ms(lambda: _hip.check(lib.rc_split_gemm_partials_f16(
                 a.data_ptr(), W3.data_ptr(), rows, N, K, part.data_ptr(), _hip.stream_ptr()), "rc_split_gemm_partials_f16"), reps)[0], 4)
             hid[f"gemm_hidden{li}_kernel"] = "rc_split_gemm_partials_f16"
-            a = part   # (not consumed: the head follows)
+            if not last:   # (behind the last hidden layer the fused head consumes the partials)
+                a = eng._act(part[1], part[0], b, code, alpha, split=True)
         elif tile:   # one kernel: three f16 products + bias + activation + re-split (csrc/rubiks_gemm.hip)
             o = torch.empty((rows, N if last else 2 * N), dtype=torch.float32 if last else torch.float16, device=Wh.device)
             hid[f"gemm_hidden{li}"] = round(event_ms(lambda: _hip.check(lib.rc_split_gemm_f16(

@@ -441,7 +441,9 @@ class SplitF32Net:
             return "fused"
         nxt = layers[i + 1]
         head_ok = i == len(layers) - 2 and self.fused_head and nxt[0] == "f32" and nxt[1].shape[0] <= 16 and N in (512, 1024)
-        if head_ok and self.fused_hidden and N % 256 == 0 and K % 128 == 0 and -(-rows // 352) * (N // 256) * 2 >= 192:
+        # the K loop cut in two doubles the workgroups: narrow layers, and wide ones on a half-empty (compacted) forest; the partials
+        # go to the fused head (last hidden layer) or to rc_split_act_f16
+        if self.fused_hidden and (head_ok or i < len(layers) - 2) and N % 256 == 0 and K % 128 == 0 and -(-rows // 352) * (N // 256) * 2 >= 192:
             return "partials"
         return "library"
 

@@ -184,7 +184,13 @@ def test_split_f32_engine_is_at_least_as_accurate_as_fp32():
         assert e_split <= 1.25 * e_f32 + 1e-7 and e_split < 2e-5 * max(1.0, scale / 10)
         # value head alone (A*'s cost) and a column window of the SoA
         assert err(eng.value_cubes(cubes), v64.reshape(-1)) <= 1.25 * e_f32 + 1e-7
-        assert torch.equal(eng.value_cubes(cubes, None, 1024, 512), eng.value_cubes(cubes)[1024:1536])
+        # (a 512-row window runs on the library GEMMs, 4 096 rows on the own kernel with its K loop cut in two: same rows, results
+        #  within fp32 rounding of each other -- the layer plan depends on the row count)
+        win, full = eng.value_cubes(cubes, None, 1024, 512), eng.value_cubes(cubes)[1024:1536]
+        assert float((win - full).abs().max()) <= 2e-6 * max(1.0, float(full.abs().max()))
+        eng.fused_hidden = False
+        assert torch.equal(eng.value_cubes(cubes, None, 1024, 512), eng.value_cubes(cubes)[1024:1536])   # one plan: bit for bit
+        eng.fused_hidden = True
 
 
 def test_split_f32_engine_drives_the_search():
