@@ -31,6 +31,10 @@ typedef __attribute__((address_space(3))) void lds_void;
 typedef const __attribute__((address_space(1))) void glb_void;
 
 constexpr int kGemmRowBytes = 128;   // one K-step: 64 halves per row
+#ifndef RC_GEMM_PPR
+#define RC_GEMM_PPR 2
+#endif
+constexpr int kPiecesPerRow = RC_GEMM_PPR;   // LDS-DMA pieces a wave issues behind the MFMAs of one 16-row fragment
 
 struct GemmArgs {
     const unsigned char *a;      // activations [M][2K] halves: hi | lo
@@ -49,7 +53,13 @@ template <int WM, int WN, int MR, int NR> struct GemmTile {
     static constexpr int LDS_BYTES = 2 * STAGE;
 };
 
-template <int WM, int WN, int MR, int NR, int ACT, bool OUT_SPLIT>
+// KIND: kOutHalves / kOutF32 = the split layer (f16 operands, three products), kBf16 = a plain bf16 layer (one product, bf16 out),
+// kPartials = the split layer with its K loop cut in two: twice the workgroups, each walks one half of the 3K / 64 K-steps and
+// stores its raw fp32 accumulators into out[half][M][N] (no bias, no activation).  Half 0 holds correction products only, half
+// 1 the rest of them (scaled by 2^-11 inside, as always) plus the main product, so y = act(out[1] + 2^-11 out[0] + bias) --
+// exactly what rc_head_split_f32 / rc_split_act_f16 compute from (c, c_corr).  For layers too narrow to fill the chip with
+// 352 x 256 tiles (the 2048 -> 1024 layer: 128 tiles).
+template <int WM, int WN, int MR, int NR, int ACT, int KIND>
 __global__ __launch_bounds__(WM *WN * 64) void k_split_gemm(GemmArgs g) {
     using T = GemmTile<WM, WN, MR, NR>;
     extern __shared__ __attribute__((aligned(1024))) unsigned char lds[];
@@ -61,11 +71,13 @@ __global__ __launch_bounds__(WM *WN * 64) void k_split_gemm(GemmArgs g) {
     // distinct activation rows and every weight column once
     const u32 nwg = gridDim.x, nn = g.N / T::BN;
     const u32 xcd = blockIdx.x % 8, q = nwg / 8, r8 = nwg % 8;
-    const u32 wg = (xcd < r8 ? xcd * (q + 1) : r8 * (q + 1) + (xcd - r8) * q) + blockIdx.x / 8;
+    const u32 wg_all = (xcd < r8 ? xcd * (q + 1) : r8 * (q + 1) + (xcd - r8) * q) + blockIdx.x / 8;
+    const u32 n_tiles = KIND == kPartials ? nwg / 2 : nwg;
+    const u32 half = wg_all / n_tiles, wg = wg_all % n_tiles;   // kPartials: the first half of the (XCD-ordered) grid walks K-half 0
     const u32 tm = wg / nn, tn = wg % nn;
     const size_t row0 = (size_t)tm * T::BM;
     const u32 col0 = tn * T::BN;
-    const u32 K = g.K, lda = 2 * K * 2, ldw = 3 * K * 2;   // bytes
+    const u32 K = g.K, lda = (KIND == kBf16 ? 1 : 2) * K * 2, ldw = (KIND == kBf16 ? 1 : 3) * K * 2;   // bytes
     const u32 last_row = (u32)(g.M - 1 - row0);            // rows past M re-read the last row; their outputs are not stored
 
     u32 src_off[T::PPW];
@@ -78,12 +90,13 @@ __global__ __launch_bounds__(WM *WN * 64) void k_split_gemm(GemmArgs g) {
     const unsigned char *a_tile = g.a + row0 * lda;
     const unsigned char *w_tile = g.w + (size_t)col0 * ldw;
 
-    auto stage = [&](u32 ks, u32 buf) {
-        const u32 kk = ks * 64, a_col = kk < 2 * K ? kk : kk - 2 * K;
+    auto stage = [&](u32 ks, u32 buf, int lo = 0, int hi = T::PPW) {   // this wave's pieces lo .. hi - 1 of stage ks
+        const u32 kk = ks * 64, a_col = (KIND == kBf16 || kk < 2 * K) ? kk : kk - 2 * K;
         const unsigned char *ab = a_tile + a_col * 2, *wb = w_tile + kk * 2;
         unsigned char *dst = lds + buf * T::STAGE;
 #pragma unroll
         for (int i = 0; i < T::PPW; ++i) {
+            if (i < lo || i >= hi) continue;
             const u32 p = i * T::WAVES + wave;
             if (p < (u32)T::PIECES) {
                 const unsigned char *src = (p < (u32)(T::BM / 8) ? ab : wb) + src_off[i];
@@ -108,19 +121,20 @@ __global__ __launch_bounds__(WM *WN * 64) void k_split_gemm(GemmArgs g) {
 #pragma unroll
         for (int n = 0; n < NR; ++n) acc[m][n] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-    const u32 nk = 3 * K / 64, scale_step = 2 * K / 64;
-    stage(0, 0);
-    for (u32 ks = 0; ks < nk; ++ks) {
+    const u32 nk_all = (KIND == kBf16 ? 1 : 3) * K / 64, scale_step = KIND == kBf16 ? 0xFFFFFFFFu : 2 * K / 64;
+    const u32 ks0 = KIND == kPartials ? half * (nk_all / 2) : 0u, nk = KIND == kPartials ? ks0 + nk_all / 2 : nk_all;
+    stage(ks0, 0);
+    for (u32 ks = ks0; ks < nk; ++ks) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
-        if (ks + 1 < nk) stage(ks + 1, (ks + 1) & 1);
+        const bool more = ks + 1 < nk;
         if (ks == scale_step) {
 #pragma unroll
             for (int m = 0; m < MR; ++m)
 #pragma unroll
                 for (int n = 0; n < NR; ++n) acc[m][n] *= (1.0f / kSplitScale);
         }
-        const unsigned char *s = lds + (ks & 1) * T::STAGE;
+        const unsigned char *s = lds + ((ks - ks0) & 1) * T::STAGE;
         f16x8 wf[NR][2];
 #pragma unroll
         for (int n = 0; n < NR; ++n)
@@ -134,7 +148,12 @@ __global__ __launch_bounds__(WM *WN * 64) void k_split_gemm(GemmArgs g) {
 #pragma unroll
             for (int kh = 0; kh < 2; ++kh)
 #pragma unroll
-                for (int n = 0; n < NR; ++n) acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[n][kh], xf[kh], acc[m][n], 0, 0, 0);
+                for (int n = 0; n < NR; ++n)
+                    acc[m][n] = KIND == kBf16 ? __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, wf[n][kh]), __builtin_bit_cast(bf16x8, xf[kh]), acc[m][n], 0, 0, 0)
+                                              : __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[n][kh], xf[kh], acc[m][n], 0, 0, 0);
+            // the next stage, two LDS-DMA pieces behind each of the first rows' MFMAs: issued in the shadow of the matrix cores
+            // (and of the SIMD's other wave) instead of all at once behind the barrier, early enough to land before the next one
+            if (more && kPiecesPerRow * m < T::PPW) stage(ks + 1, (ks + 1 - ks0) & 1, kPiecesPerRow * m, kPiecesPerRow * (m + 1));
         }
     }
 
@@ -142,7 +161,7 @@ __global__ __launch_bounds__(WM *WN * 64) void k_split_gemm(GemmArgs g) {
     const u32 cbase = col0 + wc * NR * 16 + 4 * fq;
     float4 b4[NR];
 #pragma unroll
-    for (int n = 0; n < NR; ++n) b4[n] = *reinterpret_cast<const float4 *>(g.bias + cbase + 16 * n);
+    for (int n = 0; n < NR; ++n) b4[n] = KIND == kPartials ? make_float4(0.f, 0.f, 0.f, 0.f) : *reinterpret_cast<const float4 *>(g.bias + cbase + 16 * n);
 #pragma unroll
     for (int m = 0; m < MR; ++m) {
         const size_t row = row0 + wr * MR * 16 + m * 16 + fr;
@@ -156,7 +175,13 @@ __global__ __launch_bounds__(WM *WN * 64) void k_split_gemm(GemmArgs g) {
                 if (ACT == RC_ACT_ELU) y[e] = y[e] > 0.f ? y[e] : g.alpha * expm1_neg(y[e]);
             }
             const u32 col = cbase + 16 * n;
-            if (OUT_SPLIT) {
+            if (KIND == kPartials) {
+                float *orow = reinterpret_cast<float *>(g.out) + ((size_t)half * g.M + row) * (size_t)g.N;
+                *reinterpret_cast<float4 *>(orow + col) = make_float4(y[0], y[1], y[2], y[3]);
+            } else if (KIND == kBf16) {
+                unsigned char *orow = reinterpret_cast<unsigned char *>(g.out) + row * ((size_t)g.N * 2);
+                *reinterpret_cast<uint2 *>(orow + col * 2) = make_uint2(pack_bf16(y[0], y[1]), pack_bf16(y[2], y[3]));
+            } else if (KIND == kOutHalves) {
                 float hi[4], lo[4];
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
@@ -385,24 +410,24 @@ template <int MR, int NR, int KIND> static int dispatch_split_gemm_pp(const Gemm
 #undef RC_GEMM_ACT
 }
 
-template <int WM, int WN, int MR, int NR, int ACT, bool OUT_SPLIT> static int launch_split_gemm(const GemmArgs &g, hipStream_t s) {
+template <int WM, int WN, int MR, int NR, int ACT, int KIND> static int launch_split_gemm(const GemmArgs &g, hipStream_t s) {
     using T = GemmTile<WM, WN, MR, NR>;
     static std::atomic<unsigned long long> attr_set{0};   // per device: the attribute belongs to the function ON A DEVICE
     int dev = 0;
     (void)hipGetDevice(&dev);
     if (!((attr_set.load(std::memory_order_acquire) >> (dev & 63)) & 1ull)) {
-        hipError_t e = hipFuncSetAttribute((const void *)k_split_gemm<WM, WN, MR, NR, ACT, OUT_SPLIT>,
+        hipError_t e = hipFuncSetAttribute((const void *)k_split_gemm<WM, WN, MR, NR, ACT, KIND>,
                                            hipFuncAttributeMaxDynamicSharedMemorySize, T::LDS_BYTES);
         if (e != hipSuccess) return hip_rc(e);
         attr_set.fetch_or(1ull << (dev & 63), std::memory_order_release);
     }
-    const u32 grid = (u32)(ceil_div((size_t)g.M, (size_t)T::BM) * (g.N / T::BN));
-    hipLaunchKernelGGL((k_split_gemm<WM, WN, MR, NR, ACT, OUT_SPLIT>), dim3(grid), dim3(T::THREADS), T::LDS_BYTES, s, g);
+    const u32 grid = (u32)(ceil_div((size_t)g.M, (size_t)T::BM) * (g.N / T::BN)) * (KIND == kPartials ? 2u : 1u);
+    hipLaunchKernelGGL((k_split_gemm<WM, WN, MR, NR, ACT, KIND>), dim3(grid), dim3(T::THREADS), T::LDS_BYTES, s, g);
     return launch_status();
 }
 
-template <int WM, int WN, int MR, int NR> static int dispatch_split_gemm(const GemmArgs &g, int act, bool split, hipStream_t s) {
-#define RC_GEMM_ACT(ACT) (split ? launch_split_gemm<WM, WN, MR, NR, ACT, true>(g, s) : launch_split_gemm<WM, WN, MR, NR, ACT, false>(g, s))
+template <int WM, int WN, int MR, int NR, int KIND> static int dispatch_split_gemm(const GemmArgs &g, int act, hipStream_t s) {
+#define RC_GEMM_ACT(ACT) launch_split_gemm<WM, WN, MR, NR, ACT, KIND>(g, s)
     if (act == RC_ACT_ELU) return RC_GEMM_ACT(RC_ACT_ELU);
     if (act == RC_ACT_RELU) return RC_GEMM_ACT(RC_ACT_RELU);
     return RC_GEMM_ACT(RC_ACT_NONE);
@@ -436,12 +461,13 @@ extern "C" int rc_split_gemm_f16(const uint16_t *a_hi_lo, const uint16_t *w_lo_h
     if (tile == 0) tile = (n_out % 256 == 0 && row_tiles * (n_out / 256) >= 192) ? 1 : (row_tiles * (n_out / 128) >= 192) ? 3 : 2;
     RC_REQUIRE((tile != 1 && tile != 4) || n_out % 256 == 0, RC_ERR_RANGE);
     hipStream_t s = (hipStream_t)stream;
-    if (tile == 1)   // 352 x 256, staggered wave rows
+    if (tile == 1)   // 352 x 256
+        return split ? dispatch_split_gemm<2, 4, 11, 4, kOutHalves>(g, activation, s) : dispatch_split_gemm<2, 4, 11, 4, kOutF32>(g, activation, s);
+    if (tile == 3)   // 352 x 128
+        return split ? dispatch_split_gemm<2, 4, 11, 2, kOutHalves>(g, activation, s) : dispatch_split_gemm<2, 4, 11, 2, kOutF32>(g, activation, s);
+    if (tile == 4)   // 352 x 256, the staggered-wave-row schedule (kept for comparison: measured 8 % slower)
         return split ? dispatch_split_gemm_pp<11, 4, kOutHalves>(g, activation, s) : dispatch_split_gemm_pp<11, 4, kOutF32>(g, activation, s);
-    if (tile == 3)   // 352 x 128, staggered wave rows
-        return split ? dispatch_split_gemm_pp<11, 2, kOutHalves>(g, activation, s) : dispatch_split_gemm_pp<11, 2, kOutF32>(g, activation, s);
-    if (tile == 4) return dispatch_split_gemm<2, 4, 11, 4>(g, activation, split, s);   // 352 x 256, one barrier per K-step
-    return dispatch_split_gemm<1, 4, 11, 2>(g, activation, split, s);                  // 176 x 128, one barrier per K-step
+    return split ? dispatch_split_gemm<1, 4, 11, 2, kOutHalves>(g, activation, s) : dispatch_split_gemm<1, 4, 11, 2, kOutF32>(g, activation, s);   // 176 x 128
 }
 
 extern "C" int rc_gemm_bias_act_bf16(const uint16_t *a, const uint16_t *w, const float *bias, size_t n_rows, size_t n_out, size_t k,
@@ -464,8 +490,8 @@ extern "C" int rc_gemm_bias_act_bf16(const uint16_t *a, const uint16_t *w, const
     if (tile == 0) tile = (n_out % 256 == 0 && row_tiles * (n_out / 256) >= 192) ? 1 : 3;
     RC_REQUIRE(tile != 1 || n_out % 256 == 0, RC_ERR_RANGE);
     hipStream_t s = (hipStream_t)stream;
-    if (tile == 1) return dispatch_split_gemm_pp<11, 4, kBf16>(g, activation, s);
-    return dispatch_split_gemm_pp<11, 2, kBf16>(g, activation, s);
+    if (tile == 1) return dispatch_split_gemm<2, 4, 11, 4, kBf16>(g, activation, s);
+    return dispatch_split_gemm<2, 4, 11, 2, kBf16>(g, activation, s);
 }
 
 extern "C" int rc_split_gemm_partials_f16(const uint16_t *a_hi_lo, const uint16_t *w_lo_hi_hi, size_t n_rows, size_t n_out, size_t k,
@@ -483,5 +509,5 @@ extern "C" int rc_split_gemm_partials_f16(const uint16_t *a_hi_lo, const uint16_
     g.N = (u32)n_out;
     g.K = (u32)k;
     g.alpha = 0.f;
-    return launch_split_gemm_pp<11, 4, RC_ACT_NONE, kPartials>(g, (hipStream_t)stream);
+    return launch_split_gemm<2, 4, 11, 4, RC_ACT_NONE, kPartials>(g, (hipStream_t)stream);
 }
