@@ -379,3 +379,26 @@ def test_split_layer_partials_sum_to_the_whole_layer(rows, k, n_out):
     assert float((y.float() - whole).abs().max()) <= 2e-6 * max(1.0, float(ref.abs().max()))
     assert lib.rc_split_gemm_partials_f16(a.data_ptr(), W3.data_ptr(), rows, n_out, 64, part.data_ptr(), None) == -4   # k % 128
     assert lib.rc_split_gemm_partials_f16(a.data_ptr(), W3.data_ptr(), rows, 128, k, part.data_ptr(), None) == -4      # n_out % 256
+
+
+def test_split_engine_own_kernels_on_fc_big():
+    """fc_big (480 -> 8192 -> 4096 -> 2048, heads 1024 -> 512): every hidden layer of the split engine runs on the own kernel at a
+    full batch (K up to 8192, the last one in the K-cut form) and the outputs stay closer to float64 than the fp32 module's."""
+    import copy
+    from librubiks import cube
+    from librubiks.model import F32_SPLIT, Model, ModelConfig, make_inference_net
+    torch.manual_seed(0)
+    np.random.seed(0)
+    net = Model.create(ModelConfig(architecture="fc_big")).eval()
+    cubes, _, _ = cube.scramble_batch(11264, 30, True)
+    oh = cubes.as_oh(torch.float32)[:1024]
+    eng = make_inference_net(net, F32_SPLIT)
+    assert [eng._layer_plan(cubes.n, eng.layers, i) for i in range(1, len(eng.layers) - 1)] == ["fused", "fused", "fused", "partials"]
+    with torch.no_grad():
+        p64, v64 = copy.deepcopy(net).double()(oh.double())
+        p32, v32 = net(oh)
+    ps, vs = eng.forward_cubes(cubes)
+    err = lambda a, b: float((a.double() - b).abs().max())   # noqa: E731
+    e_split = max(err(ps[:1024], p64), err(vs[:1024], v64.reshape(-1)))
+    e_f32 = max(err(p32, p64), err(v32.reshape(-1), v64.reshape(-1)))
+    assert e_split <= 1.25 * e_f32 + 1e-7
