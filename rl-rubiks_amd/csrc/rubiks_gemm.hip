@@ -6,9 +6,15 @@
 //
 // Shape of the problem (BASELINE config #2: 11 264 = 32 x 352 child rows per step, 4096 -> 2048 -> 1024): the tile is
 // 352 x 256 (8 waves, 2 x 4, 176 x 64 outputs per wave), so the 4096 -> 2048 layer is exactly 256 workgroups = one per CU
-// with no tail.  352 x 128 and 176 x 128 tiles exist for narrow layers and few rows; at 256 workgroups their K-step is
-// shorter than the operand latency, so the 2048 -> 1024 layer stays with the library.  Every tile
-// walks K in the same order: a row's result does not depend on the tile or on the other rows of the launch.
+// with no tail.  The 2048 -> 1024 layer has only 128 such tiles: each is given to two workgroups, one per half of the K loop
+// (kPartials, below).  352 x 128 and 176 x 128 tiles exist for other shapes; at 256 workgroups their K-step is shorter than
+// the operand latency, so they are the slower choice.  Every tile walks K in the same order: a row's
+// result does not depend on the tile or on the other rows of the launch.
+//
+// Schedule (k_split_gemm): one barrier per K-step; per 16-row fragment of activations two ds_read_b128 and eight MFMAs, and
+// behind the MFMAs of the first fragments the wave issues its LDS-DMA pieces of the NEXT stage two at a time -- in the shadow
+// of the matrix cores and of the SIMD's other wave, early enough to land before the next barrier.  k_split_gemm_pp is the
+// variant with the two wave rows running half a phase apart (measured 8 % slower, kept for comparison as tile 4).
 //
 // Data movement: both operands are K-contiguous ([rows][K] halves), staged global -> LDS by global_load_lds_dwordx4 in
 // 64-deep K-steps (128-byte LDS rows, two stages).  LDS-DMA writes lane-linear, so the bank swizzle is applied to the
@@ -26,7 +32,7 @@ namespace rubiks {
 typedef __attribute__((ext_vector_type(8))) _Float16 f16x8;
 typedef __attribute__((ext_vector_type(4))) float f32x4;
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
-constexpr int kOutHalves = 0, kOutF32 = 1, kBf16 = 2, kPartials = 3;   // operand / output kinds of k_split_gemm_pp
+constexpr int kOutHalves = 0, kOutF32 = 1, kBf16 = 2, kPartials = 3;   // operand / output kinds of the layer kernels
 typedef __attribute__((address_space(3))) void lds_void;
 typedef const __attribute__((address_space(1))) void glb_void;
 
@@ -37,10 +43,10 @@ constexpr int kGemmRowBytes = 128;   // one K-step: 64 halves per row
 constexpr int kPiecesPerRow = RC_GEMM_PPR;   // LDS-DMA pieces a wave issues behind the MFMAs of one 16-row fragment
 
 struct GemmArgs {
-    const unsigned char *a;      // activations [M][2K] halves: hi | lo
-    const unsigned char *w;      // weights [N][3K] halves: lo | hi | hi   (the order the K loop walks them)
+    const unsigned char *a;      // activations [M][2K] halves: hi | lo                       (kBf16: [M][K] bf16)
+    const unsigned char *w;      // weights [N][3K] halves: lo | hi | hi, as the K loop walks them  (kBf16: [N][K] bf16)
     const float *bias;
-    void *out;                   // [M][2N] halves (hi | lo) or [M][N] fp32
+    void *out;                   // [M][2N] halves (hi | lo), [M][N] fp32, [M][N] bf16, or the partials [2][M][N] fp32
     u32 M, N, K;
     float alpha;
 };
