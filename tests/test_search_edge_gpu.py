@@ -282,3 +282,34 @@ def test_production_bf16_trees_equal_oracle_on_recorded_outputs():
             n_solved += ok
             deep += ref.iterations > 40
         assert n_solved >= 10 and deep >= 10
+
+
+def test_deep_production_trees_equal_oracle_on_recorded_outputs():
+    """The same replay on DEEP trees (trained weights, depth-20 scrambles, up to 30 000 states: up to ~2 600 iterations, descents of
+    several hundred levels): re-validation in several rounds per thread, line following over many 64-level segments, the ring of
+    descent lines wrapping around, loops through transpositions -- node for node, incl. the virtual losses of the pending path."""
+    import os
+    from conftest import ROOT
+    from librubiks.model import Model
+    from librubiks.solving.agents import MCTS
+    wdir = os.path.join(ROOT, "weights", "fc_small_r1")
+    if not os.path.isdir(wdir):
+        pytest.skip("needs the trained weights")
+    net = Model.load(wdir).eval()
+    np.random.seed(5)
+    B, cap = 6, 30000
+    states = np.array([oc.scramble(20, True)[0] for _ in range(B)])
+    agent = MCTS(net, c=0.6, search_graph=True)
+    res = agent.search_batch(states, None, cap, compact=False)
+    longest = 0
+    for t in range(B):
+        tree = agent.forest.tree_arrays(t)
+        n = tree["n"]
+        table = {tree["states"][i].tobytes(): (tree["P"][i].astype(np.float32), np.float32(tree["V"][i])) for i in range(1, n + 1)}
+        ref = oa.MCTS(_TableNet(table), c=0.6, search_graph=True)
+        ok = ref.search(states[t], cap)
+        assert bool(res.solved[t]) == ok and res.nodes[t] == len(ref) == n, f"tree {t}"
+        assert list(res.queues[t]) == list(ref.action_queue) and res.iterations[t] == ref.iterations, f"tree {t}"
+        _compare(tree, ref, n)
+        longest = max(longest, int(agent.forest.path_len[t].item()))
+    assert longest > 256 and int(res.iterations.max()) > 1000      # descents deeper than one re-validation round, ring wrapped many times
