@@ -284,13 +284,14 @@ def test_production_bf16_trees_equal_oracle_on_recorded_outputs():
         assert n_solved >= 10 and deep >= 10
 
 
-def test_deep_production_trees_equal_oracle_on_recorded_outputs():
+@pytest.mark.parametrize("engine", ["bf16", "f32s"])
+def test_deep_production_trees_equal_oracle_on_recorded_outputs(engine):
     """The same replay on DEEP trees (trained weights, depth-20 scrambles, up to 30 000 states: up to ~2 600 iterations, descents of
     several hundred levels): re-validation in several rounds per thread, line following over many 64-level segments, the ring of
     descent lines wrapping around, loops through transpositions -- node for node, incl. the virtual losses of the pending path."""
     import os
     from conftest import ROOT
-    from librubiks.model import Model
+    from librubiks.model import F32_SPLIT, Model
     from librubiks.solving.agents import MCTS
     wdir = os.path.join(ROOT, "weights", "fc_small_r1")
     if not os.path.isdir(wdir):
@@ -299,7 +300,7 @@ def test_deep_production_trees_equal_oracle_on_recorded_outputs():
     np.random.seed(5)
     B, cap = 6, 30000
     states = np.array([oc.scramble(20, True)[0] for _ in range(B)])
-    agent = MCTS(net, c=0.6, search_graph=True)
+    agent = MCTS(net, c=0.6, search_graph=True, net_dtype=torch.bfloat16 if engine == "bf16" else F32_SPLIT)   # both production engines
     res = agent.search_batch(states, None, cap, compact=False)
     longest = 0
     for t in range(B):
