@@ -26,20 +26,23 @@ def main():
     ap.add_argument("--max-states", type=int, default=175_000)
     ap.add_argument("--slots", type=int, default=1024)
     ap.add_argument("--agents", default="mcts,astar")
+    ap.add_argument("--dtype", default="bf16", choices=["bf16", "f32s"], help="network engine: bf16 (fast) or f32s (fp32 accuracy, the reference's precision)")
     args = ap.parse_args()
-    from librubiks.model import Model
+    from librubiks.model import F32_SPLIT, Model
     from librubiks.solving.agents import MCTS, AStar
     from librubiks.solving.evaluation import Evaluator
     from librubiks.utils import set_seeds
     model = Model.load(os.path.join(ROOT, "weights", "fc_small_r1")).eval()
     depths = [int(d) for d in args.depths.split(",")]
-    summary = {"games_per_depth": args.games, "depths": depths, "max_states": args.max_states, "slots": args.slots}
+    nd = F32_SPLIT if args.dtype == "f32s" else torch.bfloat16
+    summary = {"games_per_depth": args.games, "depths": depths, "max_states": args.max_states, "slots": args.slots,
+               "engine": args.dtype}
     for name in args.agents.split(","):
         set_seeds()
         if name == "mcts":
-            agent, ev = MCTS(model, c=0.6, search_graph=True), Evaluator(args.games, depths, None, args.max_states, slots=args.slots)
+            agent, ev = MCTS(model, c=0.6, search_graph=True, net_dtype=nd), Evaluator(args.games, depths, None, args.max_states, slots=args.slots)
         else:
-            agent, ev = AStar(model, lambda_=0.2, expansions=100), Evaluator(args.games, depths, None, args.max_states)
+            agent, ev = AStar(model, lambda_=0.2, expansions=100, net_dtype=nd), Evaluator(args.games, depths, None, args.max_states)
         torch.cuda.synchronize()
         t = time.perf_counter()
         res, states, times = ev.eval(agent)
