@@ -5,8 +5,9 @@ bench.py -- MCTS node expansions/sec on depth-20 scrambles (BASELINE.json metric
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
 
 Workload (BASELINE.json configs[1]): 1 024 concurrent depth-20 MCTS trees per GPU (np.random.seed(0), the
-reference's scramble stream), MCTS c = 0.6 with graph search, max_states 50 000, fc_small policy/value net with
-the ADI-trained weights of weights/fc_small_r1 (glorot weights from torch.manual_seed(0) if absent).
+reference's scramble stream), MCTS c = 0.6 with graph search, max_states 175 000 (the reference's default,
+runeval.py:42-44), fc_small policy/value net with the ADI-trained weights of weights/fc_small_r1 (glorot weights
+from torch.manual_seed(0) if absent).
 A "step" is one lock-step MCTS iteration of every tree on the rank: expand the leaf's 12 children (HIP), policy /
 value network on the NEW children (11 packed rows per tree; PyTorch-ROCm GEMMs), backup + PUCT descent (HIP).
 
@@ -17,13 +18,17 @@ is then that of a long-running evaluation), then W warm-up steps, then EXACTLY K
 barrier + synchronize on both sides, harvesting and refilling included:
   value = unique states inserted into the trees of all ranks during the K timed steps / max-over-ranks seconds.
 This is done once per network precision (a "leg"):
-  f32   the reference's arithmetic (its net runs in fp32, librubiks/model.py:131-141)  ->  `value`, `dtype`
-  bf16  the production engine (BatchNorm folded, bf16 MFMA, fused input layer and head)  ->  `legs.bf16`
+  f32s  fp32 accuracy on the f16 matrix cores (the reference's net runs in fp32, librubiks/model.py:131-141)  ->  `value`, `dtype`
+  f32   the fp32 MFMA GEMM chain as is (window only)          bf16  the fast engine  ->  `legs.*`
 Each leg also reports (sum of len(agent) / wall seconds of the batched search):
   pool_run           the whole pool searched to completion / its wall time (prep, window and tail included)
   run_to_completion  BASELINE configs[1] itself: the first 1 024 scrambles as ONE batch, to completion, + solve rate
 Ranks own disjoint scramble slices (weak scaling); the only collectives are the barrier, the max/sum reductions
 of the result and one all_gather of per-game results.
+Further legs on the same line (`--extra-legs`): `astar` = BASELINE configs[2] (4 096 depth-20 scrambles, AStar lambda 0.2, N 100:
+K timed iterations + the solve run at max_states 175 000, phase times and the roofline of its dominant kernel) and `config5` =
+one GPU's share of BASELINE configs[4] (8 192 concurrent depth-24 trees: timed window + the 8 192 as one batch to completion).
+The scalars that summarise all of this are repeated in `config.results`.
 
 Also printed on the same JSON line:
   roofline      dominant kernel of the headline leg's step = the first hidden GEMM (MFMA bound)
@@ -52,6 +57,7 @@ MFMA_F32_PEAK_TFLOPS = 157.3
 # (FETCH_SIZE / WRITE_SIZE, gfx950 corrections applied by tools/summarize_pmc.py) of the same launches at 2^24 states
 PMC_FILE = "r2_env_pmc_traffic.json" if os.path.exists(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles",
                                                                   "r2_env_pmc_traffic.json")) else "r1b_env_pmc_traffic.json"
+GEMM_PMC_FILE = "r3_split_gemm_traffic.json"   # the hidden-layer kernel that runs today (k_split_gemm<2, 4, 11, 4, ...>), re-measured in round 3
 PMC_SOURCE = f"stored PMC figure: profiles/{PMC_FILE} (separate rocprofv3 --pmc passes of these launches, not this run)"
 
 
@@ -375,16 +381,19 @@ def cpu_bfs_config1():
 
 
 LEG_DTYPE = {   # leg name -> the arithmetic the network computes in (`dtype` of the JSON line)
-    "f32s": "f32 accuracy via f16x3 split: 3 f16 MFMA products per layer, fp32 accumulate (error vs float64 <= fp32's)",
+    "f32s": "f32 accuracy via f16x3 split: 3 f16 MFMA products per layer, fp32 accumulate (error vs float64 within 1.25 x the fp32 forward's)",
     "f32": "f32",
     "bf16": "bf16",
 }
 
 
-def run_leg(name, model, pool_roots, config_roots, args, world, coll_device):
+def run_leg(name, model, pool_roots, config_roots, args, world, coll_device, trees, cap, window_only=False, full_warm=True):
     """
     One network precision: steady-state window of K steps on the continuously refilled pool, the whole pool to
-    completion, and BASELINE configs[1] (the first `trees` scrambles as one batch) to completion.
+    completion, and the first `trees` scrambles as one batch to completion (BASELINE configs[1] when trees = 1 024).
+    window_only: stop after the timed window.  full_warm: the untimed warm-up of the run to completion is the same search run
+    once before (every launch size's HIP graph is then in the forest's cache, as in any evaluator that searches more than one
+    batch); otherwise 30 iterations (the first graph only; the others are captured inside the timed run).
     Returns (dict for the JSON line, engine, agent).
     """
     from librubiks.model import F32_SPLIT, InferenceNet, SplitF32Net
@@ -392,7 +401,6 @@ def run_leg(name, model, pool_roots, config_roots, args, world, coll_device):
     net_dtype = {"bf16": torch.bfloat16, "f32": torch.float32, "f32s": F32_SPLIT}[name]
     engine = SplitF32Net(model) if name == "f32s" else InferenceNet(model, dtype=net_dtype, first_layer_table=args.first_layer_table)
     agent = MCTS(engine, c=0.6, search_graph=True, net_dtype=net_dtype, level_budget=args.level_budget)
-    cap = args.solve_max_states
 
     def barrier():
         torch.cuda.synchronize()
@@ -403,11 +411,12 @@ def run_leg(name, model, pool_roots, config_roots, args, world, coll_device):
     # ---- pool: untimed prep, warm-up, timed window, rest of the pool ------------------------------------
     barrier()
     t_pool = time.perf_counter()
-    run = agent.start_batch(pool_roots, None, cap, slots=args.trees)
-    # Prep ends half way between two result flushes: finished trees are turned into results (graph completion + BFS) 256 at a
-    # time on a side stream, ~35 ms of kernels that slow the concurrent steps by 10-20 %; a 20-step window sees either all of
-    # one flush or nothing of it, the pool as a whole 1.5 %.  `result_flushes_in_window` says which it was; pool_run has them all.
-    prep_games = 2 * args.trees + type(run).GRAVE // 2
+    run = agent.start_batch(pool_roots, None, cap, slots=trees)
+    # Prep: until as many scrambles again as there are slots have been started (the slots then hold trees of every age).  Where
+    # the window falls relative to the flushes of the results forest (graph completion + BFS of 256 finished trees on a side
+    # stream, ~35 ms of kernels every 256 finished games that slow the concurrent steps by 10-20 %) is NOT chosen:
+    # `result_flushes_in_window` says what it saw, pool_run contains all of them.
+    prep_games = 2 * trees
     while not run.done and run.next_game < min(prep_games, run.n_games) and run.it < args.prep_cap:
         run.round()
     # Harvested trees are turned into host results lazily; doing that here (tens of ms of host work, the GPU idles and drops its
@@ -443,29 +452,31 @@ def run_leg(name, model, pool_roots, config_roots, args, world, coll_device):
     refills_in_window = run.stats["refills"] - refills0
     flushes_in_window = run.stats.get("flushes", 0) - flushes0
     pool = None
-    if not args.window_only:
+    if not window_only:
         while not run.done:
             run.round()
         res = run.finish()
         torch.cuda.synchronize()
         pool_seconds = time.perf_counter() - t_pool
-        pool = {"games": int(run.n_games), "slots": args.trees, "nodes": int(res.nodes.sum()), "seconds": round(pool_seconds, 3),
+        pool = {"games": int(run.n_games), "slots": trees, "nodes": int(res.nodes.sum()), "seconds": round(pool_seconds, 3),
                 "nodes_per_sec": round(float(res.nodes.sum()) / pool_seconds, 1), "solve_rate": float(res.solved.mean()),
-                "iterations": int(run.it), **{k: v for k, v in run.stats.items() if k != "iterations"}}
+                "iterations": int(run.it), **{k: (round(v, 4) if isinstance(v, float) else v) for k, v in run.stats.items() if k != "iterations"}}
     del run
-    # ---- BASELINE configs[1]: the first `trees` scrambles as one batch, to completion -----------------------
+    # ---- the first `trees` scrambles as one batch, to completion (BASELINE configs[1]) ------------------------
     rtc = local = None
-    if not args.window_only:
-        agent.forest = None
-        torch.cuda.empty_cache()
-        agent.search_batch(config_roots, None, cap, max_iterations=30)   # untimed warm-up: forest allocated, step graph captured
+    if not window_only:
+        if full_warm:
+            agent.search_batch(config_roots, None, cap)                       # untimed: the same search, all launch sizes' graphs captured
+        else:
+            agent.search_batch(config_roots, None, cap, max_iterations=30)   # untimed: forest allocated, first graph captured
         barrier()
         t1 = time.perf_counter()
         full = agent.search_batch(config_roots, None, cap)
         torch.cuda.synchronize()
         rtc_seconds = time.perf_counter() - t1
         local = {"nodes": full.nodes, "solved": full.solved, "lengths": full.lengths}
-        rtc = {"seconds": rtc_seconds, "nodes": int(full.nodes.sum())}
+        rtc = {"seconds": rtc_seconds, "nodes": int(full.nodes.sum()), "iterations": int(full.iterations.max()),
+               "launch_sizes": int(agent.refill_stats.get("compactions", 0)) + 1}
     stats = torch.tensor([seconds, float(nodes), float(steps_done), rtc["seconds"] if rtc else 0.0,
                           float(pool["nodes"]) if pool else 0.0, float(pool["seconds"]) if pool else 0.0],
                          dtype=torch.float64, device=coll_device)
@@ -480,14 +491,14 @@ def run_leg(name, model, pool_roots, config_roots, args, world, coll_device):
     out = {"dtype": LEG_DTYPE[name], "value": round(nodes / seconds, 1), "ms_per_step": round(seconds / max(steps_done, 1) * 1e3, 4),
            "nodes_in_window": nodes, "steps_timed": steps_done, "prep_iterations_untimed": prep_iters, "result_flushes_in_window": flushes_in_window,
            "refills_in_window": refills_in_window, "running_trees_rank0": running_in_window,
-           "mean_descent_depth_rank0": round(mean_path, 1)}
+           "mean_descent_depth_rank0": round(mean_path, 1), "max_states_per_tree": cap}
     if pool:
         out["pool_run"] = dict(pool, nodes=pool_nodes, seconds=round(pool_s, 3), nodes_per_sec=round(pool_nodes / pool_s, 1),
                                games=int(pool["games"]) * world,
                                note="whole pool searched to completion on `slots` tree slots; wall time includes prep, window and tail")
     if rtc:
         from librubiks.solving.sharding import gather_results
-        total = args.trees * world
+        total = trees * world
         g = gather_results(local, total, device=coll_device)
         p = float(np.mean(g["solved"]))
         out["run_to_completion"] = {
@@ -495,8 +506,132 @@ def run_leg(name, model, pool_roots, config_roots, args, world, coll_device):
             "nodes_per_sec": round(float(np.sum(g["nodes"])) / rtc_s, 1), "solve_rate": p,
             "ci95": float(1.959963984540054 * np.sqrt(p * (1 - p) / total)),
             "mean_solution_length": float(np.mean(g["lengths"][g["solved"].astype(bool)])) if np.any(g["solved"]) else None,
-            "note": "BASELINE configs[1] as ONE batch: sum len(agent) / wall seconds of the batched search (SURVEY 8(d)(i))"}
+            "lock_step_iterations_rank0": rtc["iterations"], "launch_sizes_rank0": rtc["launch_sizes"],
+            "warm_up": "the same search once before, untimed (HIP graphs of every launch size cached in the forest)" if full_warm
+                       else "30 iterations, untimed (graphs of the smaller launch sizes are captured inside the timed run)",
+            "note": "the scrambles as ONE batch: sum len(agent) / wall seconds of the batched search (SURVEY 8(d)(i))"}
     return out, engine, agent
+
+
+def astar_leg(name, model, roots, args, world, coll_device):
+    """
+    BASELINE configs[2]: `roots.n` depth-20 scrambles per GPU, batch weighted A* with the reference's defaults lambda = 0.2,
+    N = 100 (runeval.py:60,65).  Times K iterations of all problems (after W warm-up iterations of the same batch), the phases
+    of one iteration (HIP events), the dominant kernel alone on the iteration's real operands, and the search to completion
+    at max_states = `--solve-max-states`.
+    """
+    import ctypes
+    from librubiks import _hip
+    from librubiks.model import F32_SPLIT, SplitF32Net
+    from librubiks.solving.agents import AStar
+    net_dtype = {"bf16": torch.bfloat16, "f32s": F32_SPLIT}[name]
+    lam, N, cap = 0.2, 100, args.solve_max_states
+    agent = AStar(model, lam, N, net_dtype=net_dtype)
+    K, W = max(1, min(args.steps, 12)), max(1, min(args.warmup, 3))
+
+    def barrier():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    batch = agent._batch_for(roots.n, max(cap, 12 * N * (K + W + 4) + 16))
+    batch.reset(roots)
+    for _ in range(W):
+        batch.iteration(lam, batch.C)
+    barrier()
+    n0 = int(batch.n_nodes.sum().item())
+    t0 = time.perf_counter()
+    for _ in range(K):
+        batch.iteration(lam, batch.C)
+    barrier()
+    seconds = time.perf_counter() - t0
+    nodes = int(batch.n_nodes.sum().item()) - n0
+    out = {"dtype": LEG_DTYPE[name], "problems_per_gpu": int(roots.n), "lambda": lam, "expansions": N, "iterations_timed": K,
+           "warmup_iterations": W, "child_rows_per_iteration": int(roots.n) * N * 12}
+    # ---- phases of one more iteration + its dominant kernel (rank 0's view) ------------------------------------
+    phases = roof = None
+    if args.phase_reps:
+        m, st, eng = ctypes.byref(batch.struct), _hip.stream_ptr(), batch.engine
+        ev = [torch.cuda.Event(enable_timing=True) for _ in range(5)]
+        ev[0].record()
+        _hip.check(batch.lib.rc_astar_pop_expand(m, batch.C, st), "rc_astar_pop_expand")
+        ev[1].record()
+        torch.cumsum(batch.new_count, 0, dtype=torch.int32, out=batch.new_offset[1:])
+        total = int(batch.new_offset[-1].item())
+        _hip.check(batch.lib.rc_astar_gather_new(m, batch.new_offset.data_ptr(), batch.new_states.soa.data_ptr(),
+                                                 batch.new_states.stride, st), "rc_astar_gather_new")
+        ev[2].record()
+        batch._values_of_new(total)
+        ev[3].record()
+        _hip.check(batch.lib.rc_astar_push_relax(m, batch.new_offset.data_ptr(), batch.values.data_ptr(), lam, st), "rc_astar_push_relax")
+        ev[4].record()
+        torch.cuda.synchronize()
+        names = ["pop_expand", "prefix_sum+gather_new", "value_net", "push_relax"]
+        phases = {k: round(ev[i].elapsed_time(ev[i + 1]), 4) for i, k in enumerate(names)}
+        phases["new_states"] = total
+        from librubiks.solving.astar_device import NET_CHUNK
+        rows = min(total, NET_CHUNK)
+        flops_state = 2 * sum(int(l[1].shape[0]) * int(l[1].shape[1]) for l in eng.value_layers) if isinstance(eng, SplitF32Net) \
+            else 2 * sum(int(Wt.shape[0]) * int(Wt.shape[1]) for Wt, _, _ in eng.value_layers)
+        mult = 3 if isinstance(eng, SplitF32Net) else 1
+        peak = MFMA_BF16_PEAK_TFLOPS
+        tf_net = mult * flops_state * total / (phases["value_net"] * 1e-3) / 1e12
+        group = {"kernel": f"value network on the {total} new states of one iteration ({'three f16 products per layer' if mult == 3 else 'bf16'})",
+                 "bound": "mfma", "achieved": round(tf_net, 1), "peak": peak, "unit": "TFLOP/s", "frac": round(tf_net / peak, 4),
+                 "flops_per_launch": mult * flops_state * total, "ms_per_launch": phases["value_net"], "traffic": None}
+        # the dominant kernel alone: the first hidden layer on one chunk of the iteration's real input-layer activations
+        if isinstance(eng, SplitF32Net):
+            a = eng._first_from_cubes(batch.new_states, eng.value_layers, 0, rows)
+            _, Wh, B2, b, code, alpha, W3 = eng.value_layers[1]
+            Kd, Nd = int(Wh.shape[1]), int(Wh.shape[0])
+            o = torch.empty((rows, 2 * Nd), dtype=torch.float16, device=Wh.device)
+            ms = event_ms(lambda: _hip.check(batch.lib.rc_split_gemm_f16(a.data_ptr(), W3.data_ptr(), b.data_ptr(), rows, Nd, Kd, code, alpha,
+                                                                         o.data_ptr(), None, 0, _hip.stream_ptr()), "rc_split_gemm_f16"), 5)[0]
+            fl = 3 * 2 * rows * Nd * Kd
+            kname = f"rc_split_gemm_f16 [{rows} x {3 * Kd}] x [{3 * Kd} x {Nd}] f16 products + bias + ELU + re-split: first hidden layer of A*'s value network"
+        else:
+            x1 = eng.first_layer(batch.new_states, None, 0, rows)
+            Wt, bt, _ = eng.value_layers[1]
+            Kd, Nd = int(Wt.shape[1]), int(Wt.shape[0])
+            ms = event_ms(lambda: torch.addmm(bt, x1, Wt.t()), 5)[0]
+            fl = 2 * rows * Nd * Kd
+            kname = f"hidden GEMM [{rows} x {Kd}] x [{Kd} x {Nd}] + bias, bf16 MFMA via hipBLASLt: first hidden layer of A*'s value network"
+        roof = {"kernel": kname, "bound": "mfma", "achieved": round(fl / (ms * 1e-3) / 1e12, 1), "peak": peak, "unit": "TFLOP/s",
+                "frac": round(fl / (ms * 1e-3) / 1e12 / peak, 4), "flops_per_launch": fl, "ms_per_launch": round(ms, 4), "traffic": None,
+                "note": "HIP events on the launch stream; the tree-side kernels (pop_expand: per-problem heap pops + 12 children + hash "
+                        "dedup + first-occurrence election; push_relax: float64 cost, heap pushes, relaxation) are latency / atomic "
+                        "bound, their times are in phases_ms"}
+        out["phases_ms"], out["roofline"], out["roofline_net_group"] = phases, roof, group
+    # ---- search to completion ---------------------------------------------------------------------------------
+    local = None
+    if not args.window_only:
+        barrier()
+        t1 = time.perf_counter()
+        res = agent.search_batch(roots, None, cap)
+        torch.cuda.synchronize()
+        solve_s = time.perf_counter() - t1
+        local = {"nodes": res.nodes, "solved": res.solved, "lengths": res.lengths}
+    stats = torch.tensor([seconds, float(nodes), solve_s if local else 0.0], dtype=torch.float64, device=coll_device)
+    if world > 1:
+        mx, sm = stats.clone(), stats.clone()
+        dist.all_reduce(mx, op=dist.ReduceOp.MAX)
+        dist.all_reduce(sm, op=dist.ReduceOp.SUM)
+        seconds, nodes, solve_s = float(mx[0]), int(sm[1]), float(mx[2])
+    out.update({"value": round(nodes / seconds, 1), "unit": "new states/s", "ms_per_iteration": round(seconds / K * 1e3, 3),
+                "new_states_per_iteration": round(nodes / K / world, 1)})
+    if local:
+        from librubiks.solving.sharding import gather_results
+        total_games = roots.n * world
+        g = gather_results(local, total_games, device=coll_device)
+        p = float(np.mean(g["solved"]))
+        out["solve_run"] = {"games": int(total_games), "max_states_per_problem": cap, "nodes": int(np.sum(g["nodes"])), "seconds": round(solve_s, 3),
+                            "states_per_sec": round(float(np.sum(g["nodes"])) / solve_s, 1), "solve_rate": p,
+                            "ci95": float(1.959963984540054 * np.sqrt(p * (1 - p) / total_games)),
+                            "mean_solution_length": float(np.mean(g["lengths"][g["solved"].astype(bool)])) if np.any(g["solved"]) else None}
+    del agent, batch
+    torch.cuda.empty_cache()
+    return out
 
 
 def step_rooflines(engine, agent, roots, args, name):
@@ -519,11 +654,12 @@ def step_rooflines(engine, agent, roots, args, name):
         t = phases["gemm_hidden1"] * 1e-3
         own = phases.get("gemm_hidden1_kernel") == "rc_split_gemm_f16"
         gemm_traffic, gemm_traffic_src = None, None
-        tpath = os.path.join(ROOT, "profiles", "r2f_split_gemm_traffic.json")
-        if own and rows == 11264 and os.path.exists(tpath):   # a stored figure of exactly this launch shape, not measured in this run
-            gemm_traffic = json.load(open(tpath))["traffic_bytes"]
-            gemm_traffic_src = ("stored PMC figure: profiles/r2f_split_gemm_traffic.json (separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE "
-                                "passes of this kernel at this shape, gfx950 corrections applied; algorithmic bytes 310 MB)")
+        tpath = os.path.join(ROOT, "profiles", GEMM_PMC_FILE)
+        if own and rows == 11264 and os.path.exists(tpath):   # a stored figure of exactly this kernel and launch shape, not measured in this run
+            stored = json.load(open(tpath))
+            gemm_traffic = stored["traffic_bytes"]
+            gemm_traffic_src = (f"stored PMC figure: profiles/{GEMM_PMC_FILE} (separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of "
+                                f"{stored['kernel']}, gfx950 corrections applied; algorithmic bytes 310 MB)")
         roofline = {"kernel": (f"rc_split_gemm_f16 (own MFMA kernel, 352 x 256 tiles): first hidden layer of the split engine, "
                                f"[{rows} x {3 * W1[1]}] x [{3 * W1[1]} x {W1[0]}] f16 products (hi x lo, lo x hi, hi x hi) in one fp32 "
                                f"accumulator + bias + ELU + re-split to halves: the dominant kernel of a step") if own else
@@ -585,6 +721,31 @@ def step_rooflines(engine, agent, roots, args, name):
     return phases, roofline, group, roofline_input, rows
 
 
+def draw_scrambles(n_config, n_pool, depth, slice_rank, slice_world):
+    """
+    Synthetic inputs of one rank.  The first n_config * world games are the reference's scramble stream (np.random.seed(0),
+    scramble(depth, True) game after game): rank r owns games [r n_config, (r + 1) n_config) and replays only
+    those n_config * world draws.  The rest of a rank's pool (n_pool - n_config scrambles that merely keep the slots busy) comes
+    from a stream of the rank's own (seed 1 000 003 + rank), so no rank draws another rank's pool.
+    Returns (config_roots, pool_roots) as DeviceCubes; the pool starts with the rank's config scrambles.
+    """
+    from librubiks import cube
+    from librubiks.cube import DeviceCubes
+    from librubiks.solving.sharding import shard_range
+    np.random.seed(0)
+    all_cubes, _, _ = cube.scramble_batch(n_config * slice_world, depth, True)
+    lo, hi = shard_range(n_config * slice_world, slice_rank, slice_world)
+    config_roots = DeviceCubes.empty(hi - lo)
+    config_roots.soa[:, :hi - lo] = all_cubes.soa[:, lo:hi]
+    pool_roots = DeviceCubes.empty(n_pool)
+    pool_roots.soa[:, :hi - lo] = config_roots.soa[:, :hi - lo]
+    if n_pool > hi - lo:
+        np.random.seed(1_000_003 + slice_rank)
+        rest, _, _ = cube.scramble_batch(n_pool - (hi - lo), depth, True)
+        pool_roots.soa[:, hi - lo:n_pool] = rest.soa[:, :n_pool - (hi - lo)]
+    return config_roots, pool_roots
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -592,18 +753,27 @@ def main():
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--trees", type=int, default=1024, help="concurrent MCTS trees (slots) per GPU")
     ap.add_argument("--depth", type=int, default=20)
-    ap.add_argument("--legs", default="f32s,f32,bf16",
+    ap.add_argument("--legs", default="f32s,f32:window,bf16",
                     help="network engines to measure; the FIRST one is the headline `value`: f32s = fp32 accuracy on the f16 matrix "
-                         "cores (SplitF32Net), f32 = fp32 MFMA GEMMs (the reference's arithmetic as is), bf16 = the fast engine")
+                         "cores (SplitF32Net), f32 = fp32 MFMA GEMMs (the reference's arithmetic as is), bf16 = the fast engine; "
+                         "`:window` = timed window only (no pool tail, no run to completion)")
+    ap.add_argument("--extra-legs", default="astar,config5",
+                    help="astar = BASELINE configs[2] (4 096 depth-20 A* problems per GPU); config5 = one GPU's share of configs[4] "
+                         "(8 192 concurrent depth-24 trees); none = neither.  Each runs at f32s, then bf16")
+    ap.add_argument("--astar-problems", type=int, default=4096)
+    ap.add_argument("--config5-trees", type=int, default=8192)
+    ap.add_argument("--config5-max-states", type=int, default=50000,
+                    help="per-tree cap of the config5 leg: 8 192 trees x 175 000 nodes x 285 B = 408 GB do not fit 288 GB of HBM; 50 000 = 117 GB")
     ap.add_argument("--pool-factor", type=int, default=8, help="scrambles in the pool per tree slot")
     ap.add_argument("--prep-cap", type=int, default=4000, help="most untimed iterations before the timed window")
-    ap.add_argument("--window-only", action="store_true", help="skip the pool's tail and the run to completion")
+    ap.add_argument("--window-only", action="store_true", help="skip the pool's tail and the runs to completion")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-env-roofline", action="store_true")
     ap.add_argument("--phase-reps", type=int, default=20)
     ap.add_argument("--weights", default=os.path.join(ROOT, "weights", "fc_small_r1"),
                     help="checkpoint directory (model.pt + config.json); random-init weights if it does not exist")
-    ap.add_argument("--solve-max-states", type=int, default=50000, help="per-tree cap (the reference's max_states)")
+    ap.add_argument("--solve-max-states", type=int, default=175000,
+                    help="per-tree / per-problem cap = the reference's max_states (default: its CLI default, runeval.py:42-44)")
     ap.add_argument("--level-budget", default="auto",
                     help="new tree levels a PUCT descent may walk per step before it is suspended (0 = strict lock step; "
                          "auto = the agent's default: a budget while scrambles are waiting for a slot, none for the tail)")
@@ -615,42 +785,31 @@ def main():
     args = ap.parse_args()
     if args.level_budget != "auto":
         args.level_budget = int(args.level_budget)
-    legs = [x for x in args.legs.split(",") if x]
+    legs = [x.split(":")[0] for x in args.legs.split(",") if x]
+    leg_window_only = {x.split(":")[0]: x.endswith(":window") for x in args.legs.split(",") if x}
     assert legs and all(x in LEG_DTYPE for x in legs)
+    extra = [] if args.extra_legs in ("", "none") else [x for x in args.extra_legs.split(",") if x]
+    assert all(x in ("astar", "config5") for x in extra)
 
     rank, world = int(os.environ.get("RANK", 0)), int(os.environ.get("WORLD_SIZE", 1))
     local_rank = int(os.environ.get("LOCAL_RANK", 0))
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
-    # one process per GPU; RUBIKS_DIST_BACKEND=gloo lets several ranks share one GPU to rehearse the N > 1 code path
-    backend = os.environ.get("RUBIKS_DIST_BACKEND", "nccl")   # nccl == RCCL on ROCm
-    device_index = local_rank % torch.cuda.device_count()
+    from librubiks.solving.sharding import pick_backend
+    # one process per GPU over RCCL; RUBIKS_DIST_BACKEND=gloo lets several ranks share one GPU to rehearse the N > 1 code path
+    backend, device_index, coll_device = pick_backend(os.environ, torch.cuda.device_count(), local_rank)
     torch.cuda.set_device(device_index)
-    coll_device = "cuda" if backend == "nccl" else "cpu"
     if world > 1:
         if backend == "nccl":
             dist.init_process_group("nccl", device_id=torch.device("cuda", device_index))
         else:
             dist.init_process_group(backend)
 
-    from librubiks import cube
-    from librubiks.cube import DeviceCubes
     from librubiks.model import Model, ModelConfig
-    from librubiks.solving.sharding import shard_range
 
-    # ---- synthetic inputs: the reference's scramble stream; every rank draws all of it and keeps its slice -----
-    # games 0 .. trees*world - 1 are BASELINE configs[1]'s scrambles (rank r: its `trees`), the pool continues the stream
-    np.random.seed(0)
+    # ---- synthetic inputs: the reference's scramble stream for the configs' own games, a private stream for pool filler -----
     per_rank = args.trees * args.pool_factor
     slice_rank, slice_world = (rank, world) if not args.as_rank else tuple(int(x) for x in args.as_rank.split("/"))
-    all_cubes, _, _ = cube.scramble_batch(per_rank * slice_world, args.depth, True)
-    lo, hi = shard_range(args.trees * slice_world, slice_rank, slice_world)
-    config_roots = DeviceCubes.empty(hi - lo)
-    config_roots.soa[:, :hi - lo] = all_cubes.soa[:, lo:hi]
-    pool_roots = DeviceCubes.empty(per_rank)
-    pool_roots.soa[:, :hi - lo] = config_roots.soa[:, :hi - lo]           # the pool starts with the rank's config scrambles ...
-    rest_lo = args.trees * slice_world + slice_rank * (per_rank - args.trees)   # ... and continues with its slice of the rest
-    pool_roots.soa[:, hi - lo:per_rank] = all_cubes.soa[:, rest_lo:rest_lo + per_rank - (hi - lo)]
-    del all_cubes
+    config_roots, pool_roots = draw_scrambles(args.trees, per_rank, args.depth, slice_rank, slice_world)
 
     torch.manual_seed(0)
     if os.path.isdir(args.weights):
@@ -662,12 +821,34 @@ def main():
 
     results, extras = {}, {}
     for name in legs:
-        leg, engine, agent = run_leg(name, model, pool_roots, config_roots, args, world, coll_device)
+        leg, engine, agent = run_leg(name, model, pool_roots, config_roots, args, world, coll_device, args.trees, args.solve_max_states,
+                                     window_only=args.window_only or leg_window_only[name])
         results[name] = leg
         if rank == 0 and args.phase_reps:
             extras[name] = step_rooflines(engine, agent, config_roots, args, name)
         del engine, agent
         torch.cuda.empty_cache()
+    del pool_roots
+
+    # ---- BASELINE configs[2]: A* ------------------------------------------------------------------------------------------
+    astar = {}
+    if "astar" in extra:
+        a_roots, _ = draw_scrambles(args.astar_problems, args.astar_problems, 20, slice_rank, slice_world)
+        for name in ("f32s", "bf16"):
+            astar[name] = astar_leg(name, model, a_roots, args, world, coll_device)
+        del a_roots
+    # ---- one GPU's share of BASELINE configs[4]: 8 192 concurrent depth-24 trees -------------------------------------------
+    config5 = {}
+    if "config5" in extra:
+        c_roots, c_pool = draw_scrambles(args.config5_trees, 3 * args.config5_trees, 24, slice_rank, slice_world)
+        for name in ("f32s", "bf16"):
+            leg, engine, agent = run_leg(name, model, c_pool, c_roots, args, world, coll_device, args.config5_trees, args.config5_max_states,
+                                         full_warm=False)
+            leg.pop("pool_run", None)   # the pool only feeds the window here (3 x 8 192 scrambles), its total is not a result
+            config5[name] = leg
+            del engine, agent
+            torch.cuda.empty_cache()
+        del c_roots, c_pool
 
     if rank != 0:
         if world > 1:
@@ -676,29 +857,66 @@ def main():
         return
 
     head = results[legs[0]]
+    rtc_of = lambda leg: (leg.get("run_to_completion") or {})   # noqa: E731
+    summary = {   # the scalars of this line that matter, in one flat place (everything else is detail under `legs`, `astar`, `config5_share`)
+        "max_states": args.solve_max_states,
+        "value_pool_run": (head.get("pool_run") or {}).get("nodes_per_sec"),
+        "value_run_to_completion": rtc_of(head).get("nodes_per_sec"),
+        "run_to_completion_seconds": rtc_of(head).get("seconds"),
+        "solve_rate": rtc_of(head).get("solve_rate"), "solve_rate_ci95": rtc_of(head).get("ci95"),
+        "mean_solution_length": rtc_of(head).get("mean_solution_length"),
+        "result_flushes_in_window": head.get("result_flushes_in_window"),
+    }
+    for name in legs[1:]:
+        summary[f"{name}_value"] = results[name]["value"]
+        if rtc_of(results[name]):
+            summary[f"{name}_value_pool_run"] = results[name]["pool_run"]["nodes_per_sec"]
+            summary[f"{name}_value_run_to_completion"] = rtc_of(results[name])["nodes_per_sec"]
+            summary[f"{name}_solve_rate"] = rtc_of(results[name])["solve_rate"]
+    for name, leg in astar.items():
+        summary[f"astar_{name}_states_per_sec"] = leg["value"]
+        if "solve_run" in leg:
+            summary[f"astar_{name}_solve_run_states_per_sec"] = leg["solve_run"]["states_per_sec"]
+            summary[f"astar_{name}_solve_rate"] = leg["solve_run"]["solve_rate"]
+        if "roofline" in leg:
+            summary[f"astar_{name}_roofline_frac"] = leg["roofline"]["frac"]
+    for name, leg in config5.items():
+        summary[f"config5_share_{name}_value"] = leg["value"]
+        if rtc_of(leg):
+            summary[f"config5_share_{name}_run_to_completion"] = rtc_of(leg)["nodes_per_sec"]
+            summary[f"config5_share_{name}_solve_rate"] = rtc_of(leg)["solve_rate"]
     result = {
         "metric": "MCTS node expansions/sec, depth-20 scrambles", "value": head["value"],
         "unit": "node expansions/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-        "ms_per_step": head["ms_per_step"], "higher_is_better": True, "scaling": "weak",
+        "ms_per_step": head["ms_per_step"], "higher_is_better": True, "scaling": "weak", "scaling_measured": False,
         "vs_baseline": None, "dtype": head["dtype"], "data": "synthetic",
         "config": {"workload": f"{args.trees} concurrent depth-{args.depth} MCTS trees per GPU (c=0.6, graph search, max_states "
                                f"{args.solve_max_states}), slots refilled from a pool of {args.pool_factor} x {args.trees} scrambles "
                                f"per GPU; fc_small net, weights: {weights_note}",
                    "trees_per_gpu": args.trees, "pool_scrambles_per_gpu": per_rank, "select_level_budget": args.level_budget,
-                   "scramble_depth": args.depth, "parallelism": f"scramble-sharded x{world}",
+                   "scramble_depth": args.depth, "max_states": args.solve_max_states, "parallelism": f"scramble-sharded x{world}",
+                   "scrambles": "configs' own games: the reference's stream (np.random.seed(0), scramble(depth, True)), rank r owns games "
+                                "[r n, (r + 1) n); pool filler: a private stream per rank (seed 1 000 003 + rank)",
                    "timed_region": "K lock-step iterations of the stationary pool (harvest + refill included), barrier + "
-                                   "synchronize on both sides; prep and warm-up untimed; the window starts half way between two "
-                                   "result flushes (graph completion + BFS of 256 finished trees on a side stream, one per 256 "
-                                   "finished games): legs.*.result_flushes_in_window counts those that fell into it, "
-                                   "value_pool_run includes all of them"},
+                                   "synchronize on both sides; prep (until 2 x trees scrambles have been started) and warm-up untimed; "
+                                   "where the window falls relative to the result flushes (graph completion + BFS of 256 finished "
+                                   "trees on a side stream, one per 256 finished games) is not chosen: results.result_flushes_in_window",
+                   "results": summary},
         "value_note": f"headline = the '{legs[0]}' leg: the reference's network arithmetic is fp32 (librubiks/model.py:131-141); f32s reaches "
-                      "fp32 accuracy with three f16 MFMA products per layer (error against float64 not above the fp32 forward's: "
-                      "tests/test_net_gpu.py), f32 is the fp32 MFMA GEMM chain as is, bf16 the fast engine; all under `legs`",
-        "value_run_to_completion": (head.get("run_to_completion") or {}).get("nodes_per_sec"),
-        "value_pool_run": (head.get("pool_run") or {}).get("nodes_per_sec"),
-        "solve_rate": (head.get("run_to_completion") or {}).get("solve_rate"),
+                      "fp32 accuracy with three f16 MFMA products per layer (error against float64 within 1.25 x the fp32 forward's, "
+                      "in practice below it: tests/test_net_gpu.py), f32 is the fp32 MFMA GEMM chain as is, bf16 the fast engine; all under `legs`",
+        "value_run_to_completion": summary["value_run_to_completion"],
+        "value_pool_run": summary["value_pool_run"],
+        "solve_rate": summary["solve_rate"],
+        "scaling_note": "no multi-GPU curve has been measured yet (no SCALE record): the N > 1 path is covered by two-rank tests only",
         "legs": results,
     }
+    if astar:
+        result["astar"] = dict(astar, workload=f"BASELINE configs[2]: {args.astar_problems} depth-20 scrambles per GPU, AStar lambda=0.2 N=100, "
+                                               f"max_states {args.solve_max_states}")
+    if config5:
+        result["config5_share"] = dict(config5, workload=f"one GPU's share of BASELINE configs[4]: {args.config5_trees} concurrent depth-24 MCTS "
+                                                         f"trees, max_states {args.config5_max_states} (HBM: see --config5-max-states)")
     for name in legs:
         if name in extras:
             phases, roofline, group, roofline_input, rows = extras[name]
@@ -708,10 +926,16 @@ def main():
             results[name]["net_rows_per_step"] = rows
             if roofline_input:
                 results[name]["roofline_input_layer"] = roofline_input
-    result["roofline"] = results[legs[0]].get("roofline")
+    result["roofline"] = dict(results[legs[0]].get("roofline") or {})
     if not args.no_env_roofline and world == 1:
         torch.cuda.empty_cache()
         result["roofline_env"] = [r for log2n in (14, 20, 24, 26) for r in env_roofline(log2n)]
+        mr = [r for r in result["roofline_env"] if r["kernel"] == "multi_rotate" and r["units"] == 1 << 24][0]
+        # north_star's env target (>= 50 % of the HBM roofline for multi_rotate) next to the dominant kernel, where the driver keeps it
+        result["roofline"]["env_multi_rotate_2p24"] = {k: mr[k] for k in ("bound", "achieved", "peak", "frac", "traffic", "algorithmic_bytes", "ms")}
+        summary["multi_rotate_hbm_frac_2p24"] = mr["frac"]
+    if astar and "roofline" in astar.get("f32s", {}):
+        result["roofline"]["astar_dominant_kernel"] = {k: astar["f32s"]["roofline"][k] for k in ("kernel", "achieved", "peak", "frac", "ms_per_launch")}
     if not args.no_cpu_baseline and world == 1:
         result["cpu_baseline"] = cpu_baseline(model, args.depth)
     print(json.dumps(result))

@@ -34,7 +34,7 @@
 extern "C" {
 #endif
 
-#define RC_ABI_VERSION 3
+#define RC_ABI_VERSION 4
 
 #define RC_OK 0
 #define RC_ERR_NULL (-1)      /* required pointer is NULL */
@@ -314,6 +314,13 @@ typedef struct rc_mcts {
     /* per tree, [B]: 0 = ordinary iterations; 1 / 2 = first / second step of a planted root's own iteration (| 16: that
      * expansion found a solved child, reported as RC_MCTS_SOLVED when the second step has completed the tree) */
     int32_t *phase;
+    /* Optional (NULL = every tree, in order): the trees the per-iteration entry points work on.  Workgroup i serves tree
+     * active[i] (a negative entry = nobody) and that tree's network rows are 11 i .. 11 i + 10: rows are packed by POSITION in
+     * the list, not by tree index.  Dropping finished trees from a running batch is therefore a new list -- no tree moves in
+     * memory, whatever the capacity -- and the network runs on 11 n_active rows.  rc_mcts_complete_graph / rc_mcts_shorten
+     * read it the same way (the finished trees to post-process).  Device pointer, n_active <= n_trees entries. */
+    const int32_t *active;
+    uint32_t n_active;
 } rc_mcts_t;
 
 /* sizeof(rc_mcts_t) as the library was compiled: a binding that mirrors the struct (ctypes, cgo, JNI) checks its own

@@ -45,6 +45,8 @@ constexpr u32 kNoAct = 15;
 // A solved child found by the root's expansion is only reported (status) when ROOT_B has completed the tree.
 constexpr int kPhaseNormal = 0, kPhaseRootA = 1, kPhaseRootB = 2, kPhaseMask = 15, kPhaseSolved = 16;
 __device__ __forceinline__ u32 line_tag(u32 seq, int level, u32 act) { return (seq << 16) | ((u32)level << 4) | act; }
+// Tree served by workgroup `slot` (rc_mcts_t::active): -1 = nobody.  The tree's network rows are 11 slot .. 11 slot + 10.
+__device__ __forceinline__ int tree_of(const rc_mcts_t &m, u32 slot) { return m.active ? m.active[slot] : (int)slot; }
 
 // ---- plant: (re)start trees.  One workgroup per listed slot: hash table cleared, root = node 1, phase ROOT_A ------
 __global__ __launch_bounds__(kBlock) void k_mcts_plant(rc_mcts_t m, const int *__restrict__ slots, const u8 *__restrict__ roots,
@@ -95,13 +97,16 @@ __global__ __launch_bounds__(kWave) void k_mcts_expand(rc_mcts_t m, u32 max_stat
     stage_to_lds(s_lut, c_tables.lut, sizeof(kTables.lut));
     __syncthreads();
     const u8 *lut = reinterpret_cast<const u8 *>(s_lut);
-    const u32 t = blockIdx.x, lane = threadIdx.x;
+    const u32 slot = blockIdx.x, lane = threadIdx.x;
+    const int ti = tree_of(m, slot);
+    if (ti < 0) return;
+    const u32 t = (u32)ti;
     if (lane == 0) m.expanded[t] = 0;
     if (m.status[t] != RC_MCTS_RUNNING || m.pending[t]) return;   // a suspended descent has no leaf yet
     const int ph = m.phase[t] & kPhaseMask;
     const size_t base = (size_t)t * (m.capacity + 1);
     uint4 *keys = reinterpret_cast<uint4 *>(m.keys) + base;
-    const size_t col0 = (size_t)m.rows_per_tree * t;
+    const size_t col0 = (size_t)m.rows_per_tree * slot;
     if (ph == kPhaseRootB) {   // second half of the root's iteration: children 10 and 11 (nodes 12, 13) are evaluated now
         if (lane < 2) {
             const uint4 ck = keys[2 + 10 + lane];
@@ -239,12 +244,12 @@ __device__ __forceinline__ float net_row(const void *probs_or_head, const float 
 }
 
 template <bool HEAD>
-__device__ __forceinline__ float backup_children(const rc_mcts_t &m, u32 t, u32 lane, size_t base, int leaf, int ph,
+__device__ __forceinline__ float backup_children(const rc_mcts_t &m, u32 t, u32 slot, u32 lane, size_t base, int leaf, int ph,
                                                  const void *probs_or_head, const float *values, size_t ld, bool head_bf16) {
     const bool act = lane < kA;
     const u32 newm = m.new_mask[t];
     const int idx = act ? m.child_idx[(size_t)t * kA + lane] : 0;
-    const size_t row0 = (size_t)t * m.rows_per_tree;
+    const size_t row0 = (size_t)slot * m.rows_per_tree;
     // which children this step's rows hold: the new ones in child order -- or, for a root (all 12 new), 0..9 behind the
     // root's own row in ROOT_A and 10, 11 in ROOT_B
     const bool in_rows = ph == kPhaseRootA ? lane < 10 : ph == kPhaseRootB ? (act && lane >= 10) : (act && ((newm >> lane) & 1u));
@@ -311,7 +316,10 @@ template <bool HEAD>
 __global__ __launch_bounds__(kBlock) void k_mcts_backup(rc_mcts_t m, const void *__restrict__ probs_or_head,
                                                       const float *__restrict__ values, size_t ld, bool head_bf16) {
     __shared__ float s_best;
-    const u32 t = blockIdx.x, tid = threadIdx.x;
+    const u32 slot = blockIdx.x, tid = threadIdx.x;
+    const int ti = tree_of(m, slot);
+    if (ti < 0) return;
+    const u32 t = (u32)ti;
     if (!m.expanded[t]) return;
     const size_t base = (size_t)t * (m.capacity + 1);
     const int plen = m.path_len[t];
@@ -319,7 +327,7 @@ __global__ __launch_bounds__(kBlock) void k_mcts_backup(rc_mcts_t m, const void 
     const u8 *pact = m.path_act + (size_t)t * m.max_path;
     const int phase = m.phase[t];
     if (tid < kWave) {
-        const float best = backup_children<HEAD>(m, t, tid, base, pnode[plen - 1], phase & kPhaseMask, probs_or_head, values, ld, head_bf16);
+        const float best = backup_children<HEAD>(m, t, slot, tid, base, pnode[plen - 1], phase & kPhaseMask, probs_or_head, values, ld, head_bf16);
         if (tid == 0) s_best = best;
     }
     __syncthreads();
@@ -518,7 +526,10 @@ __global__ __launch_bounds__(kBlock) void k_mcts_select(rc_mcts_t m, double c, u
     u16 *s_latelist = reinterpret_cast<u16 *>(s_scratch), *s_unclist = s_latelist + kLateCap;
     int *s_seg = reinterpret_cast<int *>(s_scratch);               // [256] last lane per node bucket of a candidate segment ...
     uint2 *s_segent = reinterpret_cast<uint2 *>(s_scratch + 256);   // [64] ... and per lane {node, previous lane | action << 8 | rev(arrival) << 12}
-    const u32 t = blockIdx.x, tid = threadIdx.x;
+    const u32 slot = blockIdx.x, tid = threadIdx.x;
+    const int ti = tree_of(m, slot);
+    if (ti < 0) return;
+    const u32 t = (u32)ti;
     const bool running = m.status[t] == RC_MCTS_RUNNING;
     const bool backup = MODE > 0 && m.expanded[t];   // uniform over the workgroup
     if (!running && !backup) return;
@@ -533,7 +544,7 @@ __global__ __launch_bounds__(kBlock) void k_mcts_select(rc_mcts_t m, double c, u
     if (MODE == 0 && (phase & kPhaseMask) != kPhaseNormal) return;   // a root's first descent follows its backup in ROOT_B
     if (MODE > 0 && backup) {
         if (tid < kWave) {
-            const float best = backup_children<MODE == 2>(m, t, tid, base, pnode[plen_old - 1], phase & kPhaseMask, probs_or_head, values,
+            const float best = backup_children<MODE == 2>(m, t, slot, tid, base, pnode[plen_old - 1], phase & kPhaseMask, probs_or_head, values,
                                                            ld, head_bf16);
             if (tid == 0) s_best = best;
         }
@@ -955,7 +966,9 @@ __global__ __launch_bounds__(kBlock) void k_mcts_complete_graph(rc_mcts_t m) {
     stage_to_lds(s_lut, c_tables.lut, sizeof(kTables.lut));
     __syncthreads();
     const u8 *lut = reinterpret_cast<const u8 *>(s_lut);
-    const u32 t = blockIdx.x;
+    const int ti = tree_of(m, blockIdx.x);
+    if (ti < 0) return;
+    const u32 t = (u32)ti;
     if (m.status[t] != RC_MCTS_SOLVED) return;
     const size_t base = (size_t)t * (m.capacity + 1);
     const uint4 *keys = reinterpret_cast<const uint4 *>(m.keys) + base;
@@ -993,7 +1006,10 @@ __global__ __launch_bounds__(kBlock) void k_mcts_complete_graph(rc_mcts_t m) {
 __global__ __launch_bounds__(kBlock) void k_mcts_shorten(rc_mcts_t m) {
     __shared__ int s_scan[kBlock];
     __shared__ int s_base, s_done;
-    const u32 t = blockIdx.x, tid = threadIdx.x;
+    const u32 tid = threadIdx.x;
+    const int ti = tree_of(m, blockIdx.x);
+    if (ti < 0) return;
+    const u32 t = (u32)ti;
     if (tid == 0) m.short_len[t] = -1;
     if (m.status[t] != RC_MCTS_SOLVED) return;
     const int solved = m.solved_idx[t];
@@ -1080,6 +1096,8 @@ __global__ __launch_bounds__(kBlock) void k_mcts_shorten(rc_mcts_t m) {
 
 using namespace rubiks;
 
+static inline unsigned mcts_grid(const rc_mcts_t *m) { return m->active ? m->n_active : m->n_trees; }
+
 static int check_mcts(const rc_mcts_t *m, bool results_only_ok = false) {
     RC_REQUIRE(m != nullptr, RC_ERR_NULL);
     RC_REQUIRE(m->keys && m->nbr && m->P && m->W && m->N && m->V && m->leaf && m->hash && m->n_nodes &&
@@ -1088,6 +1106,9 @@ static int check_mcts(const rc_mcts_t *m, bool results_only_ok = false) {
                    m->ring_len && m->phase,
                RC_ERR_NULL);
     RC_REQUIRE(m->n_trees > 0 && m->capacity >= 13 && m->max_path >= 2 && m->max_path <= (uint32_t)kMaxPath, RC_ERR_RANGE);
+    // the kernels address a tree's node records through 32-bit buffer resources: (capacity + 1) * 256 bytes must stay below 2^32
+    RC_REQUIRE(m->capacity < (1u << 24), RC_ERR_RANGE);
+    RC_REQUIRE(m->active == nullptr || (m->n_active >= 1 && m->n_active <= m->n_trees), RC_ERR_RANGE);
     RC_REQUIRE((m->hash_size & (m->hash_size - 1)) == 0 && m->hash_size >= 2 * (m->capacity + 1), RC_ERR_RANGE);
     RC_REQUIRE(aligned16(m->keys) && aligned16(m->rec) && aligned16(m->child_soa) && (m->child_stride & 15u) == 0, RC_ERR_ALIGN);
     if (results_only_ok && m->node_words == (uint32_t)kA) {
@@ -1101,7 +1122,7 @@ static int check_mcts(const rc_mcts_t *m, bool results_only_ok = false) {
     }
     RC_REQUIRE(m->rows_per_tree == 11, RC_ERR_RANGE);
     RC_REQUIRE(m->ring_k >= 1 && m->ring_k <= 64 && (m->ring_k & (m->ring_k - 1)) == 0, RC_ERR_RANGE);
-    RC_REQUIRE(m->child_stride >= round_up((size_t)m->n_trees * m->rows_per_tree, 16), RC_ERR_STRIDE);
+    RC_REQUIRE(m->child_stride >= round_up((size_t)mcts_grid(m) * m->rows_per_tree, 16), RC_ERR_STRIDE);
     return RC_OK;
 }
 
@@ -1123,14 +1144,14 @@ int rc_mcts_plant(const rc_mcts_t *m, const int32_t *slots, uint32_t n_slots, co
 
 int rc_mcts_expand(const rc_mcts_t *m, uint32_t max_states, rc_stream_t stream) {
     if (int rc = check_mcts(m)) return rc;
-    hipLaunchKernelGGL(k_mcts_expand, dim3(m->n_trees), dim3(kWave), 0, (hipStream_t)stream, *m, max_states);
+    hipLaunchKernelGGL(k_mcts_expand, dim3(mcts_grid(m)), dim3(kWave), 0, (hipStream_t)stream, *m, max_states);
     return launch_status();
 }
 
 int rc_mcts_backup(const rc_mcts_t *m, const float *probs, const float *values, rc_stream_t stream) {
     if (int rc = check_mcts(m)) return rc;
     RC_REQUIRE(probs && values, RC_ERR_NULL);
-    hipLaunchKernelGGL(k_mcts_backup<false>, dim3(m->n_trees), dim3(kBlock), 0, (hipStream_t)stream, *m, (const void *)probs,
+    hipLaunchKernelGGL(k_mcts_backup<false>, dim3(mcts_grid(m)), dim3(kBlock), 0, (hipStream_t)stream, *m, (const void *)probs,
                        values, (size_t)0, false);
     return launch_status();
 }
@@ -1139,28 +1160,28 @@ int rc_mcts_backup_head(const rc_mcts_t *m, const void *head, size_t ld, int hea
     if (int rc = check_mcts(m)) return rc;
     RC_REQUIRE(head != nullptr, RC_ERR_NULL);
     RC_REQUIRE(ld >= (size_t)kActions + 1, RC_ERR_RANGE);
-    hipLaunchKernelGGL(k_mcts_backup<true>, dim3(m->n_trees), dim3(kBlock), 0, (hipStream_t)stream, *m, head,
+    hipLaunchKernelGGL(k_mcts_backup<true>, dim3(mcts_grid(m)), dim3(kBlock), 0, (hipStream_t)stream, *m, head,
                        (const float *)nullptr, ld, head_is_bf16 != 0);
     return launch_status();
 }
 
 int rc_mcts_complete_graph(const rc_mcts_t *m, rc_stream_t stream) {
     if (int rc = check_mcts(m, true)) return rc;
-    const unsigned split = m->n_trees >= 512 ? 1 : m->n_trees >= 64 ? 8 : 32;
-    hipLaunchKernelGGL(k_mcts_complete_graph, dim3(m->n_trees, split), dim3(kBlock), 0, (hipStream_t)stream, *m);
+    const unsigned n = mcts_grid(m), split = n >= 512 ? 1 : n >= 64 ? 8 : 32;
+    hipLaunchKernelGGL(k_mcts_complete_graph, dim3(n, split), dim3(kBlock), 0, (hipStream_t)stream, *m);
     return launch_status();
 }
 
 int rc_mcts_shorten(const rc_mcts_t *m, rc_stream_t stream) {
     if (int rc = check_mcts(m, true)) return rc;
     RC_REQUIRE(m->bfs && m->short_act && m->short_len, RC_ERR_NULL);
-    hipLaunchKernelGGL(k_mcts_shorten, dim3(m->n_trees), dim3(kBlock), 0, (hipStream_t)stream, *m);
+    hipLaunchKernelGGL(k_mcts_shorten, dim3(mcts_grid(m)), dim3(kBlock), 0, (hipStream_t)stream, *m);
     return launch_status();
 }
 
 int rc_mcts_select(const rc_mcts_t *m, double c, uint32_t level_budget, rc_stream_t stream) {
     if (int rc = check_mcts(m)) return rc;
-    hipLaunchKernelGGL(k_mcts_select<0>, dim3(m->n_trees), dim3(kBlock), 0, (hipStream_t)stream, *m, c, level_budget,
+    hipLaunchKernelGGL(k_mcts_select<0>, dim3(mcts_grid(m)), dim3(kBlock), 0, (hipStream_t)stream, *m, c, level_budget,
                        (const void *)nullptr, (const float *)nullptr, (size_t)0, false);
     return launch_status();
 }
@@ -1169,7 +1190,7 @@ int rc_mcts_backup_select(const rc_mcts_t *m, const float *probs, const float *v
                           rc_stream_t stream) {
     if (int rc = check_mcts(m)) return rc;
     RC_REQUIRE(probs && values, RC_ERR_NULL);
-    hipLaunchKernelGGL(k_mcts_select<1>, dim3(m->n_trees), dim3(kBlock), 0, (hipStream_t)stream, *m, c, level_budget,
+    hipLaunchKernelGGL(k_mcts_select<1>, dim3(mcts_grid(m)), dim3(kBlock), 0, (hipStream_t)stream, *m, c, level_budget,
                        (const void *)probs, values, (size_t)0, false);
     return launch_status();
 }
@@ -1179,7 +1200,7 @@ int rc_mcts_backup_select_head(const rc_mcts_t *m, const void *head, size_t ld, 
     if (int rc = check_mcts(m)) return rc;
     RC_REQUIRE(head != nullptr, RC_ERR_NULL);
     RC_REQUIRE(ld >= (size_t)kActions + 1, RC_ERR_RANGE);
-    hipLaunchKernelGGL(k_mcts_select<2>, dim3(m->n_trees), dim3(kBlock), 0, (hipStream_t)stream, *m, c, level_budget, head,
+    hipLaunchKernelGGL(k_mcts_select<2>, dim3(mcts_grid(m)), dim3(kBlock), 0, (hipStream_t)stream, *m, c, level_budget, head,
                        (const float *)nullptr, ld, head_is_bf16 != 0);
     return launch_status();
 }

@@ -210,19 +210,23 @@ class _Harvest:
         buf = free.pop() if free else torch.empty((rows,) + tuple(t.shape[1:]), dtype=t.dtype, pin_memory=True)
         return buf
 
-    def __init__(self, agent, forest: md.MCTSForest, games: np.ndarray, n: int = None):
-        """n: only the first n trees of the forest are real (a partly filled results forest)."""
+    def __init__(self, agent, forest: md.MCTSForest, games: np.ndarray, n: int = None, trees: torch.Tensor = None):
+        """n: only the first n trees of the forest are real (a partly filled results forest).
+        trees: int32 device list -- only these (finished) trees of a forest that may still be running are turned into
+        results, where they lie; games[i] is the game of trees[i]."""
         self.games, self.graph = games, agent.search_graph
         src = {"status": forest.status, "nodes": forest.n_nodes, "iterations": forest.iterations,
                "plen": forest.path_len, "sol": forest.solved_action, "pact": forest.path_act}
         if self.graph:
-            forest.complete_graphs()       # _complete_graph of all solved trees in one launch
-            forest.shorten_launch()        # ... and their BFS shortening in another
+            forest.complete_graphs(trees)       # _complete_graph of all solved trees in one launch
+            forest.shorten_launch(trees)        # ... and their BFS shortening in another
             src["slen"], src["sact"] = forest.short_len, forest.short_act
-        self.host, self.n = {}, forest.B if n is None else n
+        self.host, self.n = {}, (forest.B if n is None else n) if trees is None else int(trees.numel())
+        pick = None if trees is None else trees.long()
         for name, t in src.items():
-            self.host[name] = self._host_like(t[:self.n])
-            self.host[name][:self.n].copy_(t[:self.n], non_blocking=True)
+            part = t[:self.n] if pick is None else t[pick]
+            self.host[name] = self._host_like(part)
+            self.host[name][:self.n].copy_(part, non_blocking=True)
         self.event = torch.cuda.Event()
         self.event.record()
         self.forest = forest   # keeps the buffers alive until the copies have landed
@@ -258,7 +262,6 @@ class MCTS(DeepAgent):
 
     nu = 100
     refill_level_budget = 0    # new levels per descent and iteration while scrambles wait for a slot (0 = no limit)
-    compact_min = 32           # smallest forest that is still compacted when half of its trees have finished
 
     def __init__(self, net, c: float, search_graph: bool, net_dtype=torch.bfloat16, use_graph: bool = True,
                  max_path: int = 4096, sync_every: int = 16, level_budget="auto"):
@@ -315,9 +318,9 @@ class MCTS(DeepAgent):
         slots: run at most this many trees at a time and give the places of finished trees to the scrambles
         still waiting (continuous batching): the GPU stays full until the last games instead of idling on the
         stragglers of every batch.  Per-game results are those of a plain batch (trees are independent).
-        compact: once nobody is waiting and at most half of the trees of a forest (of `compact_min` trees or more)
-        are still running, the finished ones are harvested and the forest is compacted to the running trees, so
-        the stragglers continue on small batches instead of paying full-size network calls.
+            compact: once nobody is waiting, finished trees are dropped from the launches as the running ones become fewer
+        (`MCTSForest.set_active`: a shorter list of trees, nothing moves in memory), so the stragglers continue on small
+        network batches; the finished trees are turned into results where they lie, on a side stream.
         """
         run = self.start_batch(states, time_limit, max_states, compact=compact, slots=slots)
         assert max_iterations is None or run.S == run.n_games, "max_iterations applies to lock-step batches only"
@@ -375,12 +378,15 @@ class MCTSRun:
     per-game BatchResult.  All trees of the forest advance together, `sync_every` iterations per round; the host
     never waits for the round it has just queued: it reads the tree states of the PREVIOUS round (an asynchronous
     copy into pinned memory) while the GPU works on the current one, so the launch queue never runs dry.
-    Finished trees are copied out of the forest (`subset`) and turned into results on a side stream; with
-    `slots` < games their places go to the scrambles still waiting (`plant`: one launch clears the slots' hash tables
-    and writes the new roots, which the next two iterations evaluate and expand in step with everybody else).  While
-    games are waiting, descents may be cut at the agent's
-    `refill_level_budget` new levels per iteration (0 = off, the default since descents follow lines: a budget
-    then costs more iterations than it saves time per iteration).
+    Finished trees are turned into results on a side stream.  With `slots` < games their places go to the scrambles
+    still waiting, so what result extraction reads of them is first copied into a results forest (`bury`), then `plant`
+    clears the slots' hash tables and writes the new roots, which the next two iterations evaluate and expand in step
+    with everybody else.  Once nobody is waiting the finished trees stay where they are: they are post-processed in place
+    (`_Harvest(trees=...)`) and dropped from the iteration launches by a shorter list of trees (`MCTSForest.set_active`),
+    so narrowing a forest costs nothing, whatever the per-tree capacity (copying the survivors of 1 024 trees of capacity
+    175 000, the reference's default max_states, took 0.55 s per halving).  While games are waiting, descents may be cut
+    at the agent's `refill_level_budget` new levels per iteration (0 = off, the default since descents follow lines: a
+    budget then costs more iterations than it saves time per iteration).
     """
 
     def __init__(self, agent: "MCTS", roots: DeviceCubes, time_limit: float, max_states: int, compact: bool, slots):
@@ -390,6 +396,7 @@ class MCTSRun:
         S = self.S = self.n_games if slots is None else max(1, min(int(slots), self.n_games))
         forest = self.forest = agent._forest_for(S, max(self.cap_states, 16))
         agent.tt.tick()
+        forest.set_active(None)
         forest.plant(None, roots, 0)       # the first S scrambles; the others move in as trees finish
         self.owner = np.arange(S)          # game index of every slot; -1 once its result has been taken and nobody moved in
         self.stale_until = np.full(S, -1)  # snapshots up to this index predate the tree that now lives in the slot
@@ -403,6 +410,7 @@ class MCTSRun:
         self.side = torch.cuda.Stream()
         self.harvests = []                 # _Harvest objects in flight
         self.grave, self.grave_fill, self.grave_event, self.grave_games = None, 0, None, None
+        self.resting = []                  # finished trees left in the forest, waiting for their (batched) result extraction
         self.parts = []                    # (game ids, BatchResult)
         agent._tree, agent._tree_src = None, None
         self.snapshots = deque()           # (index, forest, event, pinned status) of rounds nobody has looked at yet
@@ -432,6 +440,33 @@ class MCTSRun:
             h = _Harvest(self.agent, g, self.grave_games[:n].copy(), n=n)
         self.harvests.append(h)
         self.grave_event, self.grave_fill = h.event, 0
+
+    def _flush_resting(self):
+        """Result extraction of the finished trees left in the forest, where they lie: one launch sequence on the side stream."""
+        if not self.resting:
+            return
+        idx_np = np.concatenate(self.resting)
+        self.resting = []
+        forest = self.forest
+        trees = _to_device_async(idx_np.astype(np.int32), forest.status.device)
+        games = self.games_of_resting[idx_np].copy()
+        self.stats["flushes"] = self.stats.get("flushes", 0) + 1
+        ev = torch.cuda.Event()
+        ev.record()
+        with torch.cuda.stream(self.side):
+            self.side.wait_event(ev)
+            self.harvests.append(_Harvest(self.agent, forest, games, trees=trees))
+
+    def _rest(self, idx_np: np.ndarray):
+        """The finished trees `idx_np` are done with iterations and nobody needs their slots: they stay in the forest and are
+        turned into results GRAVE trees at a time (few, large launch sequences next to the running iterations: see _flush_grave)."""
+        if not hasattr(self, "games_of_resting"):
+            self.games_of_resting = np.full(self.forest.B, -1, dtype=np.int64)
+        self.games_of_resting[idx_np] = self.owner[idx_np]
+        if self.agent._tree_src is None and (self.owner[idx_np] == 0).any():   # game 0's tree stays inspectable, where it is
+            self.agent._tree_src = (self.forest, int(idx_np[self.owner[idx_np] == 0][0]))
+        self.resting.append(idx_np.copy())
+        self.stats["harvests"] += 1
 
     def _harvest(self, idx_np: np.ndarray):
         """Copies the finished trees `idx_np` out of the forest (their slots are needed or dropped): what result extraction
@@ -520,22 +555,25 @@ class MCTSRun:
             self.stats["refills"] += 1
             if self.next_game >= self.n_games:
                 forest.level_budget = self.base_budget   # nobody is waiting any more: strict lock step for the tail
-        elif not waiting and self.compact and forest.B >= self.agent.compact_min and n_run <= forest.B // 2:
+        elif not waiting and self.compact and forest.rung_for(n_run) < forest.G:
+            # fewer running trees than the next smaller launch size: the finished ones rest where they are, the iterations
+            # go on with a shorter list of trees (nothing is copied)
             if len(done):
-                self._harvest(done)
+                self._rest(done)
                 owner[done] = -1
-            keep_np = np.flatnonzero(owner >= 0)
-            keep = _to_device_async(keep_np, forest.status.device)
-            small = forest.subset(keep)
-            if forest is agent.forest:   # keep the full-size forest's buffers for the next search, drop its graph
-                forest._graph = None
-            self.forest, self.owner, self.stale_until = small, owner[keep_np], self.stale_until[keep_np]
+            forest.set_active(np.flatnonzero(owner >= 0))
             self.stats["compactions"] += 1
+            if sum(len(r) for r in self.resting) >= self.GRAVE:
+                self._flush_resting()
 
     def nodes_now(self) -> int:
         """Nodes in the trees currently in the forest plus those of the trees already harvested (synchronises)."""
         self._drain(True)
-        live = torch.from_numpy(self.owner >= 0).to(self.forest.n_nodes.device)
+        live = self.owner >= 0
+        if self.resting:
+            live = live.copy()
+            live[np.concatenate(self.resting)] = True
+        live = torch.from_numpy(live).to(self.forest.n_nodes.device)
         buried = int(self.grave.n_nodes[:self.grave_fill].sum().item()) if self.grave_fill else 0
         return int(self.forest.n_nodes[live].sum().item()) + buried + sum(int(r.nodes.sum()) for _, r in self.parts)
 
@@ -549,7 +587,8 @@ class MCTSRun:
             if agent._tree_src is None and (owner == 0).any():
                 agent._tree_src = (forest, int(np.flatnonzero(owner == 0)[0]))
         elif len(left):
-            self._harvest(left)
+            self._rest(left)
+        self._flush_resting()
         self._flush_grave()
         self._drain(True)
         result = BatchResult.merge(self.n_games, self.parts, seconds)

@@ -32,7 +32,8 @@ class _McStruct(Structure):   # mirrors rc_mcts_t (include/rubiks_hip.h)
                [("child_stride", c_size_t)] + \
                [(name, c_void_p) for name in ("child_idx", "new_mask", "expanded", "select_stats", "bfs", "short_act",
                                               "short_len", "rec")] + \
-               [("ring_k", c_uint32)] + [(name, c_void_p) for name in ("ring_node", "ring_act", "ring_len", "phase")]
+               [("ring_k", c_uint32)] + [(name, c_void_p) for name in ("ring_node", "ring_act", "ring_len", "phase", "active")] + \
+               [("n_active", c_uint32)]
 
 
 _hip.register({
@@ -65,9 +66,23 @@ _RESULT_NODE = ("keys", "nbr", "leaf")          # what rc_mcts_complete_graph / 
 _RESULT_TREE = ("n_nodes", "status", "solved_idx", "solved_action", "iterations", "path_len", "pending", "path_act", "phase")
 RING_K = 32   # descent paths kept per tree for line following (rc_mcts_t::ring_k)
 ROWS = 11    # network rows per tree and iteration (rc_mcts_t::rows_per_tree)
+MIN_RUNG = 32     # smallest launch size a running forest is narrowed to (32 trees = 352 network rows = one GEMM row tile)
 NODE_WORDS = 64   # 32-bit words per node record (RC_MCTS_NODE_WORDS): line 0 = N | W | walk record, line 1 = P | nbr
 _NODE_FIELDS = {"N": (0, 12, torch.int32), "W": (12, 24, torch.float32), "rec": (24, 28, torch.int32),
                 "P": (32, 44, torch.float32), "nbr": (44, 56, torch.int32)}
+
+
+def rungs(n_trees: int) -> list:
+    """Launch sizes a forest of n_trees is narrowed to as its trees finish (`MCTSForest.set_active`), largest first: n_trees,
+    then multiples of 32 trees (352 network rows, the row tile of the layer kernels) each at most 0.8 of the one before,
+    down to MIN_RUNG.  One HIP graph is captured per size and kept for the forest's lifetime."""
+    out = [int(n_trees)]
+    while out[-1] > MIN_RUNG:
+        nxt = max(MIN_RUNG, int(out[-1] * 0.8) // 32 * 32)
+        if nxt >= out[-1]:
+            break
+        out.append(nxt)
+    return out
 
 
 class MCTSForest:
@@ -79,7 +94,7 @@ class MCTSForest:
                                       "here: rebuild the library (make -C rl-rubiks_amd)")
         dev = device or torch.device("cuda", torch.cuda.current_device())
         B, C = int(n_trees), int(capacity)
-        assert B > 0 and C >= 13 and 2 <= max_path <= 4096
+        assert B > 0 and 13 <= C < (1 << 24) and 2 <= max_path <= 4096   # 32-bit buffer offsets inside a tree: < 2^24 nodes
         self.B, self.C, self.max_path, self.device = B, C, max_path, dev
         self.hash_size = 1 << int(np.ceil(np.log2(2 * (C + 1))))
         z = lambda shape, dt: torch.zeros(shape, dtype=dt, device=dev)   # noqa: E731
@@ -134,12 +149,19 @@ class MCTSForest:
         self.short_act = z((B, max_path), torch.uint8)
         self.short_len = z((B,), torch.int32)
         s.short_act, s.short_len = self.short_act.data_ptr(), self.short_len.data_ptr()
+        # The trees the iteration kernels work on (rc_mcts_t::active): position i of the list = workgroup i = network rows
+        # 11 i .. 11 i + 10.  Finished trees are dropped from a running batch by writing a shorter list (`set_active`); no tree
+        # moves in memory.  The buffer's address is baked into the captured graphs, its content and the launch size G are not.
+        self.active_buf = torch.arange(B, dtype=torch.int32, device=dev)
+        self.rungs = rungs(B)
+        self.G = B
+        s.active, s.n_active = self.active_buf.data_ptr(), B
         self.struct = s
         self.engine = None
         self._net_fp = None
         self._oh = None
-        self._graph = None
-        self._graph_key = None
+        self._graphs = {}          # (G, c, max_states, level budget) -> captured iteration
+        self._graph_pool = None    # one memory pool for all of them: they never run concurrently
 
     def subset(self, keep: torch.Tensor, results_only: bool = False) -> "MCTSForest":
         """
@@ -177,7 +199,38 @@ class MCTSForest:
 
     def bytes_allocated(self) -> int:
         return sum(t.numel() * t.element_size() for t in (self.keys, self.node, self.V, self.leaf, self.hash, self.path_node,
-                                                           self.path_act))
+                                                           self.path_act, self.ring_node, self.ring_act, self.ring_len))
+
+    # ---- which trees the iterations work on ---------------------------------------------------------
+    def rung_for(self, n: int) -> int:
+        """Smallest launch size of the ladder that holds n trees."""
+        return min((g for g in self.rungs if g >= n), default=self.rungs[0])
+
+    def set_active(self, trees: np.ndarray = None):
+        """The iterations from now on work on `trees` (indices, any order; None = all): the list is padded with -1 to the
+        ladder's next launch size G, the network runs on 11 G rows.  Stream-ordered (an asynchronous copy into the list the
+        kernels read), so it is safe between two iterations of a running forest."""
+        if trees is None:
+            self.active_buf.copy_(torch.arange(self.B, dtype=torch.int32, device=self.device))
+            self.G = self.B
+        else:
+            n = len(trees)
+            G = self.rung_for(n)
+            host = torch.full((G,), -1, dtype=torch.int32).pin_memory()
+            host[:n] = torch.from_numpy(np.ascontiguousarray(trees, dtype=np.int32))
+            self.active_buf[:G].copy_(host, non_blocking=True)
+            self._active_host = host   # alive until the copy has run
+            self.G = G
+        self.struct.n_active = self.G
+
+    def listed(self, trees: torch.Tensor) -> "_McStruct":
+        """A copy of the forest's struct whose `active` list is `trees` (int32 device tensor): for the result kernels, which
+        post-process the finished trees of a forest where they lie."""
+        assert trees.dtype == torch.int32 and trees.is_cuda and trees.is_contiguous() and 0 < trees.numel() <= self.B
+        s = _McStruct()
+        ctypes.memmove(ctypes.byref(s), ctypes.byref(self.struct), ctypes.sizeof(_McStruct))
+        s.active, s.n_active = trees.data_ptr(), int(trees.numel())
+        return s
 
     # ---- network ---------------------------------------------------------------------------------
     def set_net(self, net, dtype=torch.bfloat16):
@@ -193,13 +246,14 @@ class MCTSForest:
             self._x1 = self.engine.workspace(ROWS * self.B)
         else:
             self._oh = torch.empty((ROWS * self.B, 480), dtype=self.engine.input_dtype, device=self.device)
-        self._graph = None
+        self._graphs = {}
 
     rows_per_tree = ROWS
 
     def _net_input(self):
-        """(device cubes holding this iteration's network input, number of rows)."""
-        return self.children, ROWS * self.B
+        """(device cubes holding this iteration's network input, number of rows): the rows of the G listed trees."""
+        rows = ROWS * self.G
+        return (self.children if rows == self.children.n else DeviceCubes(self.children.soa, rows)), rows
 
     def _evaluate_children(self):
         """child_soa -> one-hot (HIP kernel) -> network -> softmax -> static probs / values buffers."""
@@ -217,6 +271,7 @@ class MCTSForest:
         """Empties every tree and plants root t = roots[t] as node 1 (agents.py:466-469); the roots are evaluated and
         expanded by the first two iterations (rc_mcts_t::phase)."""
         assert roots.n == self.B and self.engine is not None
+        self.set_active(None)
         self.plant(None, roots, 0)
 
     def plant(self, slots, roots: DeviceCubes, first: int = 0):
@@ -251,18 +306,22 @@ class MCTSForest:
         assert not self.results_only
         if not use_graph:
             return self._iteration(c, max_states)
-        key = (float(c), int(max_states), int(self.level_budget))
-        if self._graph is None or self._graph_key != key:
+        key = (self.G, float(c), int(max_states), int(self.level_budget))
+        g = self._graphs.get(key)
+        if g is None:
             # this call's iteration runs eagerly (hipBLASLt picks its kernels, the allocator settles);
-            # the capture that follows only records launches, it does not advance the search
+            # the capture that follows only records launches, it does not advance the search.  One graph per launch size,
+            # kept for the forest's lifetime: a later search on the same forest replays them from its first iteration on.
             self._iteration(c, max_states)
             torch.cuda.synchronize()
+            if self._graph_pool is None:
+                self._graph_pool = torch.cuda.graph_pool_handle()
             g = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g):
+            with torch.cuda.graph(g, pool=self._graph_pool):
                 self._iteration(c, max_states)
-            self._graph, self._graph_key = g, key
+            self._graphs[key] = g
             return
-        self._graph.replay()
+        g.replay()
 
     def any_running(self) -> bool:
         return bool((self.status == RUNNING).any().item())
@@ -301,16 +360,25 @@ class MCTSForest:
             np.add.at(L, (nodes[1:], acts ^ 1), 100.0)
         return L
 
-    def complete_graphs(self):
-        """_complete_graph of every solved tree, on the device (agents.py:597-611)."""
-        _hip.check(self.lib.rc_mcts_complete_graph(ctypes.byref(self.struct), _hip.stream_ptr()), "rc_mcts_complete_graph")
+    def _all_trees(self) -> "_McStruct":
+        s = _McStruct()
+        ctypes.memmove(ctypes.byref(s), ctypes.byref(self.struct), ctypes.sizeof(_McStruct))
+        s.active, s.n_active = None, self.B
+        return s
 
-    def shorten_launch(self):
-        """_shorten_action_queue of every solved tree on the device -> short_len[B] (-1 = keep the naive queue), short_act[B, max_path]."""
+    def complete_graphs(self, trees: torch.Tensor = None):
+        """_complete_graph of every solved tree (of `trees`, an int32 device list, if given), on the device (agents.py:597-611)."""
+        s = self._all_trees() if trees is None else self.listed(trees)
+        _hip.check(self.lib.rc_mcts_complete_graph(ctypes.byref(s), _hip.stream_ptr()), "rc_mcts_complete_graph")
+
+    def shorten_launch(self, trees: torch.Tensor = None):
+        """_shorten_action_queue of every solved tree (of `trees`) on the device -> short_len[B] (-1 = keep the naive queue),
+        short_act[B, max_path]."""
         if self.bfs is None:
             self.bfs = torch.zeros((self.B * (self.C + 1), 2), dtype=torch.int32, device=self.device)
             self.struct.bfs = self.bfs.data_ptr()
-        _hip.check(self.lib.rc_mcts_shorten(ctypes.byref(self.struct), _hip.stream_ptr()), "rc_mcts_shorten")
+        s = self._all_trees() if trees is None else self.listed(trees)
+        _hip.check(self.lib.rc_mcts_shorten(ctypes.byref(s), _hip.stream_ptr()), "rc_mcts_shorten")
 
     def shorten_queues(self):
         """shorten_launch + the two result arrays on the host."""

@@ -16,6 +16,23 @@ def shard_range(n_items: int, rank: int, world: int):
     return lo, lo + base + (1 if rank < extra else 0)
 
 
+def pick_backend(env: dict, n_devices: int, local_rank: int):
+    """
+    (torch.distributed backend, CUDA device index of this rank, device of the tensors handed to collectives).
+    Default: "nccl" (= RCCL on ROCm) with CUDA tensors and ONE GPU PER LOCAL RANK -- more local ranks than GPUs is an error,
+    two RCCL ranks cannot share a device.  RUBIKS_DIST_BACKEND=gloo rehearses the N > 1 code path with several ranks on
+    one GPU (or none): collectives on CPU tensors, ranks mapped onto the devices round robin.
+    """
+    backend = env.get("RUBIKS_DIST_BACKEND", "nccl")
+    if backend not in ("nccl", "gloo"):
+        raise ValueError(f"RUBIKS_DIST_BACKEND must be nccl or gloo, not {backend!r}")
+    if backend == "nccl":
+        if not 0 <= local_rank < n_devices:
+            raise RuntimeError(f"local rank {local_rank} has no GPU of its own ({n_devices} visible): one process per GPU")
+        return backend, local_rank, "cuda"
+    return backend, (local_rank % n_devices if n_devices else 0), "cpu"
+
+
 def gather_results(local: dict, n_total: int, device=None) -> dict:
     """
     all_gather of per-game result vectors.  `local` maps name -> 1-D array for this rank's games (in

@@ -98,7 +98,7 @@ def test_bench_two_ranks_aggregate_their_shares():
     """
     import socket
     common = ["--steps", "6", "--warmup", "2", "--trees", "48", "--pool-factor", "2", "--legs", "bf16", "--solve-max-states",
-              "1500", "--phase-reps", "0", "--no-cpu-baseline", "--no-env-roofline", "--prep-cap", "40"]
+              "1500", "--phase-reps", "0", "--no-cpu-baseline", "--no-env-roofline", "--prep-cap", "40", "--extra-legs", "none"]
     with socket.socket() as s:
         s.bind(("127.0.0.1", 0))
         port = s.getsockname()[1]

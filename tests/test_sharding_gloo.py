@@ -18,6 +18,23 @@ def test_shard_range_covers_everything():
             assert max(hi - lo for lo, hi in spans) - min(hi - lo for lo, hi in spans) <= 1
 
 
+def test_backend_choice():
+    """bench.py's process-group set-up: RCCL with one GPU per local rank by default, gloo only on request."""
+    import pytest
+    from librubiks.solving.sharding import pick_backend
+    assert pick_backend({}, 8, 0) == ("nccl", 0, "cuda")
+    assert pick_backend({}, 8, 7) == ("nccl", 7, "cuda")
+    with pytest.raises(RuntimeError):
+        pick_backend({}, 1, 1)          # two RCCL ranks cannot share one GPU
+    with pytest.raises(RuntimeError):
+        pick_backend({}, 0, 0)
+    assert pick_backend({"RUBIKS_DIST_BACKEND": "gloo"}, 1, 1) == ("gloo", 0, "cpu")
+    assert pick_backend({"RUBIKS_DIST_BACKEND": "gloo"}, 2, 3) == ("gloo", 1, "cpu")
+    assert pick_backend({"RUBIKS_DIST_BACKEND": "gloo"}, 0, 1) == ("gloo", 0, "cpu")
+    with pytest.raises(ValueError):
+        pick_backend({"RUBIKS_DIST_BACKEND": "mpi"}, 1, 0)
+
+
 def _worker(rank, world, port, n_games, q):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     dist.init_process_group("gloo", rank=rank, world_size=world)

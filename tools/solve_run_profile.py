@@ -46,7 +46,7 @@ def main():
         state["it"] += 1
         if state["it"] % agent.sync_every == 0:
             torch.cuda.synchronize()
-            log.append((state["it"], self.B, int((self.status == md.RUNNING).sum().item()), time.perf_counter() - state["t0"]))
+            log.append((state["it"], self.G, int((self.status == md.RUNNING).sum().item()), time.perf_counter() - state["t0"]))
         return r
 
     md.MCTSForest.step = step
@@ -54,8 +54,16 @@ def main():
     res = agent.search_batch(cubes, None, args.max_states)
     total = time.perf_counter() - state["t0"]
     md.MCTSForest.step = orig_step
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    res2 = agent.search_batch(cubes, None, args.max_states)   # the same search again: every launch size's graph is in the forest's cache
+    torch.cuda.synchronize()
+    again = time.perf_counter() - t0
     out["run"] = {"seconds_total": total, "seconds_search": res.seconds, "solved": float(res.solved.mean()),
                   "nodes": int(res.nodes.sum()), "iterations_max": int(res.iterations.max()),
+                  "second_run_seconds": again, "second_run_nodes_per_sec": float(res2.nodes.sum()) / again,
+                  "second_run_same_results": bool(np.array_equal(res.nodes, res2.nodes) and np.array_equal(res.lengths, res2.lengths)),
+                  "stats": {k: v for k, v in agent.refill_stats.items()},
                   "trajectory_it_B_running_t": log[:: max(1, len(log) // 60)] + [log[-1]]}
     print(json.dumps(out["run"]), flush=True)
     # (2) step time of small forests
