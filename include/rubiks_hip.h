@@ -180,6 +180,10 @@ int rc_oh_split_f16(const int8_t *soa, size_t n, size_t stride, uint16_t *out, r
  * the K = 960 GEMM + rc_split_act_f16 for the first layer (cube.py:265-277 + model.py:123-127,150-157 at fp32 accuracy). */
 int rc_first_layer_split_f16(const int8_t *soa, size_t n, size_t stride, const uint16_t *w_hi, const uint16_t *w_lo,
                              const float *bias, uint16_t *out_hi_lo, size_t H, int activation, float alpha, rc_stream_t stream);
+/* The same with the half-range flag of rc_split_layer_t: *range_flag |= 1 when an output is beyond +-65504 or not finite. */
+int rc_first_layer_split_flag_f16(const int8_t *soa, size_t n, size_t stride, const uint16_t *w_hi, const uint16_t *w_lo,
+                                  const float *bias, uint16_t *out_hi_lo, size_t H, int activation, float alpha,
+                                  int32_t *range_flag, rc_stream_t stream);
 int rc_split_act_f16(const float *c, const float *c_corr, float corr_scale, size_t n_rows, size_t n_cols, const float *bias,
                      int activation, float alpha, uint16_t *out_hi_lo, float *out_f32, rc_stream_t stream);
 
@@ -208,6 +212,49 @@ int rc_head_split_f32(const float *c, const float *c_corr, float corr_scale, siz
  * Replaces two library GEMMs + rc_split_act_f16; the fp32 partial matrices never reach HBM. */
 int rc_split_gemm_f16(const uint16_t *a_hi_lo, const uint16_t *w_lo_hi_hi, const float *bias, size_t n_rows, size_t n_out,
                       size_t k, int activation, float alpha, uint16_t *out_hi_lo, float *out_f32, int tile, rc_stream_t stream);
+
+/* The layer kernels above with every option, as one request (zero-initialise, then fill what applies):
+ *   y = post_scale * act(acc + bias + residual) + post_shift,   acc = the layer's products in fp32 on the matrix cores
+ * residual: the skip connection of the reference's NonConvResBlock (librubiks/model.py:221-247), in the format of the
+ * layer's own input ([n_rows][2 n_out] halves hi | lo; [n_rows][n_out] bf16 for rc_gemm_layer_bf16).  post_scale / post_shift
+ * ([n_out] floats, both or neither): an eval-mode BatchNorm1d BEHIND the activation that cannot be folded into the next
+ * Linear because a skip connection reads its output too (the last shared layer of the res_* architectures, model.py:249-264).
+ * range_flag (device int, optional): OR-ed with 1 when a value written to out_hi_lo leaves IEEE half's range (|y| > 65504, or
+ * not finite) -- the f16x3 split cannot carry it; librubiks.model.SplitF32Net then falls back to the fp32 GEMM chain.
+ * Exactly one output.  rc_split_layer_f16: out_hi_lo | out_f32 | out_partials; with out_partials the K loop (3 k / 64 steps) is
+ * cut into k_splits chunks (a divisor of 3 k / 64, 2 .. 32, n_out % 256 == 0), one workgroup per tile and chunk storing raw
+ * accumulators out_partials[k_splits][n_rows][n_out] (no bias / residual / activation): the first rc_split_layer_corr_chunks(k,
+ * k_splits) of them hold correction products only and still carry the factor 2^11, the others are in units of y
+ * (rc_split_reduce_f16 finishes the layer).  rc_gemm_layer_bf16: a, w, residual, out_bf16 in bf16, one product. */
+typedef struct rc_split_layer {
+    const uint16_t *a;          /* [n_rows][2 k] halves hi | lo        (bf16 layer: [n_rows][k]) */
+    const uint16_t *w;          /* [n_out][3 k] halves lo | hi | hi    (bf16 layer: [n_out][k]) */
+    const float *bias;          /* [n_out] */
+    const uint16_t *residual;   /* optional */
+    const float *post_scale, *post_shift;   /* optional */
+    uint16_t *out_hi_lo;        /* [n_rows][2 n_out] halves */
+    float *out_f32;             /* [n_rows][n_out] */
+    float *out_partials;        /* [k_splits][n_rows][n_out] */
+    uint16_t *out_bf16;         /* [n_rows][n_out] (rc_gemm_layer_bf16 only) */
+    size_t n_rows, n_out, k;
+    int activation;             /* RC_ACT_* */
+    float alpha;
+    int tile;                   /* 0 = choose (see rc_split_gemm_f16) */
+    int k_splits;               /* 0 / 1 = whole K per workgroup */
+    int32_t *range_flag;        /* optional */
+} rc_split_layer_t;
+size_t rc_split_layer_struct_bytes(void);
+int rc_split_layer_f16(const rc_split_layer_t *layer, rc_stream_t stream);
+int rc_gemm_layer_bf16(const rc_split_layer_t *layer, rc_stream_t stream);
+int rc_split_layer_corr_chunks(size_t k, int k_splits);   /* host only; -1 on a malformed request */
+/* Finishes a layer whose products came as partial sums (rc_split_layer_f16 with out_partials, or the two fp32 library GEMMs
+ * c_corr, c as partials[0], partials[1] with n_corr = 1):
+ *   y = post_scale * act(sum_{p >= n_corr} partials[p] + 2^-11 sum_{p < n_corr} partials[p] + bias + residual) + post_shift
+ * summed in the order p = 0, 1, ... (deterministic); partial p starts at partials + p * partial_stride floats.  Writes
+ * out_hi_lo ([n_rows][2 n_cols] halves) and / or out_f32; n_cols % 8 == 0.  residual, post_*, range_flag as above. */
+int rc_split_reduce_f16(const float *partials, size_t partial_stride, int n_partials, int n_corr, size_t n_rows, size_t n_cols,
+                        const float *bias, const uint16_t *residual_hi_lo, int activation, float alpha, const float *post_scale,
+                        const float *post_shift, uint16_t *out_hi_lo, float *out_f32, int32_t *range_flag, rc_stream_t stream);
 
 /* ---- network head: last activation + skinny output layer in one pass -----------------------------------------
  * out[i][o] = bias[o] + sum_k w[o][k] * act(x[i][k])   for o < n_out <= 16   (float out, row pitch 16)

@@ -46,10 +46,17 @@ struct GemmArgs {
     const unsigned char *a;      // activations [M][2K] halves: hi | lo                       (kBf16: [M][K] bf16)
     const unsigned char *w;      // weights [N][3K] halves: lo | hi | hi, as the K loop walks them  (kBf16: [N][K] bf16)
     const float *bias;
-    void *out;                   // [M][2N] halves (hi | lo), [M][N] fp32, [M][N] bf16, or the partials [2][M][N] fp32
+    void *out;                   // [M][2N] halves (hi | lo), [M][N] fp32, [M][N] bf16, or the partials [S][M][N] fp32
     u32 M, N, K;
     float alpha;
+    // optional epilogue inputs (NULL = absent):  y = post_scale * act(acc + bias + residual) + post_shift
+    const unsigned char *res;    // residual [M][2N] halves hi | lo (kBf16: [M][N] bf16): the skip connection of a NonConvResBlock (model.py:221-247)
+    const float *post_scale, *post_shift;   // [N]: an eval-mode BatchNorm BEHIND the activation that cannot be folded into the next
+                                            // Linear because a skip connection reads its output as well
+    int *flag;                   // kOutHalves: OR-ed with 1 when an output leaves IEEE half's range (|y| > 65504 or not finite)
+    u32 S;                       // kPartials: number of K chunks (workgroups per tile)
 };
+constexpr float kHalfMax = 65504.0f;
 
 template <int WM, int WN, int MR, int NR> struct GemmTile {
     static constexpr int BM = WM * MR * 16, BN = WN * NR * 16, WAVES = WM * WN, THREADS = WAVES * 64;
@@ -78,8 +85,8 @@ __global__ __launch_bounds__(WM *WN * 64) void k_split_gemm(GemmArgs g) {
     const u32 nwg = gridDim.x, nn = g.N / T::BN;
     const u32 xcd = blockIdx.x % 8, q = nwg / 8, r8 = nwg % 8;
     const u32 wg_all = (xcd < r8 ? xcd * (q + 1) : r8 * (q + 1) + (xcd - r8) * q) + blockIdx.x / 8;
-    const u32 n_tiles = KIND == kPartials ? nwg / 2 : nwg;
-    const u32 half = wg_all / n_tiles, wg = wg_all % n_tiles;   // kPartials: the first half of the (XCD-ordered) grid walks K-half 0
+    const u32 n_tiles = KIND == kPartials ? nwg / g.S : nwg;
+    const u32 half = wg_all / n_tiles, wg = wg_all % n_tiles;   // kPartials: K chunk `half` of S; the first n_tiles workgroups of the (XCD-ordered) grid walk chunk 0
     const u32 tm = wg / nn, tn = wg % nn;
     const size_t row0 = (size_t)tm * T::BM;
     const u32 col0 = tn * T::BN;
@@ -128,7 +135,7 @@ __global__ __launch_bounds__(WM *WN * 64) void k_split_gemm(GemmArgs g) {
         for (int n = 0; n < NR; ++n) acc[m][n] = f32x4{0.f, 0.f, 0.f, 0.f};
 
     const u32 nk_all = (KIND == kBf16 ? 1 : 3) * K / 64, scale_step = KIND == kBf16 ? 0xFFFFFFFFu : 2 * K / 64;
-    const u32 ks0 = KIND == kPartials ? half * (nk_all / 2) : 0u, nk = KIND == kPartials ? ks0 + nk_all / 2 : nk_all;
+    const u32 ks0 = KIND == kPartials ? half * (nk_all / g.S) : 0u, nk = KIND == kPartials ? ks0 + nk_all / g.S : nk_all;
     stage(ks0, 0);
     for (u32 ks = ks0; ks < nk; ++ks) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -166,6 +173,7 @@ __global__ __launch_bounds__(WM *WN * 64) void k_split_gemm(GemmArgs g) {
     // epilogue: lane holds columns cbase + 16 n + 4 fq + {0..3} of row rbase + 16 m + fr
     const u32 cbase = col0 + wc * NR * 16 + 4 * fq;
     float4 b4[NR];
+    bool out_of_range = false;
 #pragma unroll
     for (int n = 0; n < NR; ++n) b4[n] = KIND == kPartials ? make_float4(0.f, 0.f, 0.f, 0.f) : *reinterpret_cast<const float4 *>(g.bias + cbase + 16 * n);
 #pragma unroll
@@ -175,12 +183,33 @@ __global__ __launch_bounds__(WM *WN * 64) void k_split_gemm(GemmArgs g) {
 #pragma unroll
         for (int n = 0; n < NR; ++n) {
             float y[4] = {acc[m][n][0] + b4[n].x, acc[m][n][1] + b4[n].y, acc[m][n][2] + b4[n].z, acc[m][n][3] + b4[n].w};
+            const u32 col = cbase + 16 * n;
+            if (KIND != kPartials && g.res) {   // skip connection: the block's input, in the activations' own format
+                if (KIND == kBf16) {
+                    const uint2 r2 = *reinterpret_cast<const uint2 *>(g.res + (row * (size_t)g.N + col) * 2);
+                    y[0] += __uint_as_float(r2.x << 16), y[1] += __uint_as_float(r2.x & 0xffff0000u);
+                    y[2] += __uint_as_float(r2.y << 16), y[3] += __uint_as_float(r2.y & 0xffff0000u);
+                } else {
+                    const unsigned char *rrow = g.res + row * ((size_t)g.N * 4);
+                    const uint2 rh = *reinterpret_cast<const uint2 *>(rrow + col * 2), rl = *reinterpret_cast<const uint2 *>(rrow + ((size_t)g.N + col) * 2);
+                    const u32 hw[2] = {rh.x, rh.y}, lw[2] = {rl.x, rl.y};
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const float hi = (float)__builtin_bit_cast(_Float16, (unsigned short)(hw[e >> 1] >> (16 * (e & 1))));
+                        const float lo = (float)__builtin_bit_cast(_Float16, (unsigned short)(lw[e >> 1] >> (16 * (e & 1))));
+                        y[e] += hi + lo * (1.0f / kSplitScale);
+                    }
+                }
+            }
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
                 if (ACT == RC_ACT_RELU) y[e] = fmaxf(y[e], 0.f);
                 if (ACT == RC_ACT_ELU) y[e] = y[e] > 0.f ? y[e] : g.alpha * expm1_neg(y[e]);
             }
-            const u32 col = cbase + 16 * n;
+            if (KIND != kPartials && g.post_scale) {
+                const float4 ps = *reinterpret_cast<const float4 *>(g.post_scale + col), pt = *reinterpret_cast<const float4 *>(g.post_shift + col);
+                y[0] = y[0] * ps.x + pt.x, y[1] = y[1] * ps.y + pt.y, y[2] = y[2] * ps.z + pt.z, y[3] = y[3] * ps.w + pt.w;
+            }
             if (KIND == kPartials) {
                 float *orow = reinterpret_cast<float *>(g.out) + ((size_t)half * g.M + row) * (size_t)g.N;
                 *reinterpret_cast<float4 *>(orow + col) = make_float4(y[0], y[1], y[2], y[3]);
@@ -191,6 +220,7 @@ __global__ __launch_bounds__(WM *WN * 64) void k_split_gemm(GemmArgs g) {
                 float hi[4], lo[4];
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
+                    out_of_range |= !(fabsf(y[e]) <= kHalfMax);   // hi would be +-inf (or y is NaN): the caller falls back to fp32
                     hi[e] = round_to_half_f32(y[e]);
                     lo[e] = (y[e] - hi[e]) * kSplitScale;
                 }
@@ -203,6 +233,7 @@ __global__ __launch_bounds__(WM *WN * 64) void k_split_gemm(GemmArgs g) {
             }
         }
     }
+    if (KIND == kOutHalves && g.flag && out_of_range) atomicOr(g.flag, 1);
 }
 
 // The same tile with the two wave rows (waves 0-3 / 4-7: one of each per SIMD) running half a phase apart: a K-step is four
@@ -234,8 +265,8 @@ __global__ __launch_bounds__(512) void k_split_gemm_pp(GemmArgs g) {
     const u32 nwg = gridDim.x, nn = g.N / T::BN;
     const u32 xcd = blockIdx.x % 8, q = nwg / 8, r8 = nwg % 8;
     const u32 wg_all = (xcd < r8 ? xcd * (q + 1) : r8 * (q + 1) + (xcd - r8) * q) + blockIdx.x / 8;
-    const u32 n_tiles = KIND == kPartials ? nwg / 2 : nwg;
-    const u32 half = wg_all / n_tiles, wg = wg_all % n_tiles;   // kPartials: the first half of the (XCD-ordered) grid walks K-half 0
+    const u32 n_tiles = KIND == kPartials ? nwg / g.S : nwg;
+    const u32 half = wg_all / n_tiles, wg = wg_all % n_tiles;   // kPartials: K chunk `half` of S; the first n_tiles workgroups of the (XCD-ordered) grid walk chunk 0
     const u32 tm = wg / nn, tn = wg % nn;
     const size_t row0 = (size_t)tm * T::BM;
     const u32 col0 = tn * T::BN;
@@ -283,7 +314,7 @@ __global__ __launch_bounds__(512) void k_split_gemm_pp(GemmArgs g) {
         for (int n = 0; n < NR; ++n) acc[m][n] = f32x4{0.f, 0.f, 0.f, 0.f};
 
     const u32 nk_all = (KIND == kBf16 ? 1 : 3) * K / 64, scale_step = KIND == kBf16 ? 0xFFFFFFFFu : 2 * K / 64;
-    const u32 ks0 = KIND == kPartials ? half * (nk_all / 2) : 0u, nk = KIND == kPartials ? ks0 + nk_all / 2 : nk_all;
+    const u32 ks0 = KIND == kPartials ? half * (nk_all / g.S) : 0u, nk = KIND == kPartials ? ks0 + nk_all / g.S : nk_all;
     stage_part(ks0, 0, 0, T::PPW);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
@@ -353,6 +384,7 @@ __global__ __launch_bounds__(512) void k_split_gemm_pp(GemmArgs g) {
 
     const u32 cbase = col0 + wc * NR * 16 + 4 * fq;
     float4 b4[NR];
+    bool out_of_range = false;
 #pragma unroll
     for (int n = 0; n < NR; ++n) b4[n] = KIND == kPartials ? make_float4(0.f, 0.f, 0.f, 0.f) : *reinterpret_cast<const float4 *>(g.bias + cbase + 16 * n);
 #pragma unroll
@@ -362,12 +394,33 @@ __global__ __launch_bounds__(512) void k_split_gemm_pp(GemmArgs g) {
 #pragma unroll
         for (int n = 0; n < NR; ++n) {
             float y[4] = {acc[m][n][0] + b4[n].x, acc[m][n][1] + b4[n].y, acc[m][n][2] + b4[n].z, acc[m][n][3] + b4[n].w};
+            const u32 col = cbase + 16 * n;
+            if (KIND != kPartials && g.res) {   // skip connection: the block's input, in the activations' own format
+                if (KIND == kBf16) {
+                    const uint2 r2 = *reinterpret_cast<const uint2 *>(g.res + (row * (size_t)g.N + col) * 2);
+                    y[0] += __uint_as_float(r2.x << 16), y[1] += __uint_as_float(r2.x & 0xffff0000u);
+                    y[2] += __uint_as_float(r2.y << 16), y[3] += __uint_as_float(r2.y & 0xffff0000u);
+                } else {
+                    const unsigned char *rrow = g.res + row * ((size_t)g.N * 4);
+                    const uint2 rh = *reinterpret_cast<const uint2 *>(rrow + col * 2), rl = *reinterpret_cast<const uint2 *>(rrow + ((size_t)g.N + col) * 2);
+                    const u32 hw[2] = {rh.x, rh.y}, lw[2] = {rl.x, rl.y};
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const float hi = (float)__builtin_bit_cast(_Float16, (unsigned short)(hw[e >> 1] >> (16 * (e & 1))));
+                        const float lo = (float)__builtin_bit_cast(_Float16, (unsigned short)(lw[e >> 1] >> (16 * (e & 1))));
+                        y[e] += hi + lo * (1.0f / kSplitScale);
+                    }
+                }
+            }
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
                 if (ACT == RC_ACT_RELU) y[e] = fmaxf(y[e], 0.f);
                 if (ACT == RC_ACT_ELU) y[e] = y[e] > 0.f ? y[e] : g.alpha * expm1_neg(y[e]);
             }
-            const u32 col = cbase + 16 * n;
+            if (KIND != kPartials && g.post_scale) {
+                const float4 ps = *reinterpret_cast<const float4 *>(g.post_scale + col), pt = *reinterpret_cast<const float4 *>(g.post_shift + col);
+                y[0] = y[0] * ps.x + pt.x, y[1] = y[1] * ps.y + pt.y, y[2] = y[2] * ps.z + pt.z, y[3] = y[3] * ps.w + pt.w;
+            }
             if (KIND == kPartials) {
                 float *orow = reinterpret_cast<float *>(g.out) + ((size_t)half * g.M + row) * (size_t)g.N;
                 *reinterpret_cast<float4 *>(orow + col) = make_float4(y[0], y[1], y[2], y[3]);
@@ -378,6 +431,7 @@ __global__ __launch_bounds__(512) void k_split_gemm_pp(GemmArgs g) {
                 float hi[4], lo[4];
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
+                    out_of_range |= !(fabsf(y[e]) <= kHalfMax);   // hi would be +-inf (or y is NaN): the caller falls back to fp32
                     hi[e] = round_to_half_f32(y[e]);
                     lo[e] = (y[e] - hi[e]) * kSplitScale;
                 }
@@ -390,6 +444,7 @@ __global__ __launch_bounds__(512) void k_split_gemm_pp(GemmArgs g) {
             }
         }
     }
+    if (KIND == kOutHalves && g.flag && out_of_range) atomicOr(g.flag, 1);
 }
 
 template <int MR, int NR, int ACT, int KIND> static int launch_split_gemm_pp(const GemmArgs &g, hipStream_t s) {
@@ -403,7 +458,7 @@ template <int MR, int NR, int ACT, int KIND> static int launch_split_gemm_pp(con
         if (e != hipSuccess) return hip_rc(e);
         attr_set.fetch_or(1ull << (dev & 63), std::memory_order_release);
     }
-    const u32 grid = (u32)(ceil_div((size_t)g.M, (size_t)T::BM) * (g.N / T::BN)) * (KIND == kPartials ? 2u : 1u);
+    const u32 grid = (u32)(ceil_div((size_t)g.M, (size_t)T::BM) * (g.N / T::BN)) * (KIND == kPartials ? g.S : 1u);
     hipLaunchKernelGGL((k_split_gemm_pp<MR, NR, ACT, KIND>), dim3(grid), dim3(T::THREADS), T::LDS_BYTES, s, g);
     return launch_status();
 }
@@ -427,7 +482,7 @@ template <int WM, int WN, int MR, int NR, int ACT, int KIND> static int launch_s
         if (e != hipSuccess) return hip_rc(e);
         attr_set.fetch_or(1ull << (dev & 63), std::memory_order_release);
     }
-    const u32 grid = (u32)(ceil_div((size_t)g.M, (size_t)T::BM) * (g.N / T::BN)) * (KIND == kPartials ? 2u : 1u);
+    const u32 grid = (u32)(ceil_div((size_t)g.M, (size_t)T::BM) * (g.N / T::BN)) * (KIND == kPartials ? g.S : 1u);
     hipLaunchKernelGGL((k_split_gemm<WM, WN, MR, NR, ACT, KIND>), dim3(grid), dim3(T::THREADS), T::LDS_BYTES, s, g);
     return launch_status();
 }
@@ -444,29 +499,57 @@ template <int WM, int WN, int MR, int NR, int KIND> static int dispatch_split_ge
 
 using namespace rubiks;
 
-extern "C" int rc_split_gemm_f16(const uint16_t *a_hi_lo, const uint16_t *w_lo_hi_hi, const float *bias, size_t n_rows, size_t n_out,
-                                 size_t k, int activation, float alpha, uint16_t *out_hi_lo, float *out_f32, int tile,
-                                 rc_stream_t stream) {
-    if (n_rows == 0) return RC_OK;
-    RC_REQUIRE(a_hi_lo && w_lo_hi_hi && bias && ((out_hi_lo != nullptr) != (out_f32 != nullptr)), RC_ERR_NULL);
-    RC_REQUIRE(aligned16(a_hi_lo) && aligned16(w_lo_hi_hi) && aligned16(bias) && aligned16(out_hi_lo) && aligned16(out_f32), RC_ERR_ALIGN);
-    RC_REQUIRE(k >= 64 && k % 64 == 0 && k <= (1u << 16) && n_out % 128 == 0 && n_rows < (1ull << 31) && n_out < (1u << 20) &&
-                   activation >= RC_ACT_NONE && activation <= RC_ACT_ELU && tile >= 0 && tile <= 4, RC_ERR_RANGE);
+// Fills the epilogue options every entry point shares; returns RC_OK or the error of a malformed request.
+static int layer_args(const rc_split_layer_t *L, GemmArgs &g) {
+    RC_REQUIRE(L != nullptr, RC_ERR_NULL);
+    RC_REQUIRE(L->a && L->w, RC_ERR_NULL);
+    RC_REQUIRE(aligned16(L->a) && aligned16(L->w) && aligned16(L->bias) && aligned16(L->residual) && aligned16(L->post_scale) &&
+                   aligned16(L->post_shift) && aligned16(L->out_hi_lo) && aligned16(L->out_f32) && aligned16(L->out_partials) &&
+                   aligned16(L->out_bf16), RC_ERR_ALIGN);
+    RC_REQUIRE(L->k >= 64 && L->k % 64 == 0 && L->k <= (1u << 16) && L->n_out % 128 == 0 && L->n_rows < (1ull << 31) && L->n_out < (1u << 20) &&
+                   L->activation >= RC_ACT_NONE && L->activation <= RC_ACT_ELU, RC_ERR_RANGE);
+    RC_REQUIRE((L->post_scale == nullptr) == (L->post_shift == nullptr), RC_ERR_NULL);
+    g.a = (const unsigned char *)L->a;
+    g.w = (const unsigned char *)L->w;
+    g.bias = L->bias;
+    g.M = (u32)L->n_rows;
+    g.N = (u32)L->n_out;
+    g.K = (u32)L->k;
+    g.alpha = L->alpha;
+    g.res = (const unsigned char *)L->residual;
+    g.post_scale = L->post_scale;
+    g.post_shift = L->post_shift;
+    g.flag = L->range_flag;
+    g.S = 1;
+    return RC_OK;
+}
+
+extern "C" size_t rc_split_layer_struct_bytes(void) { return sizeof(rc_split_layer_t); }
+
+extern "C" int rc_split_layer_f16(const rc_split_layer_t *L, rc_stream_t stream) {
     GemmArgs g;
-    g.a = (const unsigned char *)a_hi_lo;
-    g.w = (const unsigned char *)w_lo_hi_hi;
-    g.bias = bias;
-    g.out = out_hi_lo ? (void *)out_hi_lo : (void *)out_f32;
-    g.M = (u32)n_rows;
-    g.N = (u32)n_out;
-    g.K = (u32)k;
-    g.alpha = alpha;
-    const bool split = out_hi_lo != nullptr;
-    // tile 0: choose -- the 352 x 256 tile when it fills the chip, else 352 x 128, else 176 x 128
-    const size_t row_tiles = ceil_div(n_rows, (size_t)352);
-    if (tile == 0) tile = (n_out % 256 == 0 && row_tiles * (n_out / 256) >= 192) ? 1 : (row_tiles * (n_out / 128) >= 192) ? 3 : 2;
-    RC_REQUIRE((tile != 1 && tile != 4) || n_out % 256 == 0, RC_ERR_RANGE);
+    if (int rc = layer_args(L, g)) return rc;
+    if (L->n_rows == 0) return RC_OK;
     hipStream_t s = (hipStream_t)stream;
+    const int outs = (L->out_hi_lo != nullptr) + (L->out_f32 != nullptr) + (L->out_partials != nullptr);
+    RC_REQUIRE(outs == 1 && L->out_bf16 == nullptr, RC_ERR_NULL);
+    if (L->out_partials) {   // K cut into k_splits chunks, raw accumulators: no epilogue inputs
+        const u32 S = (u32)L->k_splits, nk_all = 3 * g.K / 64;
+        RC_REQUIRE(L->k_splits >= 2 && L->k_splits <= 32 && nk_all % S == 0 && nk_all / S >= 2 && L->n_out % 256 == 0, RC_ERR_RANGE);
+        g.out = (void *)L->out_partials;
+        g.S = S;
+        g.bias = nullptr;
+        return launch_split_gemm<2, 4, 11, 4, RC_ACT_NONE, kPartials>(g, s);
+    }
+    RC_REQUIRE(L->bias != nullptr && L->k_splits <= 1 && L->tile >= 0 && L->tile <= 4, RC_ERR_RANGE);
+    g.out = L->out_hi_lo ? (void *)L->out_hi_lo : (void *)L->out_f32;
+    const bool split = L->out_hi_lo != nullptr;
+    int tile = L->tile;
+    // tile 0: choose -- the 352 x 256 tile when it fills the chip, else 352 x 128, else 176 x 128
+    const size_t row_tiles = ceil_div(L->n_rows, (size_t)352);
+    if (tile == 0) tile = (L->n_out % 256 == 0 && row_tiles * (L->n_out / 256) >= 192) ? 1 : (row_tiles * (L->n_out / 128) >= 192) ? 3 : 2;
+    RC_REQUIRE((tile != 1 && tile != 4) || L->n_out % 256 == 0, RC_ERR_RANGE);
+    const int activation = L->activation;
     if (tile == 1)   // 352 x 256
         return split ? dispatch_split_gemm<2, 4, 11, 4, kOutHalves>(g, activation, s) : dispatch_split_gemm<2, 4, 11, 4, kOutF32>(g, activation, s);
     if (tile == 3)   // 352 x 128
@@ -476,44 +559,55 @@ extern "C" int rc_split_gemm_f16(const uint16_t *a_hi_lo, const uint16_t *w_lo_h
     return split ? dispatch_split_gemm<1, 4, 11, 2, kOutHalves>(g, activation, s) : dispatch_split_gemm<1, 4, 11, 2, kOutF32>(g, activation, s);   // 176 x 128
 }
 
+// number of leading K chunks of an S-way cut that hold correction products only (their sum still carries the factor 2^11)
+extern "C" int rc_split_layer_corr_chunks(size_t k, int k_splits) {
+    if (k_splits < 1 || k % 64) return -1;
+    const size_t nk_all = 3 * k / 64, scale_step = 2 * k / 64, per = nk_all / (size_t)k_splits;
+    int n = 0;
+    for (int p = 0; p < k_splits; ++p) n += (p + 1) * per <= scale_step;
+    return n;
+}
+
+extern "C" int rc_split_gemm_f16(const uint16_t *a_hi_lo, const uint16_t *w_lo_hi_hi, const float *bias, size_t n_rows, size_t n_out,
+                                 size_t k, int activation, float alpha, uint16_t *out_hi_lo, float *out_f32, int tile,
+                                 rc_stream_t stream) {
+    RC_REQUIRE(a_hi_lo && w_lo_hi_hi && bias && ((out_hi_lo != nullptr) != (out_f32 != nullptr)), RC_ERR_NULL);
+    rc_split_layer_t L = {};
+    L.a = a_hi_lo, L.w = w_lo_hi_hi, L.bias = bias, L.n_rows = n_rows, L.n_out = n_out, L.k = k, L.activation = activation, L.alpha = alpha;
+    L.out_hi_lo = out_hi_lo, L.out_f32 = out_f32, L.tile = tile, L.k_splits = 1;
+    return rc_split_layer_f16(&L, stream);
+}
+
+extern "C" int rc_gemm_layer_bf16(const rc_split_layer_t *L, rc_stream_t stream) {
+    GemmArgs g;
+    if (int rc = layer_args(L, g)) return rc;
+    if (L->n_rows == 0) return RC_OK;
+    RC_REQUIRE(L->bias && L->out_bf16 && !L->out_hi_lo && !L->out_f32 && !L->out_partials, RC_ERR_NULL);
+    RC_REQUIRE(L->tile == 0 || L->tile == 1 || L->tile == 3, RC_ERR_RANGE);
+    g.out = (void *)L->out_bf16;
+    int tile = L->tile;
+    const size_t row_tiles = ceil_div(L->n_rows, (size_t)352);
+    if (tile == 0) tile = (L->n_out % 256 == 0 && row_tiles * (L->n_out / 256) >= 192) ? 1 : 3;
+    RC_REQUIRE(tile != 1 || L->n_out % 256 == 0, RC_ERR_RANGE);
+    hipStream_t s = (hipStream_t)stream;
+    if (tile == 1) return dispatch_split_gemm<2, 4, 11, 4, kBf16>(g, L->activation, s);
+    return dispatch_split_gemm<2, 4, 11, 2, kBf16>(g, L->activation, s);
+}
+
 extern "C" int rc_gemm_bias_act_bf16(const uint16_t *a, const uint16_t *w, const float *bias, size_t n_rows, size_t n_out, size_t k,
                                      int activation, float alpha, uint16_t *out, int tile, rc_stream_t stream) {
-    if (n_rows == 0) return RC_OK;
     RC_REQUIRE(a && w && bias && out, RC_ERR_NULL);
-    RC_REQUIRE(aligned16(a) && aligned16(w) && aligned16(bias) && aligned16(out), RC_ERR_ALIGN);
-    RC_REQUIRE(k >= 64 && k % 64 == 0 && k <= (1u << 16) && n_out % 128 == 0 && n_rows < (1ull << 31) && n_out < (1u << 20) &&
-                   activation >= RC_ACT_NONE && activation <= RC_ACT_ELU && (tile == 0 || tile == 1 || tile == 3), RC_ERR_RANGE);
-    GemmArgs g;
-    g.a = (const unsigned char *)a;
-    g.w = (const unsigned char *)w;
-    g.bias = bias;
-    g.out = (void *)out;
-    g.M = (u32)n_rows;
-    g.N = (u32)n_out;
-    g.K = (u32)k;
-    g.alpha = alpha;
-    const size_t row_tiles = ceil_div(n_rows, (size_t)352);
-    if (tile == 0) tile = (n_out % 256 == 0 && row_tiles * (n_out / 256) >= 192) ? 1 : 3;
-    RC_REQUIRE(tile != 1 || n_out % 256 == 0, RC_ERR_RANGE);
-    hipStream_t s = (hipStream_t)stream;
-    if (tile == 1) return dispatch_split_gemm<2, 4, 11, 4, kBf16>(g, activation, s);
-    return dispatch_split_gemm<2, 4, 11, 2, kBf16>(g, activation, s);
+    rc_split_layer_t L = {};
+    L.a = a, L.w = w, L.bias = bias, L.n_rows = n_rows, L.n_out = n_out, L.k = k, L.activation = activation, L.alpha = alpha;
+    L.out_bf16 = out, L.tile = tile, L.k_splits = 1;
+    return rc_gemm_layer_bf16(&L, stream);
 }
 
 extern "C" int rc_split_gemm_partials_f16(const uint16_t *a_hi_lo, const uint16_t *w_lo_hi_hi, size_t n_rows, size_t n_out, size_t k,
                                           float *out_partials, rc_stream_t stream) {
-    if (n_rows == 0) return RC_OK;
     RC_REQUIRE(a_hi_lo && w_lo_hi_hi && out_partials, RC_ERR_NULL);
-    RC_REQUIRE(aligned16(a_hi_lo) && aligned16(w_lo_hi_hi) && aligned16(out_partials), RC_ERR_ALIGN);
-    RC_REQUIRE(k >= 128 && k % 128 == 0 && k <= (1u << 16) && n_out % 256 == 0 && n_rows < (1ull << 31) && n_out < (1u << 20), RC_ERR_RANGE);
-    GemmArgs g;
-    g.a = (const unsigned char *)a_hi_lo;
-    g.w = (const unsigned char *)w_lo_hi_hi;
-    g.bias = nullptr;
-    g.out = (void *)out_partials;
-    g.M = (u32)n_rows;
-    g.N = (u32)n_out;
-    g.K = (u32)k;
-    g.alpha = 0.f;
-    return launch_split_gemm<2, 4, 11, 4, RC_ACT_NONE, kPartials>(g, (hipStream_t)stream);
+    RC_REQUIRE(k >= 128 && k % 128 == 0, RC_ERR_RANGE);
+    rc_split_layer_t L = {};
+    L.a = a_hi_lo, L.w = w_lo_hi_hi, L.n_rows = n_rows, L.n_out = n_out, L.k = k, L.out_partials = out_partials, L.k_splits = 2;
+    return rc_split_layer_f16(&L, stream);
 }

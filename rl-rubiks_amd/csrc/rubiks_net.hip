@@ -541,6 +541,72 @@ __global__ __launch_bounds__(kBlock) void k_split_act(const float4 *__restrict__
     }
 }
 
+// The general form: the layer's products arrive as n_partials partial sums (K chunks of rc_split_layer_f16, or the two library
+// GEMMs), the first n_corr of which still carry the factor 2^11; optional skip connection and post-activation affine; the
+// half-range flag of the split format (rc_split_layer_t in include/rubiks_hip.h).  Summation order p = 0, 1, ...: deterministic.
+template <int ACT>
+__global__ __launch_bounds__(kBlock) void k_split_reduce(const float4 *__restrict__ partials, size_t pstride4, int n_partials, int n_corr,
+                                                         size_t n_rows, size_t n_cols, const float4 *__restrict__ bias,
+                                                         const uint4 *__restrict__ res, float alpha, const float4 *__restrict__ post_scale,
+                                                         const float4 *__restrict__ post_shift, uint4 *__restrict__ out_hl,
+                                                         float4 *__restrict__ out_f32, int *__restrict__ flag) {
+    const size_t chunks = n_cols / 8;
+    bool out_of_range = false;
+    for (size_t idx = (size_t)blockIdx.x * kBlock + threadIdx.x; idx < n_rows * chunks; idx += (size_t)gridDim.x * kBlock) {
+        const size_t r = idx / chunks, ch = idx - r * chunks;
+        float y[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        for (int p = 0; p < n_partials; ++p) {
+            if (p == n_corr) {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) y[e] *= (1.0f / kSplitScale);
+            }
+            const float4 a0 = partials[p * pstride4 + idx * 2], a1 = partials[p * pstride4 + idx * 2 + 1];
+            y[0] += a0.x, y[1] += a0.y, y[2] += a0.z, y[3] += a0.w, y[4] += a1.x, y[5] += a1.y, y[6] += a1.z, y[7] += a1.w;
+        }
+        if (n_corr >= n_partials) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) y[e] *= (1.0f / kSplitScale);
+        }
+        const float4 b0 = bias[ch * 2], b1 = bias[ch * 2 + 1];
+        y[0] += b0.x, y[1] += b0.y, y[2] += b0.z, y[3] += b0.w, y[4] += b1.x, y[5] += b1.y, y[6] += b1.z, y[7] += b1.w;
+        if (res) {
+            const uint4 rh = res[r * (2 * chunks) + ch], rl = res[r * (2 * chunks) + chunks + ch];
+            const u32 hw[4] = {rh.x, rh.y, rh.z, rh.w}, lw[4] = {rl.x, rl.y, rl.z, rl.w};
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const float hi = (float)__builtin_bit_cast(_Float16, (unsigned short)(hw[e >> 1] >> (16 * (e & 1))));
+                const float lo = (float)__builtin_bit_cast(_Float16, (unsigned short)(lw[e >> 1] >> (16 * (e & 1))));
+                y[e] += hi + lo * (1.0f / kSplitScale);
+            }
+        }
+#pragma unroll
+        for (int e = 0; e < 8; ++e)
+            y[e] = ACT == RC_ACT_RELU ? fmaxf(y[e], 0.f) : ACT == RC_ACT_ELU ? (y[e] > 0.f ? y[e] : alpha * expm1f(y[e])) : y[e];
+        if (post_scale) {
+            const float4 s0 = post_scale[ch * 2], s1 = post_scale[ch * 2 + 1], t0 = post_shift[ch * 2], t1 = post_shift[ch * 2 + 1];
+            y[0] = y[0] * s0.x + t0.x, y[1] = y[1] * s0.y + t0.y, y[2] = y[2] * s0.z + t0.z, y[3] = y[3] * s0.w + t0.w;
+            y[4] = y[4] * s1.x + t1.x, y[5] = y[5] * s1.y + t1.y, y[6] = y[6] * s1.z + t1.z, y[7] = y[7] * s1.w + t1.w;
+        }
+        if (out_f32) {
+            out_f32[idx * 2] = make_float4(y[0], y[1], y[2], y[3]);
+            out_f32[idx * 2 + 1] = make_float4(y[4], y[5], y[6], y[7]);
+        }
+        if (out_hl) {
+            float hi[8], lo[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                out_of_range |= !(fabsf(y[e]) <= 65504.0f);
+                hi[e] = round_to_half_f32(y[e]);
+                lo[e] = (y[e] - hi[e]) * kSplitScale;
+            }
+            uint4 *row = out_hl + r * (2 * chunks);
+            row[ch] = make_uint4(pack_half2(hi[0], hi[1]), pack_half2(hi[2], hi[3]), pack_half2(hi[4], hi[5]), pack_half2(hi[6], hi[7]));
+            row[chunks + ch] = make_uint4(pack_half2(lo[0], lo[1]), pack_half2(lo[2], lo[3]), pack_half2(lo[4], lo[5]), pack_half2(lo[6], lo[7]));
+        }
+    }
+    if (flag && out_of_range) atomicOr(flag, 1);
+}
+
 // Last hidden activation + output layer of the split network in one pass (the fp32 counterpart of k_head):
 //   y = act(c + corr_scale * c_corr + bias_h)   [n][K] fp32, never written;   out[i][o] = bias_o[o] + sum_k w[o][k] y[i][k]
 // on the exact fp32 MFMA (v_mfma_f32_16x16x4_f32 == an fmaf chain).  One 16-row tile per workgroup pass, K split over the
@@ -624,9 +690,10 @@ template <int ACT, bool SPLIT>
 __global__ __launch_bounds__(kMfWaves * kWave) void k_first_layer_split(const u8 *__restrict__ soa, size_t n, size_t stride,
                                                                       const uint4 *__restrict__ w_hi, const uint4 *__restrict__ w_lo,
                                                                       const float *__restrict__ bias, u32 *__restrict__ out, u32 H,
-                                                                      u32 rows_per_block, float alpha) {
+                                                                      u32 rows_per_block, float alpha, int *__restrict__ range_flag) {
     extern __shared__ __attribute__((aligned(256))) unsigned char lds[];
     constexpr int kTables = SPLIT ? 2 : 1;
+    bool out_of_range = false;
     unsigned char *wslice = lds;                                                       // [kTables][64 slots][976 B]
     const u32 tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     uint4 *onehot = reinterpret_cast<uint4 *>(lds + kTables * kSpCols * kMfPitch);     // [kTables][9] A fragments: 1.0 / 2^-11 at position p
@@ -749,6 +816,7 @@ __global__ __launch_bounds__(kMfWaves * kWave) void k_first_layer_split(const u8
                         y[c] = ACT == RC_ACT_RELU ? fmaxf(x, 0.f) : ACT == RC_ACT_ELU ? (x > 0.f ? x : alpha * expm1_neg(x)) : x;
                         hi[c] = round_to_half_f32(y[c]);
                         lo[c] = (y[c] - hi[c]) * kSplitScale;
+                        out_of_range |= row < n && !(fabsf(y[c]) <= 65504.0f);
                     } else {
                         y[c] = act_apply(x, ACT, alpha);
                     }
@@ -764,6 +832,7 @@ __global__ __launch_bounds__(kMfWaves * kWave) void k_first_layer_split(const u8
                 }
             }
     }
+    if (SPLIT && range_flag && out_of_range) atomicOr(range_flag, 1);
 }
 
 extern "C" int rc_oh_split_f16(const int8_t *soa, size_t n, size_t stride, uint16_t *out, rc_stream_t stream) {
@@ -792,6 +861,29 @@ extern "C" int rc_split_act_f16(const float *c, const float *c_corr, float corr_
     else if (activation == RC_ACT_RELU) RC_LAUNCH_SPLIT(RC_ACT_RELU);
     else RC_LAUNCH_SPLIT(RC_ACT_NONE);
 #undef RC_LAUNCH_SPLIT
+    return launch_status();
+}
+
+extern "C" int rc_split_reduce_f16(const float *partials, size_t partial_stride, int n_partials, int n_corr, size_t n_rows, size_t n_cols,
+                                   const float *bias, const uint16_t *residual_hi_lo, int activation, float alpha, const float *post_scale,
+                                   const float *post_shift, uint16_t *out_hi_lo, float *out_f32, int32_t *range_flag, rc_stream_t stream) {
+    if (n_rows == 0 || n_cols == 0) return RC_OK;
+    RC_REQUIRE(partials && bias && (out_hi_lo || out_f32), RC_ERR_NULL);
+    RC_REQUIRE((post_scale == nullptr) == (post_shift == nullptr), RC_ERR_NULL);
+    RC_REQUIRE(aligned16(partials) && aligned16(bias) && aligned16(residual_hi_lo) && aligned16(post_scale) && aligned16(post_shift) &&
+                   aligned16(out_hi_lo) && aligned16(out_f32) && n_cols % 8 == 0 && partial_stride % 4 == 0, RC_ERR_ALIGN);
+    RC_REQUIRE(activation >= RC_ACT_NONE && activation <= RC_ACT_ELU && n_partials >= 1 && n_partials <= 64 && n_corr >= 0 &&
+                   n_corr <= n_partials && (n_partials == 1 || partial_stride >= n_rows * n_cols), RC_ERR_RANGE);
+    const dim3 grid(grid_for(n_rows * (n_cols / 8), kBlock, 256 * 16)), block(kBlock);
+    hipStream_t s = (hipStream_t)stream;
+#define RC_LAUNCH_RED(ACT)                                                                                                       \
+    hipLaunchKernelGGL(k_split_reduce<ACT>, grid, block, 0, s, (const float4 *)partials, partial_stride / 4, n_partials, n_corr, n_rows, \
+                       n_cols, (const float4 *)bias, (const uint4 *)residual_hi_lo, alpha, (const float4 *)post_scale,                \
+                       (const float4 *)post_shift, (uint4 *)out_hi_lo, (float4 *)out_f32, (int *)range_flag)
+    if (activation == RC_ACT_ELU) RC_LAUNCH_RED(RC_ACT_ELU);
+    else if (activation == RC_ACT_RELU) RC_LAUNCH_RED(RC_ACT_RELU);
+    else RC_LAUNCH_RED(RC_ACT_NONE);
+#undef RC_LAUNCH_RED
     return launch_status();
 }
 
@@ -824,6 +916,12 @@ extern "C" int rc_head_split_f32(const float *c, const float *c_corr, float corr
 extern "C" int rc_first_layer_split_f16(const int8_t *soa, size_t n, size_t stride, const uint16_t *w_hi, const uint16_t *w_lo,
                                         const float *bias, uint16_t *out_hi_lo, size_t H, int activation, float alpha,
                                         rc_stream_t stream) {
+    return rc_first_layer_split_flag_f16(soa, n, stride, w_hi, w_lo, bias, out_hi_lo, H, activation, alpha, nullptr, stream);
+}
+
+extern "C" int rc_first_layer_split_flag_f16(const int8_t *soa, size_t n, size_t stride, const uint16_t *w_hi, const uint16_t *w_lo,
+                                             const float *bias, uint16_t *out_hi_lo, size_t H, int activation, float alpha,
+                                             int32_t *range_flag, rc_stream_t stream) {
     if (n == 0) return RC_OK;
     RC_CHECK_SOA(soa, n, stride);
     RC_REQUIRE(w_hi && w_lo && bias && out_hi_lo, RC_ERR_NULL);
@@ -849,7 +947,7 @@ extern "C" int rc_first_layer_split_f16(const int8_t *soa, size_t n, size_t stri
             attr_set.fetch_or(1ull << (dev_ & 63), std::memory_order_release);                                        \
         }                                                                                                             \
         hipLaunchKernelGGL((k_first_layer_split<ACT, true>), grid, block, lds_bytes, s, (const u8 *)soa, n, stride, (const uint4 *)w_hi, \
-                           (const uint4 *)w_lo, bias, (u32 *)out_hi_lo, (u32)H, rows_per_block, alpha);               \
+                           (const uint4 *)w_lo, bias, (u32 *)out_hi_lo, (u32)H, rows_per_block, alpha, (int *)range_flag); \
     } while (0)
     if (activation == RC_ACT_ELU) RC_LAUNCH_SP(RC_ACT_ELU);
     else if (activation == RC_ACT_RELU) RC_LAUNCH_SP(RC_ACT_RELU);
@@ -875,7 +973,7 @@ extern "C" int rc_first_layer_mfma2_bf16(const int8_t *soa, size_t n, size_t str
     hipStream_t s = (hipStream_t)stream;
 #define RC_LAUNCH_M2(ACT)                                                                                             \
     hipLaunchKernelGGL((k_first_layer_split<ACT, false>), grid, block, lds_bytes, s, (const u8 *)soa, n, stride,     \
-                       (const uint4 *)w1_half, (const uint4 *)w1_half, bias, (u32 *)out, (u32)H, rows_per_block, alpha)
+                       (const uint4 *)w1_half, (const uint4 *)w1_half, bias, (u32 *)out, (u32)H, rows_per_block, alpha, (int *)nullptr)
     if (activation == RC_ACT_ELU) RC_LAUNCH_M2(RC_ACT_ELU);
     else if (activation == RC_ACT_RELU) RC_LAUNCH_M2(RC_ACT_RELU);
     else RC_LAUNCH_M2(RC_ACT_NONE);

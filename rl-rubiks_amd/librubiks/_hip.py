@@ -38,7 +38,13 @@ SIGNATURES = {
     "rc_act_bf16_inplace": [P, SZ, I, ctypes.c_float, P],
     "rc_oh_split_f16": [P, SZ, SZ, P, P],
     "rc_first_layer_split_f16": [P, SZ, SZ, P, P, P, P, SZ, I, ctypes.c_float, P],
+    "rc_first_layer_split_flag_f16": [P, SZ, SZ, P, P, P, P, SZ, I, ctypes.c_float, P, P],
     "rc_split_act_f16": [P, P, ctypes.c_float, SZ, SZ, P, I, ctypes.c_float, P, P, P],
+    "rc_split_reduce_f16": [P, SZ, I, I, SZ, SZ, P, P, I, ctypes.c_float, P, P, P, P, P, P],
+    "rc_split_layer_f16": [P, P],
+    "rc_gemm_layer_bf16": [P, P],
+    "rc_split_layer_corr_chunks": [SZ, I],
+    "rc_split_layer_struct_bytes": [],
     "rc_split_gemm_f16": [P, P, P, SZ, SZ, SZ, I, ctypes.c_float, P, P, I, P],
     "rc_gemm_bias_act_bf16": [P, P, P, SZ, SZ, SZ, I, ctypes.c_float, P, I, P],
     "rc_split_gemm_partials_f16": [P, P, SZ, SZ, SZ, P, P],
@@ -49,7 +55,7 @@ SIGNATURES = {
     "rc_first_layer_mfma_bf16": [P, SZ, SZ, P, P, P, SZ, I, ctypes.c_float, I, P],
     "rc_first_layer_mfma2_bf16": [P, SZ, SZ, P, P, P, SZ, I, ctypes.c_float, P],
 }
-_RESTYPES = {"rc_error_string": c_char_p}
+_RESTYPES = {"rc_error_string": c_char_p, "rc_split_layer_struct_bytes": c_size_t}
 
 _lib = None
 _initialised_devices = set()

@@ -12,8 +12,10 @@ bf16 (MFMA through hipBLASLt) or fp32, fixed-shape buffers so that a whole searc
 captured into a HIP graph.  The forward is the only dense contraction on the hot path; everything
 else is integer work in csrc/.
 """
+import ctypes
 import json
 import os
+import warnings
 from time import time
 
 import torch
@@ -383,6 +385,49 @@ class InferenceNet:
 
 SPLIT_SCALE = 2.0 ** 11
 F32_SPLIT = "f32_split"   # `net_dtype` value selecting SplitF32Net
+HALF_MAX = 65504.0
+
+
+class SplitRangeError(ValueError):
+    """The network does not fit the f16x3 split format (a folded weight beyond IEEE half's range)."""
+
+
+class _SplitLayer(ctypes.Structure):   # mirrors rc_split_layer_t (include/rubiks_hip.h)
+    _fields_ = [(n, ctypes.c_void_p) for n in ("a", "w", "bias", "residual", "post_scale", "post_shift", "out_hi_lo", "out_f32",
+                                               "out_partials", "out_bf16")] + \
+               [(n, ctypes.c_size_t) for n in ("n_rows", "n_out", "k")] + \
+               [("activation", ctypes.c_int), ("alpha", ctypes.c_float), ("tile", ctypes.c_int), ("k_splits", ctypes.c_int),
+                ("range_flag", ctypes.c_void_p)]
+
+
+def _ptr(t):
+    return None if t is None else t.data_ptr()
+
+
+_MM_OUT = [True]
+
+
+def _mm_f32(a: torch.Tensor, b: torch.Tensor, out: torch.Tensor):
+    """out = a @ b with f16 operands and fp32 accumulation / output (hipBLASLt), into a slice of a partials buffer."""
+    if _MM_OUT[0]:
+        try:
+            return torch.mm(a, b, out_dtype=torch.float32, out=out)
+        except (RuntimeError, TypeError, NotImplementedError):
+            _MM_OUT[0] = False   # this torch has no mm.dtype_out: one extra copy
+    out.copy_(torch.mm(a, b, out_dtype=torch.float32))
+    return out
+
+
+def _layer_call(fn_name: str, **kw):
+    """One rc_split_layer_t request (tensors by keyword, see the header) on the current stream."""
+    from librubiks import _hip
+    lib = _hip.lib()
+    if lib.rc_split_layer_struct_bytes() != ctypes.sizeof(_SplitLayer):
+        raise _hip.RubiksHipError("rc_split_layer_t differs between librubiks_hip.so and librubiks/model.py: rebuild the library")
+    L = _SplitLayer()
+    for name, v in kw.items():
+        setattr(L, name, _ptr(v) if isinstance(v, torch.Tensor) or v is None else v)
+    _hip.check(getattr(lib, fn_name)(ctypes.byref(L), _hip.stream_ptr()), fn_name)
 
 
 class SplitF32Net:
@@ -406,6 +451,25 @@ class SplitF32Net:
         self.layers, self.value_layers = self._split(ref.layers), self._split(ref.value_layers)
         self.flops_per_state = ref.flops_per_state
         self.n_out = ref.layers[-1][0].shape[0]
+        # Hidden activations travel as IEEE halves hi + lo 2^-11: a value beyond +-65504 (ELU is unbounded above; nets without
+        # BatchNorm, `he` initialisation, the first batches of training) would become hi = inf.  Every kernel that writes the
+        # split format ORs this device flag when that happens; the agents read it when they collect results (`overflowed`) and
+        # repeat the search on `fallback()`, the fp32 GEMM chain -- the answer is never silently wrong.
+        self.range_flag = torch.zeros(1, dtype=torch.int32, device=self.device)
+        self._model, self._fallback = model, None
+
+    def overflowed(self) -> bool:
+        """True if an activation left half range since the last call (reads and clears the device flag: synchronises)."""
+        hit = bool(self.range_flag.item())
+        if hit:
+            self.range_flag.zero_()
+        return hit
+
+    def fallback(self) -> "InferenceNet":
+        """The same network on the fp32 MFMA GEMM chain (1/16 of the f16 rate, no range limit)."""
+        if self._fallback is None:
+            self._fallback = InferenceNet(self._model, dtype=torch.float32, device=self.device)
+        return self._fallback
 
     @staticmethod
     def _split(layers):
@@ -416,7 +480,8 @@ class SplitF32Net:
                 assert act is None
                 out.append(("f32", W.float().contiguous(), b.float().contiguous()))
                 continue
-            assert bool(torch.isfinite(W).all()) and float(W.abs().max()) < 3.0e4, "weights outside IEEE half range"
+            if not (bool(torch.isfinite(W).all()) and float(W.abs().max()) < 3.0e4):
+                raise SplitRangeError(f"layer {i}: folded weights up to {float(W.abs().max()):.3g} do not fit IEEE half")
             assert W.shape[0] % 8 == 0
             hi = W.half()
             lo = ((W - hi.double()) * SPLIT_SCALE).half()
@@ -474,15 +539,15 @@ class SplitF32Net:
         oh = oh.float()
         return torch.cat([oh, oh * (1.0 / SPLIT_SCALE)], 1).half()   # exact: entries are 0, 1 and 2^-11
 
-    @staticmethod
-    def _act(c: torch.Tensor, corr, bias: torch.Tensor, code: int, alpha: float, split: bool) -> torch.Tensor:
-        """act(c + 2^-11 corr + bias) as [hi | lo] halves (split) or as fp32."""
+    def _act(self, part: torch.Tensor, n_corr: int, bias: torch.Tensor, code: int, alpha: float, split: bool) -> torch.Tensor:
+        """act(sum of the partial products + bias) as [hi | lo] halves (split) or as fp32.  part: [P, n, w] fp32, the first n_corr
+        of them correction products (still scaled by 2^11)."""
         from librubiks import _hip
-        n, w = c.shape
-        out = torch.empty((n, 2 * w), dtype=torch.float16, device=c.device) if split else torch.empty_like(c)
-        _hip.check(_hip.lib().rc_split_act_f16(c.data_ptr(), None if corr is None else corr.data_ptr(), 1.0 / SPLIT_SCALE, n, w,
-                                               bias.data_ptr(), code, alpha, out.data_ptr() if split else None,
-                                               None if split else out.data_ptr(), _hip.stream_ptr()), "rc_split_act_f16")
+        P, n, w = part.shape
+        out = torch.empty((n, 2 * w), dtype=torch.float16, device=part.device) if split else torch.empty((n, w), dtype=torch.float32, device=part.device)
+        _hip.check(_hip.lib().rc_split_reduce_f16(part.data_ptr(), n * w, P, n_corr, n, w, bias.data_ptr(), None, code, alpha, None, None,
+                                                  out.data_ptr() if split else None, None if split else out.data_ptr(),
+                                                  self.range_flag.data_ptr(), _hip.stream_ptr()), "rc_split_reduce_f16")
         return out
 
     fused_input = True   # the input layer as one MFMA kernel from the cube states (rc_first_layer_split_f16) when shapes allow
@@ -499,8 +564,9 @@ class SplitF32Net:
             assert lo % 16 == 0 and 0 <= lo and lo + n <= cubes.n
             cubes = _CubeWindow(cubes.soa.data_ptr() + lo, n, cubes.stride)
         out = torch.empty((cubes.n, 2 * H), dtype=torch.float16, device=self.device)
-        _hip.check(_hip.lib().rc_first_layer_split_f16(_soa_ptr(cubes), cubes.n, cubes.stride, Wh.data_ptr(), Wl.data_ptr(), b.data_ptr(),
-                                                       out.data_ptr(), H, code, alpha, _hip.stream_ptr()), "rc_first_layer_split_f16")
+        _hip.check(_hip.lib().rc_first_layer_split_flag_f16(_soa_ptr(cubes), cubes.n, cubes.stride, Wh.data_ptr(), Wl.data_ptr(), b.data_ptr(),
+                                                            out.data_ptr(), H, code, alpha, self.range_flag.data_ptr(), _hip.stream_ptr()),
+                   "rc_first_layer_split_flag_f16")
         return out
 
     def _forward_cubes(self, cubes, layers, lo: int = 0, n: int = None) -> torch.Tensor:
@@ -512,52 +578,50 @@ class SplitF32Net:
     @torch.no_grad()
     def _forward(self, a: torch.Tensor, layers, first: int = 0) -> torch.Tensor:
         """a: [n, 960] half operand of the input layer (or, with first = 1, its [hi | lo] output) -> fp32 [n, n_out]."""
+        from librubiks import _hip
         for i, layer in enumerate(layers):
             if i < first:
                 continue
             last_hidden = i == len(layers) - 2
-            corr = None
+            n = a.shape[0]
             if layer[0] == "in":
                 _, B, b, code, alpha = layer[:5]
-                c = torch.mm(a, B.t(), out_dtype=torch.float32)
+                part = torch.empty((1, n, B.shape[0]), dtype=torch.float32, device=a.device)
+                _mm_f32(a, B.t(), part[0])
+                n_corr = 0
             elif layer[0] == "hid":
                 _, Wh, B2, b, code, alpha, W3 = layer
-                K = Wh.shape[1]
-                tile = self._fused_tile(a.shape[0], Wh.shape[0], K) if self.fused_hidden else 0
-                if tile:
-                    from librubiks import _hip
-                    n, w = a.shape[0], Wh.shape[0]
+                K, w = Wh.shape[1], Wh.shape[0]
+                plan = self._layer_plan(n, layers, i)
+                if plan == "fused":   # one kernel: three products, bias, activation, re-split (or fp32 in front of the output layer)
                     out = torch.empty((n, w if last_hidden else 2 * w), dtype=torch.float32 if last_hidden else torch.float16, device=a.device)
-                    _hip.check(_hip.lib().rc_split_gemm_f16(a.data_ptr(), W3.data_ptr(), b.data_ptr(), n, w, K, code, alpha,
-                                                            None if last_hidden else out.data_ptr(), out.data_ptr() if last_hidden else None,
-                                                            tile, _hip.stream_ptr()), "rc_split_gemm_f16")
+                    _layer_call("rc_split_layer_f16", a=a, w=W3, bias=b, n_rows=n, n_out=w, k=K, activation=code, alpha=alpha,
+                                out_hi_lo=None if last_hidden else out, out_f32=out if last_hidden else None,
+                                tile=self._fused_tile(n, w, K), k_splits=1, range_flag=self.range_flag)
                     a = out
                     continue
                 nxt = layers[i + 1]
-                head_ok = last_hidden and self.fused_head and nxt[0] == "f32" and nxt[1].shape[0] <= 16 and Wh.shape[0] in (512, 1024)
-                if self._layer_plan(a.shape[0], layers, i) == "partials":
-                    # too narrow for 352 x 256 tiles to fill the chip: the own kernel with its K loop cut in two (twice the workgroups),
-                    # raw fp32 partials; c = partials[1] (main + the tail of the correction), c_corr = partials[0]
-                    from librubiks import _hip
-                    part = torch.empty((2, a.shape[0], Wh.shape[0]), dtype=torch.float32, device=a.device)
-                    _hip.check(_hip.lib().rc_split_gemm_partials_f16(a.data_ptr(), W3.data_ptr(), a.shape[0], Wh.shape[0], K, part.data_ptr(),
-                                                                     _hip.stream_ptr()), "rc_split_gemm_partials_f16")
-                    c, corr = part[1], part[0]
+                head_ok = last_hidden and self.fused_head and nxt[0] == "f32" and nxt[1].shape[0] <= 16 and w in (512, 1024)
+                part = torch.empty((2, n, w), dtype=torch.float32, device=a.device)
+                if plan == "partials":
+                    # too few tiles to fill the chip: the own kernel with its K loop cut in two (twice the workgroups), raw fp32
+                    # partials; partials[0] holds correction products only, partials[1] the rest (scaled inside) + the main product
+                    _layer_call("rc_split_layer_f16", a=a, w=W3, n_rows=n, n_out=w, k=K, out_partials=part, k_splits=2)
                 else:
-                    c = torch.mm(a[:, :K], Wh.t(), out_dtype=torch.float32)   # hi x hi
-                    corr = torch.mm(a, B2.t(), out_dtype=torch.float32)       # hi x lo + lo x hi, scaled by 2^11; added in the kernel below
+                    _mm_f32(a, B2.t(), part[0])          # hi x lo + lo x hi, scaled by 2^11
+                    _mm_f32(a[:, :K], Wh.t(), part[1])   # hi x hi
+                n_corr = 1
                 if head_ok:
                     # activation + the skinny output layer in one pass: the fp32 activations are never written (rc_head_split_f32)
-                    from librubiks import _hip
-                    out = torch.empty((a.shape[0], 16), dtype=torch.float32, device=a.device)
-                    _hip.check(_hip.lib().rc_head_split_f32(c.data_ptr(), corr.data_ptr(), 1.0 / SPLIT_SCALE, a.shape[0], Wh.shape[0],
+                    out = torch.empty((n, 16), dtype=torch.float32, device=a.device)
+                    _hip.check(_hip.lib().rc_head_split_f32(part[1].data_ptr(), part[0].data_ptr(), 1.0 / SPLIT_SCALE, n, w,
                                                             b.data_ptr(), code, alpha, nxt[1].data_ptr(), nxt[2].data_ptr(), nxt[1].shape[0],
                                                             out.data_ptr(), _hip.stream_ptr()), "rc_head_split_f32")
                     return out[:, :nxt[1].shape[0]]
             else:
                 _, W, b = layer
                 return torch.addmm(b, a, W.t())
-            a = self._act(c, corr, b, code, alpha, split=not last_hidden)   # the output layer takes plain fp32 activations
+            a = self._act(part, n_corr, b, code, alpha, split=not last_hidden)   # the output layer takes plain fp32 activations
         return a
 
     # ---- InferenceNet's interface --------------------------------------------------------------------------------
@@ -647,5 +711,11 @@ def make_inference_net(net, dtype=torch.bfloat16):
     if isinstance(net, (InferenceNet, SplitF32Net, GenericNet)):
         return net
     if isinstance(net, Model) and net.config.architecture.startswith("fc"):
-        return SplitF32Net(net) if dtype == F32_SPLIT else InferenceNet(net, dtype=dtype)
+        if dtype == F32_SPLIT:
+            try:
+                return SplitF32Net(net)
+            except SplitRangeError as e:   # the reference's fp32 forward has no such limit: run these weights on the fp32 GEMM chain
+                warnings.warn(f"SplitF32Net: {e}; using the fp32 GEMM chain for this network", RuntimeWarning)
+                return InferenceNet(net, dtype=torch.float32)
+        return InferenceNet(net, dtype=dtype)
     return GenericNet(net)

@@ -7,9 +7,10 @@ Search agents of the hot path with the reference's API (librubiks/solving/agents
 plus a batched entry point the reference lacks -- `search_batch(states, ...)` runs one tree per
 scramble in lock step on one MI355X; `search` is `search_batch` with a single tree.  The trees are
 built by the rc_mcts_* HIP kernels (csrc/rubiks_mcts.hip) with the reference's exact per-tree
-semantics; the network runs through librubiks.model.InferenceNet (bf16 MFMA by default,
-`net_dtype=torch.float32` for parity runs).
+semantics; the network runs through an engine of librubiks.model chosen by `net_dtype`: F32_SPLIT (the default: fp32
+accuracy, the reference's precision, on the f16 matrix cores), torch.bfloat16 (the fast engine) or torch.float32.
 """
+import warnings
 from collections import deque
 from time import perf_counter
 
@@ -18,7 +19,7 @@ import torch
 
 from librubiks import gpu, no_grad
 from librubiks.cube.device import DeviceCubes
-from librubiks.model import Model
+from librubiks.model import F32_SPLIT, Model, net_fingerprint
 from librubiks.solving import astar_device as ad
 from librubiks.solving import bfs_device as bd
 from librubiks.solving import mcts_device as md
@@ -49,9 +50,34 @@ class Agent:
 
 
 class DeepAgent(Agent):
+    """
+    Agents that evaluate a network.  `net_dtype` selects the inference engine (librubiks.model.make_inference_net): the default
+    F32_SPLIT is the reference's precision (its forward is fp32, agents.py:551-552) on the f16 matrix cores; torch.bfloat16 is the
+    fast engine, torch.float32 the plain fp32 GEMM chain.
+    """
+    net_dtype = F32_SPLIT
+
     def __init__(self, net):
         super().__init__()
         self.net = net
+        self._fp32_for = None   # (fingerprint of `net`, fp32 engine) once a search on the split engine left half range
+
+    def _search_net(self):
+        """What this search's engine is built from: `net`, or -- after a search on the f16x3 split engine saw an activation
+        beyond IEEE half's range -- the fp32 GEMM chain of exactly those weights."""
+        if self._fp32_for is not None and self._fp32_for[0] == net_fingerprint(self.net, self.net_dtype):
+            return self._fp32_for[1]
+        return self.net
+
+    def _overflowed(self, engine) -> bool:
+        """True if `engine` (the split engine) wrote an activation it cannot represent during the search just finished: the
+        caller repeats the search, which `_search_net` then runs in fp32.  Synchronises (call where results are collected)."""
+        if not (hasattr(engine, "overflowed") and engine.overflowed()):
+            return False
+        warnings.warn("SplitF32Net: a hidden activation left IEEE half's range (|x| > 65504) during this search; it is repeated "
+                      "on the fp32 GEMM chain, and so are later searches with these weights", RuntimeWarning)
+        self._fp32_for = (net_fingerprint(self.net, self.net_dtype), engine.fallback())
+        return True
 
     @classmethod
     def from_saved(cls, loc: str, use_best: bool, **kwargs):
@@ -223,6 +249,11 @@ class _Harvest:
             src["slen"], src["sact"] = forest.short_len, forest.short_act
         self.host, self.n = {}, (forest.B if n is None else n) if trees is None else int(trees.numel())
         pick = None if trees is None else trees.long()
+        # the list is read by kernels queued on THIS (side) stream; it was allocated under another one, whose allocator would hand
+        # the block out again the moment the caller drops it: it lives as long as this harvest, and the allocator is told as well
+        self.trees = trees
+        if trees is not None:
+            trees.record_stream(torch.cuda.current_stream())
         for name, t in src.items():
             part = t[:self.n] if pick is None else t[pick]
             self.host[name] = self._host_like(part)
@@ -253,7 +284,7 @@ class _Harvest:
                           h["iterations"].astype(np.int64), status)
         for name, t in self.host.items():
             self._pinned[(t.shape[0], tuple(t.shape[1:]), t.dtype)].append(t)
-        self.host, self.forest = None, None
+        self.host, self.forest, self.trees = None, None, None
         return out
 
 
@@ -263,7 +294,7 @@ class MCTS(DeepAgent):
     nu = 100
     refill_level_budget = 0    # new levels per descent and iteration while scrambles wait for a slot (0 = no limit)
 
-    def __init__(self, net, c: float, search_graph: bool, net_dtype=torch.bfloat16, use_graph: bool = True,
+    def __init__(self, net, c: float, search_graph: bool, net_dtype=F32_SPLIT, use_graph: bool = True,
                  max_path: int = 4096, sync_every: int = 16, level_budget="auto"):
         """
         max_path: longest PUCT descent a tree may make (the reference has no limit; a tree that would exceed it
@@ -303,7 +334,7 @@ class MCTS(DeepAgent):
             self.forest = None
             torch.cuda.empty_cache()
             f = self.forest = md.MCTSForest(n_trees, capacity, self.max_path)
-        f.set_net(self.net, self.net_dtype)   # every search: `net` may have been trained or replaced since the last one
+        f.set_net(self._search_net(), self.net_dtype)   # every search: `net` may have been trained or replaced since the last one
         f.level_budget = 0 if self.level_budget == "auto" else int(self.level_budget)
         return f
 
@@ -391,6 +422,7 @@ class MCTSRun:
 
     def __init__(self, agent: "MCTS", roots: DeviceCubes, time_limit: float, max_states: int, compact: bool, slots):
         self.agent, self.roots, self.time_limit, self.compact = agent, roots, time_limit, compact
+        self.max_states, self.slots = max_states, slots
         self.cap_states = int(max_states) if max_states < int(1e10) else DEFAULT_NODE_CAP
         self.n_games = roots.n
         S = self.S = self.n_games if slots is None else max(1, min(int(slots), self.n_games))
@@ -594,10 +626,15 @@ class MCTSRun:
         result = BatchResult.merge(self.n_games, self.parts, seconds)
         if self.next_game < self.n_games:   # games that never got a slot before the time limit: unsolved, nothing explored
             result.status[self.next_game:] = md.EXHAUSTED
+        self.done = True
+        if agent._overflowed(forest.engine):   # the split engine could not represent an activation: the same search in fp32
+            again = MCTSRun(agent, self.roots, self.time_limit, self.max_states, self.compact, self.slots)
+            while not again.done:
+                again.round()
+            return again.finish()
         agent._last_forest = forest
         agent._explored_states = int(result.nodes[0])
         agent.action_queue = result.queues[0]
-        self.done = True
         return result
 
 
@@ -608,7 +645,7 @@ class AStar(DeepAgent):
     `search_batch` runs one such search per scramble, all on one GPU; `search` is the batch of one.
     """
 
-    def __init__(self, net, lambda_: float, expansions: int, net_dtype=torch.bfloat16):
+    def __init__(self, net, lambda_: float, expansions: int, net_dtype=F32_SPLIT):
         super().__init__(net)
         self.lambda_, self.expansions, self.net_dtype = float(lambda_), int(expansions), net_dtype
         self.batch = None
@@ -630,7 +667,7 @@ class AStar(DeepAgent):
             self.batch = None
             torch.cuda.empty_cache()
             b = self.batch = ad.AStarBatch(n_problems, capacity, self.expansions)
-        b.set_net(self.net, self.net_dtype)   # every search: `net` may have been trained or replaced since the last one
+        b.set_net(self._search_net(), self.net_dtype)   # every search: `net` may have been trained or replaced since the last one
         return b
 
     @no_grad
@@ -649,6 +686,9 @@ class AStar(DeepAgent):
             if not batch.any_running() or self.tt.tock() >= time_limit:
                 break
         torch.cuda.synchronize()
+        if self._overflowed(batch.engine):   # the split engine could not represent an activation: the same search in fp32
+            return self.search_batch(roots, time_limit if time_limit < 1e10 else None, max_states if max_states < int(1e10) else None,
+                                     max_iterations)
         seconds = self.tt.tock()
         status = batch.status.cpu().numpy()
         nodes = batch.n_nodes.cpu().numpy().astype(np.int64)
@@ -696,7 +736,7 @@ class AStar(DeepAgent):
     def cost(self, states: np.ndarray, indeces: np.ndarray) -> np.ndarray:
         """lambda * G[indeces] - value_net(states) (agents.py:369-383), evaluated on the device net."""
         from librubiks.model import make_inference_net
-        eng = self.batch.engine if self.batch is not None else make_inference_net(self.net, self.net_dtype)
+        eng = self.batch.engine if self.batch is not None else make_inference_net(self._search_net(), self.net_dtype)
         oh = DeviceCubes.from_numpy(np.asarray(states)).as_oh(eng.input_dtype)
         h = -eng.value(oh).cpu().numpy().astype(np.float64)
         return self.lambda_ * np.asarray(self.G)[indeces] + h
@@ -789,21 +829,27 @@ class RandomSearch(_StepAgent):
 
 
 class _DeepStepAgent(_StepAgent, DeepAgent):
-    def __init__(self, net, net_dtype=torch.bfloat16):
+    def __init__(self, net, net_dtype=F32_SPLIT):
         DeepAgent.__init__(self, net)
         self.net_dtype, self._engine = net_dtype, None
 
     def reset(self, time_limit, max_states):
         from librubiks.model import make_inference_net
         out = Agent.reset(self, time_limit, max_states)
-        self._engine = make_inference_net(self.net, self.net_dtype)   # rebuilt per search: weights may have been trained
+        self._engine = make_inference_net(self._search_net(), self.net_dtype)   # rebuilt per search: weights may have been trained
         return out
+
+    def search_batch(self, states, time_limit: float = None, max_states: int = None) -> BatchResult:
+        res = _StepAgent.search_batch(self, states, time_limit, max_states)
+        if self._overflowed(self._engine):   # the split engine could not represent an activation: the same search in fp32
+            res = _StepAgent.search_batch(self, states, time_limit, max_states)
+        return res
 
 
 class PolicySearch(_DeepStepAgent):
     """Follows the policy head: greedy argmax of softmax(policy), or samples it (reference agents.py:132-151)."""
 
-    def __init__(self, net, sample_policy=False, net_dtype=torch.bfloat16):
+    def __init__(self, net, sample_policy=False, net_dtype=F32_SPLIT):
         super().__init__(net, net_dtype)
         self.sample_policy = sample_policy
 
@@ -847,7 +893,7 @@ class EGVM(DeepAgent):
     it; the workers of a game run in parallel on the device, games run one after another.
     """
 
-    def __init__(self, net, epsilon: float, workers: int, depth: int, net_dtype=torch.bfloat16):
+    def __init__(self, net, epsilon: float, workers: int, depth: int, net_dtype=F32_SPLIT):
         super().__init__(net)
         self.epsilon, self.workers, self.depth, self.net_dtype = epsilon, workers, depth, net_dtype
 
@@ -858,11 +904,19 @@ class EGVM(DeepAgent):
     def __str__(self):
         return f"EGVM (e={self.epsilon}, w={self.workers}, d={self.depth})"
 
-    @no_grad
     def search(self, state: np.ndarray, time_limit: float = None, max_states: int = None) -> bool:
+        rng = np.random.get_state()
+        ok = self._search(state, time_limit, max_states)
+        if self._overflowed(self._engine):   # the split engine could not represent an activation: the same search (same draws) in fp32
+            np.random.set_state(rng)
+            ok = self._search(state, time_limit, max_states)
+        return ok
+
+    @no_grad
+    def _search(self, state: np.ndarray, time_limit: float = None, max_states: int = None) -> bool:
         from librubiks.model import make_inference_net
         time_limit, max_states = self.reset(time_limit, max_states)
-        engine = make_inference_net(self.net, self.net_dtype)
+        engine = self._engine = make_inference_net(self._search_net(), self.net_dtype)
         self.tt.tick()
         cur = DeviceCubes.from_numpy(np.asarray(state)[None])
         if bool(cur.is_solved()[0]):

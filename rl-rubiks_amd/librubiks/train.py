@@ -92,6 +92,15 @@ class GradBuckets:
         self.left = list(self.sizes)
 
     def wait(self):
+        """All buckets summed over the ranks and divided by the world size.  A bucket whose parameters did not ALL receive a
+        gradient in this backward pass (a loss that uses one head only, a frozen or unused branch) never fired from the hooks:
+        it is reduced here -- every rank reaches this point with the same set of such buckets, because which parameters get a
+        gradient is a property of the graph, not of the data -- so no rank steps on un-summed gradients."""
+        if self.world > 1:
+            for b, left in enumerate(self.left):
+                if left > 0:
+                    self.works.append(dist.all_reduce(self.flats[b], op=dist.ReduceOp.SUM, async_op=True))
+                    self.left[b] = 0
         for w in self.works:
             w.wait()
         self.works = []

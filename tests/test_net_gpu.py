@@ -402,3 +402,81 @@ def test_split_engine_own_kernels_on_fc_big():
     e_split = max(err(ps[:1024], p64), err(vs[:1024], v64.reshape(-1)))
     e_f32 = max(err(p32, p64), err(v32.reshape(-1), v64.reshape(-1)))
     assert e_split <= 1.25 * e_f32 + 1e-7
+
+
+def _net_with_huge_activations(factor):
+    """fc_small whose second shared layer is scaled so that its ELU outputs are of order `factor` (BatchNorm behind it has
+    unit statistics, so the network stays a finite fp32 function)."""
+    from librubiks.model import Model, ModelConfig
+    torch.manual_seed(3)
+    net = Model.create(ModelConfig()).eval()
+    with torch.no_grad():
+        net.shared_net[3].weight.mul_(factor)
+    return net
+
+
+def test_split_engine_flags_activations_beyond_half_range():
+    """
+    The f16x3 split carries a value as IEEE halves hi + lo 2^-11: an activation beyond +-65504 cannot be represented.  Every
+    kernel that writes the format (input layer, own hidden-layer kernel at full batches, the reduce kernel behind library
+    GEMMs / K-split partials) must raise the engine's device flag; ordinary networks must not.  Weights beyond half range are
+    refused when the engine is built and make_inference_net falls back to fp32 with a warning.
+    """
+    from librubiks import cube
+    from librubiks.model import F32_SPLIT, InferenceNet, SplitF32Net, make_inference_net
+    np.random.seed(1)
+    big, _, _ = cube.scramble_batch(11264, 20, True)      # full batch: the fused kernels
+    small, _, _ = cube.scramble_batch(300, 20, True)      # small batch: library GEMMs + reduce kernel
+    mid, _, _ = cube.scramble_batch(5632, 20, True)       # K cut in two + reduce kernel
+    ok = SplitF32Net(_model())
+    for cubes in (big, mid, small):
+        ok.forward_cubes(cubes)
+    assert not ok.overflowed()
+    hot = SplitF32Net(_net_with_huge_activations(2.0e5))
+    for cubes in (big, mid, small):
+        assert not hot.overflowed()
+        p, v = hot.forward_cubes(cubes)
+        assert hot.overflowed() and not hot.overflowed()      # raised by this forward, cleared by the read
+        # what the fallback computes is the fp32 engine's answer, finite
+        pf, vf = hot.fallback().forward_cubes(cubes) if hot.fallback().supports_cubes else hot.fallback()(cubes.as_oh(torch.float32))
+        assert bool(torch.isfinite(pf).all()) and bool(torch.isfinite(vf).all())
+    # input layer alone: a first-layer bias beyond half range
+    net = _model()
+    with torch.no_grad():
+        net.shared_net[0].bias.add_(1.0e5)
+    eng = SplitF32Net(net)
+    eng._first_from_cubes(small, eng.layers)
+    assert eng.overflowed()
+    # weights that do not fit IEEE half: refused at build time, fp32 instead
+    with pytest.raises(Exception):
+        SplitF32Net(_net_with_huge_activations(1.0e7))
+    with pytest.warns(RuntimeWarning):
+        e = make_inference_net(_net_with_huge_activations(1.0e7), F32_SPLIT)
+    assert isinstance(e, InferenceNet) and e.dtype == torch.float32
+
+
+def test_agents_repeat_the_search_in_fp32_when_the_split_engine_overflows():
+    """The default engine of every deep agent is the split engine; when an activation leaves half range the agent warns and
+    returns what the fp32 engine returns -- tree for tree, queue for queue."""
+    import warnings
+    from librubiks import cube
+    from librubiks.model import F32_SPLIT, InferenceNet
+    from librubiks.solving.agents import MCTS, AStar, ValueSearch
+    np.random.seed(2)
+    cubes, _, _ = cube.scramble_batch(48, 6, True)
+    states = cubes.numpy()
+    net = _net_with_huge_activations(2.0e5)
+    for make in (lambda dt: MCTS(net, c=0.6, search_graph=True, **dt), lambda dt: AStar(net, lambda_=0.2, expansions=20, **dt),
+                 lambda dt: ValueSearch(net, **dt)):
+        agent = make({})
+        assert agent.net_dtype == F32_SPLIT
+        with pytest.warns(RuntimeWarning, match="half"):
+            got = agent.search_batch(states, None, 600)
+        with warnings.catch_warnings():
+            warnings.simplefilter("error")           # the second search goes straight to fp32: no overflow, no warning
+            again = agent.search_batch(states, None, 600)
+            ref = make({"net_dtype": torch.float32}).search_batch(states, None, 600)
+        for r in (got, again):
+            assert np.array_equal(r.solved, ref.solved) and np.array_equal(r.nodes, ref.nodes) and np.array_equal(r.lengths, ref.lengths)
+            assert all(list(a) == list(b) for a, b in zip(r.queues, ref.queues))
+        assert isinstance(agent._fp32_for[1], InferenceNet)

@@ -263,8 +263,8 @@ def test_production_bf16_trees_equal_oracle_on_recorded_outputs():
     B, cap = 96, 900
     states = np.array([oc.scramble(8 + i % 13, True)[0] for i in range(B)])
     for graph_search in (True, False):
-        agent = MCTS(net, c=0.6, search_graph=graph_search)          # defaults: bf16 engine, HIP graph
-        assert agent.net_dtype == torch.bfloat16 and agent.use_graph
+        agent = MCTS(net, c=0.6, search_graph=graph_search, net_dtype=torch.bfloat16)   # the fast engine, HIP graph
+        assert agent.use_graph
         res = agent.search_batch(states, None, cap, compact=False)    # the trees stay in agent.forest
         assert agent.forest._fused and agent.forest.rows_per_tree == 11
         n_solved = deep = 0

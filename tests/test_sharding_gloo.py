@@ -156,10 +156,11 @@ def _bucket_worker(rank, world, port, q):
                               torch.nn.Linear(30, 2))
     buckets = GradBuckets(net, bucket_bytes=200)      # three buckets, one per Linear layer (last layer first)
     out = []
-    for step in range(2):                             # a second step: zero() really resets, hooks fire again
+    for step in range(3):                             # a second step: zero() really resets, hooks fire again
         buckets.zero()
         x = torch.full((3, 6), float(rank + 1 + step))
-        net(x).sum().backward()
+        # third step: a loss that does not reach the last layer -- its bucket never fires from the hooks and wait() must reduce it
+        (net(x) if step < 2 else net[:-1](x)).sum().backward()
         launched = len(buckets.works)
         local = [p.grad.clone() for p in net.parameters()]   # (already reduced where a bucket has finished: compare on rank sums)
         buckets.wait()
@@ -187,18 +188,19 @@ def test_bucketed_async_gradient_average():
     [p.join(60) for p in procs]
     assert all(p.exitcode == 0 for p in procs)
     assert got[0][1] == got[1][1] >= 3 and got[0][2] and got[1][2]
-    for step in range(2):
+    for step in range(3):
         # reference: the same two local backward passes in this process, averaged by hand
         grads = []
         for rank in range(world):
             torch.manual_seed(0)
             net = torch.nn.Sequential(torch.nn.Linear(6, 40), torch.nn.ReLU(), torch.nn.Linear(40, 30), torch.nn.ReLU(),
                                       torch.nn.Linear(30, 2))
-            net(torch.full((3, 6), float(rank + 1 + step))).sum().backward()
-            grads.append([p.grad.numpy().copy() for p in net.parameters()])
+            x = torch.full((3, 6), float(rank + 1 + step))
+            (net(x) if step < 2 else net[:-1](x)).sum().backward()
+            grads.append([p.grad.numpy().copy() if p.grad is not None else np.zeros(tuple(p.shape), dtype=np.float32) for p in net.parameters()])
         mean = [np.mean([grads[r][i] for r in range(world)], axis=0) for i in range(len(grads[0]))]
         for r in range(world):
             launched, reduced = got[r][3][step]
-            assert launched == got[r][1]                      # every bucket's all_reduce was started inside backward
+            assert launched == got[r][1] - (step == 2)        # every bucket that got its gradients was reduced inside backward
             for i, m in enumerate(mean):
                 assert np.allclose(np.array(reduced[i]), m, rtol=1e-6, atol=1e-7)
