@@ -772,6 +772,8 @@ def main():
     ap.add_argument("--phase-reps", type=int, default=20)
     ap.add_argument("--weights", default=os.path.join(ROOT, "weights", "fc_small_r1"),
                     help="checkpoint directory (model.pt + config.json); random-init weights if it does not exist")
+    ap.add_argument("--architecture", default="fc_small", choices=["fc_small", "fc_big", "res_small", "res_big"],
+                    help="network architecture when --weights does not name a checkpoint directory (random-init weights then)")
     ap.add_argument("--solve-max-states", type=int, default=175000,
                     help="per-tree / per-problem cap = the reference's max_states (default: its CLI default, runeval.py:42-44)")
     ap.add_argument("--level-budget", default="auto",
@@ -816,8 +818,8 @@ def main():
         model = Model.load(args.weights).eval()
         weights_note = f"{os.path.relpath(args.weights, ROOT)} (ADI-trained on one MI355X by tools/train_eval.py; see weights/README.md)"
     else:
-        model = Model.create(ModelConfig()).eval()
-        weights_note = "random-init (glorot, torch.manual_seed(0))"
+        model = Model.create(ModelConfig(architecture=args.architecture)).eval()
+        weights_note = f"random-init {args.architecture} (glorot, torch.manual_seed(0))"
 
     results, extras = {}, {}
     for name in legs:
@@ -892,7 +894,7 @@ def main():
         "vs_baseline": None, "dtype": head["dtype"], "data": "synthetic",
         "config": {"workload": f"{args.trees} concurrent depth-{args.depth} MCTS trees per GPU (c=0.6, graph search, max_states "
                                f"{args.solve_max_states}), slots refilled from a pool of {args.pool_factor} x {args.trees} scrambles "
-                               f"per GPU; fc_small net, weights: {weights_note}",
+                               f"per GPU; {model.config.architecture} net, weights: {weights_note}",
                    "trees_per_gpu": args.trees, "pool_scrambles_per_gpu": per_rank, "select_level_budget": args.level_budget,
                    "scramble_depth": args.depth, "max_states": args.solve_max_states, "parallelism": f"scramble-sharded x{world}",
                    "scrambles": "configs' own games: the reference's stream (np.random.seed(0), scramble(depth, True)), rank r owns games "

@@ -176,15 +176,45 @@ def _bn_affine(bn: nn.BatchNorm1d):
     return scale, bn.bias.double() - bn.running_mean.double() * scale
 
 
+class LayerOpts:
+    """What a folded layer does besides y = act(W x + b): `save` = its input is the skip connection of a residual block,
+    `add` = that input is added in front of the activation (reference model.py:221-247: activate(bn2(layer2(.)) + x)),
+    `post` = (scale, shift) of an eval-mode BatchNorm BEHIND the activation that could not be folded into the next Linear
+    because a skip connection reads its output as well."""
+    __slots__ = ("save", "add", "post")
+
+    def __init__(self, save=False, add=False, post=None):
+        self.save, self.add, self.post = save, add, post
+
+
 def _fold_stack(seq: nn.Sequential, carry=None):
     """
-    [(W, b, has_activation)] of a Linear/act/BN stack in eval mode with each BatchNorm folded into the
+    [(W, b, activation)] of a Linear/act/BN stack in eval mode with each BatchNorm folded into the
     NEXT Linear; `carry` = (scale, shift) of a BatchNorm that precedes the stack.  Returns the list
     and the trailing BatchNorm's affine (or None) for whoever consumes the stack's output.
+    NonConvResBlocks (the res_* architectures, reference model.py:221-264) become two entries each: Linear -> BN -> act
+    folds the BatchNorm into ITS OWN Linear; the entries' LayerOpts (attribute `opts` of the returned list, one per entry)
+    mark the skip connection, and a BatchNorm in front of the first block becomes a post-activation affine of the layer
+    before it.
     """
-    out, mods, i = [], list(seq), 0
+    out, opts, mods, i = _Layers(), [], list(seq), 0
+    out.opts = opts
     while i < len(mods):
         lin = mods[i]
+        if isinstance(lin, NonConvResBlock):
+            if carry is not None:   # the block's input feeds a Linear AND the skip: the BatchNorm in front of it is applied for real
+                assert out, "a residual block cannot open the network behind a BatchNorm"
+                opts[-1] = LayerOpts(opts[-1].save, opts[-1].add, (carry[0], carry[1]))
+                carry = None
+            for j, (layer, bn) in enumerate(((lin.layer1, getattr(lin, "batchnorm1", None)), (lin.layer2, getattr(lin, "batchnorm2", None)))):
+                W, b = layer.weight.double(), layer.bias.double()
+                if lin.with_batchnorm:
+                    scale, shift = _bn_affine(bn)
+                    W, b = W * scale[:, None], b * scale + shift
+                out.append((W, b, lin.activate))
+                opts.append(LayerOpts(save=j == 0, add=j == 1))
+            i += 1
+            continue
         assert isinstance(lin, nn.Linear), f"cannot fold {type(lin).__name__}"
         W, b = lin.weight.double(), lin.bias.double()
         if carry is not None:
@@ -200,7 +230,13 @@ def _fold_stack(seq: nn.Sequential, carry=None):
             carry = _bn_affine(mods[i])
             i += 1
         out.append((W, b, act))
+        opts.append(LayerOpts())
     return out, carry
+
+
+class _Layers(list):
+    """A list of folded layers with their LayerOpts in `.opts` (same length)."""
+    opts = None
 
 
 class InferenceNet:
@@ -212,7 +248,7 @@ class InferenceNet:
     """
 
     def __init__(self, model: Model, dtype=torch.bfloat16, device=None, first_layer_table: str = "auto"):
-        assert isinstance(model, Model) and model.config.architecture.startswith("fc")
+        assert isinstance(model, Model) and model.config.architecture.split("_")[0] in ("fc", "res")
         device = device or next(model.parameters()).device
         was_training = model.training
         model.eval()
@@ -221,7 +257,7 @@ class InferenceNet:
             pol, pc = _fold_stack(model.policy_net, carry)
             val, vc = _fold_stack(model.value_net, carry)
             assert pc is None and vc is None and len(pol) == len(val)
-            layers = list(trunk)
+            layers, opts = list(trunk), list(trunk.opts)
             for d, ((Wp, bp, ap), (Wv, bv, av)) in enumerate(zip(pol, val)):
                 if d == 0:   # both heads read the trunk output: stack the rows
                     W, b = torch.cat([Wp, Wv]), torch.cat([bp, bv])
@@ -229,10 +265,19 @@ class InferenceNet:
                     W = torch.block_diag(Wp, Wv)
                     b = torch.cat([bp, bv])
                 layers.append((W, b, ap))
+                opts.append(LayerOpts())
             cast = lambda ls: [(W.to(device=device, dtype=dtype).contiguous(), b.to(device=device, dtype=dtype), act)  # noqa: E731
                                for W, b, act in ls]
             self.layers = cast(layers)
             self.value_layers = cast(list(trunk) + list(val))   # A* needs the value head only (agents.py:380)
+            # skip connections / post-activation affines of the residual architectures, per layer tuple (the lists above are
+            # sliced freely by callers; the tuples are not copied)
+            self._opts = {}
+            for ls, os_ in ((self.layers, opts), (self.value_layers, list(trunk.opts) + [LayerOpts()] * len(val))):
+                for layer, o in zip(ls, os_):
+                    post = None if o.post is None else tuple(t.to(device=device, dtype=torch.float32).contiguous() for t in o.post)
+                    self._opts[id(layer)] = LayerOpts(o.save, o.add, post)
+            self.residual = any(o.save for o in opts)
         model.train(was_training)
         self.dtype, self.device = dtype, device
         self.flops_per_state = 2 * sum(W.shape[0] * W.shape[1] for W, _, _ in self.layers)
@@ -358,23 +403,32 @@ class InferenceNet:
     fused_hidden = False
 
     def _run(self, layers, x):
-        for W, b, act in layers:
+        skip = None
+        for layer in layers:
+            W, b, act = layer
+            o = self._opts.get(id(layer)) or _PLAIN
+            if o.save:
+                skip = x
             if (act is not None and self.fused_hidden and x.dtype == torch.bfloat16 and x.is_cuda and x.is_contiguous()
                     and W.shape[1] % 64 == 0 and W.shape[0] % 256 == 0 and -(-x.shape[0] // 352) * (W.shape[0] // 256) >= 192):
                 # 352 x 256 tiles on >= 3/4 of the CUs: measured 0.186 ms against 0.200 ms for hipBLASLt + the activation pass at
                 # 11 264 x 4096 x 2048 (tools/bf16_gemm_fused_probe.py); layers without activation and narrow ones stay with the library
-                from librubiks import _hip
                 if getattr(b, "_f32", None) is None:
                     b._f32 = b.float().contiguous()
                 out = torch.empty((x.shape[0], W.shape[0]), dtype=torch.bfloat16, device=x.device)
-                _hip.check(_hip.lib().rc_gemm_bias_act_bf16(x.data_ptr(), W.data_ptr(), b._f32.data_ptr(), x.shape[0], W.shape[0], W.shape[1],
-                                                            1 if isinstance(act, nn.ReLU) else 2, float(getattr(act, "alpha", 1.0)),
-                                                            out.data_ptr(), 1, _hip.stream_ptr()), "rc_gemm_bias_act_bf16")
+                _layer_call("rc_gemm_layer_bf16", a=x, w=W, bias=b._f32, residual=skip if o.add else None,
+                            post_scale=o.post[0] if o.post else None, post_shift=o.post[1] if o.post else None, out_bf16=out,
+                            n_rows=x.shape[0], n_out=W.shape[0], k=W.shape[1], activation=1 if isinstance(act, nn.ReLU) else 2,
+                            alpha=float(getattr(act, "alpha", 1.0)), tile=1, k_splits=1)
                 x = out
                 continue
             x = torch.addmm(b, x, W.t())
+            if o.add:
+                x += skip
             if act is not None:
                 x = _activate_(x, act)
+            if o.post is not None:
+                x = (x * o.post[0].to(x.dtype) + o.post[1].to(x.dtype)) if x.dtype != torch.float32 else torch.addcmul(o.post[1], x, o.post[0])
         return x
 
     @torch.no_grad()
@@ -383,6 +437,7 @@ class InferenceNet:
         return self._run(self.value_layers, oh).float().reshape(-1)
 
 
+_PLAIN = LayerOpts()
 SPLIT_SCALE = 2.0 ** 11
 F32_SPLIT = "f32_split"   # `net_dtype` value selecting SplitF32Net
 HALF_MAX = 65504.0
@@ -448,7 +503,9 @@ class SplitF32Net:
     def __init__(self, model: Model, device=None):
         ref = InferenceNet(model, dtype=torch.float64, device=device, first_layer_table="onehot")
         self.device = ref.device
-        self.layers, self.value_layers = self._split(ref.layers), self._split(ref.value_layers)
+        self._opts = {}
+        self.layers, self.value_layers = self._split(ref.layers, ref._opts), self._split(ref.value_layers, ref._opts)
+        self.residual = ref.residual
         self.flops_per_state = ref.flops_per_state
         self.n_out = ref.layers[-1][0].shape[0]
         # Hidden activations travel as IEEE halves hi + lo 2^-11: a value beyond +-65504 (ELU is unbounded above; nets without
@@ -471,10 +528,10 @@ class SplitF32Net:
             self._fallback = InferenceNet(self._model, dtype=torch.float32, device=self.device)
         return self._fallback
 
-    @staticmethod
-    def _split(layers):
+    def _split(self, layers, ref_opts):
         out = []
-        for i, (W, b, act) in enumerate(layers):
+        for i, ref_layer in enumerate(layers):
+            W, b, act = ref_layer
             W, b = W.double(), b.double()
             if i == len(layers) - 1:
                 assert act is None
@@ -492,6 +549,8 @@ class SplitF32Net:
             else:
                 out.append(("hid", hi.contiguous(), torch.cat([lo, hi], 1).contiguous(), b.float().contiguous(), code, alpha,
                             torch.cat([lo, hi, hi], 1).contiguous()))   # [W_lo | W_hi | W_hi]: the operand of rc_split_gemm_f16
+            o = ref_opts.get(id(ref_layer)) or _PLAIN
+            self._opts[id(out[-1])] = LayerOpts(o.save, o.add, None if o.post is None else tuple(t.float().contiguous() for t in o.post))
         return out
 
     fused_hidden = True   # hidden layers as one kernel each (rc_split_gemm_f16) where its tile fills the chip
@@ -539,13 +598,14 @@ class SplitF32Net:
         oh = oh.float()
         return torch.cat([oh, oh * (1.0 / SPLIT_SCALE)], 1).half()   # exact: entries are 0, 1 and 2^-11
 
-    def _act(self, part: torch.Tensor, n_corr: int, bias: torch.Tensor, code: int, alpha: float, split: bool) -> torch.Tensor:
-        """act(sum of the partial products + bias) as [hi | lo] halves (split) or as fp32.  part: [P, n, w] fp32, the first n_corr
-        of them correction products (still scaled by 2^11)."""
+    def _act(self, part: torch.Tensor, n_corr: int, bias: torch.Tensor, code: int, alpha: float, split: bool, skip=None, post=None) -> torch.Tensor:
+        """post * act(sum of the partial products + bias + skip) + post' as [hi | lo] halves (split) or as fp32.  part: [P, n, w] fp32, the
+        first n_corr of them correction products (still scaled by 2^11); skip: [n, 2 w] halves hi | lo."""
         from librubiks import _hip
         P, n, w = part.shape
         out = torch.empty((n, 2 * w), dtype=torch.float16, device=part.device) if split else torch.empty((n, w), dtype=torch.float32, device=part.device)
-        _hip.check(_hip.lib().rc_split_reduce_f16(part.data_ptr(), n * w, P, n_corr, n, w, bias.data_ptr(), None, code, alpha, None, None,
+        _hip.check(_hip.lib().rc_split_reduce_f16(part.data_ptr(), n * w, P, n_corr, n, w, bias.data_ptr(), _ptr(skip), code, alpha,
+                                                  _ptr(post[0]) if post else None, _ptr(post[1]) if post else None,
                                                   out.data_ptr() if split else None, None if split else out.data_ptr(),
                                                   self.range_flag.data_ptr(), _hip.stream_ptr()), "rc_split_reduce_f16")
         return out
@@ -579,11 +639,16 @@ class SplitF32Net:
     def _forward(self, a: torch.Tensor, layers, first: int = 0) -> torch.Tensor:
         """a: [n, 960] half operand of the input layer (or, with first = 1, its [hi | lo] output) -> fp32 [n, n_out]."""
         from librubiks import _hip
+        skip = None
         for i, layer in enumerate(layers):
             if i < first:
                 continue
             last_hidden = i == len(layers) - 2
             n = a.shape[0]
+            o = self._opts.get(id(layer)) or _PLAIN
+            if o.save:
+                skip = a
+            res, post = (skip if o.add else None), o.post
             if layer[0] == "in":
                 _, B, b, code, alpha = layer[:5]
                 part = torch.empty((1, n, B.shape[0]), dtype=torch.float32, device=a.device)
@@ -595,13 +660,14 @@ class SplitF32Net:
                 plan = self._layer_plan(n, layers, i)
                 if plan == "fused":   # one kernel: three products, bias, activation, re-split (or fp32 in front of the output layer)
                     out = torch.empty((n, w if last_hidden else 2 * w), dtype=torch.float32 if last_hidden else torch.float16, device=a.device)
-                    _layer_call("rc_split_layer_f16", a=a, w=W3, bias=b, n_rows=n, n_out=w, k=K, activation=code, alpha=alpha,
+                    _layer_call("rc_split_layer_f16", a=a, w=W3, bias=b, residual=res, post_scale=post[0] if post else None,
+                                post_shift=post[1] if post else None, n_rows=n, n_out=w, k=K, activation=code, alpha=alpha,
                                 out_hi_lo=None if last_hidden else out, out_f32=out if last_hidden else None,
                                 tile=self._fused_tile(n, w, K), k_splits=1, range_flag=self.range_flag)
                     a = out
                     continue
                 nxt = layers[i + 1]
-                head_ok = last_hidden and self.fused_head and nxt[0] == "f32" and nxt[1].shape[0] <= 16 and w in (512, 1024)
+                head_ok = last_hidden and self.fused_head and nxt[0] == "f32" and nxt[1].shape[0] <= 16 and w in (512, 1024) and res is None and not post
                 part = torch.empty((2, n, w), dtype=torch.float32, device=a.device)
                 if plan == "partials":
                     # too few tiles to fill the chip: the own kernel with its K loop cut in two (twice the workgroups), raw fp32
@@ -621,7 +687,7 @@ class SplitF32Net:
             else:
                 _, W, b = layer
                 return torch.addmm(b, a, W.t())
-            a = self._act(part, n_corr, b, code, alpha, split=not last_hidden)   # the output layer takes plain fp32 activations
+            a = self._act(part, n_corr, b, code, alpha, split=not last_hidden, skip=res, post=post)   # the output layer takes plain fp32 activations
         return a
 
     # ---- InferenceNet's interface --------------------------------------------------------------------------------
@@ -700,7 +766,7 @@ def net_fingerprint(net, dtype=None):
     """
     if isinstance(net, (InferenceNet, SplitF32Net, GenericNet)):
         return (id(net),)
-    if isinstance(net, Model) and net.config.architecture.startswith("fc"):
+    if isinstance(net, Model) and net.config.architecture.split("_")[0] in ("fc", "res"):
         tensors = list(net.parameters()) + list(net.buffers())
         return (id(net), str(dtype)) + tuple((t.data_ptr(), t._version) for t in tensors)
     return (id(net), str(dtype))   # any other module is called live through GenericNet
@@ -710,7 +776,7 @@ def make_inference_net(net, dtype=torch.bfloat16):
     """The fastest engine that preserves `net`'s eval-mode function."""
     if isinstance(net, (InferenceNet, SplitF32Net, GenericNet)):
         return net
-    if isinstance(net, Model) and net.config.architecture.startswith("fc"):
+    if isinstance(net, Model) and net.config.architecture.split("_")[0] in ("fc", "res"):
         if dtype == F32_SPLIT:
             try:
                 return SplitF32Net(net)

@@ -292,6 +292,7 @@ class MCTS(DeepAgent):
     """Batched PUCT graph search with virtual loss and max-backup (reference agents.py:415-645)."""
 
     nu = 100
+    snapshot_trees = None      # test hook: a dict -> {game: tree_arrays()} of every tree as its search left it (before graph completion)
     refill_level_budget = 0    # new levels per descent and iteration while scrambles wait for a slot (0 = no limit)
 
     def __init__(self, net, c: float, search_graph: bool, net_dtype=F32_SPLIT, use_graph: bool = True,
@@ -489,9 +490,15 @@ class MCTSRun:
             self.side.wait_event(ev)
             self.harvests.append(_Harvest(self.agent, forest, games, trees=trees))
 
+    def _snapshot(self, idx_np: np.ndarray):
+        if self.agent.snapshot_trees is not None:
+            for t in idx_np:
+                self.agent.snapshot_trees[int(self.owner[t])] = self.forest.tree_arrays(int(t))
+
     def _rest(self, idx_np: np.ndarray):
         """The finished trees `idx_np` are done with iterations and nobody needs their slots: they stay in the forest and are
         turned into results GRAVE trees at a time (few, large launch sequences next to the running iterations: see _flush_grave)."""
+        self._snapshot(idx_np)
         if not hasattr(self, "games_of_resting"):
             self.games_of_resting = np.full(self.forest.B, -1, dtype=np.int64)
         self.games_of_resting[idx_np] = self.owner[idx_np]
@@ -504,6 +511,7 @@ class MCTSRun:
         """Copies the finished trees `idx_np` out of the forest (their slots are needed or dropped): what result extraction
         reads of them goes into the results forest, which is processed GRAVE trees at a time on the side stream."""
         forest, agent = self.forest, self.agent
+        self._snapshot(idx_np)
         idx = _to_device_async(idx_np, forest.status.device)
         games = self.owner[idx_np].copy()
         keep_tree = agent._tree_src is None and (games == 0).any()   # game 0's tree stays inspectable (the reference's attributes)
@@ -615,6 +623,7 @@ class MCTSRun:
         seconds = agent.tt.tock()
         left = np.flatnonzero(owner >= 0)
         if len(left) == forest.B:
+            self._snapshot(left)
             self.harvests.append(_Harvest(agent, forest, owner.copy()))
             if agent._tree_src is None and (owner == 0).any():
                 agent._tree_src = (forest, int(np.flatnonzero(owner == 0)[0]))

@@ -247,6 +247,7 @@ class MCTSForest:
         else:
             self._oh = torch.empty((ROWS * self.B, 480), dtype=self.engine.input_dtype, device=self.device)
         self._graphs = {}
+        self._graph_pool = None   # (a pool whose graphs have all been dropped cannot be captured into again: a fresh one next time)
 
     rows_per_tree = ROWS
 

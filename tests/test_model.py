@@ -76,7 +76,20 @@ def test_make_inference_net_dispatch():
     from standin_net import StandInNet
     assert isinstance(make_inference_net(StandInNet(0)), GenericNet)
     assert isinstance(make_inference_net(Model(ModelConfig()), torch.float32), InferenceNet)
-    assert isinstance(make_inference_net(Model(ModelConfig(architecture="res_small"))), GenericNet)
+    # residual architectures run on the same engines (skip connection + unfoldable BatchNorm as layer options), on the CPU too
+    for arch in ("res_small", "res_big"):
+        for bn in (True, False):
+            m = Model(ModelConfig(architecture=arch, batchnorm=bn))
+            _randomise_bn(m)
+            m.eval()
+            eng = make_inference_net(m, torch.float32)
+            assert isinstance(eng, InferenceNet) and eng.residual
+            x = _one_hot(32, seed=5)
+            with torch.no_grad():
+                p_ref, v_ref = m(x)
+            p, v = eng(x)
+            assert torch.allclose(p, p_ref, rtol=1e-4, atol=1e-4) and torch.allclose(v, v_ref.reshape(-1), rtol=1e-4, atol=1e-4)
+            assert torch.allclose(eng.value(x), v_ref.reshape(-1), rtol=1e-4, atol=1e-4)
 
 
 def test_reference_model_tests_restated(tmp_path):

@@ -480,3 +480,90 @@ def test_agents_repeat_the_search_in_fp32_when_the_split_engine_overflows():
             assert np.array_equal(r.solved, ref.solved) and np.array_equal(r.nodes, ref.nodes) and np.array_equal(r.lengths, ref.lengths)
             assert all(list(a) == list(b) for a, b in zip(r.queues, ref.queues))
         assert isinstance(agent._fp32_for[1], InferenceNet)
+
+
+def _res_model(arch="res_small", batchnorm=True, seed=0):
+    from librubiks.model import Model, ModelConfig
+    torch.manual_seed(seed)
+    m = Model.create(ModelConfig(architecture=arch, batchnorm=batchnorm)).eval()
+    g = torch.Generator().manual_seed(seed)
+    for mod in m.modules():
+        if isinstance(mod, torch.nn.BatchNorm1d):
+            mod.running_mean.copy_((torch.randn(mod.num_features, generator=g) * 0.3).cuda())
+            mod.running_var.copy_((torch.rand(mod.num_features, generator=g) + 0.5).cuda())
+            mod.weight.data.copy_((torch.rand(mod.num_features, generator=g) + 0.5).cuda())
+            mod.bias.data.copy_((torch.randn(mod.num_features, generator=g) * 0.2).cuda())
+    return m
+
+
+@pytest.mark.parametrize("batchnorm", [True, False])
+def test_residual_architectures_run_on_the_native_engines(batchnorm):
+    """
+    res_small (reference model.py:249-264: 480 -> 4096 -> 1024, four NonConvResBlocks of 1024 -> 1024 x 2, heads) on the engines
+    the fc nets use: BatchNorm folded (a block's own into its Linear; the one in front of the first block as a post-activation
+    affine, because the skip connection reads it too), skip connection added in the layer kernels' epilogue.  Tolerances: fp32
+    engine vs the module rtol = atol = 1e-4; split engine vs float64 within 1.25 x the fp32 module's error; bf16 atol 4e-2 on
+    outputs of magnitude ~1.  All row counts: own kernels (11 264 rows), K-split partials + reduce (5 632), library GEMMs (300).
+    """
+    import copy
+    from librubiks import cube
+    from librubiks.model import F32_SPLIT, GenericNet, InferenceNet, SplitF32Net, make_inference_net
+    net = _res_model(batchnorm=batchnorm)
+    np.random.seed(4)
+    ref64 = copy.deepcopy(net).double()
+    engines = {dt: make_inference_net(net, dt) for dt in (F32_SPLIT, torch.float32, torch.bfloat16)}
+    assert isinstance(engines[F32_SPLIT], SplitF32Net) and isinstance(engines[torch.float32], InferenceNet)
+    assert not any(isinstance(e, GenericNet) for e in engines.values()) and all(e.residual for e in engines.values())
+    assert engines[torch.bfloat16].supports_cubes and engines[F32_SPLIT].supports_cubes          # fused input layer from the cube states
+    for n in (11264, 5632, 300):
+        cubes, _, _ = cube.scramble_batch(n, 25, True)
+        oh = cubes.as_oh(torch.float32)
+        with torch.no_grad():
+            p64, v64 = ref64(oh.double())
+            p32, v32 = net(oh)
+        err = lambda a, b: float((a.double() - b).abs().max())   # noqa: E731
+        e_f32 = max(err(p32, p64), err(v32.reshape(-1), v64.reshape(-1)))
+        ps, vs = engines[F32_SPLIT].forward_cubes(cubes)
+        assert not engines[F32_SPLIT].overflowed()
+        e_split = max(err(ps, p64), err(vs, v64.reshape(-1)))
+        pf, vf = engines[torch.float32](oh)
+        e_fold = max(err(pf, p64), err(vf, v64.reshape(-1)))
+        pb, vb = engines[torch.bfloat16].forward_cubes(cubes)
+        e_bf = max(err(pb, p64), err(vb, v64.reshape(-1)))
+        scale = max(1.0, float(p64.abs().max()), float(v64.abs().max()))
+        print(f"res_small bn={batchnorm} n={n}: |out| <= {scale:.2f}; max |err| vs float64: split {e_split:.2e} fp32 module {e_f32:.2e} "
+              f"fp32 engine {e_fold:.2e} bf16 {e_bf:.2e}")
+        assert e_split <= 1.25 * e_f32 + 1e-7 * scale
+        assert e_fold <= 1e-4 * scale
+        assert e_bf <= 4e-2 * scale
+        assert err(engines[F32_SPLIT].value_cubes(cubes), v64.reshape(-1)) <= 1.25 * e_f32 + 1e-7 * scale
+    # the own bf16 layer kernel (opt-in) with the skip connection in its epilogue: same numbers as the library path up to bf16 rounding
+    eng = engines[torch.bfloat16]
+    cubes, _, _ = cube.scramble_batch(11264, 25, True)
+    base = eng.forward_cubes(cubes)
+    eng.fused_hidden = True
+    own = eng.forward_cubes(cubes)
+    eng.fused_hidden = False
+    assert float((own[0] - base[0]).abs().max()) <= 4e-2 * scale and float((own[1] - base[1]).abs().max()) <= 4e-2 * scale
+
+
+def test_mcts_on_a_residual_net_uses_the_fused_path_and_equals_the_oracle():
+    """MCTS with res_small on the split engine: packed 11 rows per tree, fused input layer and head, trees exact vs the oracle replayed on
+    the recorded network outputs."""
+    from test_search_edge_gpu import _TableNet, _compare
+    from librubiks.solving.agents import MCTS
+    from oracle import agents as oa
+    net = _res_model(seed=1)
+    np.random.seed(8)
+    states = np.array([oc.scramble(3 + i % 5, True)[0] for i in range(40)])
+    agent = MCTS(net, c=0.6, search_graph=True)
+    res = agent.search_batch(states, None, 400, compact=False)
+    assert agent.forest._fused and agent.forest.rows_per_tree == 11 and agent.forest.engine.residual
+    for t in range(40):
+        tree = agent.forest.tree_arrays(t)
+        n = tree["n"]
+        table = {tree["states"][i].tobytes(): (tree["P"][i].astype(np.float32), np.float32(tree["V"][i])) for i in range(1, n + 1)}
+        ref = oa.MCTS(_TableNet(table), c=0.6, search_graph=True)
+        ok = ref.search(states[t], 400)
+        assert bool(res.solved[t]) == ok and res.nodes[t] == len(ref) == n and list(res.queues[t]) == list(ref.action_queue)
+        _compare(tree, ref, n)

@@ -314,3 +314,59 @@ def test_deep_production_trees_equal_oracle_on_recorded_outputs(engine):
         _compare(tree, ref, n)
         longest = max(longest, int(agent.forest.path_len[t].item()))
     assert longest > 256 and int(res.iterations.max()) > 1000      # descents deeper than one re-validation round, ring wrapped many times
+
+
+@pytest.mark.parametrize("engine", ["f32s", "bf16"])
+def test_production_trees_through_refill_narrowing_and_results_forest_equal_oracle(engine):
+    """
+    The continuous-batching path at production precision (trained weights, both engines): 112 scrambles on 48 tree slots, so
+    finished trees hand their slots to waiting scrambles (rc_mcts_plant into a running forest), are copied into the results
+    forest (65 B per node) and post-processed there; when nobody is waiting the forest is narrowed (MCTSForest.set_active) and
+    the last trees are post-processed where they lie.  Every tree is recorded as its search left it; the oracle is replayed on
+    the tree's own (state -> P, V) pairs and must build the same tree -- nodes, neighbours, N, W, L, P, V, leaves -- and, after
+    its own graph completion + BFS shortening (agents.py:597-633), return the same action queue the device pipeline returned.
+    """
+    import os
+    from conftest import ROOT
+    from librubiks.model import F32_SPLIT, Model
+    from librubiks.solving.agents import MCTS
+    wdir = os.path.join(ROOT, "weights", "fc_small_r1")
+    if not os.path.isdir(wdir):
+        pytest.skip("needs the trained weights")
+    net = Model.load(wdir).eval()
+    np.random.seed(23)
+    G, S, cap = 112, 48, 5000
+    states = np.array([oc.scramble(13 + i % 8, True)[0] for i in range(G)])
+    agent = MCTS(net, c=0.6, search_graph=True, net_dtype=torch.bfloat16 if engine == "bf16" else F32_SPLIT, sync_every=8)
+    agent.snapshot_trees = {}
+    res = agent.search_batch(states, None, cap, slots=S)
+    st = agent.refill_stats
+    assert st["refills"] >= 2 and st["compactions"] >= 1 and st.get("flushes", 0) >= 2      # every path was taken
+    assert sorted(agent.snapshot_trees) == list(range(G))
+    solved = unsolved = 0
+    for g in range(G):
+        tree = agent.snapshot_trees[g]
+        n = tree["n"]
+        table = {tree["states"][i].tobytes(): (tree["P"][i].astype(np.float32), np.float32(tree["V"][i])) for i in range(1, n + 1)}
+        ref = oa.MCTS(_TableNet(table), c=0.6, search_graph=True)
+        before = {}
+        complete = ref._complete_graph
+
+        def recording_complete():
+            before["neighbors"] = ref.neighbors.copy()    # the device tree was recorded before its graph completion
+            complete()
+
+        ref._complete_graph = recording_complete
+        ok = ref.search(states[g], cap)
+        assert bool(res.solved[g]) == ok and res.nodes[g] == len(ref) == n, f"game {g}"
+        assert res.iterations[g] == ref.iterations, f"game {g}"
+        assert list(res.queues[g]) == list(ref.action_queue), f"game {g}"          # after completion + shortening in the results forest
+        assert res.lengths[g] == (len(ref.action_queue) if ok else -1)
+        after = ref.neighbors
+        if "neighbors" in before:
+            ref.neighbors = before["neighbors"]
+        _compare(tree, ref, n)
+        ref.neighbors = after
+        solved += ok
+        unsolved += not ok
+    assert solved >= 40 and unsolved >= 1      # both outcomes occur (the cap stops the hardest scrambles)
