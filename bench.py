@@ -409,6 +409,8 @@ def run_leg(name, model, pool_roots, config_roots, args, world, coll_device, tre
         torch.cuda.synchronize()
 
     # ---- pool: untimed prep, warm-up, timed window, rest of the pool ------------------------------------
+    # one-off set-up, untimed: forest allocation (tens of GB of HBM, zero-filled), engine, one HIP graph per launch size
+    agent.prepare(trees, cap)
     barrier()
     t_pool = time.perf_counter()
     run = agent.start_batch(pool_roots, None, cap, slots=trees)
@@ -466,9 +468,9 @@ def run_leg(name, model, pool_roots, config_roots, args, world, coll_device, tre
     rtc = local = None
     if not window_only:
         if full_warm:
-            agent.search_batch(config_roots, None, cap)                       # untimed: the same search, all launch sizes' graphs captured
+            agent.search_batch(config_roots, None, cap)                       # untimed: the same search once before
         else:
-            agent.search_batch(config_roots, None, cap, max_iterations=30)   # untimed: forest allocated, first graph captured
+            agent.search_batch(config_roots, None, cap, max_iterations=30)   # untimed: 30 iterations (clocks, library heuristics)
         barrier()
         t1 = time.perf_counter()
         full = agent.search_batch(config_roots, None, cap)
@@ -495,7 +497,8 @@ def run_leg(name, model, pool_roots, config_roots, args, world, coll_device, tre
     if pool:
         out["pool_run"] = dict(pool, nodes=pool_nodes, seconds=round(pool_s, 3), nodes_per_sec=round(pool_nodes / pool_s, 1),
                                games=int(pool["games"]) * world,
-                               note="whole pool searched to completion on `slots` tree slots; wall time includes prep, window and tail")
+                               note="whole pool searched to completion on `slots` tree slots; wall time includes prep, window and tail "
+                                    "(not the one-off set-up before: forest allocation, HIP graph capture per launch size)")
     if rtc:
         from librubiks.solving.sharding import gather_results
         total = trees * world
@@ -507,8 +510,8 @@ def run_leg(name, model, pool_roots, config_roots, args, world, coll_device, tre
             "ci95": float(1.959963984540054 * np.sqrt(p * (1 - p) / total)),
             "mean_solution_length": float(np.mean(g["lengths"][g["solved"].astype(bool)])) if np.any(g["solved"]) else None,
             "lock_step_iterations_rank0": rtc["iterations"], "launch_sizes_rank0": rtc["launch_sizes"],
-            "warm_up": "the same search once before, untimed (HIP graphs of every launch size cached in the forest)" if full_warm
-                       else "30 iterations, untimed (graphs of the smaller launch sizes are captured inside the timed run)",
+            "warm_up": "forest allocated and HIP graphs of every launch size captured before (MCTS.prepare), then "
+                       + ("the same search once, untimed" if full_warm else "30 iterations of it, untimed"),
             "note": "the scrambles as ONE batch: sum len(agent) / wall seconds of the batched search (SURVEY 8(d)(i))"}
     return out, engine, agent
 
@@ -824,7 +827,7 @@ def main():
     results, extras = {}, {}
     for name in legs:
         leg, engine, agent = run_leg(name, model, pool_roots, config_roots, args, world, coll_device, args.trees, args.solve_max_states,
-                                     window_only=args.window_only or leg_window_only[name])
+                                     window_only=args.window_only or leg_window_only[name], full_warm=False)
         results[name] = leg
         if rank == 0 and args.phase_reps:
             extras[name] = step_rooflines(engine, agent, config_roots, args, name)

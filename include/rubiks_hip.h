@@ -405,6 +405,17 @@ int rc_mcts_backup_select(const rc_mcts_t *m, const float *probs, const float *v
                           rc_stream_t stream);
 int rc_mcts_backup_select_head(const rc_mcts_t *m, const void *head, size_t ld, int head_is_bf16, double c, uint32_t level_budget,
                                rc_stream_t stream);
+/* The tree side of an iteration as ONE launch: rc_mcts_backup_select (rc_mcts_step) / rc_mcts_backup_select_head
+ * (rc_mcts_step_head) followed by the rc_mcts_expand of the NEXT iteration, done by the wave that walked to the leaf.  An
+ * iteration is then  [network on the rows the previous step left] -> rc_mcts_step*;  trees enter through
+ * rc_mcts_plant_expanded, which is rc_mcts_plant + the root's expansion (its rows use list position == tree index: every tree
+ * listed in order, as while scrambles are still waiting for slots).  Results are those of the three-kernel form. */
+int rc_mcts_plant_expanded(const rc_mcts_t *m, const int32_t *slots, uint32_t n_slots, const int8_t *roots_soa, size_t stride,
+                           size_t first_col, uint32_t max_states, rc_stream_t stream);
+int rc_mcts_step(const rc_mcts_t *m, const float *probs, const float *values, double c, uint32_t level_budget, uint32_t max_states,
+                 rc_stream_t stream);
+int rc_mcts_step_head(const rc_mcts_t *m, const void *head, size_t ld, int head_is_bf16, double c, uint32_t level_budget,
+                      uint32_t max_states, rc_stream_t stream);
 /* _complete_graph (agents.py:597-611) for every tree with status RC_MCTS_SOLVED: each leaf is linked, both
  * ways, to those of its 12 children that already exist in the tree (looked up in the tree's hash table). */
 int rc_mcts_complete_graph(const rc_mcts_t *m, rc_stream_t stream);

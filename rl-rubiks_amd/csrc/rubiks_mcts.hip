@@ -68,14 +68,23 @@ __device__ __forceinline__ u32 line_tag(u32 seq, int level, u32 act) { return (s
 __device__ __forceinline__ int tree_of(const rc_mcts_t &m, u32 slot) { return m.active ? m.active[slot] : (int)slot; }
 
 // ---- plant: (re)start trees.  One workgroup per listed slot: hash table cleared, root = node 1, phase ROOT_A ------
+__device__ __forceinline__ void expand_leaf_wave(const rc_mcts_t &m, u32 t, u32 slot, u32 lane, const u8 *lut, u32 max_states, bool root,
+                                                 int leaf);
+
+// expand_states > 0: the root's expansion (phase ROOT_A, normally the next rc_mcts_expand) happens here as well, with
+// max_states = expand_states -- for the fused iteration rc_mcts_step*, which expands at the END of a step.  The tree's network
+// rows are those of list position == tree index (the caller plants while every tree is listed in order).
 __global__ __launch_bounds__(kBlock) void k_mcts_plant(rc_mcts_t m, const int *__restrict__ slots, const u8 *__restrict__ roots,
-                                                     size_t stride, size_t first_col) {
+                                                     size_t stride, size_t first_col, u32 expand_states) {
+    __shared__ u32 s_lut[sizeof(kTables.lut) / 4];
+    __shared__ int s_solved;
+    stage_to_lds(s_lut, c_tables.lut, sizeof(kTables.lut));
     const u32 t = slots ? (u32)slots[blockIdx.x] : blockIdx.x;
     const size_t col = first_col + blockIdx.x;
     uint4 *tab4 = reinterpret_cast<uint4 *>(m.hash + (size_t)t * m.hash_size);
     for (u32 i = threadIdx.x; i < m.hash_size / 4; i += kBlock) tab4[i] = make_uint4(0, 0, 0, 0);
     __syncthreads();
-    if (threadIdx.x != 0) return;
+    if (threadIdx.x == 0) {
     u32 w[4] = {0, 0, 0, 0};
     bool solved = true;
 #pragma unroll
@@ -108,34 +117,23 @@ __global__ __launch_bounds__(kBlock) void k_mcts_plant(rc_mcts_t m, const int *_
     m.new_mask[t] = 0;
     m.phase[t] = kPhaseRootA;
     for (u32 i = 0; i < m.ring_k; ++i) m.ring_len[(size_t)t * m.ring_k + i] = 0;   // the previous tenant's lines are void
+    s_solved = solved;
+    }
+    if (expand_states == 0) return;
+    __threadfence();     // the root's key, its hash entry and the tree words are in memory before the wave below reads them
+    __syncthreads();
+    if (threadIdx.x < kWave && !s_solved)
+        expand_leaf_wave(m, t, t, threadIdx.x, reinterpret_cast<const u8 *>(s_lut), expand_states, true, 1);
 }
 
 // ---- expand: one wave per tree, lane k < 12 owns child k ----------------------------------------
-__global__ __launch_bounds__(kWave) void k_mcts_expand(rc_mcts_t m, u32 max_states) {
-    __shared__ u32 s_lut[sizeof(kTables.lut) / 4];
-    stage_to_lds(s_lut, c_tables.lut, sizeof(kTables.lut));
-    __syncthreads();
-    const u8 *lut = reinterpret_cast<const u8 *>(s_lut);
-    const u32 slot = blockIdx.x, lane = threadIdx.x;
-    const int ti = tree_of(m, slot);
-    if (ti < 0) return;
-    const u32 t = (u32)ti;
-    if (lane == 0) m.expanded[t] = 0;
-    if (m.status[t] != RC_MCTS_RUNNING || m.pending[t]) return;   // a suspended descent has no leaf yet
-    const int ph = m.phase[t] & kPhaseMask;
+// The expansion of `leaf` (agents.py:505-544) by one full wave; the caller has established that the tree is running, not
+// suspended and not in phase ROOT_B.  `lut`: the move table staged in LDS.
+__device__ __forceinline__ void expand_leaf_wave(const rc_mcts_t &m, u32 t, u32 slot, u32 lane, const u8 *lut, u32 max_states, bool root,
+                                                 int leaf) {
     const size_t base = (size_t)t * (m.capacity + 1);
     uint4 *keys = reinterpret_cast<uint4 *>(m.keys) + base;
     const size_t col0 = (size_t)m.rows_per_tree * slot;
-    if (ph == kPhaseRootB) {   // second half of the root's iteration: children 10 and 11 (nodes 12, 13) are evaluated now
-        if (lane < 2) {
-            const uint4 ck = keys[2 + 10 + lane];
-#pragma unroll
-            for (int j = 0; j < kPlanes; ++j) m.child_soa[(size_t)j * m.child_stride + col0 + lane] = (int8_t)key_code(ck, j);
-        }
-        if (lane == 0) m.expanded[t] = 1;
-        return;
-    }
-    const bool root = ph == kPhaseRootA;
     const int n = m.n_nodes[t];
     if ((u32)n + kA > max_states || (u32)n + kA > m.capacity) {   // agents.py:476
         if (lane == 0) m.status[t] = RC_MCTS_EXHAUSTED;
@@ -143,8 +141,6 @@ __global__ __launch_bounds__(kWave) void k_mcts_expand(rc_mcts_t m, u32 max_stat
     }
     int *tab = m.hash + (size_t)t * m.hash_size;
     const u32 mask = m.hash_size - 1;
-    const int plen = m.path_len[t];
-    const int leaf = m.path_node[(size_t)t * m.max_path + plen - 1];
     const uint4 pk = keys[leaf];
     const bool act = lane < kA;
     const u32 a = lane & (kActionPad - 1);
@@ -175,7 +171,7 @@ __global__ __launch_bounds__(kWave) void k_mcts_expand(rc_mcts_t m, u32 max_stat
     const u64 newm = __ballot(act && found == 0);
     const int rank = __popcll(newm & ((1ull << lane) - 1ull));
     const int idx = found ? found : n + 1 + rank;
-    // network input: the new children, packed in child order at columns 11 t + rank (a non-root leaf has at most 11: its
+    // network input: the new children, packed in child order at columns 11 slot + rank (a non-root leaf has at most 11: its
     // parent is known); the root's step evaluates the root itself first, then children 0..9
     if (act && !found && rank < (root ? 10 : 11)) {
         const size_t col = col0 + (u32)rank + (root ? 1u : 0u);
@@ -227,6 +223,38 @@ __global__ __launch_bounds__(kWave) void k_mcts_expand(rc_mcts_t m, u32 max_stat
             m.solved_action[t] = first;
         }
     }
+}
+
+// Second half of a root's iteration (phase ROOT_B): children 10 and 11 (nodes 12, 13) are this step's network rows.
+__device__ __forceinline__ void expand_root_b(const rc_mcts_t &m, u32 t, u32 slot, u32 lane) {
+    const uint4 *keys = reinterpret_cast<const uint4 *>(m.keys) + (size_t)t * (m.capacity + 1);
+    const size_t col0 = (size_t)m.rows_per_tree * slot;
+    if (lane < 2) {
+        const uint4 ck = keys[2 + 10 + lane];
+#pragma unroll
+        for (int j = 0; j < kPlanes; ++j) m.child_soa[(size_t)j * m.child_stride + col0 + lane] = (int8_t)key_code(ck, j);
+    }
+    if (lane == 0) m.expanded[t] = 1;
+}
+
+__global__ __launch_bounds__(kWave) void k_mcts_expand(rc_mcts_t m, u32 max_states) {
+    __shared__ u32 s_lut[sizeof(kTables.lut) / 4];
+    stage_to_lds(s_lut, c_tables.lut, sizeof(kTables.lut));
+    __syncthreads();
+    const u8 *lut = reinterpret_cast<const u8 *>(s_lut);
+    const u32 slot = blockIdx.x, lane = threadIdx.x;
+    const int ti = tree_of(m, slot);
+    if (ti < 0) return;
+    const u32 t = (u32)ti;
+    if (lane == 0) m.expanded[t] = 0;
+    if (m.status[t] != RC_MCTS_RUNNING || m.pending[t]) return;   // a suspended descent has no leaf yet
+    const int ph = m.phase[t] & kPhaseMask;
+    if (ph == kPhaseRootB) {
+        expand_root_b(m, t, slot, lane);
+        return;
+    }
+    const int plen = m.path_len[t];
+    expand_leaf_wave(m, t, slot, lane, lut, max_states, ph == kPhaseRootA, m.path_node[(size_t)t * m.max_path + plen - 1]);
 }
 
 // ---- backup: P/V of the new children, W/N/L along the path (agents.py:555-571) ------------------
@@ -526,9 +554,14 @@ __device__ __forceinline__ u32 sel_hash(int node) { return ((u32)node * 0x9E3779
 // EVERY level of the path at that node to them (the chain of the node lists those levels; a repeated (node, action) pair
 // counts once, as NumPy's buffered += does), evaluates the updated rows and -- if it is the node's first level -- writes
 // them back.  One kernel, one pass over the path and one memory round trip less per iteration.
-template <int MODE>
+// FUSE (rc_mcts_step*): the kernel is the whole tree side of an iteration -- backup of the previous expansion, descent, and the
+// EXPANSION of the leaf the descent ends at (what rc_mcts_expand would do at the start of the next iteration), by the wave that
+// walked there: one launch and one dependent kernel boundary less per iteration.  Trees planted for this form have their root
+// expanded by rc_mcts_plant_expanded.
+template <int MODE, bool FUSE = false>
 __global__ __launch_bounds__(kBlock) void k_mcts_select(rc_mcts_t m, double c, u32 level_budget, const void *__restrict__ probs_or_head,
-                                                      const float *__restrict__ values, size_t ld, bool head_bf16) {
+                                                      const float *__restrict__ values, size_t ld, bool head_bf16, u32 max_states) {
+    __shared__ u32 s_lut[FUSE ? sizeof(kTables.lut) / 4 : 1];
     __shared__ float s_best;                // MODE > 0: the value backed up along the path
     __shared__ int s_first;                 // first level that has to be walked sequentially
     __shared__ int s_node[kMaxPath];        // the path: old levels, then the walked ones
@@ -556,6 +589,11 @@ __global__ __launch_bounds__(kBlock) void k_mcts_select(rc_mcts_t m, double c, u
     const bool running = m.status[t] == RC_MCTS_RUNNING;
     const bool backup = MODE > 0 && m.expanded[t];   // uniform over the workgroup
     if (!running && !backup) return;
+    if (FUSE) {
+        stage_to_lds(s_lut, c_tables.lut, sizeof(kTables.lut));
+        __syncthreads();                       // every thread has read `expanded`: it is consumed here (the expansion at the
+        if (tid == 0) m.expanded[t] = 0;       // end of this call raises it again for the next one)
+    }
     const unsigned long long t_begin = wall_clock64();
     const u32 seq = (u32)m.iterations[t] & 0xFFFFu;   // number of the path this call builds (its expansion count)
     const size_t base = (size_t)t * (m.capacity + 1);
@@ -573,7 +611,10 @@ __global__ __launch_bounds__(kBlock) void k_mcts_select(rc_mcts_t m, double c, u
         }
         if ((phase & kPhaseMask) != kPhaseNormal) {   // uniform over the workgroup
             __syncthreads();
-            if (backup_phase_done(m, t, tid, phase)) return;
+            if (backup_phase_done(m, t, tid, phase)) {
+                if (FUSE && (phase & kPhaseMask) == kPhaseRootA && tid < kWave) expand_root_b(m, t, slot, tid);   // the next step's rows
+                return;
+            }
         }
         if (!running) {   // the expansion ended the tree (a solved child): its backup is all that is left to do
             __syncthreads();
@@ -665,8 +706,8 @@ __global__ __launch_bounds__(kBlock) void k_mcts_select(rc_mcts_t m, double c, u
                 store_row12(m.W, r, w);
             }
             if (dup && arr >= 0) cnt5_add(cnt5, ovf, (u32)arr);
-            bool c0, c1, c2 = true;
-            int b0, b1, d;
+            bool c0 = false, c1 = false, c2 = true;
+            int b0 = 0, b1 = 0, d = 0;
             u32 nb0 = 0, nb1 = 0;
             uint4 cache = ocache;
             bool fast = false;
@@ -1034,6 +1075,8 @@ __global__ __launch_bounds__(kBlock) void k_mcts_select(rc_mcts_t m, double c, u
         m.path_len[t] = plen;
         m.pending[t] = suspended;   // 1 = resume at path_len - 1
     }
+    if (FUSE && stop == 1)   // the descent stands on a leaf: its expansion, the first act of the next iteration (agents.py:477)
+        expand_leaf_wave(m, t, slot, lane, reinterpret_cast<const u8 *>(s_lut), max_states, false, cur);
 }
 
 // ---- _complete_graph (agents.py:597-611): one workgroup per solved tree, one thread per (leaf, action) ----
@@ -1214,7 +1257,21 @@ int rc_mcts_plant(const rc_mcts_t *m, const int32_t *slots, uint32_t n_slots, co
     RC_REQUIRE(aligned16(roots_soa) && (stride & 15u) == 0, RC_ERR_ALIGN);
     RC_REQUIRE(n_slots <= m->n_trees && stride >= first_col + n_slots && (m->hash_size & 3u) == 0, RC_ERR_RANGE);
     hipLaunchKernelGGL(k_mcts_plant, dim3(n_slots), dim3(kBlock), 0, (hipStream_t)stream, *m, (const int *)slots, (const u8 *)roots_soa,
-                       stride, first_col);
+                       stride, first_col, 0u);
+    return launch_status();
+}
+
+int rc_mcts_plant_expanded(const rc_mcts_t *m, const int32_t *slots, uint32_t n_slots, const int8_t *roots_soa, size_t stride,
+                           size_t first_col, uint32_t max_states, rc_stream_t stream) {
+    if (int rc = check_mcts(m)) return rc;
+    if (n_slots == 0) return RC_OK;
+    RC_REQUIRE(roots_soa != nullptr, RC_ERR_NULL);
+    RC_REQUIRE(aligned16(roots_soa) && (stride & 15u) == 0, RC_ERR_ALIGN);
+    RC_REQUIRE(n_slots <= m->n_trees && stride >= first_col + n_slots && (m->hash_size & 3u) == 0 && max_states > 0, RC_ERR_RANGE);
+    // the root's network rows are those of list position == tree index: every tree must be listed, in order
+    RC_REQUIRE(m->active == nullptr || m->n_active == m->n_trees, RC_ERR_RANGE);
+    hipLaunchKernelGGL(k_mcts_plant, dim3(n_slots), dim3(kBlock), 0, (hipStream_t)stream, *m, (const int *)slots, (const u8 *)roots_soa,
+                       stride, first_col, max_states);
     return launch_status();
 }
 
@@ -1258,7 +1315,7 @@ int rc_mcts_shorten(const rc_mcts_t *m, rc_stream_t stream) {
 int rc_mcts_select(const rc_mcts_t *m, double c, uint32_t level_budget, rc_stream_t stream) {
     if (int rc = check_mcts(m)) return rc;
     hipLaunchKernelGGL(k_mcts_select<0>, dim3(mcts_grid(m)), dim3(kBlock), 0, (hipStream_t)stream, *m, c, level_budget,
-                       (const void *)nullptr, (const float *)nullptr, (size_t)0, false);
+                       (const void *)nullptr, (const float *)nullptr, (size_t)0, false, 0u);
     return launch_status();
 }
 
@@ -1267,7 +1324,7 @@ int rc_mcts_backup_select(const rc_mcts_t *m, const float *probs, const float *v
     if (int rc = check_mcts(m)) return rc;
     RC_REQUIRE(probs && values, RC_ERR_NULL);
     hipLaunchKernelGGL(k_mcts_select<1>, dim3(mcts_grid(m)), dim3(kBlock), 0, (hipStream_t)stream, *m, c, level_budget,
-                       (const void *)probs, values, (size_t)0, false);
+                       (const void *)probs, values, (size_t)0, false, 0u);
     return launch_status();
 }
 
@@ -1277,7 +1334,27 @@ int rc_mcts_backup_select_head(const rc_mcts_t *m, const void *head, size_t ld, 
     RC_REQUIRE(head != nullptr, RC_ERR_NULL);
     RC_REQUIRE(ld >= (size_t)kActions + 1, RC_ERR_RANGE);
     hipLaunchKernelGGL(k_mcts_select<2>, dim3(mcts_grid(m)), dim3(kBlock), 0, (hipStream_t)stream, *m, c, level_budget, head,
-                       (const float *)nullptr, ld, head_is_bf16 != 0);
+                       (const float *)nullptr, ld, head_is_bf16 != 0, 0u);
+    return launch_status();
+}
+
+int rc_mcts_step(const rc_mcts_t *m, const float *probs, const float *values, double c, uint32_t level_budget, uint32_t max_states,
+                 rc_stream_t stream) {
+    if (int rc = check_mcts(m)) return rc;
+    RC_REQUIRE(probs && values, RC_ERR_NULL);
+    RC_REQUIRE(max_states > 0, RC_ERR_RANGE);
+    hipLaunchKernelGGL((k_mcts_select<1, true>), dim3(mcts_grid(m)), dim3(kBlock), 0, (hipStream_t)stream, *m, c, level_budget,
+                       (const void *)probs, values, (size_t)0, false, max_states);
+    return launch_status();
+}
+
+int rc_mcts_step_head(const rc_mcts_t *m, const void *head, size_t ld, int head_is_bf16, double c, uint32_t level_budget,
+                      uint32_t max_states, rc_stream_t stream) {
+    if (int rc = check_mcts(m)) return rc;
+    RC_REQUIRE(head != nullptr, RC_ERR_NULL);
+    RC_REQUIRE(ld >= (size_t)kActions + 1 && max_states > 0, RC_ERR_RANGE);
+    hipLaunchKernelGGL((k_mcts_select<2, true>), dim3(mcts_grid(m)), dim3(kBlock), 0, (hipStream_t)stream, *m, c, level_budget, head,
+                       (const float *)nullptr, ld, head_is_bf16 != 0, max_states);
     return launch_status();
 }
 

@@ -682,7 +682,10 @@ __global__ __launch_bounds__(kBlock) void k_head_split(const float4 *__restrict_
 // It replaces rc_oh_split_f16 + the K = 960 library GEMM + rc_split_act_f16 of the input layer.
 // =================================================================================================
 constexpr int kSpCols = 64;
-constexpr int kSpSub = 2;
+#ifndef RC_FL_SUB
+#define RC_FL_SUB 2
+#endif
+constexpr int kSpSub = RC_FL_SUB;   // 32-state tiles a wave holds at once (they share every B fragment read from LDS)
 
 
 // SPLIT = false: the same kernel as the bf16 engine's input layer (one table, W1 in IEEE half; bf16 output [n][H]).
@@ -780,7 +783,9 @@ __global__ __launch_bounds__(kMfWaves * kWave) void k_first_layer_split(const u8
             for (int c = 0; c < 2; ++c) b_cur[c] = *reinterpret_cast<const uint4 *>(bbase + c * 32 * kMfPitch);
 #pragma unroll
             for (int ks = 0; ks < 30; ++ks) {
-                uint4 a_nxt[kSpSub] = {a_cur[0], a_cur[1]}, b_nxt[2] = {b_cur[0], b_cur[1]};
+                uint4 a_nxt[kSpSub], b_nxt[2] = {b_cur[0], b_cur[1]};
+#pragma unroll
+                for (int u = 0; u < kSpSub; ++u) a_nxt[u] = a_cur[u];
                 if (ks + 1 < 30) {
 #pragma unroll
                     for (int c = 0; c < 2; ++c) b_nxt[c] = *reinterpret_cast<const uint4 *>(bbase + c * 32 * kMfPitch + 32 * (ks + 1));

@@ -340,6 +340,17 @@ class MCTS(DeepAgent):
         return f
 
     @no_grad
+    def prepare(self, n_trees: int, max_states: int):
+        """One-off set-up of a batched search with `n_trees` concurrent trees of capacity `max_states`, so that the search
+        itself starts at full speed: allocates the forest (HBM, zero-filled), builds the inference engine and captures the HIP
+        graph of every launch size the forest will be narrowed to (~0.1 s per size for the split engine: the allocations of
+        its activations).  Optional: a search on an unprepared agent does the same work on the way."""
+        cap_states = int(max_states) if max_states and max_states < int(1e10) else DEFAULT_NODE_CAP
+        forest = self._forest_for(int(n_trees), max(cap_states, 16))
+        if self.use_graph:
+            forest.capture_all(self.c, cap_states)
+
+    @no_grad
     def search_batch(self, states, time_limit: float = None, max_states: int = None,
                      max_iterations: int = None, compact: bool = True, slots: int = None) -> BatchResult:
         """
@@ -354,7 +365,9 @@ class MCTS(DeepAgent):
         (`MCTSForest.set_active`: a shorter list of trees, nothing moves in memory), so the stragglers continue on small
         network batches; the finished trees are turned into results where they lie, on a side stream.
         """
-        run = self.start_batch(states, time_limit, max_states, compact=compact, slots=slots)
+        # a bounded number of iterations must end on a completed one: the three-phase form (the one-launch form of an iteration
+        # expands the NEXT leaf at its end)
+        run = self.start_batch(states, time_limit, max_states, compact=compact, slots=slots, one_launch=max_iterations is None)
         assert max_iterations is None or run.S == run.n_games, "max_iterations applies to lock-step batches only"
         # a tree's first expansion (its root's) takes two lock-step iterations, every later one a single iteration
         steps = None if max_iterations is None else max_iterations + 1
@@ -364,10 +377,10 @@ class MCTS(DeepAgent):
 
     @no_grad
     def start_batch(self, states, time_limit: float = None, max_states: int = None, compact: bool = True,
-                    slots: int = None) -> "MCTSRun":
+                    slots: int = None, one_launch: bool = True) -> "MCTSRun":
         time_limit, max_states = self.reset(time_limit, max_states)
         roots = states if isinstance(states, DeviceCubes) else DeviceCubes.from_numpy(np.asarray(states))
-        return MCTSRun(self, roots, time_limit, max_states, compact, slots)
+        return MCTSRun(self, roots, time_limit, max_states, compact, slots, one_launch)
 
     # ---- the reference's single-state API ----------------------------------------------------------
     def search(self, state: np.ndarray, time_limit: float = None, max_states: int = None) -> bool:
@@ -421,16 +434,17 @@ class MCTSRun:
     budget then costs more iterations than it saves time per iteration).
     """
 
-    def __init__(self, agent: "MCTS", roots: DeviceCubes, time_limit: float, max_states: int, compact: bool, slots):
+    def __init__(self, agent: "MCTS", roots: DeviceCubes, time_limit: float, max_states: int, compact: bool, slots, one_launch: bool = True):
         self.agent, self.roots, self.time_limit, self.compact = agent, roots, time_limit, compact
-        self.max_states, self.slots = max_states, slots
+        self.max_states, self.slots, self.one_launch = max_states, slots, one_launch
         self.cap_states = int(max_states) if max_states < int(1e10) else DEFAULT_NODE_CAP
         self.n_games = roots.n
         S = self.S = self.n_games if slots is None else max(1, min(int(slots), self.n_games))
         forest = self.forest = agent._forest_for(S, max(self.cap_states, 16))
         agent.tt.tick()
         forest.set_active(None)
-        forest.plant(None, roots, 0)       # the first S scrambles; the others move in as trees finish
+        self.plant_states = self.cap_states if one_launch else None   # one-launch iterations: roots expanded by the plant itself
+        forest.plant(None, roots, 0, self.plant_states)       # the first S scrambles; the others move in as trees finish
         self.owner = np.arange(S)          # game index of every slot; -1 once its result has been taken and nobody moved in
         self.stale_until = np.full(S, -1)  # snapshots up to this index predate the tree that now lives in the slot
         self.next_game = S
@@ -587,7 +601,7 @@ class MCTSRun:
             self._harvest(done)
             k = min(len(done), self.n_games - self.next_game)
             idx = _to_device_async(done[:k].astype(np.int32), forest.status.device)
-            forest.plant(idx, self.roots, self.next_game)   # the waiting scrambles move in: roots evaluated by the next two iterations
+            forest.plant(idx, self.roots, self.next_game, self.plant_states)   # the waiting scrambles move in: roots evaluated by the next two iterations
             owner[done] = -1
             owner[done[:k]] = np.arange(self.next_game, self.next_game + k)
             self.stale_until[done[:k]] = self.q - 1     # every snapshot queued so far predates the adoption
@@ -637,7 +651,7 @@ class MCTSRun:
             result.status[self.next_game:] = md.EXHAUSTED
         self.done = True
         if agent._overflowed(forest.engine):   # the split engine could not represent an activation: the same search in fp32
-            again = MCTSRun(agent, self.roots, self.time_limit, self.max_states, self.compact, self.slots)
+            again = MCTSRun(agent, self.roots, self.time_limit, self.max_states, self.compact, self.slots, self.one_launch)
             while not again.done:
                 again.round()
             return again.finish()

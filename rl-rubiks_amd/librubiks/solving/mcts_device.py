@@ -45,6 +45,9 @@ _hip.register({
     "rc_mcts_select": [POINTER(_McStruct), c_double, c_uint32, c_void_p],
     "rc_mcts_backup_select": [POINTER(_McStruct), c_void_p, c_void_p, c_double, c_uint32, c_void_p],
     "rc_mcts_backup_select_head": [POINTER(_McStruct), c_void_p, c_size_t, c_int, c_double, c_uint32, c_void_p],
+    "rc_mcts_plant_expanded": [POINTER(_McStruct), c_void_p, c_uint32, c_void_p, c_size_t, c_size_t, c_uint32, c_void_p],
+    "rc_mcts_step": [POINTER(_McStruct), c_void_p, c_void_p, c_double, c_uint32, c_uint32, c_void_p],
+    "rc_mcts_step_head": [POINTER(_McStruct), c_void_p, c_size_t, c_int, c_double, c_uint32, c_uint32, c_void_p],
     "rc_mcts_complete_graph": [POINTER(_McStruct), c_void_p],
     "rc_mcts_shorten": [POINTER(_McStruct), c_void_p],
 }, restypes={"rc_mcts_struct_bytes": ctypes.c_size_t})
@@ -155,6 +158,7 @@ class MCTSForest:
         self.active_buf = torch.arange(B, dtype=torch.int32, device=dev)
         self.rungs = rungs(B)
         self.G = B
+        self._listed = None   # host copy of the list (None = every tree in order)
         s.active, s.n_active = self.active_buf.data_ptr(), B
         self.struct = s
         self.engine = None
@@ -181,7 +185,7 @@ class MCTSForest:
         for name in (_RESULT_TREE if results_only else _PER_TREE):
             state[name] = getattr(self, name)[keep].contiguous()
         sub = MCTSForest(len(keep), self.C, self.max_path, self.device, _state=state, _results_only=results_only)
-        sub.level_budget = self.level_budget
+        sub.level_budget, sub._one_launch = self.level_budget, self._one_launch
         sub.set_net(self.engine, self.engine.dtype if hasattr(self.engine, "dtype") else torch.bfloat16)
         return sub
 
@@ -213,13 +217,28 @@ class MCTSForest:
         if trees is None:
             self.active_buf.copy_(torch.arange(self.B, dtype=torch.int32, device=self.device))
             self.G = self.B
+            self._listed = None
         else:
             n = len(trees)
             G = self.rung_for(n)
             host = torch.full((G,), -1, dtype=torch.int32).pin_memory()
             host[:n] = torch.from_numpy(np.ascontiguousarray(trees, dtype=np.int32))
+            if self._one_launch and n:
+                # one-launch iterations: the rows of the NEXT network call were written by the previous step's expansion, at the
+                # trees' old list positions -- they move with their trees
+                old = np.arange(self.B) if self._listed is None else self._listed
+                where = np.full(self.B, -1, dtype=np.int64)
+                where[old[old >= 0]] = np.flatnonzero(old >= 0)
+                src = where[np.asarray(trees, dtype=np.int64)]
+                assert (src >= 0).all(), "a tree that was not listed cannot be listed again without being planted"
+                if not np.array_equal(src, np.arange(n)):
+                    cols = lambda slots: torch.from_numpy((slots[:, None] * ROWS + np.arange(ROWS)[None, :]).ravel()).pin_memory().to(  # noqa: E731
+                        self.device, non_blocking=True)
+                    moved = self.children.soa[:, cols(src)]
+                    self.children.soa[:, cols(np.arange(n))] = moved
             self.active_buf[:G].copy_(host, non_blocking=True)
             self._active_host = host   # alive until the copy has run
+            self._listed = host.numpy().astype(np.int64).copy()
             self.G = G
         self.struct.n_active = self.G
 
@@ -268,20 +287,37 @@ class MCTSForest:
         self.values[:rows].copy_(values)
 
     # ---- search phases ---------------------------------------------------------------------------
-    def reset(self, roots: DeviceCubes):
+    def reset(self, roots: DeviceCubes, max_states: int = None):
         """Empties every tree and plants root t = roots[t] as node 1 (agents.py:466-469); the roots are evaluated and
-        expanded by the first two iterations (rc_mcts_t::phase)."""
+        expanded by the first two iterations (rc_mcts_t::phase).  max_states: see `plant`."""
         assert roots.n == self.B and self.engine is not None
         self.set_active(None)
-        self.plant(None, roots, 0)
+        self.plant(None, roots, 0, max_states)
 
-    def plant(self, slots, roots: DeviceCubes, first: int = 0):
+    fused_step = True   # iterations as [network -> rc_mcts_step*] (expansion at the END of a step) when the trees were planted for it
+    _one_launch = False
+
+    def plant(self, slots, roots: DeviceCubes, first: int = 0, max_states: int = None):
         """Trees `slots` (int32 device tensor, or None for all) restart from roots[first], roots[first + 1], ...: their
         hash tables are cleared by the kernel, nothing else needs clearing (a node's rows are initialised when it is
-        created).  Safe between two iterations of a running forest: other trees are not touched."""
+        created).  Safe between two iterations of a running forest: other trees are not touched.
+        max_states (the search's per-tree cap): the roots are expanded right here (rc_mcts_plant_expanded) and the forest's
+        iterations become [network -> one tree kernel that backs up, descends and expands the next leaf]; without it the
+        three-phase form [expand -> network -> backup + descent] is used.  Planting all trees chooses the form, planting some
+        (slots freed in a running forest) must keep it."""
         n = self.B if slots is None else int(slots.numel())
         assert slots is None or (slots.dtype == torch.int32 and slots.is_cuda and slots.is_contiguous())
         assert 0 <= first and first + n <= roots.n
+        one = bool(self.fused_step and max_states is not None)
+        if slots is None:
+            self._one_launch = one
+        assert one == self._one_launch, "trees planted into a running forest must use the form its iterations run in"
+        if one:
+            assert self.G == self.B, "roots are expanded into the rows of list position == tree index: plant before narrowing"
+            _hip.check(self.lib.rc_mcts_plant_expanded(ctypes.byref(self.struct), None if slots is None else slots.data_ptr(), n,
+                                                       roots.soa.data_ptr(), roots.stride, first, int(max_states), _hip.stream_ptr()),
+                       "rc_mcts_plant_expanded")
+            return
         _hip.check(self.lib.rc_mcts_plant(ctypes.byref(self.struct), None if slots is None else slots.data_ptr(), n,
                                           roots.soa.data_ptr(), roots.stride, first, _hip.stream_ptr()), "rc_mcts_plant")
 
@@ -290,6 +326,17 @@ class MCTSForest:
     def _iteration(self, c: float, max_states: int):
         st = _hip.stream_ptr()
         m = ctypes.byref(self.struct)
+        if self._one_launch:   # the rows were left by the previous step's expansion (or by the plant): network, then ONE tree kernel
+            if self._fused:
+                cubes, rows = self._net_input()
+                head = self.engine.head_cubes(cubes, None if self._x1 is None else self._x1[:rows])
+                _hip.check(self.lib.rc_mcts_step_head(m, head.data_ptr(), head.stride(0), int(head.dtype == torch.bfloat16), c,
+                                                      self.level_budget, max_states, st), "rc_mcts_step_head")
+            else:
+                self._evaluate_children()
+                _hip.check(self.lib.rc_mcts_step(m, self.probs.data_ptr(), self.values.data_ptr(), c, self.level_budget, max_states, st),
+                           "rc_mcts_step")
+            return
         _hip.check(self.lib.rc_mcts_expand(m, max_states, st), "rc_mcts_expand")
         if self._fused:   # head GEMM output (12 logits + value per row) goes straight into the backup kernel
             cubes, rows = self._net_input()
@@ -307,7 +354,7 @@ class MCTSForest:
         assert not self.results_only
         if not use_graph:
             return self._iteration(c, max_states)
-        key = (self.G, float(c), int(max_states), int(self.level_budget))
+        key = (self.G, float(c), int(max_states), int(self.level_budget), self._one_launch)
         g = self._graphs.get(key)
         if g is None:
             # this call's iteration runs eagerly (hipBLASLt picks its kernels, the allocator settles);
@@ -323,6 +370,22 @@ class MCTSForest:
             self._graphs[key] = g
             return
         g.replay()
+
+    def capture_all(self, c: float, max_states: int):
+        """Captures the iteration's HIP graph for every launch size of the ladder (`rungs`) ahead of time, on an idle forest (every
+        tree marked finished: the tree kernels return at once, the network runs on whatever the row buffers hold).  One-off set-up
+        per forest and (c, max_states): a search started afterwards replays graphs from its first iteration on, however it narrows."""
+        assert not self.results_only and self.engine is not None
+        self.status.fill_(EXHAUSTED)
+        self.pending.zero_()
+        self.expanded.zero_()
+        self._one_launch = bool(self.fused_step)
+        for G in self.rungs:
+            self.set_active(np.arange(G))
+            if (self.G, float(c), int(max_states), int(self.level_budget), self._one_launch) not in self._graphs:
+                self.step(c, max_states, use_graph=True)
+        self.set_active(None)
+        torch.cuda.synchronize()
 
     def any_running(self) -> bool:
         return bool((self.status == RUNNING).any().item())

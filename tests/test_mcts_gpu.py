@@ -237,3 +237,35 @@ def test_compaction_is_invisible(net_gpu):
     assert np.array_equal(a.status, b.status)
     assert all(list(x) == list(y) for x, y in zip(a.queues, b.queues))
     assert 0.2 < a.solved.mean() < 1.0
+
+
+def test_one_launch_iterations_equal_the_three_phase_form(net_gpu):
+    """rc_mcts_plant_expanded + [network -> rc_mcts_step*] (the expansion of the next leaf at the END of a step, by the wave that
+    walked to it) against [rc_mcts_expand -> network -> rc_mcts_backup_select*]: the same trees, game for game, with the exact
+    stand-in net and with the production engine; slots refilled in a running forest included."""
+    import os
+    from conftest import ROOT
+    from librubiks.model import Model
+    from librubiks.solving import mcts_device as md
+    from librubiks.solving.agents import MCTS
+    np.random.seed(31)
+    states = np.array([oc.scramble(2 + i % 9, True)[0] for i in range(150)])
+    nets = [(net_gpu, torch.float32, 900)]
+    wdir = os.path.join(ROOT, "weights", "fc_small_r1")
+    if os.path.isdir(wdir):
+        nets.append((Model.load(wdir).eval(), torch.bfloat16, 2500))
+    for net, dt, cap in nets:
+        out = {}
+        for one in (True, False):
+            md.MCTSForest.fused_step = one
+            try:
+                agent = MCTS(net, c=0.6, search_graph=True, net_dtype=dt, sync_every=4)
+                out[one] = (agent.search_batch(states, None, cap, compact=False), agent.search_batch(states, None, cap, slots=40))
+                assert agent.forest._one_launch == one
+            finally:
+                md.MCTSForest.fused_step = True
+        for a, b in zip(out[True], out[False]):
+            assert np.array_equal(a.solved, b.solved) and np.array_equal(a.nodes, b.nodes) and np.array_equal(a.lengths, b.lengths)
+            assert np.array_equal(a.iterations, b.iterations) and np.array_equal(a.status, b.status)
+            assert all(list(x) == list(y) for x, y in zip(a.queues, b.queues))
+        assert 0.1 < out[True][0].solved.mean() < 1.0
