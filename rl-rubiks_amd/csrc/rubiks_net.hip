@@ -685,6 +685,9 @@ constexpr int kSpCols = 64;
 #ifndef RC_FL_SUB
 #define RC_FL_SUB 2
 #endif
+#ifndef RC_FL_PINGPONG
+#define RC_FL_PINGPONG 0   // 1: the two waves of a SIMD alternate between the matrix stage and the epilogue (below; measured slower)
+#endif
 constexpr int kSpSub = RC_FL_SUB;   // 32-state tiles a wave holds at once (they share every B fragment read from LDS)
 
 
@@ -743,7 +746,18 @@ __global__ __launch_bounds__(kMfWaves * kWave) void k_first_layer_split(const u8
 
     const u32 off_a = h ? 8u : 0u, off_c = h ? 16u : 8u;
     constexpr size_t kStep = (size_t)kMfWaves * kSpSub * kMfTile;
-    for (size_t t0 = row_lo + (size_t)wave * kSpSub * kMfTile; t0 < row_hi; t0 += kStep) {
+    // A pass of a wave = [60 k-steps of MFMAs] then [epilogue: ELU + re-split of 64 values per lane, ~1 600 VALU instructions].
+    // PMC (profiles/r3_first_layer_split_pmc.txt): the matrix pipe is busy 40 % of the cycles, 9 VALU instructions per MFMA,
+    // LDS wait negligible.  RC_FL_PINGPONG=1 makes the two waves of a SIMD (w and w + 4) alternate between the two stages
+    // (the upper four enter one barrier late, stages separated by barriers, every wave runs the same number of passes so the
+    // barrier counts match): measured SLOWER, 135 against 119 us per call in tools/first_layer_split_bench.py
+    // (profiles/r3_first_layer_variants.txt), like 3 or 4 state tiles per wave (132 / 149 us).  Off.
+    const bool late_row = wave >= kMfWaves / 2;
+    const u32 n_pass = (u32)((row_hi - row_lo + kStep - 1) / kStep);
+    if (RC_FL_PINGPONG && late_row) __builtin_amdgcn_s_barrier();
+    for (u32 pass = 0; pass < n_pass; ++pass) {
+        const size_t t0 = row_lo + (size_t)pass * kStep + (size_t)wave * kSpSub * kMfTile;
+        if (!RC_FL_PINGPONG && t0 >= row_hi) break;
         u32 pk[kSpSub][5];
 #pragma unroll
         for (int u = 0; u < kSpSub; ++u) {
@@ -808,6 +822,11 @@ __global__ __launch_bounds__(kMfWaves * kWave) void k_first_layer_split(const u8
         }
         // epilogue: activation, then the lane's columns 2 r, 2 r + 1 of one state as one 4-byte store: bf16 pair, or -- split --
         // the pair of hi halves and the pair of lo halves into the [hi | lo] row of the state (row pitch 2 H halves)
+        if (RC_FL_PINGPONG) {
+            __builtin_amdgcn_sched_barrier(0);
+            __builtin_amdgcn_s_barrier();
+            __builtin_amdgcn_sched_barrier(0);
+        }
 #pragma unroll
         for (int u = 0; u < kSpSub; ++u)
 #pragma unroll
@@ -826,7 +845,7 @@ __global__ __launch_bounds__(kMfWaves * kWave) void k_first_layer_split(const u8
                         y[c] = act_apply(x, ACT, alpha);
                     }
                 }
-                if (row < n) {
+                if (row < n && row < row_hi) {
                     if (SPLIT) {
                         u32 *orow = out + row * H;   // 2 H halves = H dwords per row
                         orow[(ct * kSpCols) / 2 + r] = pack_half2(hi[0], hi[1]);
@@ -836,7 +855,13 @@ __global__ __launch_bounds__(kMfWaves * kWave) void k_first_layer_split(const u8
                     }
                 }
             }
+        if (RC_FL_PINGPONG) {
+            __builtin_amdgcn_sched_barrier(0);
+            __builtin_amdgcn_s_barrier();
+            __builtin_amdgcn_sched_barrier(0);
+        }
     }
+    if (RC_FL_PINGPONG && !late_row) __builtin_amdgcn_s_barrier();
     if (SPLIT && range_flag && out_of_range) atomicOr(range_flag, 1);
 }
 
