@@ -396,11 +396,11 @@ class InferenceNet:
         """Value head only, float32[n], straight from device-resident cube states (optionally the window lo..lo+n)."""
         return self._run(self.value_layers[1:], self.first_layer(cubes, x1, lo, n)).float().reshape(-1)
 
-    # bf16 hidden layers with an activation as one kernel (rc_gemm_bias_act_bf16) where its tile fills the chip.  Opt-in: the
-    # kernel beats hipBLASLt + the activation pass (0.186 ms against 0.200 ms at 11 264 x 4096 x 2048, +1.5 % on a steady-state
-    # MCTS step), but only at full batches, and switching kernels with the batch size would make a row's bf16 result depend on
-    # how many other rows share its launch (tests/test_full_size_gpu.py requires the pooled and the one-batch search to agree).
-    fused_hidden = False
+    # bf16 hidden layers with an activation as one kernel (rc_gemm_layer_bf16: bias, skip connection, activation fused) where its
+    # 352 x 256 tiles fill the chip: 0.168 ms against 0.195 ms for hipBLASLt + the activation pass at 11 264 x 4096 x 2048; narrower
+    # layers and smaller batches stay with the library.  (Which kernel a row runs on depends on how many rows share its launch --
+    # as it does for the library's own choice of tiles: a row's bf16 result is not bit-identical across batch shapes.)
+    fused_hidden = True
 
     def _run(self, layers, x):
         skip = None

@@ -98,7 +98,8 @@ def test_bench_two_ranks_aggregate_their_shares():
     """
     import socket
     common = ["--steps", "6", "--warmup", "2", "--trees", "48", "--pool-factor", "2", "--legs", "bf16", "--solve-max-states",
-              "1500", "--phase-reps", "0", "--no-cpu-baseline", "--no-env-roofline", "--prep-cap", "40", "--extra-legs", "none"]
+              "1500", "--phase-reps", "0", "--no-cpu-baseline", "--no-env-roofline", "--prep-cap", "40", "--astar-problems", "24",
+              "--config5-trees", "32", "--config5-max-states", "800"]
     with socket.socket() as s:
         s.bind(("127.0.0.1", 0))
         port = s.getsockname()[1]
@@ -115,4 +116,12 @@ def test_bench_two_ranks_aggregate_their_shares():
     pool = two["legs"]["bf16"]["pool_run"]
     assert pool["games"] == 2 * 96 and pool["nodes"] == sum(x["legs"]["bf16"]["pool_run"]["nodes"] for x in shares)
     assert two["legs"]["bf16"]["steps_timed"] == 6 and two["value"] > 0
-    assert two["config"]["parallelism"] == "scramble-sharded x2"
+    assert two["config"]["parallelism"] == "scramble-sharded x2" and two["scaling_measured"] is False
+    # the extra legs (A*: BASELINE configs[2]; one GPU's share of configs[4]) aggregate over the ranks as well
+    for name in ("f32s", "bf16"):
+        a2, parts2 = two["astar"][name]["solve_run"], [x["astar"][name]["solve_run"] for x in shares]
+        assert a2["games"] == 48 and a2["nodes"] == parts2[0]["nodes"] + parts2[1]["nodes"]
+        c2, cparts = two["config5_share"][name]["run_to_completion"], [x["config5_share"][name]["run_to_completion"] for x in shares]
+        assert c2["games"] == 64 and c2["nodes"] == cparts[0]["nodes"] + cparts[1]["nodes"]
+    r = two["config"]["results"]
+    assert r["value_run_to_completion"] == a["nodes_per_sec"] and "astar_f32s_states_per_sec" in r and "config5_share_bf16_value" in r
