@@ -8,6 +8,7 @@
 // wave doing the per-action work in parallel (ballots / DPP reductions instead of loops), and
 // no atomics across trees (each tree owns its node arrays and its hash table).
 #include <limits.h>
+#include <stdlib.h>
 
 #include "rubiks_common.h"
 
@@ -346,12 +347,12 @@ __device__ __forceinline__ bool backup_phase_done(const rc_mcts_t &m, u32 t, u32
 // every path edge is marked, then whoever finds the mark replaces it by old + 1.  Two threads that hold the same pair
 // write the same values, whichever of them runs first, so no ordering is needed inside a pass.
 __device__ __forceinline__ void backup_path(const rc_mcts_t &m, u32 tid, size_t base, const int *pnode, const u8 *pact, int plen,
-                                            float best) {
+                                            float best, int nt = kBlock) {
     const int edges = plen - 1;
     constexpr int kMark = 1 << 30;
-    for (int i = tid; i < edges; i += kBlock) m.N[(base + pnode[i]) * kRow + pact[i]] |= kMark;
+    for (int i = tid; i < edges; i += nt) m.N[(base + pnode[i]) * kRow + pact[i]] |= kMark;
     __syncthreads();
-    for (int i = tid; i < edges; i += kBlock) {
+    for (int i = tid; i < edges; i += nt) {
         const size_t e = (base + pnode[i]) * kRow + pact[i];
         const int nv = m.N[e];
         if (nv & kMark) m.N[e] = (nv & ~kMark) + 1;            // agents.py:568
@@ -558,8 +559,11 @@ __device__ __forceinline__ u32 sel_hash(int node) { return ((u32)node * 0x9E3779
 // EXPANSION of the leaf the descent ends at (what rc_mcts_expand would do at the start of the next iteration), by the wave that
 // walked there: one launch and one dependent kernel boundary less per iteration.  Trees planted for this form have their root
 // expanded by rc_mcts_plant_expanded.
-template <int MODE, bool FUSE = false>
-__global__ __launch_bounds__(kBlock) void k_mcts_select(rc_mcts_t m, double c, u32 level_budget, const void *__restrict__ probs_or_head,
+// NT: threads per tree.  256 in a full forest (four workgroups per CU: 1 024 trees in one round); small forests leave CUs idle, so
+// rc_mcts_step* gives a tree 512 / 1 024 threads there -- the parallel parts (staging, re-validation: one lane per path level)
+// of a 1 200-level descent take two rounds per thread instead of five.
+template <int MODE, bool FUSE = false, int NT = kBlock>
+__global__ __launch_bounds__(NT) void k_mcts_select(rc_mcts_t m, double c, u32 level_budget, const void *__restrict__ probs_or_head,
                                                       const float *__restrict__ values, size_t ld, bool head_bf16, u32 max_states) {
     __shared__ u32 s_lut[FUSE ? sizeof(kTables.lut) / 4 : 1];
     __shared__ float s_best;                // MODE > 0: the value backed up along the path
@@ -618,7 +622,7 @@ __global__ __launch_bounds__(kBlock) void k_mcts_select(rc_mcts_t m, double c, u
         }
         if (!running) {   // the expansion ended the tree (a solved child): its backup is all that is left to do
             __syncthreads();
-            backup_path(m, tid, base, pnode, pact, plen_old, s_best);
+            backup_path(m, tid, base, pnode, pact, plen_old, s_best, NT);
             return;
         }
     } else if (MODE > 0 && (phase & kPhaseMask) != kPhaseNormal) {
@@ -633,7 +637,7 @@ __global__ __launch_bounds__(kBlock) void k_mcts_select(rc_mcts_t m, double c, u
     u32 pf[8];
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-        const int k = (int)tid + i * kBlock;
+        const int k = (int)tid + i * NT;
         const u32 *rp = reinterpret_cast<const u32 *>(m.N) + (base + (size_t)(k < plen_old ? pnode[k] : 0)) * kRow;
         pf[2 * i] = rp[0];
         pf[2 * i + 1] = (kOneLine && RC_SELECT_PF_LINE1 == 0) ? 0u : rp[kRow / 2];
@@ -642,19 +646,19 @@ __global__ __launch_bounds__(kBlock) void k_mcts_select(rc_mcts_t m, double c, u
     const bool ract = rl < kA;
     const u32 rla = ract ? rl : 0;
     const int resume = m.pending[t];   // uniform over the workgroup: a suspended descent continues at its last node
-    for (int i = tid; i < kSelHash; i += kBlock) s_head[i] = -1;
-    for (int k = tid; k < plen_old; k += kBlock) {
+    for (int i = tid; i < kSelHash; i += NT) s_head[i] = -1;
+    for (int k = tid; k < plen_old; k += NT) {
         s_node[k] = pnode[k];
         s_act[k] = (k < nlev) ? pact[k] : (u8)0;
     }
     if (tid == 0) s_first = nlev;
     __syncthreads();
-    for (int k = tid; k < nlev; k += kBlock) s_next[k] = (u16)atomicExch(&s_head[sel_hash(s_node[k])], k);
+    for (int k = tid; k < nlev; k += NT) s_next[k] = (u16)atomicExch(&s_head[sel_hash(s_node[k])], k);
     __syncthreads();
     if (!resume) {
         // Pass A: one lane per level, float32 with the acceptance rule of lane_pick.  Levels it cannot settle (near
         // ties, NaNs, loss counts beyond 5 bits) are flagged for pass B.
-        for (int i = tid; i < kMaxPath / 32; i += kBlock) s_unc[i] = s_late[i] = 0;
+        for (int i = tid; i < kMaxPath / 32; i += NT) s_unc[i] = s_late[i] = 0;
         if (tid == 0) s_nlate = s_nunc = 0;
         __syncthreads();
         const float c32v = (float)c;
@@ -771,20 +775,20 @@ __global__ __launch_bounds__(kBlock) void k_mcts_select(rc_mcts_t m, double c, u
                 atomicOr(&s_unc[k >> 5], 1u << (k & 31));
             }
         };
-        for (int k = tid; k <= nlev; k += kBlock) decide(k, false);
+        for (int k = tid; k <= nlev; k += NT) decide(k, false);
         if (MODE > 0 && backup) {
             __syncthreads();
             const int nlate = s_nlate;
-            for (int i = tid; i < min(nlate, kLateCap); i += kBlock) decide((int)s_latelist[i], true);
+            for (int i = tid; i < min(nlate, kLateCap); i += NT) decide((int)s_latelist[i], true);
             if (nlate > kLateCap)   // the overflow, by the bitmap: each group of 32 lanes takes a word of flags
-                for (int k0 = 32 * (int)(tid >> 5); k0 <= nlev; k0 += 32 * (kBlock / 32))
+                for (int k0 = 32 * (int)(tid >> 5); k0 <= nlev; k0 += 32 * (NT / 32))
                     if ((s_late[k0 >> 5] >> (tid & 31)) & 1u) decide(k0 + (int)(tid & 31), true);
         }
         __syncthreads();
         // Pass B: the flagged levels in float64, NumPy's evaluation order, one 16-lane row per level.
         const int nunc = s_nunc;
         const bool by_list = nunc <= kUncCap;   // else: scan the bitmap, 16 levels per step
-        for (int i0 = 0; i0 < (by_list ? nunc : nlev + 1); i0 += kBlock / 16) {
+        for (int i0 = 0; i0 < (by_list ? nunc : nlev + 1); i0 += NT / 16) {
             if (!by_list && ((s_unc[i0 >> 5] >> (i0 & 31)) & 0xFFFFu) == 0) continue;   // uniform over the workgroup
             const int i = i0 + (int)row;
             const int k = by_list ? (i < nunc ? (int)s_unclist[i] : nlev + 1) : i;
@@ -829,9 +833,9 @@ __global__ __launch_bounds__(kBlock) void k_mcts_select(rc_mcts_t m, double c, u
         const int first = s_first;
         // (the kept prefix's virtual losses, agents.py:589-591, are implied by the path: see the note on L at the top)
         if (first < nlev) {   // from here on the chains hold the kept levels only; the walk appends its own
-            for (int i = tid; i < kSelHash; i += kBlock) s_head[i] = -1;
+            for (int i = tid; i < kSelHash; i += NT) s_head[i] = -1;
             __syncthreads();
-            for (int k = tid; k < first; k += kBlock) s_next[k] = (u16)atomicExch(&s_head[sel_hash(s_node[k])], k);
+            for (int k = tid; k < first; k += NT) s_next[k] = (u16)atomicExch(&s_head[sel_hash(s_node[k])], k);
         }
     }
     __syncthreads();   // also: the records written above are visible to wave 0 from here on
@@ -1217,6 +1221,14 @@ using namespace rubiks;
 
 static inline unsigned mcts_grid(const rc_mcts_t *m) { return m->active ? m->n_active : m->n_trees; }
 
+// Threads per tree of the one-launch iteration: 256 in a full forest; 512 / 1 024 where the forest is small enough to leave CUs
+// idle (RUBIKS_STEP_THREADS=256 pins it, for A/B measurements).
+static unsigned step_threads(unsigned n_trees) {
+    static const int pinned = [] { const char *e = getenv("RUBIKS_STEP_THREADS"); return e ? atoi(e) : 0; }();
+    if (pinned == 256 || pinned == 512 || pinned == 1024) return (unsigned)pinned;
+    return n_trees <= 256 ? 1024u : n_trees <= 512 ? 512u : 256u;
+}
+
 static int check_mcts(const rc_mcts_t *m, bool results_only_ok = false) {
     RC_REQUIRE(m != nullptr, RC_ERR_NULL);
     RC_REQUIRE(m->keys && m->nbr && m->P && m->W && m->N && m->V && m->leaf && m->hash && m->n_nodes &&
@@ -1343,8 +1355,14 @@ int rc_mcts_step(const rc_mcts_t *m, const float *probs, const float *values, do
     if (int rc = check_mcts(m)) return rc;
     RC_REQUIRE(probs && values, RC_ERR_NULL);
     RC_REQUIRE(max_states > 0, RC_ERR_RANGE);
-    hipLaunchKernelGGL((k_mcts_select<1, true>), dim3(mcts_grid(m)), dim3(kBlock), 0, (hipStream_t)stream, *m, c, level_budget,
-                       (const void *)probs, values, (size_t)0, false, max_states);
+    const unsigned g = mcts_grid(m);
+#define RC_STEP(NT_) hipLaunchKernelGGL((k_mcts_select<1, true, NT_>), dim3(g), dim3(NT_), 0, (hipStream_t)stream, *m, c, level_budget, \
+                                        (const void *)probs, values, (size_t)0, false, max_states)
+    const unsigned nt = step_threads(g);
+    if (nt == 1024) RC_STEP(1024);
+    else if (nt == 512) RC_STEP(512);
+    else RC_STEP(256);
+#undef RC_STEP
     return launch_status();
 }
 
@@ -1353,8 +1371,14 @@ int rc_mcts_step_head(const rc_mcts_t *m, const void *head, size_t ld, int head_
     if (int rc = check_mcts(m)) return rc;
     RC_REQUIRE(head != nullptr, RC_ERR_NULL);
     RC_REQUIRE(ld >= (size_t)kActions + 1 && max_states > 0, RC_ERR_RANGE);
-    hipLaunchKernelGGL((k_mcts_select<2, true>), dim3(mcts_grid(m)), dim3(kBlock), 0, (hipStream_t)stream, *m, c, level_budget, head,
-                       (const float *)nullptr, ld, head_is_bf16 != 0, max_states);
+    const unsigned g = mcts_grid(m);
+#define RC_STEP(NT_) hipLaunchKernelGGL((k_mcts_select<2, true, NT_>), dim3(g), dim3(NT_), 0, (hipStream_t)stream, *m, c, level_budget, head, \
+                                        (const float *)nullptr, ld, head_is_bf16 != 0, max_states)
+    const unsigned nt = step_threads(g);
+    if (nt == 1024) RC_STEP(1024);
+    else if (nt == 512) RC_STEP(512);
+    else RC_STEP(256);
+#undef RC_STEP
     return launch_status();
 }
 
