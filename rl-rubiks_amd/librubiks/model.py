@@ -576,7 +576,9 @@ class SplitF32Net:
         """Tile of rc_split_gemm_f16 for this layer, 0 = keep the two library GEMMs + rc_split_act_f16."""
         if k % 64 or n_out % 256:
             return 0
-        return 1 if -(-rows // 352) * (n_out // 256) >= 192 else 0   # 352 x 256 tiles, at least 3/4 of the 256 CUs busy
+        # 352 x 256 tiles, one per CU: more than 128 of them (with 128 or fewer the K loop is cut in two instead: twice the
+        # workgroups still fit one round; 160 tiles cut in two would take two rounds, 0.38 ms against 0.33 ms at 7 040 rows)
+        return 1 if -(-rows // 352) * (n_out // 256) > 128 else 0
 
     def workspace(self, rows: int):
         return None
