@@ -269,3 +269,33 @@ def test_one_launch_iterations_equal_the_three_phase_form(net_gpu):
             assert np.array_equal(a.iterations, b.iterations) and np.array_equal(a.status, b.status)
             assert all(list(x) == list(y) for x, y in zip(a.queues, b.queues))
         assert 0.1 < out[True][0].solved.mean() < 1.0
+
+
+def test_one_launch_entry_points_check_their_arguments(net_gpu):
+    """rc_mcts_plant_expanded / rc_mcts_step*: max_states must be positive, the head pointer present, and roots can only be expanded
+    while every tree is listed in order (their network rows are those of list position == tree index)."""
+    import ctypes
+    from librubiks import _hip
+    from librubiks.cube import DeviceCubes
+    from librubiks.solving import mcts_device as md
+    forest = md.MCTSForest(64, 200)
+    forest.set_net(net_gpu, torch.float32)
+    roots = DeviceCubes.from_numpy(np.array([oc.scramble(4, True)[0] for _ in range(64)]))
+    lib, m = forest.lib, ctypes.byref(forest.struct)
+    head = torch.zeros((64 * 11, 16), device="cuda")
+    assert lib.rc_mcts_plant_expanded(m, None, 64, roots.soa.data_ptr(), roots.stride, 0, 0, None) == -4          # max_states = 0
+    assert lib.rc_mcts_plant_expanded(m, None, 64, None, roots.stride, 0, 200, None) == -1
+    assert lib.rc_mcts_plant_expanded(m, None, 65, roots.soa.data_ptr(), roots.stride, 0, 200, None) == -4
+    assert lib.rc_mcts_step_head(m, None, 16, 0, 0.6, 0, 200, None) == -1
+    assert lib.rc_mcts_step_head(m, head.data_ptr(), 12, 0, 0.6, 0, 200, None) == -4                              # 13 values per row
+    assert lib.rc_mcts_step_head(m, head.data_ptr(), 16, 0, 0.6, 0, 0, None) == -4
+    assert lib.rc_mcts_step(m, None, None, 0.6, 0, 200, None) == -1
+    forest.reset(roots, 200)                       # plants and expands: fine while all 64 trees are listed
+    forest.set_active(np.arange(32))
+    assert lib.rc_mcts_plant_expanded(ctypes.byref(forest.struct), None, 32, roots.soa.data_ptr(), roots.stride, 0, 200, None) == -4
+    with pytest.raises(AssertionError):
+        forest.plant(None, roots, 0, 200)
+    s = forest.listed(torch.arange(4, dtype=torch.int32, device="cuda"))
+    s.n_active = 65
+    assert lib.rc_mcts_complete_graph(ctypes.byref(s), None) == -4                                                # list longer than the forest
+    torch.cuda.synchronize()

@@ -567,3 +567,59 @@ def test_mcts_on_a_residual_net_uses_the_fused_path_and_equals_the_oracle():
         ok = ref.search(states[t], 400)
         assert bool(res.solved[t]) == ok and res.nodes[t] == len(ref) == n and list(res.queues[t]) == list(ref.action_queue)
         _compare(tree, ref, n)
+
+
+def test_layer_request_k_splits_and_reduce_match_the_whole_kernel():
+    """rc_split_layer_f16 with out_partials and k_splits = 2, 3, 4, 6 + rc_split_reduce_f16 (ordered sum, the first
+    rc_split_layer_corr_chunks partials scaled by 2^-11, bias, skip connection, ELU, post-activation affine, re-split) against the
+    whole-K kernel with the same epilogue options, and the C-ABI's argument checks for both."""
+    from librubiks import _hip
+    from librubiks.model import _layer_call
+    lib = _hip.lib()
+    g = torch.Generator().manual_seed(11)
+    rows, k, n_out = 700, 768, 512                      # 3 k / 64 = 36 K-steps
+    halves = lambda v: (v.half(), ((v - v.half().double()) * 2048.0).half())   # noqa: E731
+    x = torch.randn(rows, k, generator=g).double() * 0.7
+    W = torch.randn(n_out, k, generator=g).double() / np.sqrt(k)
+    b = torch.randn(n_out, generator=g).cuda()
+    skip = torch.randn(rows, n_out, generator=g).double()
+    ps, pt = (torch.rand(n_out, generator=g) + 0.5).cuda(), torch.randn(n_out, generator=g).cuda()
+    (xh, xl), (wh, wl), (sh, sl) = halves(x), halves(W), halves(skip)
+    a, w3, res = torch.cat([xh, xl], 1).cuda(), torch.cat([wl, wh, wh], 1).cuda(), torch.cat([sh, sl], 1).cuda()
+    whole = torch.empty((rows, 2 * n_out), dtype=torch.float16, device="cuda")
+    flag = torch.zeros(1, dtype=torch.int32, device="cuda")
+    _layer_call("rc_split_layer_f16", a=a, w=w3, bias=b, residual=res, post_scale=ps, post_shift=pt, n_rows=rows, n_out=n_out, k=k,
+                activation=2, alpha=1.0, out_hi_lo=whole, tile=0, k_splits=1, range_flag=flag)
+    y_whole = whole[:, :n_out].double() + whole[:, n_out:].double() / 2048
+    # float64 reference of the same function of the same (split) operands
+    z = (xh.double() + xl.double() / 2048) @ (wh.double() + wl.double() / 2048).t() + b.cpu().double() + (sh.double() + sl.double() / 2048)
+    ref = torch.where(z > 0, z, torch.expm1(z)) * ps.cpu().double() + pt.cpu().double()
+    assert float((y_whole.cpu() - ref).abs().max()) < 2e-5 and int(flag.item()) == 0
+    for S in (2, 3, 4, 6):
+        part = torch.full((S, rows, n_out), float("nan"), device="cuda")
+        _layer_call("rc_split_layer_f16", a=a, w=w3, n_rows=rows, n_out=n_out, k=k, out_partials=part, k_splits=S)
+        n_corr = lib.rc_split_layer_corr_chunks(k, S)
+        assert n_corr == sum((p + 1) * (36 // S) <= 24 for p in range(S))
+        out = torch.empty((rows, 2 * n_out), dtype=torch.float16, device="cuda")
+        f32 = torch.empty((rows, n_out), device="cuda")
+        _hip.check(lib.rc_split_reduce_f16(part.data_ptr(), rows * n_out, S, n_corr, rows, n_out, b.data_ptr(), res.data_ptr(), 2, 1.0,
+                                           ps.data_ptr(), pt.data_ptr(), out.data_ptr(), f32.data_ptr(), flag.data_ptr(), None), "rc_split_reduce_f16")
+        y = out[:, :n_out].double() + out[:, n_out:].double() / 2048
+        assert float((y - y_whole).abs().max()) < 4e-6 * max(1.0, float(y_whole.abs().max())), S      # summation order differs, nothing else
+        assert float((f32.double() - y).abs().max()) < 2e-6 * max(1.0, float(y.abs().max()))          # fp32 output vs its 22-bit split
+    assert int(flag.item()) == 0
+    # argument checks
+    L = dict(a=a, w=w3, n_rows=rows, n_out=n_out, k=k)
+    bad = lambda **kw: pytest.raises(_hip.RubiksHipError, _layer_call, "rc_split_layer_f16", **{**L, **kw})   # noqa: E731
+    part = torch.empty((2, rows, n_out), device="cuda")
+    bad(out_partials=part, k_splits=5)                                   # 36 K-steps are not divisible by 5
+    bad(out_partials=part, k_splits=1)                                   # partials need at least two chunks
+    bad(out_partials=part, out_hi_lo=whole, k_splits=2)                  # exactly one output
+    bad(bias=b, out_hi_lo=whole, post_scale=ps)                          # post_scale without post_shift
+    bad(out_hi_lo=whole)                                                 # the fused epilogue needs a bias
+    assert lib.rc_split_layer_corr_chunks(100, 2) == -1
+    red = lambda **kw: lib.rc_split_reduce_f16(part.data_ptr(), kw.get("stride", rows * n_out), kw.get("P", 2), kw.get("nc", 1), rows,   # noqa: E731
+                                               kw.get("cols", n_out), b.data_ptr(), None, kw.get("act", 2), 1.0, None, None,
+                                               kw.get("o", whole.data_ptr()), None, None, None)
+    assert red() == 0 and red(o=None) == -1 and red(nc=3) == -4 and red(P=0) == -4 and red(act=7) == -4 and red(cols=n_out + 4) == -2
+    assert red(stride=rows * n_out - 4) == -4
