@@ -36,6 +36,9 @@ constexpr int kMaxPath = 4096;  // longest PUCT descent the kernels stage in LDS
 // Line tag: where the node last lay on a descent path -- path number (16 bits, 0 = never) << 16 | level << 4 |
 // action taken there (15 = it was that path's leaf).  The last ring_k paths of a tree are kept in a ring; the tag
 // only ever selects CANDIDATES for parallel validation, so a stale or aliased tag costs time, never correctness.
+#ifndef RC_LINE_WAVES_DEFAULT
+#define RC_LINE_WAVES_DEFAULT 1
+#endif
 constexpr u32 kRecLeaf = 1u << 16;
 constexpr u32 kNoAct = 15;
 // One-line re-validation, built, measured and left OFF.  The 16 spare bytes of line 0 behind the walk record cache
@@ -562,7 +565,8 @@ __device__ __forceinline__ u32 sel_hash(int node) { return ((u32)node * 0x9E3779
 // NT: threads per tree.  256 in a full forest (four workgroups per CU: 1 024 trees in one round); small forests leave CUs idle, so
 // rc_mcts_step* gives a tree 512 / 1 024 threads there -- the parallel parts (staging, re-validation: one lane per path level)
 // of a 1 200-level descent take two rounds per thread instead of five.
-template <int MODE, bool FUSE = false, int NT = kBlock>
+// LW: waves that check a line together (1: wave 0 alone, 64 levels per round; 4: waves 0-3, 256 levels per round -- see "line round").
+template <int MODE, bool FUSE = false, int NT = kBlock, int LW = 1>
 __global__ __launch_bounds__(NT) void k_mcts_select(rc_mcts_t m, double c, u32 level_budget, const void *__restrict__ probs_or_head,
                                                       const float *__restrict__ values, size_t ld, bool head_bf16, u32 max_states) {
     __shared__ u32 s_lut[FUSE ? sizeof(kTables.lut) / 4 : 1];
@@ -572,12 +576,13 @@ __global__ __launch_bounds__(NT) void k_mcts_select(rc_mcts_t m, double c, u32 l
     __shared__ u8 s_act[kMaxPath];
     __shared__ int s_head[kSelHash];        // chains of path levels by node (earlier visits of a state)
     __shared__ u16 s_next[kMaxPath];
-    __shared__ u32 s_unc[kMaxPath / 32];    // re-validation: levels float32 could not settle (bitmap: the complete set)
-    __shared__ u32 s_late[kMaxPath / 32];   // MODE > 0: later levels of nodes the path visits more than once (bitmap)
-    // 1.5 KiB used twice.  Re-validation: the same two sets as dense lists (so that their passes use every lane), as long
-    // as they fit -- what does not fit is found through the bitmaps.  Walk: the lane lists of a line segment.
-    __shared__ u32 s_scratch[384];
+    // 2.5 KiB used twice.  Re-validation: two bitmaps (levels float32 could not settle; later levels of nodes the path visits more
+    // than once) and the same two sets as dense lists (so that their passes use every lane), as long as they fit -- what does not
+    // fit is found through the bitmaps.  Walk: the lane lists of a line segment (64 lanes, or 256 with LW = 4).
+    __shared__ u32 s_pool[640];
+    u32 *s_scratch = s_pool, *s_unc = s_pool + 384, *s_late = s_pool + 512;
     __shared__ int s_nlate, s_nunc;
+    __shared__ int s_mb[64];                // LW > 1: mailbox between the walking wave and its helpers
 #ifdef RC_SELECT_FASTSTATS
     __shared__ int s_fast_ok, s_fast_no;
     if (threadIdx.x == 0) s_fast_ok = s_fast_no = 0;
@@ -839,7 +844,111 @@ __global__ __launch_bounds__(NT) void k_mcts_select(rc_mcts_t m, double c, u32 l
         }
     }
     __syncthreads();   // also: the records written above are visible to wave 0 from here on
-    if (tid >= kWave) return;
+    if (tid >= LW * kWave) return;
+
+    // ---- line round with LW waves (LW > 1) ---------------------------------------------------------------------------
+    // The walking wave (wave 0) publishes a line position in the mailbox; waves 0 .. LW - 1 then check 64 LW consecutive
+    // levels of that line at once, lane gl = 64 wave + lane taking level kb + 1 + gl, exactly as the single-wave round below
+    // does for 64 (same decisions, same acceptance rules): the levels' earlier visits are counted in the path's chains and,
+    // for the lanes above in the round, in bucket lists all 64 LW lanes enter before anyone reads them (one barrier); where
+    // the predecessor's line action leads is read from the predecessor's row by the lane itself, so no value crosses a wave
+    // except through the mailbox: per wave the first failing lane, and what the walking wave needs to go on from there.
+    // Barriers: the helpers wait at the top of their loop; every command of the walking wave is one barrier, a round three more.
+    enum { MB_CMD = 0, MB_LINE_LO, MB_LINE_HI, MB_LLEN, MB_LPOS, MB_KB, MB_WANT, MB_ARR0, MB_ROOM, MB_Q = 12, MB_LAST_NL = 16, MB_LAST_ACT = 20,
+           MB_STOP_NL = 24, MB_STOP_ACT = 28, MB_STOP_NODE = 32, MB_STOP_REC = 36 };
+    uint2 *s_segent4 = reinterpret_cast<uint2 *>(s_pool);          // [256] per lane {node, previous lane | action << 16 | rev(arrival) << 20}
+    int *s_seg4 = reinterpret_cast<int *>(s_pool + 512);           // [128] last lane per node bucket (0xFFFF = none)
+    auto line_round = [&](const u32 wv, const u32 lane, const TreeBufs &tb, const float c32) -> int {   // returns the levels appended
+        const size_t line = ((size_t)(u32)s_mb[MB_LINE_HI] << 32) | (u32)s_mb[MB_LINE_LO];
+        const int llen = s_mb[MB_LLEN], lpos = s_mb[MB_LPOS], kb = s_mb[MB_KB], want = s_mb[MB_WANT], room = s_mb[MB_ROOM];
+        const u32 arr0 = (u32)s_mb[MB_ARR0];
+        const int gl = (int)(wv * kWave + lane);
+        const bool in_line = lpos + gl < llen && gl < room;
+        const int node_i = in_line ? m.ring_node[line + lpos + gl] : 0;
+        const u32 act_i = in_line ? (u32)m.ring_act[line + lpos + gl] : kNoAct;
+        const bool has_pred = in_line && gl > 0;
+        const u32 arr_i = has_pred ? (u32)m.ring_act[line + lpos + gl - 1] : arr0;
+        const int pred = has_pred ? m.ring_node[line + lpos + gl - 1] : 0;
+        const u32x4 r = load_rec(tb, node_i);
+        const bool inner = in_line && act_i != kNoAct;
+        const int nl_i = inner ? m.nbr[(base + node_i) * kRow + act_i] : 0;               // where the line's action leads
+        const int from = has_pred ? m.nbr[(base + pred) * kRow + (arr_i & 15u)] : want;    // where the level above leads
+        const LaneEval e = lane_prepare(c32, m, (base + node_i) * kRow);
+        const u32 rb0 = r.z & 15u, rb1 = (r.z >> 8) & 15u;
+        u32 d_i = (arr_i ^ 1u) == rb0 ? rb1 : rb0;
+        u64 cnt5 = 0;
+        bool again = false, unsure = false;
+        for (int j = in_line ? s_head[sel_hash(node_i)] : -1; j >= 0;) {   // earlier visits in the chains (levels <= kb)
+            if (s_node[j] == node_i) {
+                again = true;
+                cnt5_add(cnt5, unsure, (u32)s_act[j]);
+                if (j > 0) cnt5_add(cnt5, unsure, (u32)(s_act[j - 1] ^ 1));
+            }
+            const u32 nx = s_next[j];
+            j = nx == 0xFFFFu ? -1 : (int)nx;
+        }
+        const u32 hb = ((u32)node_i * 0x9E3779B1u) >> 25;
+        if (in_line) {
+            const u32 prev_lane = (u32)atomicExch(&s_seg4[hb], gl);
+            s_segent4[gl] = make_uint2((u32)node_i, prev_lane | (act_i << 16) | ((arr_i ^ 1u) << 20));
+        }
+        __syncthreads();   // every lane of the round is in its bucket's list
+        if (in_line) {
+            for (u32 j = (u32)s_seg4[hb]; j != 0xFFFFu;) {
+                const uint2 en = s_segent4[j];
+                if ((int)j < gl && (int)en.x == node_i) {
+                    again = true;
+                    if (((en.y >> 16) & 15u) != kNoAct) cnt5_add(cnt5, unsure, (en.y >> 16) & 15u);
+                    cnt5_add(cnt5, unsure, (en.y >> 20) & 15u);
+                }
+                j = en.y & 0xFFFFu;
+            }
+        }
+        if (again) {   // the level revisits a node: its decision from its rows, in the lane
+            cnt5_add(cnt5, unsure, arr_i ^ 1u);   // own arrival edge
+            bool sure;
+            d_i = (u32)lane_pick(e, cnt5, sure);
+            unsure |= !sure;
+        }
+        const bool ok = inner && !(r.z & kRecLeaf) && !(again && unsure) && d_i == act_i && from == node_i;
+        const u64 okm = __ballot(ok);
+        const int q = ~okm ? __builtin_ctzll(~okm) : kWave;
+        if (lane == 0) s_mb[MB_Q + wv] = q;
+        if ((int)lane == kWave - 1) { s_mb[MB_LAST_NL + wv] = nl_i; s_mb[MB_LAST_ACT + wv] = (int)act_i; }
+        if (q > 0 && (int)lane == q - 1) { s_mb[MB_STOP_NL + wv] = nl_i; s_mb[MB_STOP_ACT + wv] = (int)act_i; }
+        if ((int)lane == q) {   // (q < 64) the first level of this wave that does not follow the line
+            s_mb[MB_STOP_NODE + wv] = in_line ? node_i : -1;
+            s_mb[MB_STOP_REC + 4 * wv] = (int)r.x, s_mb[MB_STOP_REC + 4 * wv + 1] = (int)r.y, s_mb[MB_STOP_REC + 4 * wv + 2] = (int)r.z,
+            s_mb[MB_STOP_REC + 4 * wv + 3] = (int)r.w;
+        }
+        __syncthreads();   // every wave's verdict is in the mailbox, and nobody reads a bucket list any more
+        if (in_line) s_seg4[hb] = 0xFFFF;   // empty again for the next round (whose entries come after the next command's barrier)
+        int total = 0;
+#pragma unroll
+        for (int w = 0; w < LW; ++w) {
+            const int qw = s_mb[MB_Q + w];
+            total += qw;
+            if (qw < kWave) break;
+        }
+        if (gl < total) {   // the leading run of levels that follow the line is appended
+            const int kk = kb + 1 + gl;
+            s_node[kk] = node_i;
+            s_act[kk] = (u8)act_i;
+            s_next[kk] = (u16)atomicExch(&s_head[sel_hash(node_i)], kk);
+        }
+        return total;
+    };
+    if (LW > 1 && tid >= kWave) {   // helper waves: rounds on command
+        const TreeBufs tbh = tree_bufs(m, base);
+        const float c32h = (float)c;
+        for (int i = (int)tid - kWave; i < 128; i += (LW - 1) * kWave) s_seg4[i] = 0xFFFF;
+        for (;;) {
+            __syncthreads();
+            const int cmd = s_mb[MB_CMD];
+            if (cmd == 0) return;
+            if (cmd == 1) line_round(tid >> 6, tid & (kWave - 1), tbh, c32h);
+        }
+    }
 
     const unsigned long long t_walk = wall_clock64();
     const long long c_walk = clock64();
@@ -923,12 +1032,43 @@ __global__ __launch_bounds__(NT) void k_mcts_select(rc_mcts_t m, double c, u32 l
             int want = next;                              // the node lane 0 must be at
             int arr0 = arg;                               // the action that leads to it
             int total = 0;
-            bool in_line = lpos + (int)lane < llen && (int)lane < room;
+            bool have = false;
+            if (LW > 1) {
+                for (;;) {
+                    if (lane == 0) {
+                        s_mb[MB_LINE_LO] = (int)(u32)line, s_mb[MB_LINE_HI] = (int)(u32)(line >> 32), s_mb[MB_LLEN] = llen, s_mb[MB_LPOS] = lpos;
+                        s_mb[MB_KB] = kb, s_mb[MB_WANT] = want, s_mb[MB_ARR0] = arr0, s_mb[MB_ROOM] = room, s_mb[MB_CMD] = 1;
+                    }
+                    __syncthreads();   // command: a round
+                    const int got = line_round(0, lane, tb, c32);
+                    ++line_rounds;
+                    total += got;
+                    if (got > 0) {
+                        want = s_mb[MB_STOP_NL + (got - 1) / kWave];
+                        arr0 = s_mb[MB_STOP_ACT + (got - 1) / kWave];
+                    }
+                    if (got < LW * kWave) {   // the run ends inside this round: the record of the level it ends at, if that is the node we are at
+                        const int ws = got / kWave;
+                        have = s_mb[MB_STOP_NODE + ws] == want;
+                        if (have) {
+                            x.x = (u32)s_mb[MB_STOP_REC + 4 * ws], x.y = (u32)s_mb[MB_STOP_REC + 4 * ws + 1];
+                            x.z = (u32)s_mb[MB_STOP_REC + 4 * ws + 2], x.w = (u32)s_mb[MB_STOP_REC + 4 * ws + 3];
+                        }
+                        break;
+                    }
+                    kb += LW * kWave;
+                    lpos += LW * kWave;
+                    room -= LW * kWave;
+                    if (lpos >= llen || room <= 0) break;   // line or room exhausted
+                }
+                if (lane == 0) s_mb[MB_CMD] = 2;
+                __syncthreads();   // command: pause -- the levels the helpers appended are in the chains
+            }
+            bool in_line = LW == 1 && lpos + (int)lane < llen && (int)lane < room;
             int node_i = in_line ? m.ring_node[line + lpos + lane] : 0;
             u32 act_i = in_line ? (u32)m.ring_act[line + lpos + lane] : kNoAct;
             u32 arr_i = (lane == 0 || !in_line) ? (u32)arr0 : (u32)m.ring_act[line + lpos + lane - 1];
-            bool have = false;
-            for (;;) {
+            for (; LW == 1;) {
                 const u32x4 r = load_rec(tb, node_i);
                 const bool inner = in_line && act_i != kNoAct;
                 const int nl_i = inner ? m.nbr[(base + node_i) * kRow + act_i] : 0;   // where the line's action leads
@@ -1040,6 +1180,10 @@ __global__ __launch_bounds__(NT) void k_mcts_select(rc_mcts_t m, double c, u32 l
         prev_act = arg;
         cur = next;
         ++plen;
+    }
+    if (LW > 1) {
+        if (lane == 0) s_mb[MB_CMD] = 0;
+        __syncthreads();   // command: the helpers leave
     }
     if (stop == 2 && lane == 0) m.status[t] = RC_MCTS_PATH_OVERFLOW;
     const int suspended = stop == 3;   // out of budget at a non-leaf: resume here next call
@@ -1223,6 +1367,11 @@ static inline unsigned mcts_grid(const rc_mcts_t *m) { return m->active ? m->n_a
 
 // Threads per tree of the one-launch iteration: 256 in a full forest; 512 / 1 024 where the forest is small enough to leave CUs
 // idle (RUBIKS_STEP_THREADS=256 pins it, for A/B measurements).
+// Waves that check a line together in the one-launch iteration (RUBIKS_LINE_WAVES=1 / 4 pins it, for A/B measurements).
+static int line_waves() {
+    static const int pinned = [] { const char *e = getenv("RUBIKS_LINE_WAVES"); return e ? atoi(e) : 0; }();
+    return pinned == 4 ? 4 : pinned == 1 ? 1 : RC_LINE_WAVES_DEFAULT;
+}
 static unsigned step_threads(unsigned n_trees) {
     static const int pinned = [] { const char *e = getenv("RUBIKS_STEP_THREADS"); return e ? atoi(e) : 0; }();
     if (pinned == 256 || pinned == 512 || pinned == 1024) return (unsigned)pinned;
@@ -1356,8 +1505,15 @@ int rc_mcts_step(const rc_mcts_t *m, const float *probs, const float *values, do
     RC_REQUIRE(probs && values, RC_ERR_NULL);
     RC_REQUIRE(max_states > 0, RC_ERR_RANGE);
     const unsigned g = mcts_grid(m);
-#define RC_STEP(NT_) hipLaunchKernelGGL((k_mcts_select<1, true, NT_>), dim3(g), dim3(NT_), 0, (hipStream_t)stream, *m, c, level_budget, \
-                                        (const void *)probs, values, (size_t)0, false, max_states)
+#define RC_STEP(NT_)                                                                                                                        \
+    do {                                                                                                                                    \
+        if (line_waves() == 4)                                                                                                              \
+            hipLaunchKernelGGL((k_mcts_select<1, true, NT_, 4>), dim3(g), dim3(NT_), 0, (hipStream_t)stream, *m, c, level_budget,            \
+                               (const void *)probs, values, (size_t)0, false, max_states);                                                  \
+        else                                                                                                                                \
+            hipLaunchKernelGGL((k_mcts_select<1, true, NT_, 1>), dim3(g), dim3(NT_), 0, (hipStream_t)stream, *m, c, level_budget,            \
+                               (const void *)probs, values, (size_t)0, false, max_states);                                                  \
+    } while (0)
     const unsigned nt = step_threads(g);
     if (nt == 1024) RC_STEP(1024);
     else if (nt == 512) RC_STEP(512);
@@ -1372,8 +1528,15 @@ int rc_mcts_step_head(const rc_mcts_t *m, const void *head, size_t ld, int head_
     RC_REQUIRE(head != nullptr, RC_ERR_NULL);
     RC_REQUIRE(ld >= (size_t)kActions + 1 && max_states > 0, RC_ERR_RANGE);
     const unsigned g = mcts_grid(m);
-#define RC_STEP(NT_) hipLaunchKernelGGL((k_mcts_select<2, true, NT_>), dim3(g), dim3(NT_), 0, (hipStream_t)stream, *m, c, level_budget, head, \
-                                        (const float *)nullptr, ld, head_is_bf16 != 0, max_states)
+#define RC_STEP(NT_)                                                                                                                        \
+    do {                                                                                                                                    \
+        if (line_waves() == 4)                                                                                                              \
+            hipLaunchKernelGGL((k_mcts_select<2, true, NT_, 4>), dim3(g), dim3(NT_), 0, (hipStream_t)stream, *m, c, level_budget, head,      \
+                               (const float *)nullptr, ld, head_is_bf16 != 0, max_states);                                                  \
+        else                                                                                                                                \
+            hipLaunchKernelGGL((k_mcts_select<2, true, NT_, 1>), dim3(g), dim3(NT_), 0, (hipStream_t)stream, *m, c, level_budget, head,      \
+                               (const float *)nullptr, ld, head_is_bf16 != 0, max_states);                                                  \
+    } while (0)
     const unsigned nt = step_threads(g);
     if (nt == 1024) RC_STEP(1024);
     else if (nt == 512) RC_STEP(512);
