@@ -36,9 +36,6 @@ constexpr int kMaxPath = 4096;  // longest PUCT descent the kernels stage in LDS
 // Line tag: where the node last lay on a descent path -- path number (16 bits, 0 = never) << 16 | level << 4 |
 // action taken there (15 = it was that path's leaf).  The last ring_k paths of a tree are kept in a ring; the tag
 // only ever selects CANDIDATES for parallel validation, so a stale or aliased tag costs time, never correctness.
-#ifndef RC_LINE_WAVES_DEFAULT
-#define RC_LINE_WAVES_DEFAULT 1
-#endif
 constexpr u32 kRecLeaf = 1u << 16;
 constexpr u32 kNoAct = 15;
 // One-line re-validation, built, measured and left OFF.  The 16 spare bytes of line 0 behind the walk record cache
@@ -1367,10 +1364,12 @@ static inline unsigned mcts_grid(const rc_mcts_t *m) { return m->active ? m->n_a
 
 // Threads per tree of the one-launch iteration: 256 in a full forest; 512 / 1 024 where the forest is small enough to leave CUs
 // idle (RUBIKS_STEP_THREADS=256 pins it, for A/B measurements).
-// Waves that check a line together in the one-launch iteration (RUBIKS_LINE_WAVES=1 / 4 pins it, for A/B measurements).
-static int line_waves() {
+// Waves that check a line together in the one-launch iteration: four where the forest is small enough to leave CUs idle (runs to
+// completion -1 ... -3 %), one in a full forest, whose 16 waves per CU gain nothing from it (RUBIKS_LINE_WAVES=1 / 4 pins it, for
+// A/B measurements; profiles/r3_line_waves_ab.txt).
+static int line_waves(unsigned n_trees) {
     static const int pinned = [] { const char *e = getenv("RUBIKS_LINE_WAVES"); return e ? atoi(e) : 0; }();
-    return pinned == 4 ? 4 : pinned == 1 ? 1 : RC_LINE_WAVES_DEFAULT;
+    return pinned == 4 ? 4 : pinned == 1 ? 1 : n_trees <= 512 ? 4 : 1;
 }
 static unsigned step_threads(unsigned n_trees) {
     static const int pinned = [] { const char *e = getenv("RUBIKS_STEP_THREADS"); return e ? atoi(e) : 0; }();
@@ -1507,7 +1506,7 @@ int rc_mcts_step(const rc_mcts_t *m, const float *probs, const float *values, do
     const unsigned g = mcts_grid(m);
 #define RC_STEP(NT_)                                                                                                                        \
     do {                                                                                                                                    \
-        if (line_waves() == 4)                                                                                                              \
+        if (line_waves(g) == 4)                                                                                                              \
             hipLaunchKernelGGL((k_mcts_select<1, true, NT_, 4>), dim3(g), dim3(NT_), 0, (hipStream_t)stream, *m, c, level_budget,            \
                                (const void *)probs, values, (size_t)0, false, max_states);                                                  \
         else                                                                                                                                \
@@ -1530,7 +1529,7 @@ int rc_mcts_step_head(const rc_mcts_t *m, const void *head, size_t ld, int head_
     const unsigned g = mcts_grid(m);
 #define RC_STEP(NT_)                                                                                                                        \
     do {                                                                                                                                    \
-        if (line_waves() == 4)                                                                                                              \
+        if (line_waves(g) == 4)                                                                                                              \
             hipLaunchKernelGGL((k_mcts_select<2, true, NT_, 4>), dim3(g), dim3(NT_), 0, (hipStream_t)stream, *m, c, level_budget, head,      \
                                (const float *)nullptr, ld, head_is_bf16 != 0, max_states);                                                  \
         else                                                                                                                                \
