@@ -1,8 +1,8 @@
 """
-Per-step timeline from a rocprofv3 --kernel-trace CSV: a step starts at each k_mcts_expand launch; for the steady steps
-print the period, the busy time per kernel (by short name) and the idle gaps on the step's own queue.
+Per-step timeline from a rocprofv3 --kernel-trace CSV: a step ends with its tree kernel (k_mcts_select; rounds 1-2: started at
+k_mcts_expand); for the chosen steps print the period, the busy time per kernel (by short name) and the idle gaps on the step's own queue.
 
-    python tools/step_timeline.py kernel_trace.csv [first_step] [n_steps]
+    python tools/step_timeline.py kernel_trace.csv [first_step] [n_steps]      (first_step < 0: counted from the end of the trace)
 """
 import csv
 import sys
@@ -16,7 +16,8 @@ k.sort()
 
 
 def short(name):
-    for key in ("k_mcts_expand", "k_mcts_select", "k_mcts_backup", "k_split_gemm", "k_first_layer_split", "k_split_act", "k_mcts_plant",
+    for key in ("k_mcts_expand", "k_mcts_select", "k_mcts_backup", "k_split_gemm", "k_first_layer_split", "k_split_act", "k_split_reduce", "k_head_split",
+                "k_first_layer_mfma", "k_head", "k_act_bf16", "k_mcts_plant",
                 "k_mcts_complete_graph", "k_mcts_shorten", "Cijk"):
         if key in name:
             if key == "Cijk":
@@ -25,8 +26,11 @@ def short(name):
     return name[:40]
 
 
-starts = [i for i, e in enumerate(k) if "k_mcts_expand" in e[2]]
+starts = [i + 1 for i, e in enumerate(k) if "k_mcts_select" in e[2]]   # a step = the launches behind the previous tree kernel up to and including this one
+starts = [i for i in starts if i < len(k)]
 print("steps in trace:", len(starts))
+if first < 0:
+    first += len(starts)
 sel = starts[first:first + count + 1]
 if len(sel) < 2:
     sys.exit("not enough steps")
