@@ -649,6 +649,34 @@ def step_rooflines(engine, agent, roots, args, name):
         forest.step(c, forest.C, use_graph=False)
     torch.cuda.synchronize()
     phases = phase_times(forest, c, forest.C, args.phase_reps)
+    # the production form of a step on the same young forest: network, then ONE tree kernel (backup + descent + next expansion)
+    forest.reset(roots, forest.C)
+    for _ in range(20):
+        forest.step(c, forest.C, use_graph=False)
+    if forest._one_launch:
+        import ctypes
+        from librubiks import _hip
+        acc_net = acc_tree = 0.0
+        for _ in range(args.phase_reps):
+            ev = [torch.cuda.Event(enable_timing=True) for _ in range(3)]
+            ev[0].record()
+            if forest._fused:
+                cubes, nrows = forest._net_input()
+                head = forest.engine.head_cubes(cubes, None if forest._x1 is None else forest._x1[:nrows])
+                ev[1].record()
+                _hip.check(forest.lib.rc_mcts_step_head(ctypes.byref(forest.struct), head.data_ptr(), head.stride(0), int(head.dtype == torch.bfloat16),
+                                                        c, forest.level_budget, forest.C, _hip.stream_ptr()), "rc_mcts_step_head")
+            else:
+                forest._evaluate_children()
+                ev[1].record()
+                _hip.check(forest.lib.rc_mcts_step(ctypes.byref(forest.struct), forest.probs.data_ptr(), forest.values.data_ptr(), c,
+                                                   forest.level_budget, forest.C, _hip.stream_ptr()), "rc_mcts_step")
+            ev[2].record()
+            torch.cuda.synchronize()
+            acc_net += ev[0].elapsed_time(ev[1])
+            acc_tree += ev[1].elapsed_time(ev[2])
+        phases["one_launch_form"] = {"net_forward": round(acc_net / args.phase_reps, 4), "tree_kernel": round(acc_tree / args.phase_reps, 4),
+                                     "note": "the step the searches run: network, then rc_mcts_step* (the rows above are its three-phase form)"}
     rows, eng, fused = forest.rows_per_tree * roots.n, forest.engine, forest._fused
     if name == "f32s":
         W1 = phases.pop("gemm_hidden1_weight")
