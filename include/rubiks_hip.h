@@ -409,7 +409,10 @@ int rc_mcts_backup_select_head(const rc_mcts_t *m, const void *head, size_t ld, 
  * (rc_mcts_step_head) followed by the rc_mcts_expand of the NEXT iteration, done by the wave that walked to the leaf.  An
  * iteration is then  [network on the rows the previous step left] -> rc_mcts_step*;  trees enter through
  * rc_mcts_plant_expanded, which is rc_mcts_plant + the root's expansion (its rows use list position == tree index: every tree
- * listed in order, as while scrambles are still waiting for slots).  Results are those of the three-kernel form. */
+ * listed in order, as while scrambles are still waiting for slots).  Results are those of the three-kernel form.
+ * Launch shape: 256 threads per tree in a forest of more than 512 listed trees, 512 / 1 024 threads and four waves checking a
+ * descent line together below that (idle CUs; same results).  RUBIKS_STEP_THREADS=256|512|1024 and RUBIKS_LINE_WAVES=1|4 in the
+ * environment pin the two choices, for A/B measurements only (read once per process). */
 int rc_mcts_plant_expanded(const rc_mcts_t *m, const int32_t *slots, uint32_t n_slots, const int8_t *roots_soa, size_t stride,
                            size_t first_col, uint32_t max_states, rc_stream_t stream);
 int rc_mcts_step(const rc_mcts_t *m, const float *probs, const float *values, double c, uint32_t level_budget, uint32_t max_states,
