@@ -481,6 +481,42 @@ __device__ __forceinline__ int lane_pick(const LaneEval &e, u64 cnt5, bool &cert
     certain = ok;
     return arg;
 }
+// The two picks every re-decided level needs -- best0 (no loss) and best1 (one loss on best0) -- sharing their scores: the second
+// pick differs from the first in ONE entry, so it is a second argmax over the same array instead of a second evaluation.
+// Same arithmetic, entry for entry, as lane_pick(e, 0, c0) followed by lane_pick(e, 1 << 5 b0, c1).
+__device__ __forceinline__ void lane_pick2(const LaneEval &e, int &b0, bool &c0, int &b1, bool &c1) {
+    float sc[kA], mg[kA];
+    float best = -INFINITY, mbest = 0.f;
+    int arg = 0;
+    bool ok = true;
+#pragma unroll
+    for (int a = 0; a < kA; ++a) {
+        sc[a] = e.u[a] + e.w[a];
+        mg[a] = fabsf(e.u[a]) + fabsf(e.w[a]);
+        ok &= sc[a] == sc[a];
+        if (sc[a] > best) { best = sc[a]; arg = a; mbest = mg[a]; }
+    }
+    bool ok0 = ok;
+#pragma unroll
+    for (int a = 0; a < kA; ++a) ok0 &= (a == arg) | (best - sc[a] > kPuctEps * (mg[a] + mbest));
+    b0 = arg, c0 = ok0;
+    // one virtual loss on b0
+    float best1 = -INFINITY, mbest1 = 0.f;
+    int arg1 = 0;
+    bool ok1 = true;
+#pragma unroll
+    for (int a = 0; a < kA; ++a) {
+        const bool hit = a == arg;
+        const float s1 = hit ? e.u[a] + (e.w[a] - 100.0f) : sc[a];
+        const float m1 = hit ? mg[a] + 100.0f : mg[a];
+        sc[a] = s1, mg[a] = m1;
+        ok1 &= s1 == s1;
+        if (s1 > best1) { best1 = s1; arg1 = a; mbest1 = m1; }
+    }
+#pragma unroll
+    for (int a = 0; a < kA; ++a) ok1 &= (a == arg1) | (best1 - sc[a] > kPuctEps * (mg[a] + mbest1));
+    b1 = arg1, c1 = ok1;
+}
 __device__ __forceinline__ void cnt5_add(u64 &cnt5, bool &overflow, u32 a) {
     overflow |= ((u32)(cnt5 >> (5 * a)) & 31u) >= 30u;
     cnt5 += 1ull << (5 * a);
@@ -722,8 +758,7 @@ __global__ __launch_bounds__(NT) void k_mcts_select(rc_mcts_t m, double c, u32 l
 #pragma unroll
                 for (int a = 0; a < kA; ++a) p[a] = (u32)a == ob0 ? ocache.x : (u32)a == ob1 ? ocache.y : ocache.z;
                 const LaneEval eb = lane_eval(c32v, n, p, w);
-                b0 = lane_pick(eb, 0, c0);
-                b1 = lane_pick(eb, 1ull << (5 * b0), c1);
+                lane_pick2(eb, b0, c0, b1, c1);
                 d = (arr == b0) ? b1 : b0;
                 if (dup) d = lane_pick(eb, cnt5, c2);
                 const u32 pair = (1u << ob0) | (1u << ob1);
@@ -742,8 +777,7 @@ __global__ __launch_bounds__(NT) void k_mcts_select(rc_mcts_t m, double c, u32 l
                 load_row12(m.P, r, p);
                 const LaneEval e = lane_eval(c32v, n, p, w);
                 c2 = true;
-                b0 = lane_pick(e, 0, c0);
-                b1 = lane_pick(e, 1ull << (5 * b0), c1);
+                lane_pick2(e, b0, c0, b1, c1);
                 d = (arr == b0) ? b1 : b0;
                 if (dup) d = lane_pick(e, cnt5, c2);
                 if (kOneLine) {   // what the next re-validation of this node may decide from line 0 alone
