@@ -81,3 +81,15 @@ def test_ticktock_restated():
     assert tt.tock() >= 0.005
     tt.reset()
     assert tt.profiles == {}
+
+
+def test_launch_size_ladder():
+    """MCTSForest narrows a running forest along a fixed ladder of launch sizes (one HIP graph each): the forest's own size, then
+    multiples of 32 trees (352 network rows = the layer kernels' row tile), each at most 0.8 of the one before, down to 32."""
+    from librubiks.solving.mcts_device import MIN_RUNG, rungs
+    for n in (1, 5, 31, 32, 33, 48, 600, 1024, 8192):
+        r = rungs(n)
+        assert r[0] == n and r == sorted(set(r), reverse=True)
+        assert all(x % 32 == 0 for x in r[1:]) and all(b <= 0.8 * a or b == MIN_RUNG for a, b in zip(r, r[1:]))
+        assert r[-1] == (MIN_RUNG if n > MIN_RUNG else n)
+    assert rungs(1024) == [1024, 800, 640, 512, 384, 288, 224, 160, 128, 96, 64, 32]
