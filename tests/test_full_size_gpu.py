@@ -187,3 +187,37 @@ def test_config5_share_8192_trees_lockstep():
             j = nb[1 + i, k]
             assert 1 <= j <= n and np.array_equal(st[j], kids[i, k])  # links lead to the rotated state ...
             assert nb[j, k ^ 1] == 1 + i                              # ... and back (agents.py:533-535)
+
+
+def test_launch_shapes_of_the_tree_kernel_give_identical_games(tmp_path):
+    """rc_mcts_step* gives a tree 512 / 1 024 threads and checks descent lines with four waves once a forest is small; pinned to the
+    full-forest shape (256 threads, one wave; RUBIKS_STEP_THREADS / RUBIKS_LINE_WAVES are read once per process, hence two child
+    processes) the same 1 024 depth-22 searches must come out identical game for game: nodes, lengths, iterations, action queues."""
+    import subprocess
+    import sys
+    if not os.path.isdir(WEIGHTS):
+        pytest.skip("needs the trained weights")
+    code = f"""
+import os, sys, numpy as np, torch
+sys.path[:0] = [{ROOT!r}, os.path.join({ROOT!r}, "rl-rubiks_amd")]
+from librubiks import cube
+from librubiks.model import Model
+from librubiks.solving.agents import MCTS
+np.random.seed(7)
+cubes, _, _ = cube.scramble_batch(1024, 22, True)
+agent = MCTS(Model.load({WEIGHTS!r}).eval(), c=0.6, search_graph=True, net_dtype=torch.bfloat16)
+r = agent.search_batch(cubes, None, 40000)
+np.savez(sys.argv[1], nodes=r.nodes, solved=r.solved, lengths=r.lengths, iterations=r.iterations,
+         qsum=np.array([sum((i + 1) * a for i, a in enumerate(q)) for q in r.queues]))
+"""
+    out = []
+    for name, env in (("pinned", {"RUBIKS_STEP_THREADS": "256", "RUBIKS_LINE_WAVES": "1"}), ("auto", {})):
+        path = str(tmp_path / f"{name}.npz")
+        p = subprocess.run([sys.executable, "-c", code, path], env={**{k: v for k, v in os.environ.items() if not k.startswith("RUBIKS_")}, **env},
+                           capture_output=True, text=True, timeout=600)
+        assert p.returncode == 0, p.stderr[-2000:]
+        out.append(np.load(path))
+    a, b = out
+    assert a["solved"].mean() > 0.9 and int(a["iterations"].max()) > 2000
+    for k in a.files:
+        assert np.array_equal(a[k], b[k]), k
