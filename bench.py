@@ -201,6 +201,7 @@ def phase_times_split(forest, c, max_states, reps):
     plus the two GEMMs of the first hidden layer alone (the dominant kernels of its step)."""
     import ctypes
     from librubiks import _hip
+    from librubiks.model import _layer_call, _mm_f32
     lib, m, eng = forest.lib, ctypes.byref(forest.struct), forest.engine
     names = ["expand", "net_forward", "backup", "select"]
     acc = {k: 0.0 for k in names}
@@ -232,13 +233,14 @@ def phase_times_split(forest, c, max_states, reps):
         plan = eng._layer_plan(rows, eng.layers, li)
         tile = eng._fused_tile(rows, N, K) if plan == "fused" else 0
         last = li == len(eng.layers) - 2
-        if plan == "partials":   # the own kernel with its K loop cut in two, raw fp32 partials for the fused head
-            part = torch.empty((2, rows, N), dtype=torch.float32, device=Wh.device)
-            hid[f"gemm_hidden{li}"] = round(event_ms(lambda: _hip.check(lib.rc_split_gemm_partials_f16(
-                a.data_ptr(), W3.data_ptr(), rows, N, K, part.data_ptr(), _hip.stream_ptr()), "rc_split_gemm_partials_f16"), reps)[0], 4)
-            hid[f"gemm_hidden{li}_kernel"] = "rc_split_gemm_partials_f16"
-            if not last:   # (behind the last hidden layer the fused head consumes the partials)
-                a = eng._act(part[1], part[0], b, code, alpha, split=True)
+        if plan != "fused" and plan != "library":   # the own kernel with its K loop cut into chunks, raw fp32 partials
+            _, cut_tile, chunks = plan
+            part = torch.empty((chunks, rows, N), dtype=torch.float32, device=Wh.device)
+            hid[f"gemm_hidden{li}"] = round(event_ms(lambda: _layer_call(
+                "rc_split_layer_f16", a=a, w=W3, n_rows=rows, n_out=N, k=K, out_partials=part, k_splits=chunks, tile=cut_tile), reps)[0], 4)
+            hid[f"gemm_hidden{li}_kernel"] = f"rc_split_layer_f16 (K loop in {chunks} chunks)"
+            if not last:   # (behind the last hidden layer the fused head / the reduce kernel consumes the partials)
+                a = eng._act(part, lib.rc_split_layer_corr_chunks(K, chunks), b, code, alpha, split=True)
         elif tile:   # one kernel: three f16 products + bias + activation + re-split (csrc/rubiks_gemm.hip)
             o = torch.empty((rows, N if last else 2 * N), dtype=torch.float32 if last else torch.float16, device=Wh.device)
             hid[f"gemm_hidden{li}"] = round(event_ms(lambda: _hip.check(lib.rc_split_gemm_f16(
@@ -246,13 +248,13 @@ def phase_times_split(forest, c, max_states, reps):
                 o.data_ptr() if last else None, tile, _hip.stream_ptr()), "rc_split_gemm_f16"), reps)[0], 4)
             hid[f"gemm_hidden{li}_kernel"] = "rc_split_gemm_f16"
             a = o
-        else:      # hi x hi GEMM (K deep) + correction GEMM (2 K deep) through the library, + rc_split_act_f16
-            hid[f"gemm_hidden{li}_main"] = round(event_ms(lambda: torch.mm(a[:, :K], Wh.t(), out_dtype=torch.float32), reps)[0], 4)
-            hid[f"gemm_hidden{li}_corr"] = round(event_ms(lambda: torch.mm(a, B2.t(), out_dtype=torch.float32), reps)[0], 4)
+        else:      # hi x hi GEMM (K deep) + correction GEMM (2 K deep) through the library, + rc_split_reduce_f16
+            part = torch.empty((2, rows, N), dtype=torch.float32, device=Wh.device)
+            hid[f"gemm_hidden{li}_main"] = round(event_ms(lambda: _mm_f32(a[:, :K], Wh.t(), part[1]), reps)[0], 4)
+            hid[f"gemm_hidden{li}_corr"] = round(event_ms(lambda: _mm_f32(a, B2.t(), part[0]), reps)[0], 4)
             hid[f"gemm_hidden{li}"] = round(hid[f"gemm_hidden{li}_main"] + hid[f"gemm_hidden{li}_corr"], 4)
             hid[f"gemm_hidden{li}_kernel"] = "hipBLASLt x2"
-            a = eng._act(torch.mm(a[:, :K], Wh.t(), out_dtype=torch.float32), torch.mm(a, B2.t(), out_dtype=torch.float32), b, code, alpha,
-                         split=not last)
+            a = eng._act(part, 1, b, code, alpha, split=not last)
     out.update(hid)
     Wh = eng.layers[1][1]
     out["gemm_hidden1_weight"] = (int(Wh.shape[0]), int(Wh.shape[1]))

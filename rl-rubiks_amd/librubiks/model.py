@@ -514,6 +514,8 @@ class SplitF32Net:
         # repeat the search on `fallback()`, the fp32 GEMM chain -- the answer is never silently wrong.
         self.range_flag = torch.zeros(1, dtype=torch.int32, device=self.device)
         self._model, self._fallback = model, None
+        self._zeros = {layer[1].shape[0]: torch.zeros(layer[1].shape[0], dtype=torch.float32, device=self.device)
+                       for layer in self.layers + self.value_layers if layer[0] == "hid"}
 
     def overflowed(self) -> bool:
         """True if an activation left half range since the last call (reads and clears the device flag: synchronises)."""
@@ -553,23 +555,41 @@ class SplitF32Net:
             self._opts[id(out[-1])] = LayerOpts(o.save, o.add, None if o.post is None else tuple(t.float().contiguous() for t in o.post))
         return out
 
+    small_batch_cut = True   # False: the K loop is cut (in two) only from 96 whole-K tiles up, smaller batches go to the library (A/B switch)
     fused_hidden = True   # hidden layers as one kernel each (rc_split_gemm_f16) where its tile fills the chip
     fused_head = True     # last activation + output layer in one pass (rc_head_split_f32) behind a library-GEMM hidden layer
 
-    def _layer_plan(self, rows: int, layers, i: int) -> str:
-        """How hidden layer i runs on `rows` rows: 'fused' (rc_split_gemm_f16), 'partials' (rc_split_gemm_partials_f16 + the fused
-        head), or 'library' (two hipBLASLt GEMMs + rc_split_act_f16 / the fused head)."""
+    def _layer_plan(self, rows: int, layers, i: int):
+        """How hidden layer i runs on `rows` rows: 'fused' (one rc_split_layer_f16 launch, whole K per workgroup), ('cut', tile, chunks)
+        (the same kernel with its K loop cut into chunks + rc_split_reduce_f16), or 'library' (two hipBLASLt GEMMs + reduce / the fused head)."""
         Wh = layers[i][1]
         N, K = Wh.shape
         if self.fused_hidden and self._fused_tile(rows, N, K):
             return "fused"
-        nxt = layers[i + 1]
-        head_ok = i == len(layers) - 2 and self.fused_head and nxt[0] == "f32" and nxt[1].shape[0] <= 16 and N in (512, 1024)
-        # the K loop cut in two doubles the workgroups: narrow layers, and wide ones on a half-empty (compacted) forest; the partials
-        # go to the fused head (last hidden layer) or to rc_split_act_f16
-        if self.fused_hidden and (head_ok or i < len(layers) - 2) and N % 256 == 0 and K % 128 == 0 and -(-rows // 352) * (N // 256) * 2 >= 192:
-            return "partials"
-        return "library"
+        cut = self._k_split(rows, N, K) if self.fused_hidden else None
+        if cut and not self.small_batch_cut and (cut[1] != 2 or -(-rows // 352) * (N // 256) < 96):
+            cut = None
+        return ("cut",) + cut if cut else "library"
+
+    @staticmethod
+    def _k_split(rows: int, n_out: int, k: int):
+        """(tile, chunks) of rc_split_layer_f16 with out_partials for a layer too small to fill the chip with whole-K tiles: the K loop
+        (3 k / 64 steps) cut into as many chunks as bring the launch to at most one workgroup per CU, 352 x 128 tiles (tile 3) for
+        few rows or shallow layers, 352 x 256 (tile 1) otherwise.  None when no cut applies.  Measured against the two library GEMMs in
+        profiles/r3_skinny_split_probe.txt (the library runs one 64 x 64 tile per workgroup over the whole K: latency-bound)."""
+        if k % 64:
+            return None
+        steps, best = 3 * k // 64, None
+        for tile, cols in ((3, 128), (1, 256)):
+            if n_out % cols:
+                continue
+            base = -(-rows // 352) * (n_out // cols)
+            chunks = max((c for c in range(2, 33) if steps % c == 0 and steps // c >= 2 and base * c <= 256), default=0)
+            if chunks:
+                key = (base * chunks, cols if rows * k >= 2048 * 4096 else -cols)   # wide tiles pay once A is large: deep layers, many rows
+                if best is None or key > best[0]:
+                    best = (key, (tile, chunks))
+        return None if best is None or best[0][0] < 128 else best[1]
 
     @staticmethod
     def _fused_tile(rows: int, n_out: int, k: int) -> int:
@@ -611,6 +631,9 @@ class SplitF32Net:
                                                   out.data_ptr() if split else None, None if split else out.data_ptr(),
                                                   self.range_flag.data_ptr(), _hip.stream_ptr()), "rc_split_reduce_f16")
         return out
+
+    def _zero_bias(self, w: int) -> torch.Tensor:
+        return self._zeros[w]   # made in __init__: never allocated (and filled) inside a graph capture
 
     fused_input = True   # the input layer as one MFMA kernel from the cube states (rc_first_layer_split_f16) when shapes allow
 
@@ -670,21 +693,28 @@ class SplitF32Net:
                     continue
                 nxt = layers[i + 1]
                 head_ok = last_hidden and self.fused_head and nxt[0] == "f32" and nxt[1].shape[0] <= 16 and w in (512, 1024) and res is None and not post
-                part = torch.empty((2, n, w), dtype=torch.float32, device=a.device)
-                if plan == "partials":
-                    # too few tiles to fill the chip: the own kernel with its K loop cut in two (twice the workgroups), raw fp32
-                    # partials; partials[0] holds correction products only, partials[1] the rest (scaled inside) + the main product
-                    _layer_call("rc_split_layer_f16", a=a, w=W3, n_rows=n, n_out=w, k=K, out_partials=part, k_splits=2)
-                else:
+                if plan == "library":
+                    part = torch.empty((2, n, w), dtype=torch.float32, device=a.device)
                     _mm_f32(a, B2.t(), part[0])          # hi x lo + lo x hi, scaled by 2^11
                     _mm_f32(a[:, :K], Wh.t(), part[1])   # hi x hi
-                n_corr = 1
+                    n_corr = 1
+                else:
+                    # too few whole-K tiles to fill the chip: the own kernel with its K loop cut into chunks (one workgroup per tile and
+                    # chunk, ~one per CU), raw fp32 partials; the first n_corr hold correction products only (still scaled by 2^11)
+                    _, tile, chunks = plan
+                    part = torch.empty((chunks, n, w), dtype=torch.float32, device=a.device)
+                    _layer_call("rc_split_layer_f16", a=a, w=W3, n_rows=n, n_out=w, k=K, out_partials=part, k_splits=chunks, tile=tile)
+                    n_corr = _hip.lib().rc_split_layer_corr_chunks(K, chunks)
                 if head_ok:
                     # activation + the skinny output layer in one pass: the fp32 activations are never written (rc_head_split_f32)
                     out = torch.empty((n, 16), dtype=torch.float32, device=a.device)
-                    _hip.check(_hip.lib().rc_head_split_f32(part[1].data_ptr(), part[0].data_ptr(), 1.0 / SPLIT_SCALE, n, w,
-                                                            b.data_ptr(), code, alpha, nxt[1].data_ptr(), nxt[2].data_ptr(), nxt[1].shape[0],
-                                                            out.data_ptr(), _hip.stream_ptr()), "rc_head_split_f32")
+                    if part.shape[0] == 2 and n_corr == 1:
+                        c, c_corr, bias_h, act_h = part[1], part[0], b, code
+                    else:   # more than two partials: summed (bias, activation) by the reduce kernel first
+                        c, c_corr, bias_h, act_h = self._act(part, n_corr, b, code, alpha, split=False), None, self._zero_bias(w), 0
+                    _hip.check(_hip.lib().rc_head_split_f32(c.data_ptr(), _ptr(c_corr), 1.0 / SPLIT_SCALE, n, w, bias_h.data_ptr(), act_h, alpha,
+                                                            nxt[1].data_ptr(), nxt[2].data_ptr(), nxt[1].shape[0], out.data_ptr(),
+                                                            _hip.stream_ptr()), "rc_head_split_f32")
                     return out[:, :nxt[1].shape[0]]
             else:
                 _, W, b = layer

@@ -393,7 +393,7 @@ def test_split_engine_own_kernels_on_fc_big():
     cubes, _, _ = cube.scramble_batch(11264, 30, True)
     oh = cubes.as_oh(torch.float32)[:1024]
     eng = make_inference_net(net, F32_SPLIT)
-    assert [eng._layer_plan(cubes.n, eng.layers, i) for i in range(1, len(eng.layers) - 1)] == ["fused", "fused", "fused", "partials"]
+    assert [eng._layer_plan(cubes.n, eng.layers, i) for i in range(1, len(eng.layers) - 1)] == ["fused", "fused", "fused", ("cut", 1, 2)]
     with torch.no_grad():
         p64, v64 = copy.deepcopy(net).double()(oh.double())
         p32, v32 = net(oh)
@@ -570,7 +570,7 @@ def test_mcts_on_a_residual_net_uses_the_fused_path_and_equals_the_oracle():
 
 
 def test_layer_request_k_splits_and_reduce_match_the_whole_kernel():
-    """rc_split_layer_f16 with out_partials and k_splits = 2, 3, 4, 6 + rc_split_reduce_f16 (ordered sum, the first
+    """rc_split_layer_f16 with out_partials and k_splits = 2 .. 18 in both tile shapes + rc_split_reduce_f16 (ordered sum, the first
     rc_split_layer_corr_chunks partials scaled by 2^-11, bias, skip connection, ELU, post-activation affine, re-split) against the
     whole-K kernel with the same epilogue options, and the C-ABI's argument checks for both."""
     from librubiks import _hip
@@ -595,9 +595,9 @@ def test_layer_request_k_splits_and_reduce_match_the_whole_kernel():
     z = (xh.double() + xl.double() / 2048) @ (wh.double() + wl.double() / 2048).t() + b.cpu().double() + (sh.double() + sl.double() / 2048)
     ref = torch.where(z > 0, z, torch.expm1(z)) * ps.cpu().double() + pt.cpu().double()
     assert float((y_whole.cpu() - ref).abs().max()) < 2e-5 and int(flag.item()) == 0
-    for S in (2, 3, 4, 6):
+    for S, tile in ((2, 0), (3, 1), (4, 0), (6, 0), (4, 3), (12, 3), (18, 3)):     # tile 3: 352 x 128 tiles (small batches)
         part = torch.full((S, rows, n_out), float("nan"), device="cuda")
-        _layer_call("rc_split_layer_f16", a=a, w=w3, n_rows=rows, n_out=n_out, k=k, out_partials=part, k_splits=S)
+        _layer_call("rc_split_layer_f16", a=a, w=w3, n_rows=rows, n_out=n_out, k=k, out_partials=part, k_splits=S, tile=tile)
         n_corr = lib.rc_split_layer_corr_chunks(k, S)
         assert n_corr == sum((p + 1) * (36 // S) <= 24 for p in range(S))
         out = torch.empty((rows, 2 * n_out), dtype=torch.float16, device="cuda")
@@ -614,6 +614,8 @@ def test_layer_request_k_splits_and_reduce_match_the_whole_kernel():
     part = torch.empty((2, rows, n_out), device="cuda")
     bad(out_partials=part, k_splits=5)                                   # 36 K-steps are not divisible by 5
     bad(out_partials=part, k_splits=1)                                   # partials need at least two chunks
+    bad(out_partials=part, k_splits=36)                                  # ... of at least two K-steps each
+    bad(out_partials=part, k_splits=2, tile=2)                           # partials come in 352 x 256 and 352 x 128 tiles only
     bad(out_partials=part, out_hi_lo=whole, k_splits=2)                  # exactly one output
     bad(bias=b, out_hi_lo=whole, post_scale=ps)                          # post_scale without post_shift
     bad(out_hi_lo=whole)                                                 # the fused epilogue needs a bias
@@ -623,3 +625,37 @@ def test_layer_request_k_splits_and_reduce_match_the_whole_kernel():
                                                kw.get("o", whole.data_ptr()), None, None, None)
     assert red() == 0 and red(o=None) == -1 and red(nc=3) == -4 and red(P=0) == -4 and red(act=7) == -4 and red(cols=n_out + 4) == -2
     assert red(stride=rows * n_out - 4) == -4
+
+
+def test_split_engine_small_batches_run_the_cut_kernel():
+    """Below the whole-K tile's fill point the hidden layers run as the own kernel with its K loop cut into chunks (~256 workgroups)
+    + the reduce kernel -- the launches of a narrowed forest.  Every plan the ladder reaches is checked against float64 (closer than
+    the fp32 module), and the plans themselves are pinned."""
+    import copy
+    from librubiks import cube
+    from librubiks.model import F32_SPLIT, Model, ModelConfig, SplitF32Net, make_inference_net
+    torch.manual_seed(3)
+    np.random.seed(3)
+    net = Model.create(ModelConfig(architecture="fc_small")).eval().cuda()
+    eng = make_inference_net(net, F32_SPLIT)
+    assert SplitF32Net._k_split(352, 2048, 4096) == (3, 16) and SplitF32Net._k_split(352, 1024, 2048) == (3, 32)
+    assert SplitF32Net._k_split(2816, 2048, 4096) == (1, 4) and SplitF32Net._k_split(2816, 1024, 2048) == (3, 4)
+    assert SplitF32Net._k_split(5632, 2048, 4096) == (1, 2) and SplitF32Net._k_split(7040, 2048, 4096) is None
+    seen = set()
+    for trees in (32, 64, 96, 128, 192, 256, 320, 384, 512, 640, 1024):
+        rows = trees * 11
+        cubes, _, _ = cube.scramble_batch(rows, 25, True)
+        plans = tuple(eng._layer_plan(rows, eng.layers, i) for i in (1, 2))
+        seen.update(plans)
+        oh = cubes.as_oh(torch.float32)
+        with torch.no_grad():
+            p64, v64 = copy.deepcopy(net).double()(oh.double())
+            p32, v32 = net(oh)
+        ps, vs = eng.forward_cubes(cubes)
+        e_split = max(float((ps.double() - p64).abs().max()), float((vs.double() - v64.reshape(-1)).abs().max()))
+        e_f32 = max(float((p32.double() - p64).abs().max()), float((v32.reshape(-1).double() - v64.reshape(-1)).abs().max()))
+        assert e_split < 2e-5 and e_split <= 2.0 * e_f32 + 1e-6, (trees, plans, e_split, e_f32)
+        vo = eng.value_cubes(cubes)
+        assert float((vo.double() - v64.reshape(-1)).abs().max()) < 2e-5
+    assert "library" not in seen and "fused" in seen and sum(isinstance(p, tuple) for p in seen) >= 6, seen
+    assert not eng.overflowed()
