@@ -34,7 +34,7 @@
 extern "C" {
 #endif
 
-#define RC_ABI_VERSION 4
+#define RC_ABI_VERSION 5
 
 #define RC_OK 0
 #define RC_ERR_NULL (-1)      /* required pointer is NULL */
@@ -222,7 +222,8 @@ int rc_split_gemm_f16(const uint16_t *a_hi_lo, const uint16_t *w_lo_hi_hi, const
  * range_flag (device int, optional): OR-ed with 1 when a value written to out_hi_lo leaves IEEE half's range (|y| > 65504, or
  * not finite) -- the f16x3 split cannot carry it; librubiks.model.SplitF32Net then falls back to the fp32 GEMM chain.
  * Exactly one output.  rc_split_layer_f16: out_hi_lo | out_f32 | out_partials; with out_partials the K loop (3 k / 64 steps) is
- * cut into k_splits chunks (a divisor of 3 k / 64, 2 .. 32, n_out % 256 == 0), one workgroup per tile and chunk storing raw
+ * cut into k_splits chunks (a divisor of 3 k / 64 leaving >= 2 steps per chunk, 2 .. 32; tile 0 / 1: 352 x 256 tiles, n_out % 256
+ * == 0; tile 3: 352 x 128 tiles for small batches, n_out % 128 == 0), one workgroup per tile and chunk storing raw
  * accumulators out_partials[k_splits][n_rows][n_out] (no bias / residual / activation): the first rc_split_layer_corr_chunks(k,
  * k_splits) of them hold correction products only and still carry the factor 2^11, the others are in units of y
  * (rc_split_reduce_f16 finishes the layer).  rc_gemm_layer_bf16: a, w, residual, out_bf16 in bf16, one product. */
@@ -242,6 +243,8 @@ typedef struct rc_split_layer {
     int tile;                   /* 0 = choose (see rc_split_gemm_f16) */
     int k_splits;               /* 0 / 1 = whole K per workgroup */
     int32_t *range_flag;        /* optional */
+    int products;               /* rc_split_layer_f16: 0 / 3 = the three products of the split layer; 1 = ONE f16 product of a [n_rows][k]
+                                 * and w [n_out][k] as they are (the input layer: a = [onehot | 2^-11 onehot], w = [W_hi | W_lo], k = 960) */
 } rc_split_layer_t;
 size_t rc_split_layer_struct_bytes(void);
 int rc_split_layer_f16(const rc_split_layer_t *layer, rc_stream_t stream);

@@ -55,6 +55,7 @@ struct GemmArgs {
                                             // Linear because a skip connection reads its output as well
     int *flag;                   // kOutHalves: OR-ed with 1 when an output leaves IEEE half's range (|y| > 65504 or not finite)
     u32 S;                       // kPartials: number of K chunks (workgroups per tile)
+    u32 P;                       // products of the f16 kinds: 3 = the split layer (a hi | lo, w lo | hi | hi), 1 = a [M][K] x w [N][K] as they are
 };
 constexpr float kHalfMax = 65504.0f;
 
@@ -90,7 +91,8 @@ __global__ __launch_bounds__(WM *WN * 64) void k_split_gemm(GemmArgs g) {
     const u32 tm = wg / nn, tn = wg % nn;
     const size_t row0 = (size_t)tm * T::BM;
     const u32 col0 = tn * T::BN;
-    const u32 K = g.K, lda = (KIND == kBf16 ? 1 : 2) * K * 2, ldw = (KIND == kBf16 ? 1 : 3) * K * 2;   // bytes
+    const bool one = KIND == kBf16 || g.P == 1;   // one product: a is [M][K], w is [N][K]
+    const u32 K = g.K, lda = (one ? 1 : 2) * K * 2, ldw = (one ? 1 : 3) * K * 2;   // bytes
     const u32 last_row = (u32)(g.M - 1 - row0);            // rows past M re-read the last row; their outputs are not stored
 
     u32 src_off[T::PPW];
@@ -104,7 +106,7 @@ __global__ __launch_bounds__(WM *WN * 64) void k_split_gemm(GemmArgs g) {
     const unsigned char *w_tile = g.w + (size_t)col0 * ldw;
 
     auto stage = [&](u32 ks, u32 buf, int lo = 0, int hi = T::PPW) {   // this wave's pieces lo .. hi - 1 of stage ks
-        const u32 kk = ks * 64, a_col = (KIND == kBf16 || kk < 2 * K) ? kk : kk - 2 * K;
+        const u32 kk = ks * 64, a_col = (one || kk < 2 * K) ? kk : kk - 2 * K;
         const unsigned char *ab = a_tile + a_col * 2, *wb = w_tile + kk * 2;
         unsigned char *dst = lds + buf * T::STAGE;
 #pragma unroll
@@ -134,7 +136,7 @@ __global__ __launch_bounds__(WM *WN * 64) void k_split_gemm(GemmArgs g) {
 #pragma unroll
         for (int n = 0; n < NR; ++n) acc[m][n] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-    const u32 nk_all = (KIND == kBf16 ? 1 : 3) * K / 64, scale_step = KIND == kBf16 ? 0xFFFFFFFFu : 2 * K / 64;
+    const u32 nk_all = (one ? 1 : 3) * K / 64, scale_step = one ? 0xFFFFFFFFu : 2 * K / 64;
     const u32 ks0 = KIND == kPartials ? half * (nk_all / g.S) : 0u, nk = KIND == kPartials ? ks0 + nk_all / g.S : nk_all;
     stage(ks0, 0);
     for (u32 ks = ks0; ks < nk; ++ks) {
@@ -270,7 +272,8 @@ __global__ __launch_bounds__(512) void k_split_gemm_pp(GemmArgs g) {
     const u32 tm = wg / nn, tn = wg % nn;
     const size_t row0 = (size_t)tm * T::BM;
     const u32 col0 = tn * T::BN;
-    const u32 K = g.K, lda = (KIND == kBf16 ? 1 : 2) * K * 2, ldw = (KIND == kBf16 ? 1 : 3) * K * 2;   // bytes
+    const bool one = KIND == kBf16 || g.P == 1;   // one product: a is [M][K], w is [N][K]
+    const u32 K = g.K, lda = (one ? 1 : 2) * K * 2, ldw = (one ? 1 : 3) * K * 2;   // bytes
     const u32 last_row = (u32)(g.M - 1 - row0);
 
     // LDS-DMA piece p = i * 8 + wave covers stage rows 8 p .. 8 p + 7 (activation rows first, then weight rows); lane l moves
@@ -281,7 +284,7 @@ __global__ __launch_bounds__(512) void k_split_gemm_pp(GemmArgs g) {
 
     constexpr int kHalf = (T::PPW + 1) / 2;
     auto stage_part = [&](u32 ks, u32 buf, int lo, int hi) {   // this wave's pieces lo .. hi - 1 of stage ks
-        const u32 kk = ks * 64, a_col = (KIND == kBf16 || kk < 2 * K) ? kk : kk - 2 * K;
+        const u32 kk = ks * 64, a_col = (one || kk < 2 * K) ? kk : kk - 2 * K;
         const unsigned char *ab = a_tile + a_col * 2, *wb = w_tile + kk * 2;
         unsigned char *dst = lds + buf * T::STAGE;
         u32 rl = r_lane, cl = c_lane;
@@ -313,7 +316,7 @@ __global__ __launch_bounds__(512) void k_split_gemm_pp(GemmArgs g) {
 #pragma unroll
         for (int n = 0; n < NR; ++n) acc[m][n] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-    const u32 nk_all = (KIND == kBf16 ? 1 : 3) * K / 64, scale_step = KIND == kBf16 ? 0xFFFFFFFFu : 2 * K / 64;
+    const u32 nk_all = (one ? 1 : 3) * K / 64, scale_step = one ? 0xFFFFFFFFu : 2 * K / 64;
     const u32 ks0 = KIND == kPartials ? half * (nk_all / g.S) : 0u, nk = KIND == kPartials ? ks0 + nk_all / g.S : nk_all;
     stage_part(ks0, 0, 0, T::PPW);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -521,6 +524,8 @@ static int layer_args(const rc_split_layer_t *L, GemmArgs &g) {
     g.post_shift = L->post_shift;
     g.flag = L->range_flag;
     g.S = 1;
+    RC_REQUIRE(L->products == 0 || L->products == 1 || L->products == 3, RC_ERR_RANGE);
+    g.P = L->products == 1 ? 1u : 3u;
     return RC_OK;
 }
 
@@ -534,7 +539,7 @@ extern "C" int rc_split_layer_f16(const rc_split_layer_t *L, rc_stream_t stream)
     const int outs = (L->out_hi_lo != nullptr) + (L->out_f32 != nullptr) + (L->out_partials != nullptr);
     RC_REQUIRE(outs == 1 && L->out_bf16 == nullptr, RC_ERR_NULL);
     if (L->out_partials) {   // K cut into k_splits chunks, raw accumulators: no epilogue inputs
-        const u32 S = (u32)L->k_splits, nk_all = 3 * g.K / 64;
+        const u32 S = (u32)L->k_splits, nk_all = g.P * g.K / 64;
         RC_REQUIRE(L->k_splits >= 2 && L->k_splits <= 32 && nk_all % S == 0 && nk_all / S >= 2 && (L->tile == 0 || L->tile == 1 || L->tile == 3) &&
                        L->n_out % (L->tile == 3 ? 128 : 256) == 0, RC_ERR_RANGE);
         g.out = (void *)L->out_partials;

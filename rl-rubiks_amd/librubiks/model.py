@@ -452,7 +452,7 @@ class _SplitLayer(ctypes.Structure):   # mirrors rc_split_layer_t (include/rubik
                                                "out_partials", "out_bf16")] + \
                [(n, ctypes.c_size_t) for n in ("n_rows", "n_out", "k")] + \
                [("activation", ctypes.c_int), ("alpha", ctypes.c_float), ("tile", ctypes.c_int), ("k_splits", ctypes.c_int),
-                ("range_flag", ctypes.c_void_p)]
+                ("range_flag", ctypes.c_void_p), ("products", ctypes.c_int)]
 
 
 def _ptr(t):
@@ -635,6 +635,7 @@ class SplitF32Net:
     def _zero_bias(self, w: int) -> torch.Tensor:
         return self._zeros[w]   # made in __init__: never allocated (and filled) inside a graph capture
 
+    gemm_input_rows = 0   # > 0: from this many rows the input layer runs on the GEMM kernel (measured slower in whole searches: off)
     fused_input = True   # the input layer as one MFMA kernel from the cube states (rc_first_layer_split_f16) when shapes allow
 
     def _first_from_cubes(self, cubes, layers, lo: int = 0, n: int = None):
@@ -649,6 +650,15 @@ class SplitF32Net:
             assert lo % 16 == 0 and 0 <= lo and lo + n <= cubes.n
             cubes = _CubeWindow(cubes.soa.data_ptr() + lo, n, cubes.stride)
         out = torch.empty((cubes.n, 2 * H), dtype=torch.float16, device=self.device)
+        if self.gemm_input_rows and cubes.n >= self.gemm_input_rows and H % 256 == 0:
+            # the explicit one-hot operand [oh | 2^-11 oh] (21.6 MB at 11 264 rows) through the hidden layers' GEMM kernel as ONE f16 product
+            # with K = 960 (the same sums in another order, 1e-7 apart).  Off by default: faster alone from ~6 000 rows (125 -> 111 us at
+            # 11 264, profiles/r3_first_layer_gemm_probe.txt) but 2 % SLOWER in whole searches on the same box (profiles/r3_input_gemm_ab.txt)
+            oh = torch.empty((cubes.n, 2 * OH_WIDTH), dtype=torch.float16, device=self.device)
+            _hip.check(_hip.lib().rc_oh_split_f16(_soa_ptr(cubes), cubes.n, cubes.stride, oh.data_ptr(), _hip.stream_ptr()), "rc_oh_split_f16")
+            _layer_call("rc_split_layer_f16", a=oh, w=B, bias=b, n_rows=cubes.n, n_out=H, k=2 * OH_WIDTH, activation=code, alpha=alpha,
+                        out_hi_lo=out, tile=1, k_splits=1, products=1, range_flag=self.range_flag)
+            return out
         _hip.check(_hip.lib().rc_first_layer_split_flag_f16(_soa_ptr(cubes), cubes.n, cubes.stride, Wh.data_ptr(), Wl.data_ptr(), b.data_ptr(),
                                                             out.data_ptr(), H, code, alpha, self.range_flag.data_ptr(), _hip.stream_ptr()),
                    "rc_first_layer_split_flag_f16")

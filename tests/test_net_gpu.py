@@ -659,3 +659,44 @@ def test_split_engine_small_batches_run_the_cut_kernel():
         assert float((vo.double() - v64.reshape(-1)).abs().max()) < 2e-5
     assert "library" not in seen and "fused" in seen and sum(isinstance(p, tuple) for p in seen) >= 6, seen
     assert not eng.overflowed()
+
+
+def test_layer_request_one_product_and_the_input_layer_on_it():
+    """rc_split_layer_t.products = 1: the GEMM kernel as ONE f16 product of a [n][k] and w [n_out][k] (fp32 accumulation, the split
+    epilogue) against float64; then the input layer of the split engine both ways -- fused one-hot kernel / explicit one-hot operand on
+    the GEMM kernel (big batches) -- the same sums in another order."""
+    from librubiks import _hip, cube
+    from librubiks.model import F32_SPLIT, Model, ModelConfig, SplitF32Net, _layer_call, make_inference_net
+    g = torch.Generator().manual_seed(5)
+    rows, k, n_out = 1000, 960, 512
+    a = (torch.randn(rows, k, generator=g) * 0.5).half().cuda()
+    w = (torch.randn(n_out, k, generator=g) / 30).half().cuda()
+    b = torch.randn(n_out, generator=g).cuda()
+    ref = a.double() @ w.double().t() + b.double()
+    ref = torch.where(ref > 0, ref, torch.expm1(ref))
+    for tile in (0, 1, 2, 3):
+        out = torch.empty((rows, 2 * n_out), dtype=torch.float16, device="cuda")
+        _layer_call("rc_split_layer_f16", a=a, w=w, bias=b, n_rows=rows, n_out=n_out, k=k, activation=2, alpha=1.0, out_hi_lo=out, tile=tile, k_splits=1,
+                    products=1)
+        y = out[:, :n_out].double() + out[:, n_out:].double() / 2048
+        assert float((y - ref).abs().max()) < 3e-6, tile
+    f32 = torch.empty((rows, n_out), device="cuda")
+    _layer_call("rc_split_layer_f16", a=a, w=w, bias=b, n_rows=rows, n_out=n_out, k=k, activation=2, alpha=1.0, out_f32=f32, tile=0, k_splits=1, products=1)
+    assert float((f32.double() - ref).abs().max()) < 3e-6
+    with pytest.raises(_hip.RubiksHipError):
+        _layer_call("rc_split_layer_f16", a=a, w=w, bias=b, n_rows=rows, n_out=n_out, k=k, activation=2, alpha=1.0, out_f32=f32, products=2)
+    # the engine's input layer
+    torch.manual_seed(1)
+    np.random.seed(1)
+    net = Model.create(ModelConfig(architecture="fc_small")).eval().cuda()
+    eng = make_inference_net(net, F32_SPLIT)
+    cubes, _, _ = cube.scramble_batch(11264, 30, True)
+    assert SplitF32Net.gemm_input_rows == 0      # off by default (slower in whole searches, DESIGN section 8)
+    fused = eng._first_from_cubes(cubes, eng.layers)
+    eng.gemm_input_rows = 8192
+    on_gemm = eng._first_from_cubes(cubes, eng.layers)
+    H = fused.shape[1] // 2
+    val = lambda t: t[:, :H].double() + t[:, H:].double() / 2048   # noqa: E731
+    assert float((val(on_gemm) - val(fused)).abs().max()) < 1e-6
+    del eng.gemm_input_rows
+    assert not eng.overflowed()

@@ -1,5 +1,6 @@
-"""Same-box A/B of the small-batch K-cut plans of the split engine (SplitF32Net.small_batch_cut): config #2 as one batch to
-completion and as a pool of games at the reference's cap, fp32-accurate engine.   python tools/kcut_ab.py"""
+"""Same-box A/B of a switch of the split engine (a class attribute of SplitF32Net, default small_batch_cut on / off): config #2 as one
+batch to completion and as a pool of games at the reference's cap, fp32-accurate engine, variants alternating in one process.
+    python tools/engine_ab.py [attribute value_a value_b]        e.g.  gemm_input_rows 8192 0"""
 import json
 import os
 import sys
@@ -20,8 +21,10 @@ batch, _, _ = cube.scramble_batch(1024, 20, True)
 pool, _, _ = cube.scramble_batch(4096, 20, True)
 model = Model.load(os.path.join(ROOT, "weights", "fc_small_r1")).eval()
 out = {}
-for name, on in (("cut", True), ("library", False), ("cut_again", True), ("library_again", False)):
-    SplitF32Net.small_batch_cut = on
+ATTR = sys.argv[1] if len(sys.argv) > 1 else "small_batch_cut"
+VALS = [int(v) for v in sys.argv[2:4]] if len(sys.argv) > 3 else [True, False]
+for name, on in ((f"{ATTR}={VALS[0]}", VALS[0]), (f"{ATTR}={VALS[1]}", VALS[1]), (f"{ATTR}={VALS[0]} again", VALS[0]), (f"{ATTR}={VALS[1]} again", VALS[1])):
+    setattr(SplitF32Net, ATTR, type(getattr(SplitF32Net, ATTR))(on))
     agent = MCTS(model, c=0.6, search_graph=True)
     agent.prepare(1024, CAP)
     agent.search_batch(batch, None, CAP)
