@@ -75,13 +75,16 @@ _NODE_FIELDS = {"N": (0, 12, torch.int32), "W": (12, 24, torch.float32), "rec": 
                 "P": (32, 44, torch.float32), "nbr": (44, 56, torch.int32)}
 
 
+RUNG_RATIO = 0.95   # measured on configs[1] to completion, same box: 0.8 1.772 s, 0.9 1.735, 0.93 1.715, 0.95 1.710, 0.97 1.703 (profiles/r3_rung_ratio_ab.txt)
+
+
 def rungs(n_trees: int) -> list:
     """Launch sizes a forest of n_trees is narrowed to as its trees finish (`MCTSForest.set_active`), largest first: n_trees,
-    then multiples of 32 trees (352 network rows, the row tile of the layer kernels) each at most 0.8 of the one before,
-    down to MIN_RUNG.  One HIP graph is captured per size and kept for the forest's lifetime."""
+    then multiples of 32 trees (352 network rows, the row tile of the layer kernels) each at most RUNG_RATIO of the one before,
+    down to MIN_RUNG (26 sizes for 1 024 trees).  One HIP graph is captured per size and kept for the forest's lifetime."""
     out = [int(n_trees)]
     while out[-1] > MIN_RUNG:
-        nxt = max(MIN_RUNG, int(out[-1] * 0.8) // 32 * 32)
+        nxt = max(MIN_RUNG, int(out[-1] * RUNG_RATIO) // 32 * 32)
         if nxt >= out[-1]:
             break
         out.append(nxt)

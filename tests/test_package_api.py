@@ -85,11 +85,12 @@ def test_ticktock_restated():
 
 def test_launch_size_ladder():
     """MCTSForest narrows a running forest along a fixed ladder of launch sizes (one HIP graph each): the forest's own size, then
-    multiples of 32 trees (352 network rows = the layer kernels' row tile), each at most 0.8 of the one before, down to 32."""
+    multiples of 32 trees (352 network rows = the layer kernels' row tile), each at most 0.95 of the one before, down to 32."""
     from librubiks.solving.mcts_device import MIN_RUNG, rungs
     for n in (1, 5, 31, 32, 33, 48, 600, 1024, 8192):
         r = rungs(n)
         assert r[0] == n and r == sorted(set(r), reverse=True)
-        assert all(x % 32 == 0 for x in r[1:]) and all(b <= 0.8 * a or b == MIN_RUNG for a, b in zip(r, r[1:]))
+        assert all(x % 32 == 0 for x in r[1:]) and all(b <= 0.95 * a or b == MIN_RUNG for a, b in zip(r, r[1:]))
         assert r[-1] == (MIN_RUNG if n > MIN_RUNG else n)
-    assert rungs(1024) == [1024, 800, 640, 512, 384, 288, 224, 160, 128, 96, 64, 32]
+    assert rungs(1024) == [1024, 960, 896, 832, 768, 704, 640, 608, 576, 544, 512, 480, 448, 416, 384, 352, 320, 288, 256, 224, 192, 160, 128, 96,
+                           64, 32]

@@ -22,9 +22,14 @@ pool, _, _ = cube.scramble_batch(4096, 20, True)
 model = Model.load(os.path.join(ROOT, "weights", "fc_small_r1")).eval()
 out = {}
 ATTR = sys.argv[1] if len(sys.argv) > 1 else "small_batch_cut"
-VALS = [int(v) for v in sys.argv[2:4]] if len(sys.argv) > 3 else [True, False]
+VALS = [float(v) if "." in v else int(v) for v in sys.argv[2:4]] if len(sys.argv) > 3 else [True, False]
+OWNER = SplitF32Net
+if "." in ATTR:      # e.g. mcts_device.RUNG_RATIO: a module constant of librubiks.solving
+    import importlib
+    mod, ATTR = ATTR.rsplit(".", 1)
+    OWNER = importlib.import_module("librubiks.solving." + mod)
 for name, on in ((f"{ATTR}={VALS[0]}", VALS[0]), (f"{ATTR}={VALS[1]}", VALS[1]), (f"{ATTR}={VALS[0]} again", VALS[0]), (f"{ATTR}={VALS[1]} again", VALS[1])):
-    setattr(SplitF32Net, ATTR, type(getattr(SplitF32Net, ATTR))(on))
+    setattr(OWNER, ATTR, type(getattr(OWNER, ATTR))(on))
     agent = MCTS(model, c=0.6, search_graph=True)
     agent.prepare(1024, CAP)
     agent.search_batch(batch, None, CAP)
