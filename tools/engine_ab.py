@@ -29,8 +29,11 @@ if "." in ATTR:      # e.g. mcts_device.RUNG_RATIO: a module constant of librubi
     mod, ATTR = ATTR.rsplit(".", 1)
     OWNER = importlib.import_module("librubiks.solving." + mod)
 for name, on in ((f"{ATTR}={VALS[0]}", VALS[0]), (f"{ATTR}={VALS[1]}", VALS[1]), (f"{ATTR}={VALS[0]} again", VALS[0]), (f"{ATTR}={VALS[1]} again", VALS[1])):
-    setattr(OWNER, ATTR, type(getattr(OWNER, ATTR))(on))
-    agent = MCTS(model, c=0.6, search_graph=True)
+    if ATTR == "sync_every":      # a constructor argument of the agent
+        agent = MCTS(model, c=0.6, search_graph=True, sync_every=int(on))
+    else:
+        setattr(OWNER, ATTR, type(getattr(OWNER, ATTR))(on))
+        agent = MCTS(model, c=0.6, search_graph=True)
     agent.prepare(1024, CAP)
     agent.search_batch(batch, None, CAP)
     runs = []
