@@ -92,3 +92,10 @@ def test_mcts_struct_mirror_has_the_compiled_size():
     from librubiks import _hip
     from librubiks.solving import mcts_device as md
     assert _hip.load().rc_mcts_struct_bytes() == ctypes.sizeof(md._McStruct)
+
+
+def test_graft_entry_build_accepts_the_built_library():
+    """__graft_entry__.build() (the driver's build check) compares the library's ABI version with the header's, not with a literal."""
+    import re
+    src = open(os.path.join(ROOT, "__graft_entry__.py")).read()
+    assert "RC_ABI_VERSION" in src and not re.search(r"rc_abi_version\(\)\s*==\s*\d", src)
