@@ -503,7 +503,7 @@ def test_residual_architectures_run_on_the_native_engines(batchnorm):
     the fc nets use: BatchNorm folded (a block's own into its Linear; the one in front of the first block as a post-activation
     affine, because the skip connection reads it too), skip connection added in the layer kernels' epilogue.  Tolerances: fp32
     engine vs the module rtol = atol = 1e-4; split engine vs float64 within 1.25 x the fp32 module's error; bf16 atol 4e-2 on
-    outputs of magnitude ~1.  All row counts: own kernels (11 264 rows), K-split partials + reduce (5 632), library GEMMs (300).
+    outputs of magnitude ~1.  All row counts: own kernels (11 264 rows), K cut in two + reduce (5 632), K cut into 16-32 chunks (300).
     """
     import copy
     from librubiks import cube
