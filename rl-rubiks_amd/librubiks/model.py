@@ -491,7 +491,9 @@ class SplitF32Net:
     MFMA runs at 1/16 of the f16 rate).  Every float travels as two IEEE halves, x = hi + lo * 2^-11 (22 significant
     bits), and a layer is three f16 MFMA products with fp32 accumulation,
         y = act(hi_x W_hi^T + 2^-11 (hi_x W_lo^T + lo_x W_hi^T) + b),
-    i.e. two library GEMMs per layer (K and 2K deep) and one HIP kernel (bias + activation + re-split).  BatchNorm is
+    run by the own MFMA kernel (csrc/rubiks_gemm.hip): one launch per layer with the epilogue fused where whole-K tiles fill the chip,
+    else with the K loop cut into chunks + a reduce kernel (`_layer_plan`); shapes the kernel does not take fall back to two library
+    GEMMs.  The input layer is a one-hot MFMA kernel straight from the cube states.  BatchNorm is
     folded in float64 as in InferenceNet, the two heads are merged, the 13-wide output layer runs in plain fp32.
     Against the float64 forward the error is BELOW that of the fp32 GEMM chain (tests/test_net_gpu.py), at ~2.5x its
     speed; it is the reference-precision engine of bench.py.  Same interface as InferenceNet.
@@ -557,7 +559,7 @@ class SplitF32Net:
 
     small_batch_cut = True   # False: the K loop is cut (in two) only from 96 whole-K tiles up, smaller batches go to the library (A/B switch)
     fused_hidden = True   # hidden layers as one kernel each (rc_split_gemm_f16) where its tile fills the chip
-    fused_head = True     # last activation + output layer in one pass (rc_head_split_f32) behind a library-GEMM hidden layer
+    fused_head = True     # last activation + output layer in one pass (rc_head_split_f32) behind a hidden layer that came as partials
 
     def _layer_plan(self, rows: int, layers, i: int):
         """How hidden layer i runs on `rows` rows: 'fused' (one rc_split_layer_f16 launch, whole K per workgroup), ('cut', tile, chunks)
