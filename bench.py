@@ -383,7 +383,7 @@ def cpu_bfs_config1():
 
 
 LEG_DTYPE = {   # leg name -> the arithmetic the network computes in (`dtype` of the JSON line)
-    "f32s": "f32 accuracy via f16x3 split: 3 f16 MFMA products per layer, fp32 accumulate (error vs float64 within 1.25 x the fp32 forward's)",
+    "f32s": "f32 (f16x3 split: three f16 MFMA products per layer, fp32 accumulate)",
     "f32": "f32",
     "bf16": "bf16",
 }
@@ -693,11 +693,10 @@ def step_rooflines(engine, agent, roots, args, name):
             gemm_traffic = stored["traffic_bytes"]
             gemm_traffic_src = (f"stored PMC figure: profiles/{GEMM_PMC_FILE} (separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of "
                                 f"{stored['kernel']}, gfx950 corrections applied; algorithmic bytes 310 MB)")
-        roofline = {"kernel": (f"rc_split_gemm_f16 (own MFMA kernel, 352 x 256 tiles): first hidden layer of the split engine, "
-                               f"[{rows} x {3 * W1[1]}] x [{3 * W1[1]} x {W1[0]}] f16 products (hi x lo, lo x hi, hi x hi) in one fp32 "
-                               f"accumulator + bias + ELU + re-split to halves: the dominant kernel of a step") if own else
-                              (f"first hidden layer of the split engine: f16 GEMMs [{rows} x {W1[1]}] x [{W1[1]} x {W1[0]}] (hi x hi) and "
-                               f"[{rows} x {2 * W1[1]}] x [{2 * W1[1]} x {W1[0]}] (hi x lo + lo x hi), fp32 out, via hipBLASLt: the dominant kernels of a step"),
+        roofline = {"kernel": (f"rc_split_gemm_f16 (own MFMA kernel, 352 x 256 tiles), first hidden layer: [{rows} x {3 * W1[1]}] x [{3 * W1[1]} x {W1[0]}] "
+                               f"f16 products (hi.lo, lo.hi, hi.hi) in one fp32 accumulator + bias + ELU + re-split") if own else
+                              (f"first hidden layer of the split engine via hipBLASLt: f16 GEMMs [{rows} x {W1[1]}] x [{W1[1]} x {W1[0]}] (hi.hi) and "
+                               f"[{rows} x {2 * W1[1]}] x [{2 * W1[1]} x {W1[0]}] (hi.lo + lo.hi), fp32 out"),
                     "bound": "mfma", "achieved": round(executed / t / 1e12, 1), "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s",
                     "frac": round(executed / t / 1e12 / MFMA_BF16_PEAK_TFLOPS, 4), "traffic": gemm_traffic, "traffic_source": gemm_traffic_src,
                     "flops_per_launch": executed,
@@ -779,6 +778,58 @@ def draw_scrambles(n_config, n_pool, depth, slice_rank, slice_world):
     return config_roots, pool_roots
 
 
+def launch_ranks(n, argv, script=os.path.abspath(__file__)):
+    """
+    `python bench.py --gpus N` without a launcher (no RANK / WORLD_SIZE in the environment): this process starts the N ranks as
+    children -- the same script with RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* set, i.e. what torch.distributed.run would have
+    exported -- and relays rank 0's line as its own single stdout line.  It never touches the GPU itself (nothing here makes a
+    HIP call, and no process that has initialised the GPU is ever exec'ed over).  A rank that dies takes the others with it
+    and its exit code becomes ours.
+    """
+    import socket
+    import subprocess
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        procs.append(subprocess.Popen([sys.executable, script, *argv], env=env,
+                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL, text=True))
+    import threading
+    chunks = []
+    reader = threading.Thread(target=lambda: chunks.append(procs[0].stdout.read()), daemon=True)   # drains rank 0's pipe while we wait
+    reader.start()
+    rc = 0
+    try:
+        while rc == 0 and any(p.poll() is None for p in procs):
+            time.sleep(0.2)
+            rc = next((p.returncode for p in procs if p.poll() not in (None, 0)), 0)
+        rc = rc or next((p.returncode for p in procs if p.returncode), 0)
+    finally:
+        for p in procs:
+            if p.poll() is None:
+                p.terminate()
+        for p in procs:
+            try:
+                p.wait(timeout=20)
+            except subprocess.TimeoutExpired:
+                p.kill()
+        reader.join(timeout=20)
+    out0 = "".join(chunks)
+    if rc:
+        print(f"bench.py: a rank exited with code {rc}", file=sys.stderr)
+        return rc
+    lines = [ln for ln in (out0 or "").splitlines() if ln.startswith("{")]
+    if len(lines) != 1:
+        print(f"bench.py: rank 0 printed {len(lines)} result lines", file=sys.stderr)
+        return 1
+    print(lines[0], flush=True)
+    return 0
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -817,7 +868,11 @@ def main():
     ap.add_argument("--as-rank", default=None, metavar="R/W",
                     help="single process, no process group: take rank R's share of a W-rank run's scrambles (tests compare "
                          "the ranks of a distributed run with these)")
+    ap.add_argument("--detail", default=os.path.join(ROOT, "bench_detail.json"),
+                    help="file that receives the full result (per-leg detail, phases, the roofline_env ladder); the stdout line names it")
     args = ap.parse_args()
+    if args.gpus > 1 and "RANK" not in os.environ and "WORLD_SIZE" not in os.environ and not args.as_rank:
+        sys.exit(launch_ranks(args.gpus, sys.argv[1:]))   # no launcher around us: start the ranks ourselves (before any HIP call)
     if args.level_budget != "auto":
         args.level_budget = int(args.level_budget)
     legs = [x.split(":")[0] for x in args.legs.split(",") if x]
@@ -932,10 +987,9 @@ def main():
                    "scramble_depth": args.depth, "max_states": args.solve_max_states, "parallelism": f"scramble-sharded x{world}",
                    "scrambles": "configs' own games: the reference's stream (np.random.seed(0), scramble(depth, True)), rank r owns games "
                                 "[r n, (r + 1) n); pool filler: a private stream per rank (seed 1 000 003 + rank)",
-                   "timed_region": "K lock-step iterations of the stationary pool (harvest + refill included), barrier + "
-                                   "synchronize on both sides; prep (until 2 x trees scrambles have been started) and warm-up untimed; "
-                                   "where the window falls relative to the result flushes (graph completion + BFS of 256 finished "
-                                   "trees on a side stream, one per 256 finished games) is not chosen: results.result_flushes_in_window",
+                   "timed_region": "K lock-step iterations of the stationary pool (harvest + refill included) between barrier + synchronize; "
+                                   "prep (until 2 x trees scrambles have been started) and warm-up untimed; result flushes (graph completion + "
+                                   "BFS of 256 finished trees on a side stream) fall where they fall: results.result_flushes_in_window",
                    "results": summary},
         "value_note": f"headline = the '{legs[0]}' leg: the reference's network arithmetic is fp32 (librubiks/model.py:131-141); f32s reaches "
                       "fp32 accuracy with three f16 MFMA products per layer (error against float64 within 1.25 x the fp32 forward's, "
@@ -973,10 +1027,77 @@ def main():
         result["roofline"]["astar_dominant_kernel"] = {k: astar["f32s"]["roofline"][k] for k in ("kernel", "achieved", "peak", "frac", "ms_per_launch")}
     if not args.no_cpu_baseline and world == 1:
         result["cpu_baseline"] = cpu_baseline(model, args.depth)
-    print(json.dumps(result))
+    emit(result, args.detail)
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
+
+
+LINE_LIMIT = 8000   # bytes of the final stdout line: the driver's record keeps the last 8 KB of output and parses the line from there
+
+
+def _short(text, n):
+    text = str(text)
+    return text if len(text) <= n else text[:n - 3] + "..."
+
+
+def compact_line(full, detail_name="bench_detail.json"):
+    """
+    The ONE stdout line of a run, built from the full result: what the bench contract names (metric ... config, roofline,
+    cpu_baseline) and the flat scalars of `config.results`; the per-leg detail (`legs`, `astar`, `config5_share`, `adi`, the
+    `roofline_env` ladder, boundary-call timings, notes) stays in `detail_name`, which the line names.  Always < LINE_LIMIT bytes:
+    free text is clipped, and should the scalars ever outgrow the limit the least important groups are dropped (and listed).
+    """
+    cfg = full["config"]
+    line = {k: full[k] for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+                                 "scaling_measured", "vs_baseline", "data") if k in full}
+    line["dtype"] = _short(full["dtype"], 96)
+    line["config"] = {"workload": _short(cfg["workload"], 420), "trees_per_gpu": cfg.get("trees_per_gpu"), "max_states": cfg.get("max_states"),
+                      "scramble_depth": cfg.get("scramble_depth"), "parallelism": cfg.get("parallelism"),
+                      "timed_region": _short(cfg.get("timed_region", ""), 330), "results": dict(cfg.get("results") or {})}
+    roof = full.get("roofline") or {}
+    keep = ("kernel", "bound", "achieved", "peak", "unit", "frac", "traffic", "algorithmic_bytes", "flops_per_launch", "ms_per_launch", "ms",
+            "fp32_equivalent_tflops")
+    line["roofline"] = {k: (_short(roof[k], 200) if k == "kernel" else roof[k]) for k in keep if k in roof}
+    for sub in ("env_multi_rotate_2p24", "astar_dominant_kernel", "adi_dominant_kernel", "adi_env"):
+        if sub in roof:
+            line["roofline"][sub] = {k: (_short(v, 140) if isinstance(v, str) else v) for k, v in roof[sub].items() if k in keep}
+    cpu = full.get("cpu_baseline")
+    if cpu:
+        line["cpu_baseline"] = {k: (_short(cpu[k], 220) if k == "sample" else cpu[k])
+                                for k in ("value", "unit", "cores", "host_cpus", "kind", "sample", "env_ops", "bfs_config1", "adi") if k in cpu}
+    line["detail"] = detail_name
+    dropped = []
+    for victim in (("cpu_baseline", "env_ops"), ("cpu_baseline", "bfs_config1"), ("roofline", "adi_env"), ("roofline", "astar_dominant_kernel")):
+        if len(json.dumps(line)) < LINE_LIMIT - 64:
+            break
+        if victim[1] in line.get(victim[0], {}):
+            del line[victim[0]][victim[1]]
+            dropped.append(".".join(victim))
+    if len(json.dumps(line)) >= LINE_LIMIT - 64:   # last resort: keep the scalars in the order they were added until the line fits
+        res, n_cut = line["config"]["results"], 0
+        while res and len(json.dumps(line)) >= LINE_LIMIT - 160:
+            res.popitem()
+            n_cut += 1
+        dropped.append(f"config.results: the last {n_cut} scalars")
+    if dropped:
+        line["dropped_to_detail"] = dropped
+    return line
+
+
+def emit(full, detail_path):
+    """Writes the full result to `detail_path` (and to gpurun_out/ when that exists) and prints the compact line, last, on stdout."""
+    text = json.dumps(full)
+    for path in {detail_path, *([os.path.join(ROOT, "gpurun_out", os.path.basename(detail_path))] if os.path.isdir(os.path.join(ROOT, "gpurun_out")) else [])}:
+        try:
+            with open(path, "w") as f:
+                f.write(text + "\n")
+        except OSError as e:   # a read-only checkout must not cost the run its line
+            print(f"bench.py: could not write {path}: {e}", file=sys.stderr)
+    line = json.dumps(compact_line(full, os.path.basename(detail_path)))
+    assert len(line) < LINE_LIMIT and "\n" not in line
+    sys.stdout.flush()
+    print(line, flush=True)
 
 
 if __name__ == "__main__":

@@ -1,0 +1,139 @@
+"""
+bench.py's contract with the driver, checked without a GPU:
+  * the ONE stdout line is built from the full result by `compact_line`, is valid JSON, stays under 8 000 bytes (the driver's
+    record keeps the last 8 KB of output: round 3's 26 KB line came back unparsed) and carries what the contract names;
+  * `python bench.py --gpus N` without a launcher starts its N ranks itself (`launch_ranks`), relays rank 0's line and
+    fails fast, with the rank's exit code, when one of them dies.
+The canned full result is a real one: round 3's line (profiles/r3h_bench.json, 26 KB).
+"""
+import json
+import os
+import subprocess
+import sys
+import textwrap
+import time
+
+import pytest
+
+from conftest import ROOT
+
+sys.path.insert(0, ROOT)
+import bench  # noqa: E402
+
+CANNED = os.path.join(ROOT, "profiles", "r3h_bench.json")
+
+
+def _full():
+    with open(CANNED) as f:
+        return json.load(f)
+
+
+def test_line_is_small_and_complete():
+    full = _full()
+    assert len(json.dumps(full)) > 20_000          # the thing that did not parse
+    line = bench.compact_line(full)
+    text = json.dumps(line)
+    assert len(text) < bench.LINE_LIMIT <= 8000 and "\n" not in text
+    back = json.loads(text)
+    assert back == line
+    for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
+                "dtype", "data", "config", "roofline", "cpu_baseline", "detail"):
+        assert key in back, key
+    assert back["value"] == full["value"] and back["ms_per_step"] == full["ms_per_step"]
+    assert isinstance(back["config"]["workload"], str) and back["config"]["workload"]
+    assert "model" not in back["config"]
+    assert back["config"]["results"] == full["config"]["results"]          # every flat scalar survives
+    roof = back["roofline"]
+    for key in ("bound", "achieved", "peak", "unit", "frac", "traffic"):
+        assert key in roof, key
+    assert roof["bound"] in ("hbm", "mfma") and abs(roof["frac"] - roof["achieved"] / roof["peak"]) < 1e-3
+    assert roof["env_multi_rotate_2p24"]["bound"] == "hbm" and "astar_dominant_kernel" in roof
+    cpu = back["cpu_baseline"]
+    for key in ("value", "unit", "cores", "kind", "sample"):
+        assert key in cpu, key
+    assert cpu["kind"] in ("port", "reference")
+    for bulky in ("legs", "astar", "config5_share", "roofline_env"):
+        assert bulky not in back
+    assert "boundary_calls" not in cpu
+    assert "dropped_to_detail" not in back
+
+
+def test_line_stays_under_the_limit_whatever_the_result_holds():
+    full = _full()
+    full["config"]["workload"] = "w" * 5000
+    full["config"]["timed_region"] = "t" * 5000
+    full["roofline"]["kernel"] = "k" * 5000
+    full["cpu_baseline"]["sample"] = "s" * 5000
+    full["dtype"] = "d" * 500
+    for i in range(400):
+        full["config"]["results"][f"extra_scalar_{i}"] = 1234567.8 + i
+    line = bench.compact_line(full)
+    text = json.dumps(line)
+    assert len(text) < bench.LINE_LIMIT
+    assert line["dropped_to_detail"]                      # and it says what it left to the detail file
+    assert line["value"] == full["value"] and "frac" in line["roofline"] and "value" in line["cpu_baseline"]
+    assert "value_run_to_completion" in line["config"]["results"]     # the first scalars are the last to go
+
+
+def test_emit_writes_the_detail_file_and_prints_one_line(tmp_path, capsys):
+    full = _full()
+    path = str(tmp_path / "bench_detail.json")
+    bench.emit(full, path)
+    out = capsys.readouterr().out
+    lines = [ln for ln in out.splitlines() if ln.strip()]
+    assert len(lines) == 1 and lines[0].startswith("{") and len(lines[0]) < 8000
+    assert json.loads(lines[0])["detail"] == "bench_detail.json"
+    with open(path) as f:
+        assert json.load(f) == full
+
+
+RANK_SCRIPT = textwrap.dedent("""
+    import json, os, sys, time
+    rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+    assert os.environ["LOCAL_RANK"] == str(rank) and os.environ["MASTER_ADDR"] == "127.0.0.1" and int(os.environ["MASTER_PORT"]) > 0
+    mode = sys.argv[sys.argv.index("--mode") + 1]
+    if mode == "die" and rank == 1:
+        sys.exit(7)
+    if mode == "die":
+        time.sleep(120)            # a survivor that would wait for ever
+    print("rank", rank, "chatter")
+    if rank == 0:
+        print(json.dumps({"n_gpus": world, "argv": sys.argv[1:]}))
+""")
+
+
+def test_gpus_n_without_a_launcher_starts_its_ranks_and_relays_rank0(tmp_path, capsys):
+    script = tmp_path / "rank.py"
+    script.write_text(RANK_SCRIPT)
+    env_before = {k: os.environ.get(k) for k in ("RANK", "WORLD_SIZE")}
+    rc = bench.launch_ranks(3, ["--gpus", "3", "--mode", "ok"], script=str(script))
+    out = capsys.readouterr().out
+    assert rc == 0
+    lines = out.splitlines()
+    assert len(lines) == 1                      # rank 0's result line alone, none of the chatter
+    assert json.loads(lines[0]) == {"n_gpus": 3, "argv": ["--gpus", "3", "--mode", "ok"]}
+    assert env_before == {k: os.environ.get(k) for k in ("RANK", "WORLD_SIZE")}
+
+
+def test_a_dead_rank_ends_the_launch_quickly_with_its_code(tmp_path, capsys):
+    script = tmp_path / "rank.py"
+    script.write_text(RANK_SCRIPT)
+    t0 = time.perf_counter()
+    rc = bench.launch_ranks(2, ["--mode", "die"], script=str(script))
+    assert rc == 7 and time.perf_counter() - t0 < 15
+    assert capsys.readouterr().out == ""
+
+
+def test_main_takes_the_launcher_branch_before_touching_the_gpu():
+    """`python bench.py --gpus 2` with no RANK / WORLD_SIZE must reach launch_ranks; under a launcher (RANK set) it must not."""
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")}
+    probe = textwrap.dedent(f"""
+        import sys
+        sys.path.insert(0, {ROOT!r})
+        import bench
+        bench.launch_ranks = lambda n, argv, **kw: (print("LAUNCH", n, argv), 0)[1]
+        sys.argv = ["bench.py", "--gpus", "2", "--steps", "3"]
+        bench.main()
+    """)
+    out = subprocess.run([sys.executable, "-c", probe], env=env, capture_output=True, text=True, timeout=120)
+    assert out.returncode == 0 and out.stdout.strip() == "LAUNCH 2 ['--gpus', '2', '--steps', '3']", out.stderr[-1500:]

@@ -76,25 +76,39 @@ def test_mcts_default_budget():
         assert res.solved.sum() >= 6
 
 
-def _bench_line(args, env_extra, launcher=()):
+def _bench_line(args, env_extra, launcher=(), detail=None):
+    """Runs bench.py; returns (the one stdout line, the full result it wrote to its detail file)."""
     import json
     import subprocess
     import sys
-    env = dict(os.environ, **env_extra)
-    cmd = [sys.executable, *launcher, os.path.join(ROOT, "bench.py"), *args]
-    out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900)
-    assert out.returncode == 0, out.stderr[-2000:]
-    lines = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
-    assert len(lines) == 1, out.stdout[-2000:]
-    return json.loads(lines[0])
+    import tempfile
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")}
+    env.update(env_extra)
+    with tempfile.TemporaryDirectory() as tmp:
+        detail = os.path.join(tmp, "bench_detail.json")
+        cmd = [sys.executable, *launcher, os.path.join(ROOT, "bench.py"), *args, "--detail", detail]
+        out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900)
+        assert out.returncode == 0, out.stderr[-2000:]
+        lines = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
+        assert len(lines) == 1, out.stdout[-2000:]
+        assert len(lines[0]) < 8000 and out.stdout.rstrip().endswith(lines[0])     # short, and the last thing on stdout
+        line = json.loads(lines[0])
+        assert line["detail"] == "bench_detail.json"
+        with open(detail) as f:
+            full = json.load(f)
+    for k in ("value", "ms_per_step", "n_gpus", "steps", "warmup", "scaling"):
+        assert line[k] == full[k], k
+    assert line["config"]["results"] == full["config"]["results"]
+    return line, full
 
 
 def test_bench_two_ranks_aggregate_their_shares():
     """
-    bench.py as the driver launches it for N = 2 (torch.distributed.run, one process per rank; here both ranks on
-    this one GPU with the gloo backend): rank r searches its slice of the scrambles and the line aggregates them.
+    bench.py for N = 2, both ways it can be started: under torch.distributed.run (one process per rank, RANK / WORLD_SIZE in
+    the environment) and as plain `python bench.py --gpus 2`, which starts its two ranks itself.  Both ranks share this one GPU
+    (gloo backend): rank r searches its slice of the scrambles and the line aggregates them.
     Each rank's share is also run alone (`--as-rank r/2`: same slice, same forest sizes, hence the same bf16 GEMM
-    shapes and bit-identical trees): the distributed line must report exactly the sum of the two.
+    shapes and bit-identical trees): the distributed results must be exactly the sum of the two.
     """
     import socket
     common = ["--steps", "6", "--warmup", "2", "--trees", "48", "--pool-factor", "2", "--legs", "bf16", "--solve-max-states",
@@ -103,11 +117,13 @@ def test_bench_two_ranks_aggregate_their_shares():
     with socket.socket() as s:
         s.bind(("127.0.0.1", 0))
         port = s.getsockname()[1]
-    two = _bench_line(["--gpus", "2", *common], {"RUBIKS_DIST_BACKEND": "gloo"},
-                      launcher=("-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
-                                "--master-port", str(port)))
-    shares = [_bench_line(["--gpus", "1", "--as-rank", f"{r}/2", *common], {}) for r in range(2)]
-    assert two["n_gpus"] == 2 and two["scaling"] == "weak" and two["dtype"] == "bf16"
+    line, two = _bench_line(["--gpus", "2", *common], {"RUBIKS_DIST_BACKEND": "gloo"},
+                            launcher=("-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                                      "--master-port", str(port)))
+    line_plain, two_plain = _bench_line(["--gpus", "2", *common], {"RUBIKS_DIST_BACKEND": "gloo"})
+    shares = [_bench_line(["--gpus", "1", "--as-rank", f"{r}/2", *common], {})[1] for r in range(2)]
+    assert line["n_gpus"] == 2 and line["scaling"] == "weak" and line["dtype"] == "bf16"
+    assert line_plain["n_gpus"] == 2 and line_plain["config"].keys() == line["config"].keys()
     a = two["legs"]["bf16"]["run_to_completion"]
     parts = [x["legs"]["bf16"]["run_to_completion"] for x in shares]
     assert a["games"] == 96 and [p["games"] for p in parts] == [48, 48]
@@ -117,11 +133,16 @@ def test_bench_two_ranks_aggregate_their_shares():
     assert pool["games"] == 2 * 96 and pool["nodes"] == sum(x["legs"]["bf16"]["pool_run"]["nodes"] for x in shares)
     assert two["legs"]["bf16"]["steps_timed"] == 6 and two["value"] > 0
     assert two["config"]["parallelism"] == "scramble-sharded x2" and two["scaling_measured"] is False
+    # the self-launched run searched the same games to the same trees
+    ap = two_plain["legs"]["bf16"]
+    assert ap["run_to_completion"]["nodes"] == a["nodes"] and ap["run_to_completion"]["solve_rate"] == a["solve_rate"]
+    assert ap["pool_run"]["nodes"] == pool["nodes"]
     # the extra legs (A*: BASELINE configs[2]; one GPU's share of configs[4]) aggregate over the ranks as well
     for name in ("f32s", "bf16"):
         a2, parts2 = two["astar"][name]["solve_run"], [x["astar"][name]["solve_run"] for x in shares]
         assert a2["games"] == 48 and a2["nodes"] == parts2[0]["nodes"] + parts2[1]["nodes"]
+        assert two_plain["astar"][name]["solve_run"]["nodes"] == a2["nodes"]
         c2, cparts = two["config5_share"][name]["run_to_completion"], [x["config5_share"][name]["run_to_completion"] for x in shares]
         assert c2["games"] == 64 and c2["nodes"] == cparts[0]["nodes"] + cparts[1]["nodes"]
-    r = two["config"]["results"]
+    r = line["config"]["results"]
     assert r["value_run_to_completion"] == a["nodes_per_sec"] and "astar_f32s_states_per_sec" in r and "config5_share_bf16_value" in r
