@@ -34,7 +34,7 @@
 extern "C" {
 #endif
 
-#define RC_ABI_VERSION 5
+#define RC_ABI_VERSION 6
 
 #define RC_OK 0
 #define RC_ERR_NULL (-1)      /* required pointer is NULL */
@@ -371,6 +371,10 @@ typedef struct rc_mcts {
      * read it the same way (the finished trees to post-process).  Device pointer, n_active <= n_trees entries. */
     const int32_t *active;
     uint32_t n_active;
+    /* rc_mcts_select's re-validation re-decides in float64 the levels float32 could not settle ("pass B"): from a list while
+     * there are at most unc_list_cap of them (the kernel clamps it to 128, the production value), from a bitmap beyond.  Tests
+     * lower it to drive the bitmap form with the few unsettled levels real networks produce; results do not depend on it. */
+    uint32_t unc_list_cap;
 } rc_mcts_t;
 
 /* sizeof(rc_mcts_t) as the library was compiled: a binding that mirrors the struct (ctypes, cgo, JNI) checks its own

@@ -621,6 +621,7 @@ __global__ __launch_bounds__(NT) void k_mcts_select(rc_mcts_t m, double c, u32 l
     if (threadIdx.x == 0) s_fast_ok = s_fast_no = 0;
 #endif
     constexpr int kLateCap = 640, kUncCap = 128;
+    const u32 unc_cap = min(m.unc_list_cap, (u32)kUncCap);   // tests lower it to reach the bitmap form of pass B with few flagged levels
     u16 *s_latelist = reinterpret_cast<u16 *>(s_scratch), *s_unclist = s_latelist + kLateCap;
     int *s_seg = reinterpret_cast<int *>(s_scratch);               // [256] last lane per node bucket of a candidate segment ...
     uint2 *s_segent = reinterpret_cast<uint2 *>(s_scratch + 256);   // [64] ... and per lane {node, previous lane | action << 8 | rev(arrival) << 12}
@@ -807,7 +808,7 @@ __global__ __launch_bounds__(NT) void k_mcts_select(rc_mcts_t m, double c, u32 l
                 if (k < nlev && d != (int)s_act[k]) atomicMin(&s_first, k);
             } else {
                 const int pos = atomicAdd(&s_nunc, 1);
-                if (pos < kUncCap) s_unclist[pos] = (u16)k;
+                if (pos < kUncCap) s_unclist[pos] = (u16)k;   // (the list is written up to its size; pass B reads it only while nunc <= unc_cap)
                 atomicOr(&s_unc[k >> 5], 1u << (k & 31));
             }
         };
@@ -823,9 +824,14 @@ __global__ __launch_bounds__(NT) void k_mcts_select(rc_mcts_t m, double c, u32 l
         __syncthreads();
         // Pass B: the flagged levels in float64, NumPy's evaluation order, one 16-lane row per level.
         const int nunc = s_nunc;
-        const bool by_list = nunc <= kUncCap;   // else: scan the bitmap, 16 levels per step
-        for (int i0 = 0; i0 < (by_list ? nunc : nlev + 1); i0 += NT / 16) {
-            if (!by_list && ((s_unc[i0 >> 5] >> (i0 & 31)) & 0xFFFFu) == 0) continue;   // uniform over the workgroup
+        const bool by_list = nunc <= (int)unc_cap;   // else: scan the bitmap, kStep = NT / 16 levels per step (one 16-lane row each)
+        constexpr int kStep = NT / 16;                // 16 / 32 / 64: a quarter of a flag word, one word, two words
+        for (int i0 = 0; i0 < (by_list ? nunc : nlev + 1); i0 += kStep) {
+            if (!by_list) {                           // skip steps without a flagged level (uniform over the workgroup)
+                const u32 w0 = s_unc[i0 >> 5];
+                const u32 any = kStep == 16 ? ((w0 >> (i0 & 31)) & 0xFFFFu) : kStep == 32 ? w0 : (w0 | s_unc[(i0 >> 5) + 1]);
+                if (any == 0) continue;
+            }
             const int i = i0 + (int)row;
             const int k = by_list ? (i < nunc ? (int)s_unclist[i] : nlev + 1) : i;
             const bool live = k <= nlev && ((s_unc[k >> 5] >> (k & 31)) & 1u);
@@ -978,6 +984,7 @@ __global__ __launch_bounds__(NT) void k_mcts_select(rc_mcts_t m, double c, u32 l
             const int cmd = s_mb[MB_CMD];
             if (cmd == 0) return;
             if (cmd == 1) line_round(tid >> 6, tid & (kWave - 1), tbh, c32h);
+            else __syncthreads();   // pause: every helper has read the 2 before the walking wave may write its next command
         }
     }
 
@@ -1094,6 +1101,7 @@ __global__ __launch_bounds__(NT) void k_mcts_select(rc_mcts_t m, double c, u32 l
                 }
                 if (lane == 0) s_mb[MB_CMD] = 2;
                 __syncthreads();   // command: pause -- the levels the helpers appended are in the chains
+                __syncthreads();   // ... and the helpers have read it (they answer a pause with this barrier): MB_CMD may change again
             }
             bool in_line = LW == 1 && lpos + (int)lane < llen && (int)lane < room;
             int node_i = in_line ? m.ring_node[line + lpos + lane] : 0;
@@ -1242,13 +1250,10 @@ __global__ __launch_bounds__(NT) void k_mcts_select(rc_mcts_t m, double c, u32 l
             m.select_stats[8 * t + 2] = (int)(t_walk - t_begin);            // 10 ns ticks: staging + re-validation
             m.select_stats[8 * t + 3] = (int)(wall_clock64() - t_walk);     // ... sequential walk
             m.select_stats[8 * t + 4] = (int)(clock64() - c_walk);          // shader cycles of the walk
-#ifdef RC_SELECT_FASTSTATS
-            m.select_stats[8 * t + 5] = s_fast_ok;
-            m.select_stats[8 * t + 6] = s_fast_no;
-#else
-            m.select_stats[8 * t + 5] = slow_levels;
+            // low half: float64 fall-backs of this walk; high half: the most levels pass A has left to pass B in any call so far
+            const int unc_now = resume ? 0 : min(s_nunc, 0x7FFF), unc_max = max(m.select_stats[8 * t + 5] >> 16, unc_now);
+            m.select_stats[8 * t + 5] = (unc_max << 16) | min(slow_levels, 0xFFFF);
             m.select_stats[8 * t + 6] = revisits;
-#endif
             m.select_stats[8 * t + 7] = (line_rounds << 16) | min(line_levels, 0xFFFF);
         }
         m.path_len[t] = plen;

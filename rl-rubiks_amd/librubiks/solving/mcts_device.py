@@ -33,7 +33,7 @@ class _McStruct(Structure):   # mirrors rc_mcts_t (include/rubiks_hip.h)
                [(name, c_void_p) for name in ("child_idx", "new_mask", "expanded", "select_stats", "bfs", "short_act",
                                               "short_len", "rec")] + \
                [("ring_k", c_uint32)] + [(name, c_void_p) for name in ("ring_node", "ring_act", "ring_len", "phase", "active")] + \
-               [("n_active", c_uint32)]
+               [("n_active", c_uint32), ("unc_list_cap", c_uint32)]
 
 
 _hip.register({
@@ -163,6 +163,7 @@ class MCTSForest:
         self.G = B
         self._listed = None   # host copy of the list (None = every tree in order)
         s.active, s.n_active = self.active_buf.data_ptr(), B
+        s.unc_list_cap = 128
         self.struct = s
         self.engine = None
         self._net_fp = None
