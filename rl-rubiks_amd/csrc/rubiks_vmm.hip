@@ -1,0 +1,146 @@
+// Node storage on demand (HIP virtual memory management).
+//
+// The reference grows a tree's node arrays by doubling whenever they fill (librubiks/solving/agents.py:450-459), so a search
+// with max_states = 175 000 only ever pays for the nodes it creates.  The forests here are tree-major arrays with
+// capacity + 1 rows per tree: allocated up front, 1 024 trees x 175 000 nodes x 285 B are 51 GB although a depth-20 tree ends at
+// 12-14 k nodes on average, and 8 192 trees at that cap (408 GB) do not fit the 288 GB of HBM at all.
+// Here an array is a RESERVED virtual address range of its full size; physical HBM is created and mapped into it chunk by
+// chunk (a multiple of the allocation granularity, 2 MiB on MI355X) as the trees grow.  Addresses never change, so the kernels,
+// the rc_mcts_t struct and every captured HIP graph stay as they are; the host maps ahead of the trees' growth at the points
+// where it already looks at their node counts (MCTSRun.round).
+#include <mutex>
+#include <unordered_map>
+#include <vector>
+
+#include "rubiks_common.h"
+
+using namespace rubiks;
+
+namespace {
+
+struct Range {
+    size_t bytes = 0, chunk = 0;
+    int device = 0;
+    std::vector<hipMemGenericAllocationHandle_t> handles;   // one per chunk, 0 = not mapped
+    std::vector<char> mapped;
+    size_t mapped_bytes = 0;
+};
+std::mutex g_mu;
+std::unordered_map<void *, Range> g_ranges;
+
+hipMemAllocationProp device_prop(int device) {
+    hipMemAllocationProp prop = {};
+    prop.type = hipMemAllocationTypePinned;
+    prop.location.type = hipMemLocationTypeDevice;
+    prop.location.id = device;
+    return prop;
+}
+
+}  // namespace
+
+extern "C" {
+
+int rc_vmm_granularity(size_t *out_bytes) {
+    RC_REQUIRE(out_bytes != nullptr, RC_ERR_NULL);
+    int device = 0;
+    if (hipError_t e = hipGetDevice(&device); e != hipSuccess) return hip_rc(e);
+    const hipMemAllocationProp prop = device_prop(device);
+    return hip_rc(hipMemGetAllocationGranularity(out_bytes, &prop, hipMemAllocationGranularityRecommended));
+}
+
+int rc_vmm_reserve(size_t bytes, size_t chunk_bytes, void **out_base) {
+    RC_REQUIRE(out_base != nullptr, RC_ERR_NULL);
+    *out_base = nullptr;
+    size_t gran = 0;
+    if (int rc = rc_vmm_granularity(&gran)) return rc;
+    RC_REQUIRE(bytes > 0 && chunk_bytes > 0 && chunk_bytes % gran == 0, RC_ERR_RANGE);
+    Range r;
+    r.chunk = chunk_bytes;
+    r.bytes = (bytes + chunk_bytes - 1) / chunk_bytes * chunk_bytes;
+    if (hipError_t e = hipGetDevice(&r.device); e != hipSuccess) return hip_rc(e);
+    void *base = nullptr;
+    if (hipError_t e = hipMemAddressReserve(&base, r.bytes, chunk_bytes, nullptr, 0); e != hipSuccess) return hip_rc(e);
+    r.handles.assign(r.bytes / chunk_bytes, hipMemGenericAllocationHandle_t{});
+    r.mapped.assign(r.bytes / chunk_bytes, 0);
+    std::lock_guard<std::mutex> lock(g_mu);
+    g_ranges.emplace(base, std::move(r));
+    *out_base = base;
+    return RC_OK;
+}
+
+// Backs [offset, offset + bytes) of the range with physical memory (chunks already mapped are left alone).  Host-synchronous;
+// kernels running on other parts of the range are not disturbed.  *out_new_bytes: physical bytes this call added.
+int rc_vmm_map(void *base, size_t offset, size_t bytes, size_t *out_new_bytes) {
+    if (out_new_bytes) *out_new_bytes = 0;
+    RC_REQUIRE(base != nullptr, RC_ERR_NULL);
+    std::lock_guard<std::mutex> lock(g_mu);
+    auto it = g_ranges.find(base);
+    RC_REQUIRE(it != g_ranges.end(), RC_ERR_RANGE);
+    Range &r = it->second;
+    RC_REQUIRE(offset <= r.bytes && bytes <= r.bytes - offset, RC_ERR_RANGE);
+    if (bytes == 0) return RC_OK;
+    const size_t c0 = offset / r.chunk, c1 = (offset + bytes - 1) / r.chunk;
+    const hipMemAllocationProp prop = device_prop(r.device);
+    hipMemAccessDesc access = {};
+    access.location = prop.location;
+    access.flags = hipMemAccessFlagsProtReadWrite;
+    for (size_t c = c0; c <= c1; ++c) {
+        if (r.mapped[c]) continue;
+        // runs of unmapped chunks are created and mapped as ONE allocation: fewer driver calls where a forest maps a lot at once
+        size_t e = c;
+        while (e + 1 <= c1 && !r.mapped[e + 1]) ++e;
+        const size_t run = (e - c + 1) * r.chunk;
+        hipMemGenericAllocationHandle_t h{};
+        if (hipError_t err = hipMemCreate(&h, run, &prop, 0); err != hipSuccess) return hip_rc(err);
+        char *at = static_cast<char *>(base) + c * r.chunk;
+        if (hipError_t err = hipMemMap(at, run, 0, h, 0); err != hipSuccess) {
+            (void)hipMemRelease(h);
+            return hip_rc(err);
+        }
+        if (hipError_t err = hipMemSetAccess(at, run, &access, 1); err != hipSuccess) {
+            (void)hipMemUnmap(at, run);
+            (void)hipMemRelease(h);
+            return hip_rc(err);
+        }
+        r.handles[c] = h;                       // the run's handle lives with its first chunk; the others are marked mapped
+        for (size_t k = c; k <= e; ++k) r.mapped[k] = (k == c) ? (char)1 : (char)2;
+        r.mapped_bytes += run;
+        if (out_new_bytes) *out_new_bytes += run;
+        c = e;
+    }
+    return RC_OK;
+}
+
+int rc_vmm_mapped_bytes(void *base, size_t *out_bytes) {
+    RC_REQUIRE(base != nullptr && out_bytes != nullptr, RC_ERR_NULL);
+    std::lock_guard<std::mutex> lock(g_mu);
+    auto it = g_ranges.find(base);
+    RC_REQUIRE(it != g_ranges.end(), RC_ERR_RANGE);
+    *out_bytes = it->second.mapped_bytes;
+    return RC_OK;
+}
+
+// Unmaps and releases everything, then frees the address range.  The caller has synchronised with every kernel that uses it.
+int rc_vmm_release(void *base) {
+    RC_REQUIRE(base != nullptr, RC_ERR_NULL);
+    std::lock_guard<std::mutex> lock(g_mu);
+    auto it = g_ranges.find(base);
+    RC_REQUIRE(it != g_ranges.end(), RC_ERR_RANGE);
+    Range &r = it->second;
+    int rc = RC_OK;
+    const size_t n = r.mapped.size();
+    for (size_t c = 0; c < n; ++c) {
+        if (r.mapped[c] != 1) continue;
+        size_t e = c;
+        while (e + 1 < n && r.mapped[e + 1] == 2) ++e;
+        const size_t run = (e - c + 1) * r.chunk;
+        if (hipError_t err = hipMemUnmap(static_cast<char *>(base) + c * r.chunk, run); err != hipSuccess && rc == RC_OK) rc = hip_rc(err);
+        if (hipError_t err = hipMemRelease(r.handles[c]); err != hipSuccess && rc == RC_OK) rc = hip_rc(err);
+        c = e;
+    }
+    if (hipError_t err = hipMemAddressFree(base, r.bytes); err != hipSuccess && rc == RC_OK) rc = hip_rc(err);
+    g_ranges.erase(it);
+    return rc;
+}
+
+}  // extern "C"

@@ -633,6 +633,10 @@ class MCTSRun:
 
     def finish(self) -> BatchResult:
         agent, forest, owner = self.agent, self.forest, self.owner
+        if self.one_launch and bool(forest.expanded.any().item()):
+            # the search stopped on time or on a step count (or its last step solved a tree): the expansions that step left
+            # pending are backed up and followed by their descent, as the reference's loop would have done (agents.py:476-490)
+            forest.close_pending(agent.c)
         torch.cuda.synchronize()
         seconds = agent.tt.tock()
         left = np.flatnonzero(owner >= 0)

@@ -352,6 +352,25 @@ class MCTSForest:
             _hip.check(self.lib.rc_mcts_backup_select(m, self.probs.data_ptr(), self.values.data_ptr(), c, self.level_budget, st),
                        "rc_mcts_backup_select")
 
+    def close_pending(self, c: float):
+        """One-launch iterations end with the NEXT leaf's expansion, so a search that stops while trees are running (time limit,
+        step count) -- or right after the step whose expansion solved a tree -- leaves expansions that were never backed up.
+        This is the second half of the three-phase iteration for them: network on the rows the last step left, backup, and the
+        descent that follows (agents.py:555-595), no new expansion.  Afterwards every tree is where the reference's loop
+        (expand_leaf, then find_leaf, agents.py:476-490) leaves it after that many iterations.  Trees without a pending expansion
+        are not touched."""
+        assert self._one_launch and not self.results_only
+        st, m = _hip.stream_ptr(), ctypes.byref(self.struct)
+        if self._fused:
+            cubes, rows = self._net_input()
+            head = self.engine.head_cubes(cubes, None if self._x1 is None else self._x1[:rows])
+            _hip.check(self.lib.rc_mcts_backup_select_head(m, head.data_ptr(), head.stride(0), int(head.dtype == torch.bfloat16),
+                                                           c, 0, st), "rc_mcts_backup_select_head")
+        else:
+            self._evaluate_children()
+            _hip.check(self.lib.rc_mcts_backup_select(m, self.probs.data_ptr(), self.values.data_ptr(), c, 0, st), "rc_mcts_backup_select")
+        self.expanded.zero_()
+
     def step(self, c: float, max_states: int, use_graph: bool = True):
         """One lock-step iteration of every running tree: expand -> network -> backup + select (one kernel).
         A freshly planted tree spends its first two steps on its root (evaluation + expansion, then backup + first descent)."""

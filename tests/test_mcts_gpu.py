@@ -271,6 +271,45 @@ def test_one_launch_iterations_equal_the_three_phase_form(net_gpu):
         assert 0.1 < out[True][0].solved.mean() < 1.0
 
 
+def test_one_launch_search_stopped_midway_ends_on_completed_iterations(net_gpu):
+    """A one-launch search that is stopped while trees are running (what a time limit does) has expanded one leaf more than it
+    has backed up; `MCTSRun.finish` closes those iterations (network on the pending rows, backup, the descent that follows, no new
+    expansion).  S one-launch steps + the closing step must leave every tree exactly where S iterations of the three-phase form
+    leave it (`max_iterations=S`) -- nodes, N, W, P, V, neighbours, the pending path's virtual losses -- and both equal the oracle
+    after S iterations."""
+    from librubiks.solving.agents import MCTS
+    np.random.seed(41)
+    B, cap, S = 40, 600, 23
+    states = np.array([oc.scramble(6 + i % 9, True)[0] for i in range(B)])
+    for dt_net in ((net_gpu, torch.float32),):
+        net, dt = dt_net
+        a = MCTS(net, c=0.6, search_graph=False, net_dtype=dt, sync_every=4)
+        run = a.start_batch(states, None, cap, compact=False, one_launch=True)
+        while run.it < S:
+            run.round(S - run.it)
+        assert run.it == S and bool(run.forest.expanded.any().item())          # expansions are pending
+        ra = run.finish()
+        assert not bool(run.forest.expanded.any().item())
+        b = MCTS(net, c=0.6, search_graph=False, net_dtype=dt, sync_every=4)
+        rb = b.search_batch(states, None, cap, max_iterations=S, compact=False)
+        assert not b.forest._one_launch and a.forest._one_launch
+        assert np.array_equal(ra.nodes, rb.nodes) and np.array_equal(ra.iterations, rb.iterations) and np.array_equal(ra.status, rb.status)
+        assert np.array_equal(ra.solved, rb.solved) and all(list(x) == list(y) for x, y in zip(ra.queues, rb.queues))
+        assert (ra.status == 0).sum() >= B // 2 and ra.iterations.max() == S      # most trees were stopped mid-search
+        onet = oa.TorchNet(net, device="cuda")
+        for t in range(B):
+            ta, tb = a.forest.tree_arrays(t), b.forest.tree_arrays(t)
+            assert ta["n"] == tb["n"]
+            for k in ("states", "neighbors", "P", "V", "W", "N", "L", "leaves"):
+                assert np.array_equal(ta[k], tb[k]), (t, k)
+            if t % 8 == 0:
+                ref = oa.MCTS(onet, c=0.6, search_graph=False)
+                ref.search(states[t], cap, max_iterations=S)
+                n = len(ref)
+                assert ta["n"] == n and np.array_equal(ta["N"][:n + 1], ref.N[:n + 1]) and np.array_equal(ta["L"][:n + 1], ref.L[:n + 1])
+                assert np.array_equal(ta["W"][1:n + 1], ref.W[1:n + 1]) and np.array_equal(ta["neighbors"][:n + 1], ref.neighbors[:n + 1])
+
+
 def test_one_launch_entry_points_check_their_arguments(net_gpu):
     """rc_mcts_plant_expanded / rc_mcts_step*: max_states must be positive, the head pointer present, and roots can only be expanded
     while every tree is listed in order (their network rows are those of list position == tree index)."""

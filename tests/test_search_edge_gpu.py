@@ -316,6 +316,55 @@ def test_deep_production_trees_equal_oracle_on_recorded_outputs(engine):
     assert longest > 256 and int(res.iterations.max()) > 1000      # descents deeper than one re-validation round, ring wrapped many times
 
 
+@pytest.mark.parametrize("n_trees,unc_cap", [(6, 0), (300, 0), (600, 0), (6, 128)])
+def test_unsettled_levels_are_redecided_whatever_the_launch_shape(n_trees, unc_cap):
+    """
+    Pass B of the tree kernel's re-validation (float64 re-decision of the levels float32 could not settle) has two forms: a dense
+    list while at most `unc_list_cap` levels are flagged, a scan of the flag bitmap beyond -- NT / 16 levels per step, i.e. 16, 32
+    or 64 at 256 / 512 / 1 024 threads per tree (full forest / <= 512 / <= 256 listed trees).  Round 3's scan tested only the
+    first 16 flags of a step, so at 512 and 1 024 threads flagged levels were silently skipped and a stale path prefix kept.
+    Here the value head carries an offset of 2^18 (values keep a resolution of 2^-5): float32 then cannot tell PUCT scores closer
+    than ~0.5 apart, and with the trained network a large share of the levels of a deep descent is left to pass B -- more than the list's 128 in the plain run
+    (unc_cap 128), and with unc_cap 0 every flagged level goes through the bitmap.  The trees must be what the oracle builds from
+    the same (state -> P, V) pairs, node for node, in every launch shape.
+    """
+    import copy
+    import os
+    from conftest import ROOT
+    from librubiks.model import F32_SPLIT, Model
+    from librubiks.solving.agents import MCTS
+    wdir = os.path.join(ROOT, "weights", "fc_small_r1")
+    if not os.path.isdir(wdir):
+        pytest.skip("needs the trained weights")
+    net = copy.deepcopy(Model.load(wdir).eval())
+    with torch.no_grad():
+        net.value_net[-1].bias += 262144.0
+    np.random.seed(5)
+    cap = 12000 if n_trees <= 6 else 2500
+    states = np.array([oc.scramble(20, True)[0] for _ in range(n_trees)])
+    agent = MCTS(net, c=0.6, search_graph=True, net_dtype=F32_SPLIT)
+    forest = agent._forest_for(n_trees, cap)
+    forest.struct.unc_list_cap = unc_cap           # before the first step: the captured graphs carry the struct
+    res = agent.search_batch(states, None, cap, compact=False)
+    assert agent.forest is forest
+    stats = forest.select_stats.cpu().numpy()
+    most_unsettled = int((stats[:, 5] >> 16).max())
+    assert most_unsettled > (128 if unc_cap else 16), most_unsettled      # the form under test was reached
+    check = range(n_trees) if n_trees <= 6 else range(0, n_trees, max(1, n_trees // 12))
+    longest = 0
+    for t in check:
+        tree = forest.tree_arrays(t)
+        n = tree["n"]
+        table = {tree["states"][i].tobytes(): (tree["P"][i].astype(np.float32), np.float32(tree["V"][i])) for i in range(1, n + 1)}
+        ref = oa.MCTS(_TableNet(table), c=0.6, search_graph=True)
+        ok = ref.search(states[t], cap)
+        assert bool(res.solved[t]) == ok and res.nodes[t] == len(ref) == n, f"tree {t}"
+        assert list(res.queues[t]) == list(ref.action_queue) and res.iterations[t] == ref.iterations, f"tree {t}"
+        _compare(tree, ref, n)
+        longest = max(longest, int(forest.path_len[t].item()))
+    assert longest > 64
+
+
 @pytest.mark.parametrize("engine", ["f32s", "bf16"])
 def test_production_trees_through_refill_narrowing_and_results_forest_equal_oracle(engine):
     """
