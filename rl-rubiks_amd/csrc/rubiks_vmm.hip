@@ -21,12 +21,23 @@ namespace {
 struct Range {
     size_t bytes = 0, chunk = 0;
     int device = 0;
-    std::vector<hipMemGenericAllocationHandle_t> handles;   // one per chunk, 0 = not mapped
+    std::vector<hipMemGenericAllocationHandle_t> handles;   // one per chunk
     std::vector<char> mapped;
     size_t mapped_bytes = 0;
 };
 std::mutex g_mu;
 std::unordered_map<void *, Range> g_ranges;
+
+// One allocation per chunk.  Measured on MI355X / ROCm 7.2 (tools/vmm_raw_probe.py, profiles/r4_vmm_probe.txt): hipMemSetAccess
+// returns hipErrorInvalidValue for a piece whose virtual address is not aligned to the piece's own size (2 MiB pieces anywhere in
+// a 2 MiB-aligned reservation work, a 64 MiB piece at a 16 MiB-aligned address does not), so the range is reserved with the chunk
+// size as its alignment and every chunk is created, mapped and made accessible by itself: ~10 us per chunk.
+// A failed HIP call leaves its code as the thread's "last error", which the next hipGetLastError() of anybody -- torch checks it
+// after every launch -- would report as its own: read it away.
+int failed(hipError_t e) {
+    (void)hipGetLastError();
+    return hip_rc(e);
+}
 
 hipMemAllocationProp device_prop(int device) {
     hipMemAllocationProp prop = {};
@@ -86,27 +97,23 @@ int rc_vmm_map(void *base, size_t offset, size_t bytes, size_t *out_new_bytes) {
     access.flags = hipMemAccessFlagsProtReadWrite;
     for (size_t c = c0; c <= c1; ++c) {
         if (r.mapped[c]) continue;
-        // runs of unmapped chunks are created and mapped as ONE allocation: fewer driver calls where a forest maps a lot at once
-        size_t e = c;
-        while (e + 1 <= c1 && !r.mapped[e + 1]) ++e;
-        const size_t run = (e - c + 1) * r.chunk;
+        const size_t run = r.chunk;
         hipMemGenericAllocationHandle_t h{};
-        if (hipError_t err = hipMemCreate(&h, run, &prop, 0); err != hipSuccess) return hip_rc(err);
+        if (hipError_t err = hipMemCreate(&h, run, &prop, 0); err != hipSuccess) return failed(err);
         char *at = static_cast<char *>(base) + c * r.chunk;
         if (hipError_t err = hipMemMap(at, run, 0, h, 0); err != hipSuccess) {
             (void)hipMemRelease(h);
-            return hip_rc(err);
+            return failed(err);
         }
         if (hipError_t err = hipMemSetAccess(at, run, &access, 1); err != hipSuccess) {
             (void)hipMemUnmap(at, run);
             (void)hipMemRelease(h);
-            return hip_rc(err);
+            return failed(err);
         }
-        r.handles[c] = h;                       // the run's handle lives with its first chunk; the others are marked mapped
-        for (size_t k = c; k <= e; ++k) r.mapped[k] = (k == c) ? (char)1 : (char)2;
+        r.handles[c] = h;
+        r.mapped[c] = 1;
         r.mapped_bytes += run;
         if (out_new_bytes) *out_new_bytes += run;
-        c = e;
     }
     return RC_OK;
 }
@@ -130,13 +137,9 @@ int rc_vmm_release(void *base) {
     int rc = RC_OK;
     const size_t n = r.mapped.size();
     for (size_t c = 0; c < n; ++c) {
-        if (r.mapped[c] != 1) continue;
-        size_t e = c;
-        while (e + 1 < n && r.mapped[e + 1] == 2) ++e;
-        const size_t run = (e - c + 1) * r.chunk;
-        if (hipError_t err = hipMemUnmap(static_cast<char *>(base) + c * r.chunk, run); err != hipSuccess && rc == RC_OK) rc = hip_rc(err);
-        if (hipError_t err = hipMemRelease(r.handles[c]); err != hipSuccess && rc == RC_OK) rc = hip_rc(err);
-        c = e;
+        if (!r.mapped[c]) continue;
+        if (hipError_t err = hipMemUnmap(static_cast<char *>(base) + c * r.chunk, r.chunk); err != hipSuccess && rc == RC_OK) rc = failed(err);
+        if (hipError_t err = hipMemRelease(r.handles[c]); err != hipSuccess && rc == RC_OK) rc = failed(err);
     }
     if (hipError_t err = hipMemAddressFree(base, r.bytes); err != hipSuccess && rc == RC_OK) rc = hip_rc(err);
     g_ranges.erase(it);

@@ -30,7 +30,7 @@ _hip.check(lib.rc_vmm_granularity(ctypes.byref(g)), "gran")
 print("granularity", g.value, flush=True)
 MB = 1 << 20
 free0 = torch.cuda.mem_get_info()[0]
-for chunk_mb in (2, 16, 64):
+for chunk_mb in (2,):
     base = P()
     total = 64 << 30
     t0 = time.perf_counter()
@@ -45,10 +45,10 @@ for chunk_mb in (2, 16, 64):
         ts.append(time.perf_counter() - t0)
     # one call mapping a run of 4 GB
     t0 = time.perf_counter()
-    _hip.check(lib.rc_vmm_map(base, 32 << 30, 4 << 30, ctypes.byref(new)), "map run")
+    _hip.check(lib.rc_vmm_map(base, 32 << 30, 4 << 30, ctypes.byref(new)), "map 4 GB (runs of <= 32 MB inside)")
     t_run = time.perf_counter() - t0
     print(f"chunk {chunk_mb} MB: reserve 64 GB {t_res*1e3:.2f} ms; single-chunk map median {np.median(ts)*1e6:.0f} us max {np.max(ts)*1e6:.0f} us; "
-          f"4 GB run in one call {t_run*1e3:.2f} ms (new {new.value >> 20} MB); free now {torch.cuda.mem_get_info()[0] >> 20} MB", flush=True)
+          f"4 GB in one call {t_run*1e3:.1f} ms (new {new.value >> 20} MB); free now {torch.cuda.mem_get_info()[0] >> 20} MB", flush=True)
     # torch view of the first chunk
     t = torch.as_tensor(CAI(base.value, chunk_mb * MB), device="cuda")
     t.fill_(7)
@@ -56,7 +56,15 @@ for chunk_mb in (2, 16, 64):
     v32 = t.view(torch.int32)
     v32[:16] = torch.arange(16, dtype=torch.int32, device="cuda")
     assert v32[:16].cpu().tolist() == list(range(16))
-    del t, v32
+    # integrity over many chunks: a 4 GB pattern written and read back through the view (chunks at 32 GB .. 36 GB)
+    w = torch.as_tensor(CAI(base.value + (32 << 30), 4 << 30), device="cuda").view(torch.int64)
+    ar = torch.arange(w.numel(), dtype=torch.int64, device="cuda")
+    w.copy_(ar * 2654435761 % 1000003)
+    torch.cuda.synchronize()
+    assert bool((w == ar * 2654435761 % 1000003).all().item())
+    assert int(w[(2 * MB) // 8 - 1].item()) == ((2 * MB) // 8 - 1) * 2654435761 % 1000003      # last element of a chunk
+    print("   4 GB pattern across 2048 chunks: ok", flush=True)
+    del t, v32, w, ar
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     _hip.check(lib.rc_vmm_release(base), "release")
@@ -131,8 +139,9 @@ _hip.check(lib.rc_vmm_release(base), "release")
 base = P()
 _hip.check(lib.rc_vmm_reserve(200 << 30, chunk, ctypes.byref(base)), "reserve")
 t0 = time.perf_counter()
-_hip.check(lib.rc_vmm_map(base, 0, 100 << 30, ctypes.byref(new)), "map 100 GB")
-print(f"100 GB in one run: {time.perf_counter()-t0:.3f} s", flush=True)
+for i in range(100):
+    _hip.check(lib.rc_vmm_map(base, i << 30, 1 << 30, ctypes.byref(new)), "map 1 GB")
+print(f"100 GB in 1 GB runs: {time.perf_counter()-t0:.3f} s", flush=True)
 t0 = time.perf_counter()
 for i in range(4096):
     _hip.check(lib.rc_vmm_map(base, (100 << 30) + 2 * i * chunk, chunk, ctypes.byref(new)), "map")
@@ -143,7 +152,27 @@ print(f"fill 100 GB: {e0.elapsed_time(e1):.1f} ms = {100*1.073741824/e0.elapsed_
 reg = torch.empty(20 << 30, dtype=torch.uint8, device="cuda")
 e0.record(); reg.fill_(1); e1.record(); torch.cuda.synchronize()
 print(f"fill 20 GB of a torch allocation: {20*1.073741824/e0.elapsed_time(e1)*1e3:.0f} GB/s", flush=True)
-del big, reg
+# random 256-byte rows (the tree kernels' access pattern) from a 64 GB region: VMM range vs a torch allocation
+rows = (64 << 30) // 256
+idx = torch.randint(0, rows, (1 << 24,), device="cuda")
+out = torch.empty((1 << 24, 64), dtype=torch.int32, device="cuda")
+v = big[:64 << 30].view(torch.int32).view(rows, 64)
+for name, src in (("vmm", v), ("torch", None)):
+    if src is None:
+        del big, v
+        reg64 = torch.empty(64 << 30, dtype=torch.uint8, device="cuda")
+        reg64.fill_(1)
+        src = reg64.view(torch.int32).view(rows, 64)
+    torch.index_select(src, 0, idx, out=out)
+    torch.cuda.synchronize()
+    e0.record()
+    for _ in range(5):
+        torch.index_select(src, 0, idx, out=out)
+    e1.record(); torch.cuda.synchronize()
+    ms = e0.elapsed_time(e1) / 5
+    print(f"gather of 2^24 random 256-B rows out of 64 GB, {name}: {ms:.2f} ms = {(1 << 24) * 256 / ms / 1e6:.0f} GB/s read", flush=True)
+del reg, src, out
+reg64 = None
 t0 = time.perf_counter()
 _hip.check(lib.rc_vmm_release(base), "release")
 print(f"release: {time.perf_counter()-t0:.3f} s; free MB {torch.cuda.mem_get_info()[0] >> 20}", flush=True)
