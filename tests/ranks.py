@@ -65,6 +65,15 @@ def run_ranks(target, world: int, make_args, timeout: float = 300.0) -> list:
         except OSError:
             return ""
 
+    def report(headline):
+        """The failure text: what was noticed first, then exit code and stderr of EVERY rank (the rank that is noticed first
+        is often the one whose collective broke because another rank had died)."""
+        time.sleep(0.5)
+        parts = [headline]
+        for r, p in enumerate(procs):
+            parts.append(f"--- rank {r}: {'alive' if p.exitcode is None else f'exit code {p.exitcode}'}; stderr:\n{stderr_of(r)}")
+        return "\n".join(parts)
+
     got, deadline = [], time.monotonic() + timeout
     try:
         for p in procs:
@@ -75,18 +84,18 @@ def run_ranks(target, world: int, make_args, timeout: float = 300.0) -> list:
             except queue.Empty:
                 item = None
             if isinstance(item, tuple) and len(item) == 3 and item[0] == _ERROR:
-                raise AssertionError(f"rank {item[1]} raised:\n{item[2]}")
+                raise AssertionError(report(f"rank {item[1]} raised:\n{item[2]}"))
             if item is not None:
                 got.append(item)
                 continue
             for r, p in enumerate(procs):
                 if p.exitcode not in (None, 0):
-                    raise AssertionError(f"rank {r} died with exit code {p.exitcode} before reporting; its stderr:\n{stderr_of(r)}")
+                    raise AssertionError(report(f"rank {r} died with exit code {p.exitcode} before reporting"))
             if time.monotonic() > deadline:
-                raise AssertionError(f"no result from {world - len(got)} of {world} ranks after {timeout:.0f} s; stderr of rank 0:\n{stderr_of(0)}")
+                raise AssertionError(report(f"no result from {world - len(got)} of {world} ranks after {timeout:.0f} s"))
         for r, p in enumerate(procs):
             p.join(max(1.0, deadline - time.monotonic()))
-            assert p.exitcode == 0, f"rank {r} ended with exit code {p.exitcode}; its stderr:\n{stderr_of(r)}"
+            assert p.exitcode == 0, report(f"rank {r} ended with exit code {p.exitcode}")
     finally:
         for p in procs:
             if p.is_alive():

@@ -118,8 +118,8 @@ def _eval_rank(rank, world, port, q):
     import torch.distributed as dist
     here = os.path.dirname(os.path.abspath(__file__))
     sys.path[:0] = [here, os.path.dirname(here), os.path.join(os.path.dirname(here), "rl-rubiks_amd")]
-    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
-    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from ranks import init_gloo
+    init_gloo(rank, world, port, seconds=120)
     import torch
     from standin_net import StandInNet
     from librubiks.solving.agents import MCTS
@@ -133,22 +133,12 @@ def _eval_rank(rank, world, port, q):
 
 def test_evaluator_two_ranks_share_the_games(standin_net):
     """One process per rank (both on this GPU, gloo): each searches its slice, every rank ends with all results."""
-    import socket
     import torch
-    import torch.multiprocessing as mp
     from librubiks.solving.agents import MCTS
     from librubiks.solving.evaluation import Evaluator
     np.random.seed(9)
     r0, s0, _ = Evaluator(21, [2, 5], None, 400).eval(MCTS(standin_net.cuda(), 0.6, True, net_dtype=torch.float32, sync_every=4))
-    with socket.socket() as s:
-        s.bind(("127.0.0.1", 0))
-        port = s.getsockname()[1]
-    ctx = mp.get_context("spawn")
-    q = ctx.Queue()
-    procs = [ctx.Process(target=_eval_rank, args=(r, 2, port, q)) for r in range(2)]
-    [p.start() for p in procs]
-    got = sorted(q.get(timeout=300) for _ in range(2))
-    [p.join(120) for p in procs]
-    assert all(p.exitcode == 0 for p in procs)
+    from ranks import run_ranks
+    got = run_ranks(_eval_rank, 2, lambda r, port, q: (r, 2, port, q), timeout=300)
     for _, res, states in got:
         assert res == r0.tolist() and states == s0.tolist()

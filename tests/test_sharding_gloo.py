@@ -1,12 +1,13 @@
 """N > 1 path on CPU: two gloo ranks shard the games, gather per-game results, agree on the summary."""
 import os
-import socket
+import time
 
 import numpy as np
+import pytest
 import torch.distributed as dist
-import torch.multiprocessing as mp
 
 from librubiks.solving.sharding import gather_results, shard_range, summarize
+from ranks import init_gloo, run_ranks
 
 
 def test_shard_range_covers_everything():
@@ -36,8 +37,7 @@ def test_backend_choice():
 
 
 def _worker(rank, world, port, n_games, q):
-    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
-    dist.init_process_group("gloo", rank=rank, world_size=world)
+    init_gloo(rank, world, port)
     lo, hi = shard_range(n_games, rank, world)
     g = np.arange(lo, hi)
     local = {"solved": (g % 3 == 0), "lengths": np.where(g % 3 == 0, g % 11, -1), "nodes": 100 + g}
@@ -49,16 +49,7 @@ def _worker(rank, world, port, n_games, q):
 
 def test_two_rank_gather_uneven():
     n_games, world = 37, 2
-    with socket.socket() as s:
-        s.bind(("127.0.0.1", 0))
-        port = s.getsockname()[1]
-    ctx = mp.get_context("spawn")
-    q = ctx.Queue()
-    procs = [ctx.Process(target=_worker, args=(r, world, port, n_games, q)) for r in range(world)]
-    [p.start() for p in procs]
-    got = sorted(q.get(timeout=120) for _ in range(world))
-    [p.join(60) for p in procs]
-    assert all(p.exitcode == 0 for p in procs)
+    got = run_ranks(_worker, world, lambda r, port, q: (r, world, port, n_games, q), timeout=120)
     g = np.arange(n_games)
     for rank, full, summary in got:
         assert full["nodes"] == (100 + g).tolist()
@@ -71,8 +62,7 @@ def test_two_rank_gather_uneven():
 
 def _grad_worker(rank, world, port, q):
     import torch
-    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
-    dist.init_process_group("gloo", rank=rank, world_size=world)
+    init_gloo(rank, world, port)
     from librubiks.train import average_gradients
     torch.manual_seed(0)
     net = torch.nn.Sequential(torch.nn.Linear(6, 4), torch.nn.ReLU(), torch.nn.Linear(4, 2))
@@ -88,16 +78,7 @@ def _grad_worker(rank, world, port, q):
 def test_data_parallel_gradient_average():
     """Config #4's only collective: the mean of per-rank gradients in one flat all_reduce."""
     world = 2
-    with socket.socket() as s:
-        s.bind(("127.0.0.1", 0))
-        port = s.getsockname()[1]
-    ctx = mp.get_context("spawn")
-    q = ctx.Queue()
-    procs = [ctx.Process(target=_grad_worker, args=(r, world, port, q)) for r in range(world)]
-    [p.start() for p in procs]
-    got = sorted(q.get(timeout=120) for _ in range(world))
-    [p.join(60) for p in procs]
-    assert all(p.exitcode == 0 for p in procs)
+    got = run_ranks(_grad_worker, world, lambda r, port, q: (r, world, port, q), timeout=120)
     mean = [np.mean([np.array(got[r][1][i]) for r in range(world)], axis=0) for i in range(len(got[0][1]))]
     for r in range(world):
         for i, m in enumerate(mean):
@@ -116,8 +97,7 @@ class _ToyAgent:
 
 
 def _search_worker(rank, world, port, states, q):
-    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
-    dist.init_process_group("gloo", rank=rank, world_size=world)
+    init_gloo(rank, world, port)
     from librubiks.solving.sharding import sharded_search_batch
     got = sharded_search_batch(_ToyAgent(), states, None, 100)
     q.put((rank, {k: v.tolist() for k, v in got.items()}))
@@ -131,16 +111,7 @@ def test_sharded_search_batch_two_ranks():
     rng = np.random.default_rng(0)
     states = rng.integers(0, 24, size=(41, 20)).astype(np.int8)
     whole = sharded_search_batch(_ToyAgent(), states, None, 100)      # no process group: plain search
-    with socket.socket() as s:
-        s.bind(("127.0.0.1", 0))
-        port = s.getsockname()[1]
-    ctx = mp.get_context("spawn")
-    q = ctx.Queue()
-    procs = [ctx.Process(target=_search_worker, args=(r, 2, port, states, q)) for r in range(2)]
-    [p.start() for p in procs]
-    got = sorted(q.get(timeout=120) for _ in range(2))
-    [p.join(60) for p in procs]
-    assert all(p.exitcode == 0 for p in procs)
+    got = run_ranks(_search_worker, 2, lambda r, port, q: (r, 2, port, states, q), timeout=120)
     for _, full in got:
         for k in ("solved", "lengths", "nodes"):
             assert full[k] == whole[k].tolist()
@@ -148,8 +119,7 @@ def test_sharded_search_batch_two_ranks():
 
 def _bucket_worker(rank, world, port, q):
     import torch
-    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
-    dist.init_process_group("gloo", rank=rank, world_size=world)
+    init_gloo(rank, world, port)
     from librubiks.train import GradBuckets
     torch.manual_seed(0)
     net = torch.nn.Sequential(torch.nn.Linear(6, 40), torch.nn.ReLU(), torch.nn.Linear(40, 30), torch.nn.ReLU(),
@@ -177,16 +147,7 @@ def test_bucketed_async_gradient_average():
     """GradBuckets: gradients live in flat buckets, every bucket is all-reduced during backward, result = mean over ranks."""
     import torch
     world = 2
-    with socket.socket() as s:
-        s.bind(("127.0.0.1", 0))
-        port = s.getsockname()[1]
-    ctx = mp.get_context("spawn")
-    q = ctx.Queue()
-    procs = [ctx.Process(target=_bucket_worker, args=(r, world, port, q)) for r in range(world)]
-    [p.start() for p in procs]
-    got = sorted(q.get(timeout=120) for _ in range(world))
-    [p.join(60) for p in procs]
-    assert all(p.exitcode == 0 for p in procs)
+    got = run_ranks(_bucket_worker, world, lambda r, port, q: (r, world, port, q), timeout=120)
     assert got[0][1] == got[1][1] >= 3 and got[0][2] and got[1][2]
     for step in range(3):
         # reference: the same two local backward passes in this process, averaged by hand
@@ -204,3 +165,30 @@ def test_bucketed_async_gradient_average():
             assert launched == got[r][1] - (step == 2)        # every bucket that got its gradients was reduced inside backward
             for i, m in enumerate(mean):
                 assert np.allclose(np.array(reduced[i]), m, rtol=1e-6, atol=1e-7)
+
+
+def _dying_worker(rank, world, port, how, q):
+    init_gloo(rank, world, port)
+    if rank == 1:
+        if how == "raise":
+            raise RuntimeError("rank 1 gives up before the collective")
+        os.write(2, b"rank 1 aborts without a traceback\n")
+        os._exit(3)
+    dist.barrier()                 # rank 0 waits for a peer that is gone
+    q.put((rank, "unreachable"))
+
+
+@pytest.mark.parametrize("how", ["raise", "exit"])
+def test_a_dead_rank_fails_the_test_quickly_with_its_output(how):
+    """What `run_ranks` is for (round 3: one rank died in an assert, the other sat in a gloo collective and the queue wait was
+    longer than the box's 420-s silence limit): the failure comes within seconds, carries the dead rank's traceback or stderr,
+    and no rank outlives the test."""
+    import multiprocessing
+    t0 = time.monotonic()
+    with pytest.raises(AssertionError) as e:
+        run_ranks(_dying_worker, 2, lambda r, port, q: (r, 2, port, how, q), timeout=120)
+    assert time.monotonic() - t0 < 15
+    text = str(e.value)
+    assert ("rank 1 gives up before the collective" in text and "Traceback" in text) if how == "raise" else \
+        ("exit code 3" in text and "rank 1 aborts without a traceback" in text)
+    assert not multiprocessing.active_children()

@@ -99,8 +99,8 @@ def _train_rank(rank, world, port, q):
     import torch.distributed as dist
     here = os.path.dirname(os.path.abspath(__file__))
     sys.path[:0] = [here, os.path.dirname(here), os.path.join(os.path.dirname(here), "rl-rubiks_amd")]
-    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
-    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from ranks import init_gloo
+    init_gloo(rank, world, port, seconds=120)
     from librubiks.model import Model, ModelConfig
     from librubiks.solving.agents import MCTS
     from librubiks.train import Train
@@ -120,18 +120,8 @@ def _train_rank(rank, world, port, q):
 
 def test_data_parallel_training_two_ranks():
     """Config #4 layout: ranks generate different games (half each), average gradients, keep identical weights."""
-    import socket
-    import torch.multiprocessing as mp
-    with socket.socket() as s:
-        s.bind(("127.0.0.1", 0))
-        port = s.getsockname()[1]
-    ctx = mp.get_context("spawn")
-    q = ctx.Queue()
-    procs = [ctx.Process(target=_train_rank, args=(r, 2, port, q)) for r in range(2)]
-    [p.start() for p in procs]
-    got = sorted(q.get(timeout=300) for _ in range(2))
-    [p.join(120) for p in procs]
-    assert all(p.exitcode == 0 for p in procs)
+    from ranks import run_ranks
+    got = run_ranks(_train_rank, 2, lambda r, port, q: (r, 2, port, q), timeout=300)
     (_, g0, sum0, head0, draw0, loss0), (_, g1, sum1, head1, draw1, loss1) = got
     assert g0 == g1 == 16                                  # 32 games per rollout split over two ranks
     assert sum0 == sum1 and head0 == head1                 # the same averaged gradients -> the same weights
@@ -145,8 +135,8 @@ def _train_eval_rank(rank, world, port, q, out_dir):
     import torch.distributed as dist
     here = os.path.dirname(os.path.abspath(__file__))
     sys.path[:0] = [here, os.path.dirname(here), os.path.join(os.path.dirname(here), "rl-rubiks_amd")]
-    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
-    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from ranks import init_gloo
+    init_gloo(rank, world, port, seconds=120)
     from librubiks.model import Model, ModelConfig
     from librubiks.solving.agents import MCTS
     from librubiks.solving.evaluation import Evaluator
@@ -186,21 +176,11 @@ def test_data_parallel_training_evaluates_one_common_scramble_set(tmp_path):
     the Evaluator shards ONE scramble set over the ranks, so both ranks report the same (depths x games) results, and
     those are what a single process gets for the final weights from the same position of the common np.random stream.
     """
-    import socket
-    import torch.multiprocessing as mp
     from librubiks.model import Model
     from librubiks.solving.agents import MCTS
     from librubiks.solving.evaluation import Evaluator
-    with socket.socket() as s:
-        s.bind(("127.0.0.1", 0))
-        port = s.getsockname()[1]
-    ctx = mp.get_context("spawn")
-    q = ctx.Queue()
-    procs = [ctx.Process(target=_train_eval_rank, args=(r, 2, port, q, str(tmp_path))) for r in range(2)]
-    [p.start() for p in procs]
-    got = sorted(q.get(timeout=600) for _ in range(2))
-    [p.join(120) for p in procs]
-    assert all(p.exitcode == 0 for p in procs)
+    from ranks import run_ranks
+    got = run_ranks(_train_eval_rank, 2, lambda r, port, q: (r, 2, port, q, str(tmp_path)), timeout=600)
     (_, res0, st0, sol0, n_wait0, share0), (_, res1, st1, sol1, n_wait1, share1) = got
     assert res0 == res1 and st0 == st1 and sol0 == sol1 and len(res0) == 2          # two evaluations, identical on both ranks
     assert n_wait0 == n_wait1 == 4                                                   # 2 rollouts x 2 optimizer steps
