@@ -180,7 +180,7 @@ def test_data_parallel_training_evaluates_one_common_scramble_set(tmp_path):
     from librubiks.solving.agents import MCTS
     from librubiks.solving.evaluation import Evaluator
     from ranks import run_ranks
-    got = run_ranks(_train_eval_rank, 2, lambda r, port, q: (r, 2, port, q, str(tmp_path)), timeout=600)
+    got = run_ranks(_train_eval_rank, 2, lambda r, port, q: (r, 2, port, q, str(tmp_path)), timeout=300)
     (_, res0, st0, sol0, n_wait0, share0), (_, res1, st1, sol1, n_wait1, share1) = got
     assert res0 == res1 and st0 == st1 and sol0 == sol1 and len(res0) == 2          # two evaluations, identical on both ranks
     assert n_wait0 == n_wait1 == 4                                                   # 2 rollouts x 2 optimizer steps
