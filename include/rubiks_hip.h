@@ -375,6 +375,13 @@ typedef struct rc_mcts {
      * there are at most unc_list_cap of them (the kernel clamps it to 128, the production value), from a bitmap beyond.  Tests
      * lower it to drive the bitmap form with the few unsettled levels real networks produce; results do not depend on it. */
     uint32_t unc_list_cap;
+    /* Optional (NULL = every row of the node arrays is backed by memory): [B] number of node rows (indices 0 .. mapped_rows[t] - 1)
+     * of tree t that the per-node arrays keys / node records / V / leaf currently have memory behind -- for forests whose node
+     * arrays are reserved address ranges mapped on demand (rc_vmm_*: the reference grows its arrays as a tree grows,
+     * agents.py:450-459).  A tree whose next expansion would reach beyond it simply does not expand in that iteration (it stays
+     * RUNNING, `expanded` stays 0, its iteration count does not advance) and tries again in the next one: the host maps ahead
+     * of the trees' growth, the kernels never touch a row that is not there. */
+    const int32_t *mapped_rows;
 } rc_mcts_t;
 
 /* sizeof(rc_mcts_t) as the library was compiled: a binding that mirrors the struct (ctypes, cgo, JNI) checks its own
@@ -434,6 +441,27 @@ int rc_mcts_complete_graph(const rc_mcts_t *m, rc_stream_t stream);
  * order of the reference's FIFO queue (frontier order, then action order), so the returned queue is the
  * reference's.  Overwrites the tree's hash table (used as the two frontier arrays). */
 int rc_mcts_shorten(const rc_mcts_t *m, rc_stream_t stream);
+
+/* Copies the finished (or suspended) trees src_trees[0 .. n) of `src` into slots dst_first .. dst_first + n - 1 of `dst`: rows
+ * 0 .. n_nodes of keys, leaf and -- into a search forest (dst->node_words == RC_MCTS_NODE_WORDS) -- the node records and V, or --
+ * into a results-only forest (dst->node_words == 12) -- the neighbour rows alone; plus the tree's whole hash table.  Only rows
+ * that exist are touched (both forests may be mapped on demand); the per-tree words are the caller's to copy.  Same capacity
+ * and hash_size on both sides; src must be a search forest.  Replaces whole-capacity tensor copies (capacity x 285 B per
+ * tree) where finished trees leave a running forest (MCTSForest.bury / subset). */
+int rc_mcts_copy_trees(const rc_mcts_t *src, const rc_mcts_t *dst, const int32_t *src_trees, uint32_t n, uint32_t dst_first,
+                       rc_stream_t stream);
+
+/* ---- node storage on demand (HIP virtual memory management) ---------------------------------------------------------------
+ * The reference's node arrays grow by doubling as a tree grows (librubiks/solving/agents.py:450-459): max_states = 175 000 costs
+ * only the nodes a search creates.  rc_vmm_reserve reserves an address range of the array's full size, rc_vmm_map puts memory
+ * behind [offset, offset + bytes) of it, chunk by chunk (chunk_bytes: a multiple of 2 MiB; a chunk already mapped is left
+ * alone); addresses never change, so structs, kernels and captured graphs are unaffected.  rc_vmm_map is host-synchronous and
+ * may be called while kernels work on other parts of the range.  rc_vmm_release: after the caller has synchronised. */
+int rc_vmm_granularity(size_t *out_bytes);
+int rc_vmm_reserve(size_t bytes, size_t chunk_bytes, void **out_base);
+int rc_vmm_map(void *base, size_t offset, size_t bytes, size_t *out_new_bytes);
+int rc_vmm_mapped_bytes(void *base, size_t *out_bytes);
+int rc_vmm_release(void *base);
 
 /* ---- batched weighted A*: B independent problems, N expansions each per iteration --------------
  *

@@ -140,6 +140,9 @@ __device__ __forceinline__ void expand_leaf_wave(const rc_mcts_t &m, u32 t, u32 
         if (lane == 0) m.status[t] = RC_MCTS_EXHAUSTED;
         return;
     }
+    // node arrays mapped on demand: rows n + 1 .. n + 12 must have memory behind them.  If the host has not got that far the tree
+    // sits this iteration out (nothing is written, `expanded` stays 0) and the descent of the next one ends at the same leaf.
+    if (m.mapped_rows && n + kA >= m.mapped_rows[t]) return;
     int *tab = m.hash + (size_t)t * m.hash_size;
     const u32 mask = m.hash_size - 1;
     const uint4 pk = keys[leaf];
@@ -1395,6 +1398,36 @@ __global__ __launch_bounds__(kBlock) void k_mcts_shorten(rc_mcts_t m) {
     }
 }
 
+// ---- finished trees leave a forest: rows 0 .. n_nodes of what the destination keeps, and the tree's hash table ---------
+// grid (trees, parts): the parts of a tree's workgroups stride over its rows.  FULL: into a search forest (records + V),
+// else into a results-only forest (neighbour rows as a plain [rows][12] array).
+template <bool FULL>
+__global__ __launch_bounds__(kBlock) void k_mcts_copy_trees(rc_mcts_t src, rc_mcts_t dst, const int *__restrict__ src_trees, u32 dst_first) {
+    const u32 ts = (u32)src_trees[blockIdx.x], td = dst_first + blockIdx.x;
+    const size_t sb = (size_t)ts * (src.capacity + 1), db = (size_t)td * (dst.capacity + 1);
+    const u32 rows = (u32)src.n_nodes[ts] + 1u;
+    const u32 tid = blockIdx.y * kBlock + threadIdx.x, nt = gridDim.y * kBlock;
+    const uint4 *skeys = reinterpret_cast<const uint4 *>(src.keys) + sb;
+    uint4 *dkeys = reinterpret_cast<uint4 *>(dst.keys) + db;
+    for (u32 i = tid; i < rows; i += nt) {
+        dkeys[i] = skeys[i];
+        dst.leaf[db + i] = src.leaf[sb + i];
+        if (FULL) dst.V[db + i] = src.V[sb + i];
+    }
+    if (FULL) {   // the whole 256-byte record: 16 lanes per row
+        const uint4 *srec = reinterpret_cast<const uint4 *>(src.N) + sb * (kRow / 4);
+        uint4 *drec = reinterpret_cast<uint4 *>(dst.N) + db * (kRow / 4);
+        for (size_t i = tid; i < (size_t)rows * (kRow / 4); i += nt) drec[i] = srec[i];
+    } else {      // words 44 .. 55 of the record -> row of 12
+        const uint4 *snbr = reinterpret_cast<const uint4 *>(src.nbr);
+        uint4 *dnbr = reinterpret_cast<uint4 *>(dst.nbr);
+        for (u32 i = tid; i < rows * 3u; i += nt) dnbr[(db + i / 3u) * 3u + i % 3u] = snbr[(sb + i / 3u) * (kRow / 4) + i % 3u];
+    }
+    const uint4 *shash = reinterpret_cast<const uint4 *>(src.hash + (size_t)ts * src.hash_size);
+    uint4 *dhash = reinterpret_cast<uint4 *>(dst.hash + (size_t)td * dst.hash_size);
+    for (u32 i = tid; i < src.hash_size / 4; i += nt) dhash[i] = shash[i];
+}
+
 }  // namespace rubiks
 
 using namespace rubiks;
@@ -1508,6 +1541,23 @@ int rc_mcts_shorten(const rc_mcts_t *m, rc_stream_t stream) {
     if (int rc = check_mcts(m, true)) return rc;
     RC_REQUIRE(m->bfs && m->short_act && m->short_len, RC_ERR_NULL);
     hipLaunchKernelGGL(k_mcts_shorten, dim3(mcts_grid(m)), dim3(kBlock), 0, (hipStream_t)stream, *m);
+    return launch_status();
+}
+
+int rc_mcts_copy_trees(const rc_mcts_t *src, const rc_mcts_t *dst, const int32_t *src_trees, uint32_t n, uint32_t dst_first,
+                       rc_stream_t stream) {
+    if (int rc = check_mcts(src)) return rc;
+    if (int rc = check_mcts(dst, true)) return rc;
+    if (n == 0) return RC_OK;
+    RC_REQUIRE(src_trees != nullptr, RC_ERR_NULL);
+    RC_REQUIRE(n <= src->n_trees && dst_first <= dst->n_trees && n <= dst->n_trees - dst_first, RC_ERR_RANGE);
+    RC_REQUIRE(src->capacity == dst->capacity && src->hash_size == dst->hash_size && (src->hash_size & 3u) == 0, RC_ERR_RANGE);
+    RC_REQUIRE(src->keys != dst->keys, RC_ERR_RANGE);
+    const unsigned parts = n >= 256 ? 2 : n >= 32 ? 8 : 32;
+    if (dst->node_words == (uint32_t)kRow)
+        hipLaunchKernelGGL(k_mcts_copy_trees<true>, dim3(n, parts), dim3(kBlock), 0, (hipStream_t)stream, *src, *dst, (const int *)src_trees, dst_first);
+    else
+        hipLaunchKernelGGL(k_mcts_copy_trees<false>, dim3(n, parts), dim3(kBlock), 0, (hipStream_t)stream, *src, *dst, (const int *)src_trees, dst_first);
     return launch_status();
 }
 

@@ -236,16 +236,18 @@ class _Harvest:
         buf = free.pop() if free else torch.empty((rows,) + tuple(t.shape[1:]), dtype=t.dtype, pin_memory=True)
         return buf
 
-    def __init__(self, agent, forest: md.MCTSForest, games: np.ndarray, n: int = None, trees: torch.Tensor = None):
+    def __init__(self, agent, forest: md.MCTSForest, games: np.ndarray, n: int = None, trees: torch.Tensor = None,
+                 trees_host: np.ndarray = None):
         """n: only the first n trees of the forest are real (a partly filled results forest).
         trees: int32 device list -- only these (finished) trees of a forest that may still be running are turned into
-        results, where they lie; games[i] is the game of trees[i]."""
+        results, where they lie; games[i] is the game of trees[i].  trees_host: the same list on the host (a forest whose rows
+        are mapped on demand gives the BFS scratch of exactly these trees its memory)."""
         self.games, self.graph = games, agent.search_graph
         src = {"status": forest.status, "nodes": forest.n_nodes, "iterations": forest.iterations,
                "plen": forest.path_len, "sol": forest.solved_action, "pact": forest.path_act}
         if self.graph:
             forest.complete_graphs(trees)       # _complete_graph of all solved trees in one launch
-            forest.shorten_launch(trees)        # ... and their BFS shortening in another
+            forest.shorten_launch(trees, trees_host)   # ... and their BFS shortening in another
             src["slen"], src["sact"] = forest.short_len, forest.short_act
         self.host, self.n = {}, (forest.B if n is None else n) if trees is None else int(trees.numel())
         pick = None if trees is None else trees.long()
@@ -445,6 +447,7 @@ class MCTSRun:
         forest.set_active(None)
         self.plant_states = self.cap_states if one_launch else None   # one-launch iterations: roots expanded by the plant itself
         forest.plant(None, roots, 0, self.plant_states)       # the first S scrambles; the others move in as trees finish
+        forest._steps_covered = 2 * agent.sync_every          # (a planted tree has rows for its first ~680 iterations)
         self.owner = np.arange(S)          # game index of every slot; -1 once its result has been taken and nobody moved in
         self.stale_until = np.full(S, -1)  # snapshots up to this index predate the tree that now lives in the slot
         self.next_game = S
@@ -484,7 +487,7 @@ class MCTSRun:
         ev.record()
         with torch.cuda.stream(self.side):
             self.side.wait_event(ev)
-            h = _Harvest(self.agent, g, self.grave_games[:n].copy(), n=n)
+            h = _Harvest(self.agent, g, self.grave_games[:n].copy(), n=n, trees_host=np.arange(n))
         self.harvests.append(h)
         self.grave_event, self.grave_fill = h.event, 0
 
@@ -502,7 +505,7 @@ class MCTSRun:
         ev.record()
         with torch.cuda.stream(self.side):
             self.side.wait_event(ev)
-            self.harvests.append(_Harvest(self.agent, forest, games, trees=trees))
+            self.harvests.append(_Harvest(self.agent, forest, games, trees=trees, trees_host=idx_np))
 
     def _snapshot(self, idx_np: np.ndarray):
         if self.agent.snapshot_trees is not None:
@@ -526,24 +529,23 @@ class MCTSRun:
         reads of them goes into the results forest, which is processed GRAVE trees at a time on the side stream."""
         forest, agent = self.forest, self.agent
         self._snapshot(idx_np)
-        idx = _to_device_async(idx_np, forest.status.device)
         games = self.owner[idx_np].copy()
         keep_tree = agent._tree_src is None and (games == 0).any()   # game 0's tree stays inspectable (the reference's attributes)
         if not keep_tree and len(idx_np) < self.GRAVE // 2:
             if self.grave is None:
-                self.grave = md.MCTSForest(self.GRAVE, forest.C, forest.max_path, forest.device, _results_only=True)
+                self.grave = md.MCTSForest(self.GRAVE, forest.C, forest.max_path, forest.device, _results_only=True, vmm=forest.vmm)
                 self.grave_games = np.zeros(self.GRAVE, dtype=np.int64)
             if self.grave_fill + len(idx_np) > self.GRAVE:
                 self._flush_grave()
             if self.grave_event is not None:     # the previous batch must have been read before its slots are overwritten
                 torch.cuda.current_stream().wait_event(self.grave_event)
                 self.grave_event = None
-            self.grave.bury(self.grave_fill, forest, idx)
+            self.grave.bury(self.grave_fill, forest, idx_np)
             self.grave_games[self.grave_fill:self.grave_fill + len(idx_np)] = games
             self.grave_fill += len(idx_np)
             self.stats["harvests"] += 1
             return
-        sub = forest.subset(idx, results_only=not keep_tree)
+        sub = forest.subset(idx_np, results_only=not keep_tree)
         ev = torch.cuda.Event()
         ev.record()
         with torch.cuda.stream(self.side):
@@ -564,18 +566,25 @@ class MCTSRun:
             forest.step(agent.c, self.cap_states, agent.use_graph)
         self.it += n_steps
         self.stats["iterations"] = self.it
-        self.snapshots.append((self.q, forest, *forest.status_snapshot()))
+        self.snapshots.append((self.q, forest, *forest.status_snapshot(), self.it))
         self.q += 1
         t1 = perf_counter()
         self.stats["host_enqueue_s"] += t1 - t0
         if len(self.snapshots) < 2 and self.it > 1:
             return            # look at round r - 1 while round r runs
-        qi, f_snap, ev, st_host = self.snapshots.popleft()
+        qi, f_snap, ev, st_host, it_then = self.snapshots.popleft()
         ev.synchronize()
         t2 = perf_counter()
         self.stats["host_wait_s"] += t2 - t1   # time the host had to spare: it waited for the GPU, not the other way round
         try:
-            self._act_on(qi, f_snap, st_host)
+            if f_snap is forest:
+                # the host's look at the node counts: rows for everything the iterations queued since that snapshot, the next
+                # round and one more can reach (forests mapped on demand; otherwise only the counts are noted)
+                queued = self.it - it_then
+                forest.grow(st_host[1].numpy(), queued + 2 * agent.sync_every)
+                forest._steps_covered = 2 * agent.sync_every
+                self.stats["mapped_gb"] = round(forest.bytes_allocated() / 1e9, 2)
+            self._act_on(qi, f_snap, st_host[0])
         finally:
             self.stats["host_process_s"] += perf_counter() - t2
 
@@ -601,7 +610,7 @@ class MCTSRun:
             self._harvest(done)
             k = min(len(done), self.n_games - self.next_game)
             idx = _to_device_async(done[:k].astype(np.int32), forest.status.device)
-            forest.plant(idx, self.roots, self.next_game, self.plant_states)   # the waiting scrambles move in: roots evaluated by the next two iterations
+            forest.plant(idx, self.roots, self.next_game, self.plant_states, slots_host=done[:k])   # the waiting scrambles move in: roots evaluated by the next two iterations
             owner[done] = -1
             owner[done[:k]] = np.arange(self.next_game, self.next_game + k)
             self.stale_until[done[:k]] = self.q - 1     # every snapshot queued so far predates the adoption
@@ -639,6 +648,7 @@ class MCTSRun:
             forest.close_pending(agent.c)
         torch.cuda.synchronize()
         seconds = agent.tt.tock()
+        forest.grow(forest.n_nodes.cpu().numpy(), 0)     # the final node counts (what result extraction reads of a tree)
         left = np.flatnonzero(owner >= 0)
         if len(left) == forest.B:
             self._snapshot(left)

@@ -6,8 +6,10 @@ on torch's current stream and reads results back; no cube arithmetic happens on 
 Per node (tree-major, 1-based, row 0 = "no neighbour" sentinel like the reference's arrays,
 librubiks/solving/agents.py:417-459):  packed state 16 B, neighbors 12 x i32, P / W 12 x f32,
 N 12 x i32, virtual-loss count 12 x u16, V f32, leaf u8, a 16-byte walk record (what a PUCT descent does at the
-node, see csrc/rubiks_mcts.hip) plus 2 hash slots x i32  ->  ~285 B, so 1 024 trees x 175 000 nodes (the
-reference's default max_states) is ~51 GB of the 288 GB HBM3E.
+node, see csrc/rubiks_mcts.hip) plus 2 hash slots x i32  ->  ~285 B per node.
+Large forests reserve ADDRESS SPACE for capacity + 1 rows per tree and map memory behind the rows as the trees grow
+(librubiks/_vmm.py, `MCTSForest.grow`): the reference's default max_states = 175 000 costs what the trees reach, not
+1 024 x 175 000 x 285 B = 51 GB, and 8 192 trees at that cap (408 GB of rows) fit the 288 GB of HBM3E.
 """
 import ctypes
 from ctypes import POINTER, Structure, c_double, c_int, c_size_t, c_uint32, c_void_p
@@ -16,6 +18,7 @@ import numpy as np
 import torch
 
 from librubiks import _hip
+from librubiks._vmm import VmmArray
 from librubiks.cube.device import DeviceCubes
 from librubiks.model import make_inference_net, net_fingerprint
 
@@ -33,7 +36,7 @@ class _McStruct(Structure):   # mirrors rc_mcts_t (include/rubiks_hip.h)
                [(name, c_void_p) for name in ("child_idx", "new_mask", "expanded", "select_stats", "bfs", "short_act",
                                               "short_len", "rec")] + \
                [("ring_k", c_uint32)] + [(name, c_void_p) for name in ("ring_node", "ring_act", "ring_len", "phase", "active")] + \
-               [("n_active", c_uint32), ("unc_list_cap", c_uint32)]
+               [("n_active", c_uint32), ("unc_list_cap", c_uint32), ("mapped_rows", c_void_p)]
 
 
 _hip.register({
@@ -50,6 +53,7 @@ _hip.register({
     "rc_mcts_step_head": [POINTER(_McStruct), c_void_p, c_size_t, c_int, c_double, c_uint32, c_uint32, c_void_p],
     "rc_mcts_complete_graph": [POINTER(_McStruct), c_void_p],
     "rc_mcts_shorten": [POINTER(_McStruct), c_void_p],
+    "rc_mcts_copy_trees": [POINTER(_McStruct), POINTER(_McStruct), c_void_p, c_uint32, c_uint32, c_void_p],
 }, restypes={"rc_mcts_struct_bytes": ctypes.c_size_t})
 
 
@@ -92,8 +96,11 @@ def rungs(n_trees: int) -> list:
 
 
 class MCTSForest:
-    def __init__(self, n_trees: int, capacity: int, max_path: int = 4096, device=None, _state: dict = None,
-                 _results_only: bool = False):
+    VMM_MIN_BYTES = 1 << 30   # node records of at least this many bytes: the per-node arrays are mapped on demand (None: never)
+    GROW_ROWS = 8192          # rows a tree's mapping grows by (8 192 node records = one 2 MiB chunk)
+
+    def __init__(self, n_trees: int, capacity: int, max_path: int = 4096, device=None, _results_only: bool = False, vmm: bool = None):
+        """vmm: per-node arrays as reserved address ranges with memory mapped behind the rows in use (`grow`); None = by size."""
         self.lib = _hip.lib()
         if self.lib.rc_mcts_struct_bytes() != ctypes.sizeof(_McStruct):
             raise _hip.RubiksHipError(f"rc_mcts_t is {self.lib.rc_mcts_struct_bytes()} bytes in librubiks_hip.so but {ctypes.sizeof(_McStruct)} "
@@ -105,32 +112,55 @@ class MCTSForest:
         self.hash_size = 1 << int(np.ceil(np.log2(2 * (C + 1))))
         z = lambda shape, dt: torch.zeros(shape, dtype=dt, device=dev)   # noqa: E731
         rows = B * (C + 1)
-        layout = {   # search state: zero-initialised, or adopted from another forest (`subset`)
+        if vmm is None:
+            vmm = self.VMM_MIN_BYTES is not None and rows * NODE_WORDS * 4 >= self.VMM_MIN_BYTES
+        self.vmm = bool(vmm)
+        self.results_only = _results_only
+        per_node = {   # [B][capacity + 1] rows each
             "keys": ((rows, 4), torch.int32), "node": ((rows, NODE_WORDS), torch.int32), "nbr": ((rows, N_ACT), torch.int32),
-            "V": ((rows,), torch.float32), "leaf": ((rows,), torch.uint8), "hash": ((B, self.hash_size), torch.int32),
+            "V": ((rows,), torch.float32), "leaf": ((rows,), torch.uint8),
+        }
+        per_tree = {
+            "hash": ((B, self.hash_size), torch.int32),
             "n_nodes": ((B,), torch.int32), "status": ((B,), torch.int32), "solved_idx": ((B,), torch.int32),
             "solved_action": ((B,), torch.int32), "iterations": ((B,), torch.int32), "path_len": ((B,), torch.int32),
             "pending": ((B,), torch.int32), "path_node": ((B, max_path), torch.int32), "path_act": ((B, max_path), torch.uint8),
             "ring_node": ((B, RING_K, max_path), torch.int32), "ring_act": ((B, RING_K, max_path), torch.uint8),
             "ring_len": ((B, RING_K), torch.int32), "phase": ((B,), torch.int32),
         }
-        for name, (shape, dt) in layout.items():
-            if name == "nbr" and not _results_only:
-                continue            # a field of the node record (below); a results-only forest keeps it as a plain array instead
-            if _state is not None and name in _state:
-                t = _state[name]
-                assert tuple(t.shape) == shape and t.dtype == dt and t.is_contiguous(), name
-            elif _results_only and name not in _RESULT_NODE + _RESULT_TREE + ("hash",):
+        self._ranges = {}     # name -> (VmmArray, bytes per row) of the arrays mapped on demand
+        for name, (shape, dt) in per_node.items():
+            if name == ("node" if _results_only else "nbr"):
+                continue      # a search forest keeps nbr as a field of the node record, a results-only forest as a plain array
+            if _results_only and name not in _RESULT_NODE:
                 t = z((1,) + shape[1:], dt)   # arrays that turning finished trees into results never touches: one row, so that pointers are valid
+            elif self.vmm:    # no memory yet, and none of these arrays needs clearing: a node's rows are written when it is created
+                bpr = int(np.prod(shape[1:], dtype=np.int64)) * torch.empty(0, dtype=dt).element_size()
+                arr = VmmArray(rows * bpr, dev)
+                self._ranges[name] = (arr, bpr)
+                t = arr.tensor(dt, shape)
+            else:
+                t = z(shape, dt)
+            setattr(self, name, t)
+        for name, (shape, dt) in per_tree.items():
+            if _results_only and name not in _RESULT_TREE + ("hash",):
+                t = z((1,) + shape[1:], dt)
             else:
                 t = z(shape, dt)
             setattr(self, name, t)
         # the reference's per-action node arrays (agents.py:421-427) are strided views of the 256-byte node records: one or two
         # adjacent cache lines per node for the kernels, the same [rows, 12] tensors for everything that inspects a tree
         for name, (lo, hi, dt) in _NODE_FIELDS.items():
-            if not (name == "nbr" and _results_only):
+            if _results_only:
+                if name != "nbr":
+                    setattr(self, name, z((1, hi - lo), dt))
+            else:
                 setattr(self, name, self.node[:, lo:hi].view(dt))
-        self.results_only = _results_only
+        # rows 0 .. mapped_host[t] - 1 of tree t have memory behind them (every row, if the arrays are ordinary allocations)
+        self.mapped_host = np.full(B, 0 if self.vmm else C + 1, dtype=np.int32)
+        self.mapped_rows = z((B,), torch.int32) if self.vmm else None
+        self.nodes_seen = np.zeros(B, dtype=np.int64)   # node counts as of the last look the host had (`grow`, `MCTSRun`)
+        self._steps_covered = 0                         # iterations that may be queued before the mapping has to be looked at again
         # Network rows per tree: only the NEW children of the expanded leaf are evaluated, and a non-root leaf has at most
         # 11 of them (its parent is known): 11 row slots per tree.  A planted root takes two iterations (rc_mcts_t::phase).
         self.children = DeviceCubes.empty(ROWS * B, dev)
@@ -164,6 +194,7 @@ class MCTSForest:
         self._listed = None   # host copy of the list (None = every tree in order)
         s.active, s.n_active = self.active_buf.data_ptr(), B
         s.unc_list_cap = 128
+        s.mapped_rows = self.mapped_rows.data_ptr() if self.vmm else None
         self.struct = s
         self.engine = None
         self._net_fp = None
@@ -171,43 +202,121 @@ class MCTSForest:
         self._graphs = {}          # (G, c, max_states, level budget) -> captured iteration
         self._graph_pool = None    # one memory pool for all of them: they never run concurrently
 
-    def subset(self, keep: torch.Tensor, results_only: bool = False) -> "MCTSForest":
+    # ---- memory behind the rows (forests mapped on demand) ---------------------------------------------
+    def ensure_rows(self, trees: np.ndarray, rows: np.ndarray) -> int:
+        """Memory behind rows 0 .. rows[i] - 1 of tree trees[i] in every per-node array (never less than a tree already has; in
+        steps of GROW_ROWS); the kernels learn of it in stream order.  Returns the bytes newly mapped.  No-op without vmm."""
+        if not self.vmm:
+            return 0
+        trees = np.asarray(trees, dtype=np.int64).reshape(-1)
+        want = np.minimum(self.C + 1, (np.asarray(rows, dtype=np.int64).reshape(-1) + self.GROW_ROWS - 1) // self.GROW_ROWS * self.GROW_ROWS)
+        more = want > self.mapped_host[trees]
+        if not more.any():
+            return 0
+        new = 0
+        for t, r in zip(trees[more], want[more]):
+            base = int(t) * (self.C + 1)
+            for arr, bpr in self._ranges.values():
+                new += arr.ensure((base + int(self.mapped_host[t])) * bpr, (base + int(r)) * bpr)
+            self.mapped_host[t] = r
+        self.mapped_rows.copy_(torch.from_numpy(self.mapped_host.copy()).pin_memory(), non_blocking=True)
+        return new
+
+    def grow(self, n_nodes: np.ndarray, steps_ahead: int):
+        """The host's look at the trees: `n_nodes` (host array, [B]) are node counts at some point of the stream, and up to
+        `steps_ahead` iterations may run beyond that point before the next look (a tree gains at most 12 nodes per iteration).
+        Maps what those iterations can reach."""
+        self.nodes_seen = np.asarray(n_nodes, dtype=np.int64).copy()
+        if self.vmm:
+            self.ensure_rows(np.arange(self.B), self.nodes_seen + N_ACT * (steps_ahead + 1) + 2)
+
+    def _grow_now(self):
+        """Direct steppers (tests, tools) have no MCTSRun looking after the mapping: a synchronising look, 256 iterations ahead."""
+        self.grow(self.n_nodes.cpu().numpy(), 256)
+        self._steps_covered = 256
+
+    def ensure_bfs(self, trees: np.ndarray = None):
+        """rc_mcts_shorten's scratch ([rows][2] int32) behind the rows of `trees` (all if None) as counted by `nodes_seen`."""
+        if self.bfs is None:
+            rows = self.B * (self.C + 1)
+            if self.vmm:
+                self._ranges_bfs = VmmArray(rows * 8, self.device)
+                self.bfs = self._ranges_bfs.tensor(torch.int32, (rows, 2))
+            else:
+                self.bfs = torch.zeros((rows, 2), dtype=torch.int32, device=self.device)
+            self.struct.bfs = self.bfs.data_ptr()
+        if self.vmm:
+            for t in (range(self.B) if trees is None else np.asarray(trees).reshape(-1)):
+                base = int(t) * (self.C + 1)
+                self._ranges_bfs.ensure(base * 8, (base + int(self.nodes_seen[t]) + 2) * 8)
+
+    def close(self):
+        """Returns the mapped memory (forests mapped on demand; others free theirs with their tensors).  Synchronises."""
+        if self.vmm and self._ranges is not None:
+            torch.cuda.synchronize()
+            self._graphs, self._graph_pool = {}, None
+            for name in list(self._ranges) + list(_NODE_FIELDS):
+                if hasattr(self, name):
+                    delattr(self, name)
+            self.bfs = None
+            for arr, _ in self._ranges.values():
+                arr.close()
+            if getattr(self, "_ranges_bfs", None) is not None:
+                self._ranges_bfs.close()
+            self._ranges = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:   # noqa: BLE001 -- interpreter shutdown
+            pass
+
+    def subset(self, keep: np.ndarray, results_only: bool = False) -> "MCTSForest":
         """
-        A new, smaller forest holding only the trees `keep` (int64 indices), with their search state copied on the
-        device.  Used to drop finished trees from a batch: the survivors continue exactly where they were, on GEMMs
-        of len(keep) x 11 rows instead of B x 11.
-        results_only: the trees are finished and only wait to be turned into results (graph completion, BFS
-        shortening, paths): just the arrays those steps read are copied (65 of ~280 bytes per node), the forest
-        cannot be stepped or inspected.
+        A new, smaller forest holding only the trees `keep` (host indices), copied on the device by rc_mcts_copy_trees: the
+        rows that exist, nothing beyond.  `nodes_seen` must hold their final node counts (`grow`; the trees are finished).
+        results_only: the trees only wait to be turned into results (graph completion, BFS shortening, paths): just the
+        arrays those steps read are copied (65 of ~285 bytes per node), the forest cannot be stepped or inspected.
         """
-        B, C1 = self.B, self.C + 1
-        state = {}
-        for name in (_RESULT_NODE if results_only else _PER_NODE):
-            t = getattr(self, name)     # (nbr: a strided view of the node records, gathered into a plain array)
-            state[name] = t.view(B, C1, *t.shape[1:])[keep].reshape(len(keep) * C1, *t.shape[1:]).contiguous()
-        state["hash"] = self.hash[keep].contiguous()
-        for name in (_RESULT_TREE if results_only else _PER_TREE):
-            state[name] = getattr(self, name)[keep].contiguous()
-        sub = MCTSForest(len(keep), self.C, self.max_path, self.device, _state=state, _results_only=results_only)
+        keep = np.asarray(keep, dtype=np.int64)
+        sub = MCTSForest(len(keep), self.C, self.max_path, self.device, _results_only=results_only, vmm=self.vmm)
         sub.level_budget, sub._one_launch = self.level_budget, self._one_launch
         sub.set_net(self.engine, self.engine.dtype if hasattr(self.engine, "dtype") else torch.bfloat16)
+        sub.adopt(0, self, keep)
         return sub
 
-    def bury(self, pos: int, other: "MCTSForest", idx: torch.Tensor):
-        """Copies what result extraction reads of the (finished) trees `idx` of `other` into this results-only forest's slots
-        pos .. pos + len(idx) - 1."""
-        assert self.results_only and other.C == self.C and other.max_path == self.max_path and pos + len(idx) <= self.B
-        k, C1 = len(idx), self.C + 1
-        for name in _RESULT_NODE:
-            dst, src = getattr(self, name), getattr(other, name)
-            dst.view(self.B, C1, *dst.shape[1:])[pos:pos + k] = src.view(other.B, C1, *src.shape[1:])[idx]
-        self.hash[pos:pos + k] = other.hash[idx]
-        for name in _RESULT_TREE:
-            getattr(self, name)[pos:pos + k] = getattr(other, name)[idx]
+    def adopt(self, pos: int, other: "MCTSForest", trees: np.ndarray):
+        """Copies the (finished) trees `trees` of `other` into this forest's slots pos .. pos + len(trees) - 1: what this kind
+        of forest keeps of a tree (results-only: keys, neighbours, leaf flags, hash table and the per-tree words result
+        extraction reads), rows 0 .. n_nodes only."""
+        trees = np.asarray(trees, dtype=np.int64)
+        k = len(trees)
+        assert other.C == self.C and other.max_path == self.max_path and pos + k <= self.B and not other.results_only
+        n = other.nodes_seen[trees]
+        self.ensure_rows(np.arange(pos, pos + k), n + 2)
+        self.nodes_seen[pos:pos + k] = n
+        idx = torch.from_numpy(trees.astype(np.int32)).pin_memory().to(self.device, non_blocking=True)
+        _hip.check(self.lib.rc_mcts_copy_trees(ctypes.byref(other.struct), ctypes.byref(self.struct), idx.data_ptr(), k, pos,
+                                               _hip.stream_ptr()), "rc_mcts_copy_trees")
+        pick = idx.long()
+        for name in (_RESULT_TREE if self.results_only else _PER_TREE):
+            getattr(self, name)[pos:pos + k] = getattr(other, name)[pick]
+
+    def bury(self, pos: int, other: "MCTSForest", trees: np.ndarray):
+        """`adopt` into a results-only forest (the trees leave `other` for good)."""
+        assert self.results_only
+        self.adopt(pos, other, trees)
 
     def bytes_allocated(self) -> int:
-        return sum(t.numel() * t.element_size() for t in (self.keys, self.node, self.V, self.leaf, self.hash, self.path_node,
-                                                           self.path_act, self.ring_node, self.ring_act, self.ring_len))
+        """HBM behind the forest's search state: mapped bytes of the arrays mapped on demand + the ordinary allocations."""
+        plain = [t for name, t in (("keys", self.keys), ("node", getattr(self, "node", None)), ("V", self.V), ("leaf", self.leaf))
+                 if t is not None and name not in (self._ranges or {})]
+        plain += [self.hash, self.path_node, self.path_act, self.ring_node, self.ring_act, self.ring_len]
+        return sum(t.numel() * t.element_size() for t in plain) + sum(arr.mapped_bytes for arr, _ in (self._ranges or {}).values())
+
+    def bytes_reserved(self) -> int:
+        """Address space of the arrays mapped on demand (what an up-front allocation of the same forest would cost in HBM)."""
+        return sum(arr.nbytes for arr, _ in (self._ranges or {}).values())
 
     # ---- which trees the iterations work on ---------------------------------------------------------
     def rung_for(self, n: int) -> int:
@@ -301,7 +410,7 @@ class MCTSForest:
     fused_step = True   # iterations as [network -> rc_mcts_step*] (expansion at the END of a step) when the trees were planted for it
     _one_launch = False
 
-    def plant(self, slots, roots: DeviceCubes, first: int = 0, max_states: int = None):
+    def plant(self, slots, roots: DeviceCubes, first: int = 0, max_states: int = None, slots_host: np.ndarray = None):
         """Trees `slots` (int32 device tensor, or None for all) restart from roots[first], roots[first + 1], ...: their
         hash tables are cleared by the kernel, nothing else needs clearing (a node's rows are initialised when it is
         created).  Safe between two iterations of a running forest: other trees are not touched.
@@ -313,6 +422,10 @@ class MCTSForest:
         assert slots is None or (slots.dtype == torch.int32 and slots.is_cuda and slots.is_contiguous())
         assert 0 <= first and first + n <= roots.n
         one = bool(self.fused_step and max_states is not None)
+        if self.vmm:   # a root and its children need rows before the kernel runs; the first GROW_ROWS rows of every planted tree
+            which = np.arange(self.B) if slots is None else (slots_host if slots_host is not None else slots.cpu().numpy())
+            self.ensure_rows(which, np.full(len(which), self.GROW_ROWS))
+            self.nodes_seen[which] = 0
         if slots is None:
             self._one_launch = one
         assert one == self._one_launch, "trees planted into a running forest must use the form its iterations run in"
@@ -375,6 +488,10 @@ class MCTSForest:
         """One lock-step iteration of every running tree: expand -> network -> backup + select (one kernel).
         A freshly planted tree spends its first two steps on its root (evaluation + expansion, then backup + first descent)."""
         assert not self.results_only
+        if self.vmm:
+            if self._steps_covered <= 0:
+                self._grow_now()
+            self._steps_covered -= 1
         if not use_graph:
             return self._iteration(c, max_states)
         key = (self.G, float(c), int(max_states), int(self.level_budget), self._one_launch)
@@ -458,12 +575,10 @@ class MCTSForest:
         s = self._all_trees() if trees is None else self.listed(trees)
         _hip.check(self.lib.rc_mcts_complete_graph(ctypes.byref(s), _hip.stream_ptr()), "rc_mcts_complete_graph")
 
-    def shorten_launch(self, trees: torch.Tensor = None):
+    def shorten_launch(self, trees: torch.Tensor = None, trees_host: np.ndarray = None):
         """_shorten_action_queue of every solved tree (of `trees`) on the device -> short_len[B] (-1 = keep the naive queue),
         short_act[B, max_path]."""
-        if self.bfs is None:
-            self.bfs = torch.zeros((self.B * (self.C + 1), 2), dtype=torch.int32, device=self.device)
-            self.struct.bfs = self.bfs.data_ptr()
+        self.ensure_bfs(trees_host)
         s = self._all_trees() if trees is None else self.listed(trees)
         _hip.check(self.lib.rc_mcts_shorten(ctypes.byref(s), _hip.stream_ptr()), "rc_mcts_shorten")
 
@@ -473,9 +588,11 @@ class MCTSForest:
         return self.short_len.cpu().numpy(), self.short_act.cpu().numpy()
 
     def status_snapshot(self):
-        """(event, pinned int32[B]): the per-tree status as of the work queued so far, readable once the event has passed."""
-        host = torch.empty(self.B, dtype=torch.int32, pin_memory=True)
-        host.copy_(self.status, non_blocking=True)
+        """(event, pinned int32[2, B]): per-tree status (row 0) and node count (row 1) as of the work queued so far, readable once
+        the event has passed."""
+        host = torch.empty((2, self.B), dtype=torch.int32, pin_memory=True)
+        host[0].copy_(self.status, non_blocking=True)
+        host[1].copy_(self.n_nodes, non_blocking=True)
         ev = torch.cuda.Event()
         ev.record()
         return ev, host

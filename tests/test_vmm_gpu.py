@@ -1,0 +1,192 @@
+"""
+Node storage on demand (rc_vmm_*, librubiks/_vmm.py, MCTSForest(vmm=True)): the reference's node arrays grow as a tree grows
+(librubiks/solving/agents.py:450-459); here a forest reserves address space for capacity + 1 rows per tree and maps memory
+behind the rows in use.  What must hold:
+  * a mapped range behaves like any allocation (exact data, torch views, growth next to running work);
+  * rc_mcts_copy_trees copies exactly what the whole-capacity tensor copies of rounds 1-3 copied of the rows that exist;
+  * searches on forests mapped on demand -- also with so little mapped ahead that trees have to WAIT for their rows (the
+    kernels' `mapped_rows` guard) -- build the reference's trees node for node: the exact-tree tests of the continuous
+    batching path (refill, narrowing, results forest) and of the deep production trees are repeated in that mode;
+  * BASELINE configs[1] at the reference's max_states = 175 000 (1 024 x 175 001 rows reserved = 46 GB of node records)
+    keeps less than 20 GB mapped.
+"""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import ROOT
+
+pytestmark = pytest.mark.gpu
+
+from oracle import agents as oa  # noqa: E402  (checker only)
+from oracle import cube as oc  # noqa: E402
+
+WEIGHTS = os.path.join(ROOT, "weights", "fc_small_r1")
+
+
+def test_vmm_array_maps_on_demand():
+    from librubiks._vmm import CHUNK, VmmArray
+    free0 = torch.cuda.mem_get_info()[0]
+    arr = VmmArray(40 << 30, torch.device("cuda", 0))            # 40 GB of addresses, no memory yet
+    assert arr.mapped_bytes == 0 and torch.cuda.mem_get_info()[0] > free0 - (1 << 30)
+    t = arr.tensor(torch.int64, ((40 << 30) // 8,))
+    assert t.data_ptr() == arr.ptr and t.is_cuda
+    assert arr.ensure(0, 3 * CHUNK) == 3 * CHUNK and arr.ensure(CHUNK, 2 * CHUNK) == 0      # chunks are mapped once
+    lo = (17 << 30) + 12345 * 8                                    # a range that starts and ends inside chunks
+    assert arr.ensure(lo, lo + 5 * CHUNK) == 6 * CHUNK
+    assert arr.mapped_bytes == 9 * CHUNK
+    a, b = lo // 8, (lo + 5 * CHUNK) // 8
+    t[a:b] = torch.arange(a, b, dtype=torch.int64, device="cuda") * 7
+    t[:3 * CHUNK // 8].fill_(-5)
+    torch.cuda.synchronize()
+    assert torch.equal(t[a:b], torch.arange(a, b, dtype=torch.int64, device="cuda") * 7) and int(t[3 * CHUNK // 8 - 1].item()) == -5
+    # growth next to running work that uses the mapped part
+    x = torch.randn(4096, 4096, device="cuda")
+    for i in range(20):
+        y = x @ x
+        t[a:b].add_(1)
+        arr.ensure((20 << 30) + i * CHUNK, (20 << 30) + (i + 1) * CHUNK)
+    torch.cuda.synchronize()
+    assert torch.equal(t[a:b], torch.arange(a, b, dtype=torch.int64, device="cuda") * 7 + 20) and y.shape == x.shape
+    assert arr.mapped_bytes == 29 * CHUNK
+    del t
+    arr.close()
+    assert arr.ptr == 0 and torch.cuda.mem_get_info()[0] > free0 - (1 << 30)
+
+
+def _roots(n, depth, seed):
+    np.random.seed(seed)
+    return np.array([oc.scramble(depth, True)[0] for _ in range(n)])
+
+
+@pytest.mark.parametrize("vmm", [False, True])
+def test_copy_trees_keeps_exactly_the_rows_that_exist(standin_net, vmm):
+    """Finished trees leave a forest through rc_mcts_copy_trees (MCTSForest.subset / bury): every array of the copy equals the
+    source on rows 0 .. n_nodes, in both kinds of destination (search forest, results-only forest), whether or not the forests
+    are mapped on demand; graph completion + BFS shortening on the copies give the source's own action queues."""
+    from librubiks.cube import DeviceCubes
+    from librubiks.solving import mcts_device as md
+    from librubiks.solving.agents import MCTS
+    states = _roots(24, 6, 3)
+    agent = MCTS(standin_net.cuda(), c=0.6, search_graph=True, net_dtype=torch.float32)
+    md_vmm = md.MCTSForest.VMM_MIN_BYTES
+    md.MCTSForest.VMM_MIN_BYTES = 0 if vmm else None
+    try:
+        res = agent.search_batch(states, None, 700, compact=False)
+        forest = agent.forest
+        assert forest.vmm == vmm and res.solved.any()
+        keep = np.array([5, 0, 17, 23, 11])
+        full = forest.subset(keep)
+        slim = forest.subset(keep, results_only=True)
+        assert full.vmm == vmm and slim.results_only
+        for i, t in enumerate(keep):
+            n = int(forest.n_nodes[t].item())
+            a, b = forest.tree_arrays(int(t)), full.tree_arrays(i)
+            assert a["n"] == b["n"] == n
+            for k in ("states", "neighbors", "P", "V", "W", "N", "L", "leaves"):
+                assert np.array_equal(a[k], b[k]), (t, k)
+            lo_s, lo_d = int(t) * (forest.C + 1), i * (slim.C + 1)
+            assert torch.equal(slim.keys[lo_d:lo_d + n + 1], forest.keys[lo_s:lo_s + n + 1])
+            assert torch.equal(slim.nbr[lo_d:lo_d + n + 1], forest.nbr[lo_s:lo_s + n + 1])
+            assert torch.equal(slim.leaf[lo_d:lo_d + n + 1], forest.leaf[lo_s:lo_s + n + 1])
+            assert torch.equal(slim.hash[i], forest.hash[t]) and torch.equal(full.hash[i], forest.hash[t])
+            assert int(slim.n_nodes[i].item()) == n and int(slim.status[i].item()) == int(forest.status[t].item())
+        for f in (full, slim):
+            f.complete_graphs()
+            lens, acts = f.shorten_queues()
+            for i, t in enumerate(keep):
+                if res.solved[t] and lens[i] >= 0:
+                    assert list(acts[i, :lens[i]]) == list(res.queues[t])
+        if vmm:
+            assert 0 < slim.bytes_allocated() < slim.bytes_reserved()
+    finally:
+        md.MCTSForest.VMM_MIN_BYTES = md_vmm
+
+
+@pytest.fixture
+def scarce_rows(monkeypatch):
+    """Every forest is mapped on demand, 16 rows at a time: the host's look-ahead is all a tree has, and right after a plant
+    (16 rows: the root's expansion fits, the next one does not) trees wait for their rows."""
+    from librubiks import _vmm
+    from librubiks.solving import mcts_device as md
+    made = []
+    init = _vmm.VmmArray.__init__
+
+    def counting(self, *a, **k):
+        init(self, *a, **k)
+        made.append(self)
+
+    monkeypatch.setattr(_vmm.VmmArray, "__init__", counting)
+    monkeypatch.setattr(md.MCTSForest, "VMM_MIN_BYTES", 0)
+    monkeypatch.setattr(md.MCTSForest, "GROW_ROWS", 16)
+    return made
+
+
+def test_trees_that_wait_for_their_rows_are_still_the_reference_trees(scarce_rows, standin_net):
+    """Stand-in net (exact arithmetic): 64 trees searched on a forest that maps 16 rows at a time, against the restated reference
+    agent tree by tree; `iterations` counts expansions, not steps, so the waits do not show in any result."""
+    from librubiks.solving.agents import MCTS
+    net = standin_net.cuda()
+    states = _roots(64, 7, 12)
+    agent = MCTS(net, c=0.6, search_graph=True, net_dtype=torch.float32, sync_every=4)
+    res = agent.search_batch(states, None, 900, compact=False)
+    assert agent.forest.vmm and len(scarce_rows) >= 4
+    onet = oa.TorchNet(net, device="cuda")
+    for t in range(0, 64, 5):
+        ref = oa.MCTS(onet, c=0.6, search_graph=True)
+        ok = ref.search(states[t], 900)
+        tree = agent.forest.tree_arrays(t)
+        n = len(ref)
+        assert bool(res.solved[t]) == ok and res.nodes[t] == n == tree["n"] and res.iterations[t] == ref.iterations
+        assert list(res.queues[t]) == list(ref.action_queue)
+        assert np.array_equal(tree["N"][:n + 1], ref.N[:n + 1]) and np.array_equal(tree["W"][1:n + 1], ref.W[1:n + 1])
+        assert np.array_equal(tree["states"][1:n + 1], ref.states[1:n + 1])
+
+
+@pytest.mark.parametrize("engine", ["f32s", "bf16"])
+def test_refill_narrowing_and_results_forest_on_rows_mapped_on_demand(scarce_rows, engine):
+    import test_search_edge_gpu as edge
+    edge.test_production_trees_through_refill_narrowing_and_results_forest_equal_oracle(engine)
+    assert len(scarce_rows) >= 8          # search forest + results forest, several arrays each
+
+
+def test_deep_production_trees_on_rows_mapped_on_demand(scarce_rows):
+    import test_search_edge_gpu as edge
+    edge.test_deep_production_trees_equal_oracle_on_recorded_outputs("f32s")
+    assert len(scarce_rows) >= 4
+
+
+def test_config2_at_the_reference_cap_keeps_a_fraction_mapped():
+    """BASELINE configs[1] at max_states = 175 000 (runeval.py:42-44): 1 024 x 175 001 rows are reserved, what the trees reach is
+    mapped.  Every returned solution is replayed; the budget rule holds for whoever is unsolved."""
+    from librubiks import cube
+    from librubiks.model import Model, ModelConfig
+    from librubiks.solving.agents import MCTS
+    if os.path.isdir(WEIGHTS):
+        net = Model.load(WEIGHTS).eval()
+    else:
+        torch.manual_seed(0)
+        net = Model.create(ModelConfig()).eval()
+    np.random.seed(0)
+    cubes, _, _ = cube.scramble_batch(1024, 20, True)
+    states = cubes.numpy()
+    agent = MCTS(net, c=0.6, search_graph=True)
+    cap = 175_000
+    res = agent.search_batch(cubes, None, cap)
+    forest = agent.forest
+    assert forest.vmm and forest.C >= cap and forest.bytes_reserved() > 45e9
+    assert forest.bytes_allocated() < 20e9, forest.bytes_allocated()
+    assert (res.nodes <= cap).all() and (res.nodes >= 13).all()
+    for t in np.flatnonzero(res.solved):
+        state = states[t]
+        for a in res.queues[t]:
+            state = oc.rotate(state, *oc.ACTION_SPACE[a])
+        assert oc.is_solved(state) and res.lengths[t] == len(res.queues[t])
+    for t in np.flatnonzero(~res.solved):
+        assert res.lengths[t] == -1 and (res.nodes[t] + 12 > cap or res.status[t] == 3)
+    if os.path.isdir(WEIGHTS):
+        assert res.solved.mean() > 0.97
+    # the rows of every tree that were mapped cover what the tree reached, and not the whole capacity
+    assert (forest.mapped_host >= np.minimum(cap + 1, forest.nodes_seen + 1)).all() and forest.mapped_host.mean() < 0.25 * cap
