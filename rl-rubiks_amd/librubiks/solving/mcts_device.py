@@ -314,6 +314,10 @@ class MCTSForest:
         plain += [self.hash, self.path_node, self.path_act, self.ring_node, self.ring_act, self.ring_len]
         return sum(t.numel() * t.element_size() for t in plain) + sum(arr.mapped_bytes for arr, _ in (self._ranges or {}).values())
 
+    def bytes_mapped(self) -> int:
+        """HBM currently behind the arrays mapped on demand."""
+        return sum(arr.mapped_bytes for arr, _ in (self._ranges or {}).values())
+
     def bytes_reserved(self) -> int:
         """Address space of the arrays mapped on demand (what an up-front allocation of the same forest would cost in HBM)."""
         return sum(arr.nbytes for arr, _ in (self._ranges or {}).values())
