@@ -54,7 +54,7 @@ HBM_PEAK_GBPS = 8000.0      # MI355X_MICROARCH.md: HBM3E peak
 MFMA_BF16_PEAK_TFLOPS = 2500.0   # dense bf16
 MFMA_F32_PEAK_TFLOPS = 157.3
 # `traffic` of roofline_env is NOT measured inside this run: it is the stored figure of separate rocprofv3 --pmc passes
-# (FETCH_SIZE / WRITE_SIZE, gfx950 corrections applied by tools/summarize_pmc.py) of the same launches at 2^24 states
+# (FETCH_SIZE / WRITE_SIZE, gfx950 corrections applied by tools/rocprof_summary.py traffic) of the same launches at 2^24 states
 PMC_FILE = "r2_env_pmc_traffic.json" if os.path.exists(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles",
                                                                   "r2_env_pmc_traffic.json")) else "r1b_env_pmc_traffic.json"
 GEMM_PMC_FILE = "r3_split_gemm_traffic.json"   # the hidden-layer kernel that runs today (k_split_gemm<2, 4, 11, 4, ...>), re-measured in round 3
@@ -86,7 +86,7 @@ def env_roofline(log2n=24):
     out = DeviceCubes.empty(n)
     res = []
     # HBM bytes per launch from the committed rocprofv3 PMC passes of these same launches (FETCH_SIZE and
-    # WRITE_SIZE in separate runs, gfx950 corrections applied: tools/summarize_pmc.py); None if absent
+    # WRITE_SIZE in separate runs, gfx950 corrections applied: tools/rocprof_summary.py traffic); None if absent
     pmc_path = os.path.join(ROOT, "profiles", PMC_FILE)
     pmc = json.load(open(pmc_path)) if os.path.exists(pmc_path) and log2n == 24 else {}
 
@@ -412,8 +412,10 @@ def run_leg(name, model, pool_roots, config_roots, args, world, coll_device, tre
 
     # ---- pool: untimed prep, warm-up, timed window, rest of the pool ------------------------------------
     # one-off set-up, untimed: forest allocation (tens of GB of HBM, zero-filled), engine, one HIP graph per launch size
+    t_prep = time.perf_counter()
     agent.prepare(trees, cap)
     barrier()
+    prepare_seconds = time.perf_counter() - t_prep
     t_pool = time.perf_counter()
     run = agent.start_batch(pool_roots, None, cap, slots=trees)
     # Prep: until as many scrambles again as there are slots have been started (the slots then hold trees of every age).  Where
@@ -425,7 +427,7 @@ def run_leg(name, model, pool_roots, config_roots, args, world, coll_device, tre
         run.round()
     # Harvested trees are turned into host results lazily; doing that here (tens of ms of host work, the GPU idles and drops its
     # clocks) instead of inside nodes_now() right in front of the timed window, then two more untimed rounds to bring the clocks
-    # back: the first ~10 steps after such a pause were measured 5-30 % slow (tools/window0_probe.py).
+    # back: the first ~10 steps after such a pause were measured 5-30 % slow (round 3 probe: profiles/README.md).
     run.nodes_now()
     for _ in range(2):
         if not run.done:
@@ -481,6 +483,8 @@ def run_leg(name, model, pool_roots, config_roots, args, world, coll_device, tre
         local = {"nodes": full.nodes, "solved": full.solved, "lengths": full.lengths}
         rtc = {"seconds": rtc_seconds, "nodes": int(full.nodes.sum()), "iterations": int(full.iterations.max()),
                "launch_sizes": int(agent.refill_stats.get("compactions", 0)) + 1}
+    forest_gb = {"hbm_behind_the_forest_gb": round(agent.forest.bytes_allocated() / 1e9, 2), "mapped_on_demand": bool(agent.forest.vmm),
+                 "node_rows_reserved_gb": round(agent.forest.bytes_reserved() / 1e9, 2)}
     stats = torch.tensor([seconds, float(nodes), float(steps_done), rtc["seconds"] if rtc else 0.0,
                           float(pool["nodes"]) if pool else 0.0, float(pool["seconds"]) if pool else 0.0],
                          dtype=torch.float64, device=coll_device)
@@ -495,7 +499,8 @@ def run_leg(name, model, pool_roots, config_roots, args, world, coll_device, tre
     out = {"dtype": LEG_DTYPE[name], "value": round(nodes / seconds, 1), "ms_per_step": round(seconds / max(steps_done, 1) * 1e3, 4),
            "nodes_in_window": nodes, "steps_timed": steps_done, "prep_iterations_untimed": prep_iters, "result_flushes_in_window": flushes_in_window,
            "refills_in_window": refills_in_window, "running_trees_rank0": running_in_window,
-           "mean_descent_depth_rank0": round(mean_path, 1), "max_states_per_tree": cap}
+           "mean_descent_depth_rank0": round(mean_path, 1), "max_states_per_tree": cap,
+           "prepare_seconds_rank0": round(prepare_seconds, 3), "forest_rank0": forest_gb}
     if pool:
         out["pool_run"] = dict(pool, nodes=pool_nodes, seconds=round(pool_s, 3), nodes_per_sec=round(pool_nodes / pool_s, 1),
                                games=int(pool["games"]) * world,
@@ -512,6 +517,7 @@ def run_leg(name, model, pool_roots, config_roots, args, world, coll_device, tre
             "ci95": float(1.959963984540054 * np.sqrt(p * (1 - p) / total)),
             "mean_solution_length": float(np.mean(g["lengths"][g["solved"].astype(bool)])) if np.any(g["solved"]) else None,
             "lock_step_iterations_rank0": rtc["iterations"], "launch_sizes_rank0": rtc["launch_sizes"],
+            "seconds_incl_prepare_rank0": round(rtc["seconds"] + prepare_seconds, 3),
             "warm_up": "forest allocated and HIP graphs of every launch size captured before (MCTS.prepare), then "
                        + ("the same search once, untimed" if full_warm else "30 iterations of it, untimed"),
             "note": "the scrambles as ONE batch: sum len(agent) / wall seconds of the batched search (SURVEY 8(d)(i))"}
@@ -637,6 +643,138 @@ def astar_leg(name, model, roots, args, world, coll_device):
     del agent, batch
     torch.cuda.empty_cache()
     return out
+
+
+def adi_leg(name, model, args, world, coll_device):
+    """
+    BASELINE configs[3]: the data generation of one Autodidactic-Iteration rollout (reference train.py:257-339) for a batch of
+    `--adi-states` states (512 games x 32 moves = 16 384 -> 196 608 substates), device resident:
+        sequence_scrambler -> expand12 -> is_solved (substates, states) -> value network on the substates -> rc_adi_targets -> one-hot of the states
+    Timed: K calls of Train.ADI_traindata after W warm-up calls (K, W capped at 20 / 3), barrier + synchronize on both sides;
+    value = states of all ranks / max-over-ranks seconds.  With N ranks every rank generates games / N games (the reference's
+    data-parallel layout of config #4).  Phases: the same steps once more between HIP events; roofline: the dominant kernel
+    (first hidden layer of the value network on the substates' real input-layer activations).
+    """
+    from librubiks import _hip, cube as pcube
+    from librubiks.model import F32_SPLIT, SplitF32Net
+    from librubiks.train import Train
+    net_dtype = {"bf16": torch.bfloat16, "f32s": F32_SPLIT}[name]
+    depth = 32
+    games = max(1, args.adi_states // depth // world)
+    tr = Train(rollouts=1, batch_size=1000, rollout_games=games, rollout_depth=depth, optim_fn=torch.optim.Adam, alpha_update=0, lr=1e-4,
+               gamma=1, update_interval=0, agent=None, evaluator=None, evaluation_interval=0, tau=1, reward_method="lapanfix",
+               adi_net_dtype=net_dtype)
+    K, W = max(1, min(args.steps, 20)), max(1, min(args.warmup, 3))
+
+    def barrier():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    np.random.seed(1234 + int(os.environ.get("RANK", 0)))
+    for _ in range(W):
+        tr.ADI_traindata(model, 0.5)
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(K):
+        out = tr.ADI_traindata(model, 0.5)
+    barrier()
+    seconds = time.perf_counter() - t0
+    n = games * depth
+    assert out[0].shape == (n, 480) and out[1].shape == (n,)
+    stats = torch.tensor([seconds], dtype=torch.float64, device=coll_device)
+    if world > 1:
+        dist.all_reduce(stats, op=dist.ReduceOp.MAX)
+    seconds = float(stats[0])
+    res = {"dtype": LEG_DTYPE[name], "games_per_gpu": games, "depth": depth, "states_per_rollout": n * world, "substates_per_rollout": 12 * n * world,
+           "rollouts_timed": K, "warmup_rollouts": W, "value": round(n * world * K / seconds, 1), "unit": "states/s",
+           "ms_per_rollout": round(seconds / K * 1e3, 3), "substates_per_sec": round(12 * n * world * K / seconds, 1),
+           "reward_method": "lapanfix"}
+    if not args.phase_reps:
+        return res
+    # ---- the same steps between HIP events (rank 0's view), and the dominant kernel alone -------------------------------------
+    lib, eng = _hip.lib(), tr._adi_engine(model)
+    names = ["sequence_scrambler (host RNG + moves to the device + rc_sequence_states)", "expand12", "is_solved (substates + states)",
+             "value_net", "rc_adi_targets", "as_oh(states, f32)"]
+    acc = np.zeros(len(names))
+    reps = 5
+    for _ in range(reps):
+        ev = [torch.cuda.Event(enable_timing=True) for _ in range(len(names) + 1)]
+        ev[0].record()
+        states = pcube.sequence_scrambler_device(games, depth, with_solved=True)
+        ev[1].record()
+        kids = states.expand12()
+        ev[2].record()
+        kid_solved = kids.is_solved().view(torch.uint8)
+        state_solved = states.is_solved().view(torch.uint8)
+        ev[3].record()
+        values = eng.value_cubes(kids)
+        ev[4].record()
+        pol = torch.empty(n, dtype=torch.int64, device="cuda")
+        val = torch.empty(n, dtype=torch.float32, device="cuda")
+        _hip.check(lib.rc_adi_targets(values.data_ptr(), kid_solved.data_ptr(), state_solved.data_ptr(), n, depth, 1.0, 1, pol.data_ptr(),
+                                      val.data_ptr(), _hip.stream_ptr()), "rc_adi_targets")
+        ev[5].record()
+        states.as_oh(torch.float32)
+        ev[6].record()
+        torch.cuda.synchronize()
+        acc += [ev[i].elapsed_time(ev[i + 1]) for i in range(len(names))]
+    res["phases_ms"] = {k: round(float(v) / reps, 4) for k, v in zip(names, acc)}
+    rows = 12 * n
+    env_bytes = 260 * n + 21 * (12 * n) + 21 * n + 1940 * n      # expand12 + is_solved (flags) on substates and states + one-hot f32 (SURVEY 8(d))
+    env_ms = res["phases_ms"]["expand12"] + res["phases_ms"]["is_solved (substates + states)"] + res["phases_ms"]["as_oh(states, f32)"]
+    res["roofline_env"] = {"kernel": f"expand12 ({n} parents) + is_solved ({13 * n} states) + as_oh f32 ({n} states): the rollout's environment kernels",
+                           "bound": "hbm", "algorithmic_bytes": int(env_bytes), "ms": round(env_ms, 4), "achieved": round(env_bytes / (env_ms * 1e-3) / 1e9, 1),
+                           "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": round(env_bytes / (env_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4), "traffic": None,
+                           "note": "a rollout's arrays are a few MB: these launches are bound by launch latency, not by HBM (roofline_env of the main line has the kernels at 2^14 .. 2^26 states)"}
+    if isinstance(eng, SplitF32Net):
+        a = eng._first_from_cubes(kids, eng.value_layers, 0, rows)
+        _, Wh, B2, b, code, alpha, W3 = eng.value_layers[1]
+        Kd, Nd = int(Wh.shape[1]), int(Wh.shape[0])
+        o = torch.empty((rows, 2 * Nd), dtype=torch.float16, device=Wh.device)
+        ms = event_ms(lambda: _hip.check(lib.rc_split_gemm_f16(a.data_ptr(), W3.data_ptr(), b.data_ptr(), rows, Nd, Kd, code, alpha, o.data_ptr(), None, 0,
+                                                               _hip.stream_ptr()), "rc_split_gemm_f16"), 5)[0]
+        fl = 3 * 2 * rows * Nd * Kd
+        kname = f"rc_split_gemm_f16 [{rows} x {3 * Kd}] x [{3 * Kd} x {Nd}] f16 products + bias + ELU + re-split: first hidden layer of the ADI value network"
+        flops_state = 3 * 2 * sum(int(l[1].shape[0]) * int(l[1].shape[1]) for l in eng.value_layers)
+    else:
+        x1 = eng.first_layer(kids, None, 0, rows)
+        Wt, bt, _ = eng.value_layers[1]
+        Kd, Nd = int(Wt.shape[1]), int(Wt.shape[0])
+        ms = event_ms(lambda: torch.addmm(bt, x1, Wt.t()), 5)[0]
+        fl = 2 * rows * Nd * Kd
+        kname = f"hidden GEMM [{rows} x {Kd}] x [{Kd} x {Nd}] + bias, bf16 MFMA via hipBLASLt: first hidden layer of the ADI value network"
+        flops_state = 2 * sum(int(Wt.shape[0]) * int(Wt.shape[1]) for Wt, _, _ in eng.value_layers)
+    tf = fl / (ms * 1e-3) / 1e12
+    res["roofline"] = {"kernel": kname, "bound": "mfma", "achieved": round(tf, 1), "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s",
+                       "frac": round(tf / MFMA_BF16_PEAK_TFLOPS, 4), "flops_per_launch": fl, "ms_per_launch": round(ms, 4), "traffic": None}
+    tfn = flops_state * rows / (res["phases_ms"]["value_net"] * 1e-3) / 1e12
+    res["roofline_net_group"] = {"kernel": f"value network on the {rows} substates of a rollout", "bound": "mfma", "achieved": round(tfn, 1),
+                                 "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(tfn / MFMA_BF16_PEAK_TFLOPS, 4),
+                                 "flops_per_launch": flops_state * rows, "ms_per_launch": res["phases_ms"]["value_net"], "traffic": None}
+    return res
+
+
+def cpu_adi(model, games=64, depth=32):
+    """The restated reference data generation (oracle/train.py, NumPy + torch CPU fp32 value network) on the host cores: a
+    bounded sample of config #4's rollout (64 x 32 = 2 048 states, an eighth of the 16 384), torch's default thread count."""
+    import copy
+    from oracle import agents as oa
+    from oracle import train as ot
+    cpu_model = copy.deepcopy(model).cpu().float().eval()
+    value = oa.TorchNet(cpu_model, device="cpu").value
+    np.random.seed(7)
+    ot.adi_traindata(value, 4, depth, "lapanfix", 0.5)          # warm-up
+    t0 = time.perf_counter()
+    reps = 0
+    while time.perf_counter() - t0 < 6.0 or reps < 1:
+        ot.adi_traindata(value, games, depth, "lapanfix", 0.5)
+        reps += 1
+    dt = time.perf_counter() - t0
+    return {"value": round(reps * games * depth / dt, 1), "unit": "states/s", "cores": torch.get_num_threads(), "kind": "port",
+            "sample": f"{reps} x oracle.train.adi_traindata({games} games x {depth} moves = {games * depth} states, {12 * games * depth} substates), "
+                      f"NumPy cube ops + torch CPU fp32 value network, {dt:.1f} s"}
 
 
 def step_rooflines(engine, agent, roots, args, name):
@@ -841,13 +979,16 @@ def main():
                     help="network engines to measure; the FIRST one is the headline `value`: f32s = fp32 accuracy on the f16 matrix "
                          "cores (SplitF32Net), f32 = fp32 MFMA GEMMs (the reference's arithmetic as is), bf16 = the fast engine; "
                          "`:window` = timed window only (no pool tail, no run to completion)")
-    ap.add_argument("--extra-legs", default="astar,config5",
+    ap.add_argument("--extra-legs", default="astar,config5,adi",
                     help="astar = BASELINE configs[2] (4 096 depth-20 A* problems per GPU); config5 = one GPU's share of configs[4] "
-                         "(8 192 concurrent depth-24 trees); none = neither.  Each runs at f32s, then bf16")
+                         "(8 192 concurrent depth-24 trees); adi = configs[3] (data generation of a 16 384-state ADI rollout); none = "
+                         "none of them.  Each runs at f32s, then bf16")
+    ap.add_argument("--adi-states", type=int, default=16384, help="states per ADI rollout of the `adi` leg (BASELINE configs[3]: 16 384 = 512 games x 32 moves)")
     ap.add_argument("--astar-problems", type=int, default=4096)
     ap.add_argument("--config5-trees", type=int, default=8192)
-    ap.add_argument("--config5-max-states", type=int, default=50000,
-                    help="per-tree cap of the config5 leg: 8 192 trees x 175 000 nodes x 285 B = 408 GB do not fit 288 GB of HBM; 50 000 = 117 GB")
+    ap.add_argument("--config5-max-states", type=int, default=175000,
+                    help="per-tree cap of the config5 leg = the reference's max_states: 8 192 x 175 001 node rows (408 GB) are reserved address "
+                         "space, memory is mapped behind the rows the trees reach (rounds 1-3 allocated up front and had to stop at 50 000)")
     ap.add_argument("--pool-factor", type=int, default=8, help="scrambles in the pool per tree slot")
     ap.add_argument("--prep-cap", type=int, default=4000, help="most untimed iterations before the timed window")
     ap.add_argument("--window-only", action="store_true", help="skip the pool's tail and the runs to completion")
@@ -879,7 +1020,7 @@ def main():
     leg_window_only = {x.split(":")[0]: x.endswith(":window") for x in args.legs.split(",") if x}
     assert legs and all(x in LEG_DTYPE for x in legs)
     extra = [] if args.extra_legs in ("", "none") else [x for x in args.extra_legs.split(",") if x]
-    assert all(x in ("astar", "config5") for x in extra)
+    assert all(x in ("astar", "config5", "adi") for x in extra)
 
     rank, world = int(os.environ.get("RANK", 0)), int(os.environ.get("WORLD_SIZE", 1))
     local_rank = int(os.environ.get("LOCAL_RANK", 0))
@@ -940,6 +1081,13 @@ def main():
             torch.cuda.empty_cache()
         del c_roots, c_pool
 
+    # ---- BASELINE configs[3]: data generation of an ADI rollout ---------------------------------------------------------------
+    adi = {}
+    if "adi" in extra:
+        for name in ("f32s", "bf16"):
+            adi[name] = adi_leg(name, model, args, world, coll_device)
+        torch.cuda.empty_cache()
+
     if rank != 0:
         if world > 1:
             dist.barrier()
@@ -953,6 +1101,8 @@ def main():
         "value_pool_run": (head.get("pool_run") or {}).get("nodes_per_sec"),
         "value_run_to_completion": rtc_of(head).get("nodes_per_sec"),
         "run_to_completion_seconds": rtc_of(head).get("seconds"),
+        "run_to_completion_seconds_incl_prepare": rtc_of(head).get("seconds_incl_prepare_rank0"),
+        "prepare_seconds": head.get("prepare_seconds_rank0"), "forest_gb": (head.get("forest_rank0") or {}).get("hbm_behind_the_forest_gb"),
         "solve_rate": rtc_of(head).get("solve_rate"), "solve_rate_ci95": rtc_of(head).get("ci95"),
         "mean_solution_length": rtc_of(head).get("mean_solution_length"),
         "result_flushes_in_window": head.get("result_flushes_in_window"),
@@ -970,11 +1120,18 @@ def main():
             summary[f"astar_{name}_solve_rate"] = leg["solve_run"]["solve_rate"]
         if "roofline" in leg:
             summary[f"astar_{name}_roofline_frac"] = leg["roofline"]["frac"]
+    for name, leg in adi.items():
+        summary[f"adi_{name}_states_per_sec"] = leg["value"]
+        summary[f"adi_{name}_ms_per_rollout"] = leg["ms_per_rollout"]
+        if "roofline" in leg:
+            summary[f"adi_{name}_roofline_frac"] = leg["roofline"]["frac"]
     for name, leg in config5.items():
+        summary["config5_share_max_states"] = args.config5_max_states
         summary[f"config5_share_{name}_value"] = leg["value"]
         if rtc_of(leg):
             summary[f"config5_share_{name}_run_to_completion"] = rtc_of(leg)["nodes_per_sec"]
             summary[f"config5_share_{name}_solve_rate"] = rtc_of(leg)["solve_rate"]
+            summary[f"config5_share_{name}_forest_gb"] = leg["forest_rank0"]["hbm_behind_the_forest_gb"]
     result = {
         "metric": "MCTS node expansions/sec, depth-20 scrambles", "value": head["value"],
         "unit": "node expansions/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -1003,9 +1160,12 @@ def main():
     if astar:
         result["astar"] = dict(astar, workload=f"BASELINE configs[2]: {args.astar_problems} depth-20 scrambles per GPU, AStar lambda=0.2 N=100, "
                                                f"max_states {args.solve_max_states}")
+    if adi:
+        result["adi"] = dict(adi, workload=f"BASELINE configs[3]: data generation of one ADI rollout, {args.adi_states} states ({args.adi_states // 32 // world} games x 32 moves "
+                                           f"per GPU) -> {12 * args.adi_states} substates, reward method lapanfix (reference train.py:257-339)")
     if config5:
         result["config5_share"] = dict(config5, workload=f"one GPU's share of BASELINE configs[4]: {args.config5_trees} concurrent depth-24 MCTS "
-                                                         f"trees, max_states {args.config5_max_states} (HBM: see --config5-max-states)")
+                                                         f"trees, max_states {args.config5_max_states}")
     for name in legs:
         if name in extras:
             phases, roofline, group, roofline_input, rows = extras[name]
@@ -1025,8 +1185,13 @@ def main():
         summary["multi_rotate_hbm_frac_2p24"] = mr["frac"]
     if astar and "roofline" in astar.get("f32s", {}):
         result["roofline"]["astar_dominant_kernel"] = {k: astar["f32s"]["roofline"][k] for k in ("kernel", "achieved", "peak", "frac", "ms_per_launch")}
+    if adi and "roofline" in adi.get("f32s", {}):
+        result["roofline"]["adi_dominant_kernel"] = {k: adi["f32s"]["roofline"][k] for k in ("kernel", "achieved", "peak", "frac", "ms_per_launch")}
+        result["roofline"]["adi_env"] = {k: adi["f32s"]["roofline_env"][k] for k in ("bound", "achieved", "peak", "frac", "algorithmic_bytes", "ms")}
     if not args.no_cpu_baseline and world == 1:
         result["cpu_baseline"] = cpu_baseline(model, args.depth)
+        if adi:
+            result["cpu_baseline"]["adi"] = cpu_adi(model)
     emit(result, args.detail)
     if world > 1:
         dist.barrier()

@@ -37,10 +37,7 @@ typedef __attribute__((address_space(3))) void lds_void;
 typedef const __attribute__((address_space(1))) void glb_void;
 
 constexpr int kGemmRowBytes = 128;   // one K-step: 64 halves per row
-#ifndef RC_GEMM_PPR
-#define RC_GEMM_PPR 2
-#endif
-constexpr int kPiecesPerRow = RC_GEMM_PPR;   // LDS-DMA pieces a wave issues behind the MFMAs of one 16-row fragment
+constexpr int kPiecesPerRow = 2;   // LDS-DMA pieces a wave issues behind the MFMAs of one 16-row fragment
 
 struct GemmArgs {
     const unsigned char *a;      // activations [M][2K] halves: hi | lo                       (kBf16: [M][K] bf16)

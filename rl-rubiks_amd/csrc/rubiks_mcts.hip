@@ -38,25 +38,9 @@ constexpr int kMaxPath = 4096;  // longest PUCT descent the kernels stage in LDS
 // only ever selects CANDIDATES for parallel validation, so a stale or aliased tag costs time, never correctness.
 constexpr u32 kRecLeaf = 1u << 16;
 constexpr u32 kNoAct = 15;
-// One-line re-validation, built, measured and left OFF.  The 16 spare bytes of line 0 behind the walk record cache
-// what re-deciding a level needs of line 1 in the common case: {P[best0], P[best1], max P of the other ten actions, -}, valid while
-// kRecCached is set in rec.z.  A level is then re-decided from line 0 alone with the other actions' P replaced by that upper
-// bound: if the float32 winner (same acceptance margins as lane_pick) is one of the recorded pair for every decision the level
-// needs, the true evaluation gives the same winners (scores are monotone in P), the neighbours come from the old record, and
-// line 1 is never read.  Anything else -- a third action in reach, a near tie, NaNs -- falls back to the two-line evaluation.
-// Measured in the steady-state pool (profiles/r3_select_one_line_ab.txt, tools/select_ab.sh): 76 % of the levels are settled
-// from line 0, HBM fetch per launch falls from 105 MB to 64 MB (41 MB without the up-front request of line 1), and the kernel
-// gets SLOWER, 81.9 -> 97.8 us: the re-validation is bound by its instruction stream (one wave per SIMD and tree, ~500 dependent
-// VALU instructions per level), not by HBM, and the levels that fall back evaluate twice.  Every exact-tree test passes with
-// it on (-DRC_SELECT_ONE_LINE=1).
-#ifndef RC_SELECT_ONE_LINE
-#define RC_SELECT_ONE_LINE 0
-#endif
-constexpr bool kOneLine = RC_SELECT_ONE_LINE != 0;
-#ifndef RC_SELECT_PF_LINE1
-#define RC_SELECT_PF_LINE1 1   // request line 1 of every level up front as well (0: only line 0; levels that fall back pay the miss)
-#endif
-constexpr u32 kRecCached = 1u << 17;
+// (Round 3 built a "one-line" re-validation -- P[best0], P[best1] and the largest other P cached in the spare 16 bytes of line 0,
+// 76 % of the levels re-decided without reading line 1, HBM fetch per launch 105 -> 64 MB -- and measured it SLOWER, 81.9 -> 97.8 us:
+// the pass is bound by its instruction stream, not by HBM.  The code is gone; the measurement is profiles/r3_select_one_line_ab.txt.)
 
 // Life of a tree slot.  A planted root is evaluated and expanded inside the ordinary lock-step iterations, on the 11 network
 // rows every tree owns, in two steps (the root's expansion creates 12 new children, one more than the rows of a step):
@@ -619,10 +603,6 @@ __global__ __launch_bounds__(NT) void k_mcts_select(rc_mcts_t m, double c, u32 l
     u32 *s_scratch = s_pool, *s_unc = s_pool + 384, *s_late = s_pool + 512;
     __shared__ int s_nlate, s_nunc;
     __shared__ int s_mb[64];                // LW > 1: mailbox between the walking wave and its helpers
-#ifdef RC_SELECT_FASTSTATS
-    __shared__ int s_fast_ok, s_fast_no;
-    if (threadIdx.x == 0) s_fast_ok = s_fast_no = 0;
-#endif
     constexpr int kLateCap = 640, kUncCap = 128;
     const u32 unc_cap = min(m.unc_list_cap, (u32)kUncCap);   // tests lower it to reach the bitmap form of pass B with few flagged levels
     u16 *s_latelist = reinterpret_cast<u16 *>(s_scratch), *s_unclist = s_latelist + kLateCap;
@@ -682,7 +662,7 @@ __global__ __launch_bounds__(NT) void k_mcts_select(rc_mcts_t m, double c, u32 l
         const int k = (int)tid + i * NT;
         const u32 *rp = reinterpret_cast<const u32 *>(m.N) + (base + (size_t)(k < plen_old ? pnode[k] : 0)) * kRow;
         pf[2 * i] = rp[0];
-        pf[2 * i + 1] = (kOneLine && RC_SELECT_PF_LINE1 == 0) ? 0u : rp[kRow / 2];
+        pf[2 * i + 1] = rp[kRow / 2];
     }
     const u32 row = tid >> 4, rl = tid & 15;
     const bool ract = rl < kA;
@@ -739,8 +719,6 @@ __global__ __launch_bounds__(NT) void k_mcts_select(rc_mcts_t m, double c, u32 l
             u32 n[kA], p[kA], w[kA];
             load_row12(m.N, r, n);
             load_row12(m.W, r, w);
-            const uint4 orec = kOneLine ? rec[(size_t)node * kRowRec] : make_uint4(0, 0, 0, 0);
-            const uint4 ocache = kOneLine ? rec[(size_t)node * kRowRec + 1] : make_uint4(0, 0, 0, 0);   // same cache line as N, W, rec
             if (MODE > 0 && backup && !late && taken) {   // N[path, a] += 1 (once per pair), W[path, a] = max(W, best)  (agents.py:562,568)
 #pragma unroll
                 for (int a = 0; a < kA; ++a)
@@ -754,60 +732,15 @@ __global__ __launch_bounds__(NT) void k_mcts_select(rc_mcts_t m, double c, u32 l
             if (dup && arr >= 0) cnt5_add(cnt5, ovf, (u32)arr);
             bool c0 = false, c1 = false, c2 = true;
             int b0 = 0, b1 = 0, d = 0;
-            u32 nb0 = 0, nb1 = 0;
-            uint4 cache = ocache;
-            bool fast = false;
-            if (kOneLine && (orec.z & kRecCached) && !ovf) {
-                const u32 ob0 = orec.z & 15u, ob1 = (orec.z >> 8) & 15u;
-#pragma unroll
-                for (int a = 0; a < kA; ++a) p[a] = (u32)a == ob0 ? ocache.x : (u32)a == ob1 ? ocache.y : ocache.z;
-                const LaneEval eb = lane_eval(c32v, n, p, w);
-                lane_pick2(eb, b0, c0, b1, c1);
-                d = (arr == b0) ? b1 : b0;
-                if (dup) d = lane_pick(eb, cnt5, c2);
-                const u32 pair = (1u << ob0) | (1u << ob1);
-                fast = c0 && c1 && c2 && ((pair >> b0) & 1u) && ((pair >> b1) & 1u) && ((pair >> d) & 1u) && b0 != b1;
-                if (fast) {
-                    nb0 = (u32)b0 == ob0 ? orec.x : orec.y;
-                    nb1 = (u32)b1 == ob0 ? orec.x : orec.y;
-                    cache = make_uint4((u32)b0 == ob0 ? ocache.x : ocache.y, (u32)b1 == ob0 ? ocache.x : ocache.y, ocache.z, 0);
-                }
-            }
-#ifdef RC_SELECT_FASTSTATS
-            if (kOneLine) atomicAdd(fast ? &s_fast_ok : &s_fast_no, 1);
-#endif
-            bool cacheable = fast;
-            if (!fast) {
-                load_row12(m.P, r, p);
-                const LaneEval e = lane_eval(c32v, n, p, w);
-                c2 = true;
-                lane_pick2(e, b0, c0, b1, c1);
-                d = (arr == b0) ? b1 : b0;
-                if (dup) d = lane_pick(e, cnt5, c2);
-                if (kOneLine) {   // what the next re-validation of this node may decide from line 0 alone
-                    float pm = 0.f, p0 = 0.f, p1 = 0.f;
-                    bool finite = true;
-#pragma unroll
-                    for (int a = 0; a < kA; ++a) {
-                        const float pa = __uint_as_float(p[a]);
-                        finite &= pa == pa && pa >= 0.f && pa < INFINITY;
-                        if (a == b0) p0 = pa;
-                        else if (a == b1) p1 = pa;
-                        else pm = fmaxf(pm, pa);
-                    }
-                    cacheable = finite && b0 != b1;
-                    cache = make_uint4(__float_as_uint(p0), __float_as_uint(p1), __float_as_uint(pm), 0);
-                }
-            }
+            load_row12(m.P, r, p);
+            const LaneEval e = lane_eval(c32v, n, p, w);
+            lane_pick2(e, b0, c0, b1, c1);
+            d = (arr == b0) ? b1 : b0;
+            if (dup) d = lane_pick(e, cnt5, c2);
             if (c0 && c1 && c2 && !ovf) {
-                if (!fast) {
-                    nb0 = (u32)m.nbr[r + b0];
-                    nb1 = (u32)m.nbr[r + b1];
-                }
-                rec[(size_t)node * kRowRec] = make_uint4(nb0, nb1, (u32)b0 | ((u32)b1 << 8) | (kOneLine && cacheable ? kRecCached : 0u),   // the old path is line seq - 1
+                const u32 nb0 = (u32)m.nbr[r + b0], nb1 = (u32)m.nbr[r + b1];
+                rec[(size_t)node * kRowRec] = make_uint4(nb0, nb1, (u32)b0 | ((u32)b1 << 8),   // the old path is line seq - 1
                                        line_tag((seq - 1) & 0xFFFFu, k, k < nlev ? (u32)s_act[k] : kNoAct));
-                if (kOneLine && cacheable && !fast) rec[(size_t)node * kRowRec + 1] = cache;
-                else if (kOneLine && fast && (cache.x != ocache.x)) rec[(size_t)node * kRowRec + 1] = cache;
                 if (k < nlev && d != (int)s_act[k]) atomicMin(&s_first, k);
             } else {
                 const int pos = atomicAdd(&s_nunc, 1);

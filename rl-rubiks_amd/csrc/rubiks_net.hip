@@ -482,7 +482,7 @@ extern "C" int rc_act_bf16_inplace(uint16_t *x, size_t n, int activation, float 
 //   hi_a hi_b + 2^-11 (hi_a lo_b + lo_a hi_b) + O(2^-22),
 // three f16 MFMA products accumulated in fp32 (each f16 x f16 product is exact in fp32).  Measured against float64 on
 // the hidden layer's shape, the result is CLOSER than the fp32 MFMA GEMM (mean |error| 4.0e-7 vs 1.1e-6 at |y| ~ 1)
-// at 2.8 x its speed (tools/split_gemm_probe.py).  The two kernels here produce the operands: the split one-hot
+// at 2.8 x its speed (round 2 probe).  The two kernels here produce the operands: the split one-hot
 // input and the bias + activation + re-split between two layers.
 constexpr u32 kHalfOne = 0x3C00u, kHalfScaleInv = 0x1000u;   // 1.0 and 2^-11 as IEEE half
 
@@ -681,23 +681,8 @@ __global__ __launch_bounds__(kBlock) void k_head_split(const float4 *__restrict_
 // (the 128-column kernel is bound by its LDS reads, not by the matrix cores); (3) the epilogue re-splits into halves.
 // It replaces rc_oh_split_f16 + the K = 960 library GEMM + rc_split_act_f16 of the input layer.
 // =================================================================================================
-#ifdef RC_FL_STAMPS
-__device__ unsigned long long g_fl_stamps[8];   // measurement builds only: cycles per stage, summed over all waves
-#define FL_STAMP(i) do { const long long now_ = clock64(); if (lane == 0) atomicAdd(&g_fl_stamps[i], (unsigned long long)(now_ - t_prev)); t_prev = now_; } while (0)
-#else
-#define FL_STAMP(i) do { } while (0)
-#endif
 constexpr int kSpCols = 64;
-#ifndef RC_FL_SUB
-#define RC_FL_SUB 2
-#endif
-#ifndef RC_FL_AFRAG_REG
-#define RC_FL_AFRAG_REG 0   // 1: one-hot A fragments built in registers instead of read from a 9-entry LDS table
-#endif
-#ifndef RC_FL_PINGPONG
-#define RC_FL_PINGPONG 0   // 1: the two waves of a SIMD alternate between the matrix stage and the epilogue (below; measured slower)
-#endif
-constexpr int kSpSub = RC_FL_SUB;   // 32-state tiles a wave holds at once (they share every B fragment read from LDS)
+constexpr int kSpSub = 2;   // 32-state tiles a wave holds at once (they share every B fragment read from LDS); 3 / 4 measured slower
 
 
 // SPLIT = false: the same kernel as the bf16 engine's input layer (one table, W1 in IEEE half; bf16 output [n][H]).
@@ -757,19 +742,13 @@ __global__ __launch_bounds__(kMfWaves * kWave) void k_first_layer_split(const u8
     constexpr size_t kStep = (size_t)kMfWaves * kSpSub * kMfTile;
     // A pass of a wave = [60 k-steps of MFMAs] then [epilogue: ELU + re-split of 64 values per lane, ~1 600 VALU instructions].
     // PMC (profiles/r3_first_layer_split_pmc.txt): the matrix pipe is busy 40 % of the cycles, 9 VALU instructions per MFMA,
-    // LDS wait negligible.  RC_FL_PINGPONG=1 makes the two waves of a SIMD (w and w + 4) alternate between the two stages
-    // (the upper four enter one barrier late, stages separated by barriers, every wave runs the same number of passes so the
-    // barrier counts match): measured SLOWER, 135 against 119 us per call in tools/first_layer_split_bench.py
-    // (profiles/r3_first_layer_variants.txt), like 3 or 4 state tiles per wave (132 / 149 us).  Off.
-    const bool late_row = wave >= kMfWaves / 2;
+    // LDS wait negligible.  Measured and dropped in round 3 (profiles/r3_first_layer_variants.txt): the two waves of a SIMD
+    // alternating between the two stages by barriers (135 against 119 us per call), 3 or 4 state tiles per wave (132 / 149 us),
+    // the one-hot fragment built in registers instead of read from LDS (+ 43 %).
     const u32 n_pass = (u32)((row_hi - row_lo + kStep - 1) / kStep);
-    if (RC_FL_PINGPONG && late_row) __builtin_amdgcn_s_barrier();
     for (u32 pass = 0; pass < n_pass; ++pass) {
         const size_t t0 = row_lo + (size_t)pass * kStep + (size_t)wave * kSpSub * kMfTile;
-        if (!RC_FL_PINGPONG && t0 >= row_hi) break;
-#ifdef RC_FL_STAMPS
-        long long t_prev = clock64();
-#endif
+        if (t0 >= row_hi) break;
         u32 pk[kSpSub][5];
 #pragma unroll
         for (int u = 0; u < kSpSub; ++u) {
@@ -783,7 +762,6 @@ __global__ __launch_bounds__(kMfWaves * kWave) void k_first_layer_split(const u8
                 pk[u][q] = (raw[4 * q] & 31u) | (raw[4 * q + 1] & 31u) << 8 | (raw[4 * q + 2] & 31u) << 16 | (raw[4 * q + 3] & 31u) << 24;
         }
         auto code = [&](int u, int j) -> u32 { return (pk[u][j >> 2] >> (8 * (j & 3))) & 0xffu; };
-        FL_STAMP(0);   // cube codes loaded and packed
         f32x16 acc[kSpSub][2];
 #pragma unroll
         for (int u = 0; u < kSpSub; ++u)
@@ -795,22 +773,13 @@ __global__ __launch_bounds__(kMfWaves * kWave) void k_first_layer_split(const u8
         // NOT unrolled: unrolling all 60 steps overflows the 256 registers a wave has at two waves per SIMD)
 #pragma unroll 1
         for (int tbl = 0; tbl < kTables; ++tbl) {
-            const uint4 *frag = onehot + 9 * tbl;   // (building the fragment in registers instead was measured: 43 % slower)
+            const uint4 *frag = onehot + 9 * tbl;
             const unsigned char *bbase = wslice + ((size_t)tbl * kSpCols + r) * kMfPitch + 16 * h;   // + c * 32 * pitch + 32 * ks
             auto a_frag = [&](int u, int ks) -> uint4 {
                 const int m2 = ks / 3, ph = ks % 3;
                 const u32 pos = ph == 0 ? code(u, 2 * m2) - off_a : ph == 1 ? (h ? code(u, 2 * m2 + 1) : code(u, 2 * m2) - 16u)
                                                                              : code(u, 2 * m2 + 1) - off_c;
-#if RC_FL_AFRAG_REG
-                // the fragment in registers: 1.0 (or 2^-11) as a half at position pos of eight, zero when pos > 7 -- a 64-bit
-                // shift and two selects instead of a 1 KiB-per-wave LDS read (the loop reads 4 KiB of LDS per 4 MFMAs: as much as
-                // the CU's LDS delivers in the time the matrix pipe needs for them)
-                const unsigned long long v = (unsigned long long)(tbl ? kHalfScaleInv : kHalfOne) << ((pos & 3u) << 4);
-                const unsigned long long lo = pos < 4u ? v : 0ull, hi = (pos - 4u) < 4u ? v : 0ull;
-                return make_uint4((u32)lo, (u32)(lo >> 32), (u32)hi, (u32)(hi >> 32));
-#else
                 return frag[min(pos, 8u)];
-#endif
             };
             uint4 a_cur[kSpSub], b_cur[2];
 #pragma unroll
@@ -844,15 +813,6 @@ __global__ __launch_bounds__(kMfWaves * kWave) void k_first_layer_split(const u8
         }
         // epilogue: activation, then the lane's columns 2 r, 2 r + 1 of one state as one 4-byte store: bf16 pair, or -- split --
         // the pair of hi halves and the pair of lo halves into the [hi | lo] row of the state (row pitch 2 H halves)
-        if (RC_FL_PINGPONG) {
-            __builtin_amdgcn_sched_barrier(0);
-            __builtin_amdgcn_s_barrier();
-            __builtin_amdgcn_sched_barrier(0);
-        }
-#ifdef RC_FL_STAMPS
-        asm volatile("s_nop 0" :: "v"(acc[0][0][0]), "v"(acc[kSpSub - 1][1][15]));   // the accumulators are complete here
-#endif
-        FL_STAMP(1);   // matrix stage
 #pragma unroll
         for (int u = 0; u < kSpSub; ++u)
 #pragma unroll
@@ -871,11 +831,7 @@ __global__ __launch_bounds__(kMfWaves * kWave) void k_first_layer_split(const u8
                         y[c] = act_apply(x, ACT, alpha);
                     }
                 }
-#ifdef RC_FL_FEWER_STORES   // experiment only (wrong results): every RC_FL_FEWER_STORES-th store is issued
-                if (row < n && row < row_hi && (i % RC_FL_FEWER_STORES) == 0) {
-#else
                 if (row < n && row < row_hi) {
-#endif
                     if (SPLIT) {
                         u32 *orow = out + row * H;   // 2 H halves = H dwords per row
                         orow[(ct * kSpCols) / 2 + r] = pack_half2(hi[0], hi[1]);
@@ -885,14 +841,7 @@ __global__ __launch_bounds__(kMfWaves * kWave) void k_first_layer_split(const u8
                     }
                 }
             }
-        FL_STAMP(2);   // epilogue issued (stores in flight)
-        if (RC_FL_PINGPONG) {
-            __builtin_amdgcn_sched_barrier(0);
-            __builtin_amdgcn_s_barrier();
-            __builtin_amdgcn_sched_barrier(0);
-        }
     }
-    if (RC_FL_PINGPONG && !late_row) __builtin_amdgcn_s_barrier();
     if (SPLIT && range_flag && out_of_range) atomicOr(range_flag, 1);
 }
 
@@ -1104,13 +1053,3 @@ extern "C" int rc_first_layer_bf16(const int8_t *soa, size_t n, size_t stride, c
     return launch_status();
 }
 
-#ifdef RC_FL_STAMPS
-extern "C" int rc_debug_fl_stamps(unsigned long long *out8, int reset) {   // measurement builds only (not in include/rubiks_hip.h)
-    hipError_t e = hipMemcpyFromSymbol(out8, HIP_SYMBOL(g_fl_stamps), sizeof(unsigned long long) * 8);
-    if (e == hipSuccess && reset) {
-        unsigned long long z[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-        e = hipMemcpyToSymbol(HIP_SYMBOL(g_fl_stamps), z, sizeof(z));
-    }
-    return hip_rc(e);
-}
-#endif

@@ -28,7 +28,7 @@ struct Range {
 std::mutex g_mu;
 std::unordered_map<void *, Range> g_ranges;
 
-// One allocation per chunk.  Measured on MI355X / ROCm 7.2 (tools/vmm_raw_probe.py, profiles/r4_vmm_probe.txt): hipMemSetAccess
+// One allocation per chunk.  Measured on MI355X / ROCm 7.2 (profiles/r4_vmm_raw_probe.txt, profiles/r4_vmm_probe.txt): hipMemSetAccess
 // returns hipErrorInvalidValue for a piece whose virtual address is not aligned to the piece's own size (2 MiB pieces anywhere in
 // a 2 MiB-aligned reservation work, a 64 MiB piece at a 16 MiB-aligned address does not), so the range is reserved with the chunk
 // size as its alignment and every chunk is created, mapped and made accessible by itself: ~10 us per chunk.

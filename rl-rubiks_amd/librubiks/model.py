@@ -412,7 +412,7 @@ class InferenceNet:
             if (act is not None and self.fused_hidden and x.dtype == torch.bfloat16 and x.is_cuda and x.is_contiguous()
                     and W.shape[1] % 64 == 0 and W.shape[0] % 256 == 0 and -(-x.shape[0] // 352) * (W.shape[0] // 256) >= 192):
                 # 352 x 256 tiles on >= 3/4 of the CUs: measured 0.186 ms against 0.200 ms for hipBLASLt + the activation pass at
-                # 11 264 x 4096 x 2048 (tools/bf16_gemm_fused_probe.py); layers without activation and narrow ones stay with the library
+                # 11 264 x 4096 x 2048 (round 3 probe); layers without activation and narrow ones stay with the library
                 if getattr(b, "_f32", None) is None:
                     b._f32 = b.float().contiguous()
                 out = torch.empty((x.shape[0], W.shape[0]), dtype=torch.bfloat16, device=x.device)

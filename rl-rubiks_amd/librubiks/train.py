@@ -18,7 +18,7 @@ import torch.distributed as dist
 
 from librubiks import _hip, cube, gpu, no_grad
 from librubiks.cube.device import DeviceCubes
-from librubiks.model import InferenceNet, Model
+from librubiks.model import Model, make_inference_net, net_fingerprint
 from librubiks.utils import NullLogger, TickTock
 
 _FIX = {"paper": 0, "reward0": 0, "lapanfix": 1, "schultzfix": 2}
@@ -176,8 +176,7 @@ class Train:
         kid_solved = kids.is_solved().view(torch.uint8)
         state_solved = states.is_solved().view(torch.uint8)
         values = torch.empty(12 * n, dtype=torch.float32, device=states.soa.device)
-        engine = InferenceNet(net, self.adi_net_dtype) if isinstance(net, Model) and \
-            net.config.architecture.startswith("fc") and self.adi_net_dtype != torch.float32 else None
+        engine = self._adi_engine(net)
         for lo in range(0, 12 * n, self.adi_chunk):   # chunked like the reference's adi_ff_batches (train.py:301-310)
             m = min(self.adi_chunk, 12 * n - lo)
             if engine is not None and engine.supports_cubes and lo % 16 == 0:
@@ -199,6 +198,20 @@ class Train:
         loss_weights = ((1 - alpha) * weighted / ws + alpha * np.ones_like(weighted) / us) * (ws + us)
         return states.as_oh(torch.float32), policy_targets, value_targets, \
             torch.from_numpy(loss_weights).float().to(values.device)
+
+    _engine_cache = None
+
+    def _adi_engine(self, net):
+        """The value network of the data generation: the torch module itself in fp32 (`adi_net_dtype=torch.float32`, the
+        reference's arithmetic and the default), or one of the inference engines -- F32_SPLIT: fp32 accuracy on the f16 matrix
+        cores, torch.bfloat16: the fast engine -- straight from the device-resident substates (no one-hot matrix).  Rebuilt when
+        the generator's weights change (`net_fingerprint`)."""
+        if self.adi_net_dtype == torch.float32 or not (isinstance(net, Model) and net.config.architecture.startswith("fc")):
+            return None
+        fp = net_fingerprint(net, self.adi_net_dtype)
+        if self._engine_cache is None or self._engine_cache[0] != fp:
+            self._engine_cache = (fp, make_inference_net(net, self.adi_net_dtype))
+        return self._engine_cache[1]
 
     # ---- training loop (train.py:111-255) ----------------------------------------------------------
     def _shard_over_ranks(self):

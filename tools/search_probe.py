@@ -1,0 +1,156 @@
+"""
+MCTS search probes on one MI355X with the trained weights (the programs profiles are taken of, and same-box A/B runs):
+
+  solve  [--dtype f32s|bf16] [--max-states N] [--trees B] [--out file.json]
+         BASELINE configs[1] to completion: warm-up search, one search with the trajectory (iteration, launch size, running trees,
+         wall time) logged at the agent's sync points, the same search again (every graph cached).  Under
+         `rocprofv3 --kernel-trace --output-format csv` this is the trace `tools/rocprof_summary.py timeline` reads.
+  window [bf16|f32s] [K]
+         the steady-state pool (8 192 scrambles on 1 024 slots): 12 consecutive timed windows of K steps with the refills in each;
+         the program for PMC passes on the tree kernel in a full forest.
+  rtc    [f32s|bf16] [reps]
+         configs[1] to completion `reps` times (prepared forest, 30 warm-up iterations): seconds per run, best M nodes/s.
+  ab     <owner.attribute> <value_a> <value_b>
+         same-box A/B of a module / class attribute (e.g. mcts_device.RUNG_RATIO 0.9 0.95, model.SplitF32Net.small_batch_cut 1 0,
+         agents.MCTS.sync_every via `sync_every 16 32`): variants alternate a, b, a, b in one process; per variant configs[1] to
+         completion three times and a 4 096-game pool.
+"""
+import argparse
+import importlib
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path[:0] = [ROOT, os.path.join(ROOT, "rl-rubiks_amd")]
+from librubiks import cube  # noqa: E402
+from librubiks.model import F32_SPLIT, Model  # noqa: E402
+from librubiks.solving import mcts_device as md  # noqa: E402
+from librubiks.solving.agents import MCTS  # noqa: E402
+
+WEIGHTS = os.path.join(ROOT, "weights", "fc_small_r1")
+DT = {"bf16": torch.bfloat16, "f32s": F32_SPLIT}
+
+
+def _timed(fn):
+    torch.cuda.synchronize()
+    t = time.perf_counter()
+    r = fn()
+    torch.cuda.synchronize()
+    return r, time.perf_counter() - t
+
+
+def solve(argv):
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--out", default=os.path.join(ROOT, "gpurun_out", "solve_run.json"))
+    ap.add_argument("--trees", type=int, default=1024)
+    ap.add_argument("--max-states", type=int, default=175000)
+    ap.add_argument("--dtype", default="f32s", choices=list(DT))
+    args = ap.parse_args(argv)
+    np.random.seed(0)
+    cubes, _, _ = cube.scramble_batch(args.trees, 20, True)
+    agent = MCTS(Model.load(WEIGHTS).eval(), c=0.6, search_graph=True, net_dtype=DT[args.dtype])
+    _, prep = _timed(lambda: agent.prepare(args.trees, args.max_states))
+    agent.search_batch(cubes, None, args.max_states, max_iterations=30)
+    log, state, orig = [], {"it": 0, "t0": None}, md.MCTSForest.step
+
+    def step(self, *a, **k):
+        r = orig(self, *a, **k)
+        state["it"] += 1
+        if state["it"] % agent.sync_every == 0:
+            torch.cuda.synchronize()
+            log.append((state["it"], self.G, int((self.status == md.RUNNING).sum().item()), round(time.perf_counter() - state["t0"], 4)))
+        return r
+
+    md.MCTSForest.step = step
+    state["t0"] = time.perf_counter()
+    res, total = _timed(lambda: agent.search_batch(cubes, None, args.max_states))
+    md.MCTSForest.step = orig
+    res2, again = _timed(lambda: agent.search_batch(cubes, None, args.max_states))
+    out = {"dtype": args.dtype, "prepare_seconds": prep, "seconds_logged_run": total, "solved": float(res.solved.mean()), "nodes": int(res.nodes.sum()),
+           "iterations_max": int(res.iterations.max()), "second_run_seconds": again, "second_run_nodes_per_sec": float(res2.nodes.sum()) / again,
+           "second_run_same_results": bool(np.array_equal(res.nodes, res2.nodes) and np.array_equal(res.lengths, res2.lengths)),
+           "forest_gb": round(agent.forest.bytes_allocated() / 1e9, 2), "forest_mapped_on_demand": agent.forest.vmm,
+           "stats": dict(agent.refill_stats), "trajectory_it_G_running_t": log[:: max(1, len(log) // 60)] + log[-1:]}
+    print(json.dumps({k: v for k, v in out.items() if k != "trajectory_it_G_running_t"}), flush=True)
+    with open(args.out, "w") as f:
+        json.dump(out, f, indent=1)
+
+
+def window(argv):
+    dt, K = DT[argv[0] if argv else "bf16"], int(argv[1]) if len(argv) > 1 else 20
+    np.random.seed(0)
+    cubes, _, _ = cube.scramble_batch(8192, 20, True)
+    agent = MCTS(Model.load(WEIGHTS).eval(), c=0.6, search_graph=True, net_dtype=dt)
+    run = agent.start_batch(cubes, None, 175000, slots=1024)
+    while run.next_game < 2048 + 128:
+        run.round()
+    for w in range(12):
+        torch.cuda.synchronize()
+        r0, n0 = run.stats["refills"], run.nodes_now()
+        torch.cuda.synchronize()
+        t, left = time.perf_counter(), K
+        while left > 0:
+            b = run.it
+            run.round(left)
+            left -= run.it - b
+        torch.cuda.synchronize()
+        dtm = time.perf_counter() - t
+        print(f"window {w}: {dtm / K * 1e3:.4f} ms/step, {(run.nodes_now() - n0) / dtm / 1e6:.2f} M/s, refills {run.stats['refills'] - r0}", flush=True)
+
+
+def rtc(argv):
+    name, reps = (argv[0] if argv else "f32s"), int(argv[1]) if len(argv) > 1 else 3
+    np.random.seed(0)
+    cubes, _, _ = cube.scramble_batch(1024, 20, True)
+    agent = MCTS(Model.load(WEIGHTS).eval(), c=0.6, search_graph=True, net_dtype=DT[name])
+    _, prep = _timed(lambda: agent.prepare(1024, 175000))
+    agent.search_batch(cubes, None, 175000, max_iterations=30)
+    secs = []
+    for _ in range(reps):
+        res, s = _timed(lambda: agent.search_batch(cubes, None, 175000))
+        secs.append(s)
+    print(f"{name}: prepare {prep:.3f} s; seconds {[round(x, 3) for x in secs]}, {res.nodes.sum() / min(secs) / 1e6:.2f} M nodes/s best, iterations "
+          f"{int(res.iterations.max())}, solved {res.solved.mean():.3f}, forest {agent.forest.bytes_allocated() / 1e9:.1f} GB "
+          f"({'mapped on demand' if agent.forest.vmm else 'allocated up front'}), env {dict((k, v) for k, v in os.environ.items() if k.startswith('RUBIKS_'))}")
+
+
+def ab(argv):
+    attr, vals = argv[0], [float(v) if "." in v else int(v) for v in argv[1:3]]
+    CAP = 175000
+    np.random.seed(0)
+    batch, _, _ = cube.scramble_batch(1024, 20, True)
+    pool, _, _ = cube.scramble_batch(4096, 20, True)
+    model = Model.load(WEIGHTS).eval()
+    owner = None
+    if "." in attr:
+        path, attr = attr.rsplit(".", 1)
+        mod, _, cls = path.partition(".")
+        owner = importlib.import_module("librubiks." + ("solving." if mod in ("mcts_device", "agents", "astar_device") else "") + mod)
+        owner = getattr(owner, cls) if cls else owner
+    for name, v in ((f"{attr}={vals[0]}", vals[0]), (f"{attr}={vals[1]}", vals[1]), (f"{attr}={vals[0]} again", vals[0]), (f"{attr}={vals[1]} again", vals[1])):
+        if owner is None:
+            agent = MCTS(model, c=0.6, search_graph=True, **{attr: int(v)})      # a constructor argument of the agent
+        else:
+            setattr(owner, attr, type(getattr(owner, attr))(v))
+            agent = MCTS(model, c=0.6, search_graph=True)
+        agent.prepare(1024, CAP)
+        agent.search_batch(batch, None, CAP)
+        runs = []
+        for _ in range(3):
+            r, s = _timed(lambda: agent.search_batch(batch, None, CAP))
+            runs.append(s)
+        rp, tp = _timed(lambda: agent.search_batch(pool, None, CAP, slots=1024))
+        print(name, json.dumps({"batch_seconds": [round(x, 4) for x in runs], "batch_nodes_per_sec": round(float(r.nodes.sum()) / min(runs)),
+                                "solved": float(r.solved.mean()), "nodes": int(r.nodes.sum()), "pool_seconds": round(tp, 4),
+                                "pool_nodes_per_sec": round(float(rp.nodes.sum()) / tp)}), flush=True)
+        del agent
+        torch.cuda.empty_cache()
+
+
+if __name__ == "__main__":
+    {"solve": solve, "window": window, "rtc": rtc, "ab": ab}[sys.argv[1]](sys.argv[2:])
