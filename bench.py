@@ -61,6 +61,16 @@ GEMM_PMC_FILE = "r3_split_gemm_traffic.json"   # the hidden-layer kernel that ru
 PMC_SOURCE = f"stored PMC figure: profiles/{PMC_FILE} (separate rocprofv3 --pmc passes of these launches, not this run)"
 
 
+_T0 = time.perf_counter()
+
+
+def progress(what):
+    """One short line per finished leg on stderr: where a run was when something went wrong, and a sign of life for the box's
+    silence watchdog.  (The final stdout line stays the last thing printed.)"""
+    free, total = torch.cuda.mem_get_info()
+    print(f"[bench {time.perf_counter() - _T0:6.1f} s] {what}; HBM in use {(total - free) / 1e9:.0f} GB", file=sys.stderr, flush=True)
+
+
 def event_ms(fn, reps, warm=2):
     for _ in range(warm):
         fn()
@@ -1055,6 +1065,8 @@ def main():
         leg, engine, agent = run_leg(name, model, pool_roots, config_roots, args, world, coll_device, args.trees, args.solve_max_states,
                                      window_only=args.window_only or leg_window_only[name], full_warm=False)
         results[name] = leg
+        if rank == 0:
+            progress(f"mcts leg {name} done")
         if rank == 0 and args.phase_reps:
             extras[name] = step_rooflines(engine, agent, config_roots, args, name)
         del engine, agent
@@ -1067,6 +1079,8 @@ def main():
         a_roots, _ = draw_scrambles(args.astar_problems, args.astar_problems, 20, slice_rank, slice_world)
         for name in ("f32s", "bf16"):
             astar[name] = astar_leg(name, model, a_roots, args, world, coll_device)
+            if rank == 0:
+                progress(f"astar leg {name} done")
         del a_roots
     # ---- one GPU's share of BASELINE configs[4]: 8 192 concurrent depth-24 trees -------------------------------------------
     config5 = {}
@@ -1077,6 +1091,8 @@ def main():
                                          full_warm=False)
             leg.pop("pool_run", None)   # the pool only feeds the window here (3 x 8 192 scrambles), its total is not a result
             config5[name] = leg
+            if rank == 0:
+                progress(f"config5 leg {name} done")
             del engine, agent
             torch.cuda.empty_cache()
         del c_roots, c_pool
@@ -1086,6 +1102,8 @@ def main():
     if "adi" in extra:
         for name in ("f32s", "bf16"):
             adi[name] = adi_leg(name, model, args, world, coll_device)
+            if rank == 0:
+                progress(f"adi leg {name} done")
         torch.cuda.empty_cache()
 
     if rank != 0:
