@@ -12,6 +12,7 @@ Large forests reserve ADDRESS SPACE for capacity + 1 rows per tree and map memor
 1 024 x 175 000 x 285 B = 51 GB, and 8 192 trees at that cap (408 GB of rows) fit the 288 GB of HBM3E.
 """
 import ctypes
+import os
 from ctypes import POINTER, Structure, c_double, c_int, c_size_t, c_uint32, c_void_p
 
 import numpy as np
@@ -96,7 +97,9 @@ def rungs(n_trees: int) -> list:
 
 
 class MCTSForest:
-    VMM_MIN_BYTES = 1 << 30   # node records of at least this many bytes: the per-node arrays are mapped on demand (None: never)
+    # node records of at least this many bytes: the per-node arrays are mapped on demand (None: never).  RUBIKS_VMM_MIN_GB
+    # overrides it for a process (0 = every forest, "never" = none): A/B runs and diagnosis.
+    VMM_MIN_BYTES = (lambda v: 1 << 30 if v is None else None if v == "never" else int(float(v) * (1 << 30)))(os.environ.get("RUBIKS_VMM_MIN_GB"))
     GROW_ROWS = 8192          # rows a tree's mapping grows by (8 192 node records = one 2 MiB chunk)
 
     def __init__(self, n_trees: int, capacity: int, max_path: int = 4096, device=None, _results_only: bool = False, vmm: bool = None):
