@@ -530,10 +530,23 @@ class MCTSRun:
         forest, agent = self.forest, self.agent
         self._snapshot(idx_np)
         games = self.owner[idx_np].copy()
-        keep_tree = agent._tree_src is None and (games == 0).any()   # game 0's tree stays inspectable (the reference's attributes)
-        if not keep_tree and len(idx_np) < self.GRAVE // 2:
+        if agent._tree_src is None and (games == 0).any():
+            # game 0's tree stays inspectable (the reference's attributes): a search forest of its own, with this one tree
+            first = idx_np[games == 0][:1]
+            one = forest.subset(first, results_only=False)
+            ev = torch.cuda.Event()
+            ev.record()
+            with torch.cuda.stream(self.side):
+                self.side.wait_event(ev)
+                self.harvests.append(_Harvest(agent, one, np.zeros(1, dtype=np.int64)))
+            agent._tree_src = (one, 0)
+            idx_np, games = idx_np[games != 0], games[games != 0]
+            if len(idx_np) == 0:
+                self.stats["harvests"] += 1
+                return
+        if len(idx_np) < self.GRAVE // 2:
             if self.grave is None:
-                self.grave = md.MCTSForest(self.GRAVE, forest.C, forest.max_path, forest.device, _results_only=True, vmm=forest.vmm)
+                self.grave = md.MCTSForest(self.GRAVE, forest.C, forest.max_path, forest.device, _results_only=True, vmm=False)
                 self.grave_games = np.zeros(self.GRAVE, dtype=np.int64)
             if self.grave_fill + len(idx_np) > self.GRAVE:
                 self._flush_grave()
@@ -545,14 +558,12 @@ class MCTSRun:
             self.grave_fill += len(idx_np)
             self.stats["harvests"] += 1
             return
-        sub = forest.subset(idx_np, results_only=not keep_tree)
+        sub = forest.subset(idx_np, results_only=True)
         ev = torch.cuda.Event()
         ev.record()
         with torch.cuda.stream(self.side):
             self.side.wait_event(ev)
             self.harvests.append(_Harvest(agent, sub, games))
-        if keep_tree:
-            agent._tree_src = (sub, int(np.flatnonzero(games == 0)[0]))
         self.stats["harvests"] += 1
 
     def round(self, max_steps: int = None):

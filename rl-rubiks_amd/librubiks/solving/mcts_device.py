@@ -271,8 +271,12 @@ class MCTSForest:
     def __del__(self):
         try:
             self.close()
-        except Exception:   # noqa: BLE001 -- interpreter shutdown
-            pass
+        except Exception as e:   # noqa: BLE001 -- nothing to raise into; but a failed release must not pass unseen
+            try:
+                import sys
+                print(f"MCTSForest: releasing the node store failed: {e!r}", file=sys.stderr)
+            except Exception:   # noqa: BLE001 -- interpreter shutdown
+                pass
 
     def subset(self, keep: np.ndarray, results_only: bool = False) -> "MCTSForest":
         """
@@ -282,7 +286,9 @@ class MCTSForest:
         arrays those steps read are copied (65 of ~285 bytes per node), the forest cannot be stepped or inspected.
         """
         keep = np.asarray(keep, dtype=np.int64)
-        sub = MCTSForest(len(keep), self.C, self.max_path, self.device, _results_only=results_only, vmm=self.vmm)
+        # an ordinary allocation (the caching allocator hands the block of the previous harvest out again): forests that come and
+        # go with every harvest are not worth reserving, mapping and unmapping address ranges for
+        sub = MCTSForest(len(keep), self.C, self.max_path, self.device, _results_only=results_only, vmm=False)
         sub.level_budget, sub._one_launch = self.level_budget, self._one_launch
         sub.set_net(self.engine, self.engine.dtype if hasattr(self.engine, "dtype") else torch.bfloat16)
         sub.adopt(0, self, keep)

@@ -80,7 +80,7 @@ def test_copy_trees_keeps_exactly_the_rows_that_exist(standin_net, vmm):
         keep = np.array([5, 0, 17, 23, 11])
         full = forest.subset(keep)
         slim = forest.subset(keep, results_only=True)
-        assert full.vmm == vmm and slim.results_only
+        assert not full.vmm and not slim.vmm and slim.results_only      # forests that come and go with a harvest are ordinary allocations
         for i, t in enumerate(keep):
             n = int(forest.n_nodes[t].item())
             a, b = forest.tree_arrays(int(t)), full.tree_arrays(i)
@@ -100,7 +100,7 @@ def test_copy_trees_keeps_exactly_the_rows_that_exist(standin_net, vmm):
                 if res.solved[t] and lens[i] >= 0:
                     assert list(acts[i, :lens[i]]) == list(res.queues[t])
         if vmm:
-            assert 0 < slim.bytes_mapped() <= slim.bytes_reserved() and slim.bytes_mapped() <= slim.bytes_allocated()
+            assert 0 < forest.bytes_mapped() <= forest.bytes_reserved() and forest.bytes_mapped() <= forest.bytes_allocated()
     finally:
         md.MCTSForest.VMM_MIN_BYTES = md_vmm
 
@@ -149,7 +149,7 @@ def test_trees_that_wait_for_their_rows_are_still_the_reference_trees(scarce_row
 def test_refill_narrowing_and_results_forest_on_rows_mapped_on_demand(scarce_rows, engine):
     import test_search_edge_gpu as edge
     edge.test_production_trees_through_refill_narrowing_and_results_forest_equal_oracle(engine)
-    assert len(scarce_rows) >= 8          # search forest + results forest, several arrays each
+    assert len(scarce_rows) >= 4          # the search forest's arrays
 
 
 def test_deep_production_trees_on_rows_mapped_on_demand(scarce_rows):
