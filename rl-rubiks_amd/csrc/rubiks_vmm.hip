@@ -20,6 +20,8 @@ namespace {
 
 struct Range {
     size_t bytes = 0, chunk = 0;
+    void *raw = nullptr;      // what hipMemAddressReserve returned (the range handed out starts at the next multiple of `chunk`)
+    size_t raw_bytes = 0;
     int device = 0;
     std::vector<hipMemGenericAllocationHandle_t> handles;   // one per chunk
     std::vector<char> mapped;
@@ -28,10 +30,13 @@ struct Range {
 std::mutex g_mu;
 std::unordered_map<void *, Range> g_ranges;
 
-// One allocation per chunk.  Measured on MI355X / ROCm 7.2 (profiles/r4_vmm_raw_probe.txt, profiles/r4_vmm_probe.txt): hipMemSetAccess
-// returns hipErrorInvalidValue for a piece whose virtual address is not aligned to the piece's own size (2 MiB pieces anywhere in
-// a 2 MiB-aligned reservation work, a 64 MiB piece at a 16 MiB-aligned address does not), so the range is reserved with the chunk
-// size as its alignment and every chunk is created, mapped and made accessible by itself: ~10 us per chunk.
+// One allocation per chunk, every chunk at an address that is a multiple of the chunk size.  Measured on MI355X / ROCm 7.2
+// (profiles/r4_vmm_raw_probe.txt, r4_vmm_raw_probe2.txt): hipMemSetAccess returns hipErrorInvalidValue for a piece whose virtual
+// address is not aligned to the piece's own size, and hipMemAddressReserve's alignment argument does not deliver that for more
+// than 2 MiB -- so one chunk more than asked for is reserved and the range starts at the first multiple of the chunk size inside
+// (pieces of 4 .. 64 MiB placed like that map and hold their data).  A map call costs ~10 us + ~15 us per 1 000 chunks the
+// process has mapped already (80 000 chunks of 2 MiB: 47 s in all), and it returns only when the GPU has finished everything
+// queued before it: large forests take larger chunks, and the host maps in few, large steps (MCTSForest.grow).
 // A failed HIP call leaves its code as the thread's "last error", which the next hipGetLastError() of anybody -- torch checks it
 // after every launch -- would report as its own: read it away.
 int failed(hipError_t e) {
@@ -62,15 +67,15 @@ int rc_vmm_granularity(size_t *out_bytes) {
 int rc_vmm_reserve(size_t bytes, size_t chunk_bytes, void **out_base) {
     RC_REQUIRE(out_base != nullptr, RC_ERR_NULL);
     *out_base = nullptr;
-    size_t gran = 0;
-    if (int rc = rc_vmm_granularity(&gran)) return rc;
-    RC_REQUIRE(bytes > 0 && chunk_bytes > 0 && chunk_bytes % gran == 0, RC_ERR_RANGE);
+    constexpr size_t kMin = 2u << 20;
+    RC_REQUIRE(bytes > 0 && chunk_bytes >= kMin && (chunk_bytes & (chunk_bytes - 1)) == 0 && chunk_bytes <= (1u << 30), RC_ERR_RANGE);
     Range r;
     r.chunk = chunk_bytes;
     r.bytes = (bytes + chunk_bytes - 1) / chunk_bytes * chunk_bytes;
-    if (hipError_t e = hipGetDevice(&r.device); e != hipSuccess) return hip_rc(e);
-    void *base = nullptr;
-    if (hipError_t e = hipMemAddressReserve(&base, r.bytes, chunk_bytes, nullptr, 0); e != hipSuccess) return hip_rc(e);
+    r.raw_bytes = r.bytes + (chunk_bytes > kMin ? chunk_bytes : 0);
+    if (hipError_t e = hipGetDevice(&r.device); e != hipSuccess) return failed(e);
+    if (hipError_t e = hipMemAddressReserve(&r.raw, r.raw_bytes, kMin, nullptr, 0); e != hipSuccess) return failed(e);
+    void *base = reinterpret_cast<void *>((reinterpret_cast<uintptr_t>(r.raw) + chunk_bytes - 1) / chunk_bytes * chunk_bytes);
     r.handles.assign(r.bytes / chunk_bytes, hipMemGenericAllocationHandle_t{});
     r.mapped.assign(r.bytes / chunk_bytes, 0);
     std::lock_guard<std::mutex> lock(g_mu);
@@ -141,7 +146,7 @@ int rc_vmm_release(void *base) {
         if (hipError_t err = hipMemUnmap(static_cast<char *>(base) + c * r.chunk, r.chunk); err != hipSuccess && rc == RC_OK) rc = failed(err);
         if (hipError_t err = hipMemRelease(r.handles[c]); err != hipSuccess && rc == RC_OK) rc = failed(err);
     }
-    if (hipError_t err = hipMemAddressFree(base, r.bytes); err != hipSuccess && rc == RC_OK) rc = hip_rc(err);
+    if (hipError_t err = hipMemAddressFree(r.raw, r.raw_bytes); err != hipSuccess && rc == RC_OK) rc = failed(err);
     g_ranges.erase(it);
     return rc;
 }

@@ -32,16 +32,31 @@ class _Span:
 
 
 class VmmArray:
-    """`nbytes` of reserved device address space; `tensor` views it, `ensure` puts memory behind a byte range of it."""
+    """`nbytes` of reserved device address space; `tensor` views it, `ensure` puts memory behind a byte range of it.
+    chunk: the unit memory arrives in (a power of two >= 2 MiB).  A map call costs ~10 us plus ~15 us per 1 000 chunks the
+    process has mapped already, and returns only when the GPU has finished the work queued before it
+    (profiles/r4_vmm_raw_probe2.txt, r4_vmm_stress.txt): big arrays take bigger chunks, callers map in few large steps."""
 
-    def __init__(self, nbytes: int, device):
+    _parked = {}   # (nbytes, chunk, device index) -> released arrays, memory still mapped: the next array of that shape takes one over
+
+    def __new__(cls, nbytes: int, device, chunk: int = CHUNK):
+        nb = (int(nbytes) + chunk - 1) // chunk * chunk
+        free = cls._parked.get((nb, chunk, torch.device(device).index))
+        if free:
+            return free.pop()
+        return super().__new__(cls)
+
+    def __init__(self, nbytes: int, device, chunk: int = CHUNK):
+        if getattr(self, "ptr", 0):      # taken over from the park: same address range, same chunks mapped
+            return
         self.lib = _hip.lib()
-        self.device = device
-        self.nbytes = (int(nbytes) + CHUNK - 1) // CHUNK * CHUNK
+        self.device = torch.device(device)
+        self.chunk = int(chunk)
+        self.nbytes = (int(nbytes) + chunk - 1) // chunk * chunk
         base = c_void_p()
-        _hip.check(self.lib.rc_vmm_reserve(self.nbytes, CHUNK, ctypes.byref(base)), "rc_vmm_reserve")
+        _hip.check(self.lib.rc_vmm_reserve(self.nbytes, self.chunk, ctypes.byref(base)), "rc_vmm_reserve")
         self.ptr = int(base.value)
-        self.have = np.zeros(self.nbytes // CHUNK, dtype=bool)     # host mirror of what is mapped: most calls need no library call
+        self.have = np.zeros(self.nbytes // self.chunk, dtype=bool)     # host mirror of what is mapped: most calls need no library call
         self.mapped_bytes = 0
 
     def tensor(self, dtype, shape) -> torch.Tensor:
@@ -53,29 +68,46 @@ class VmmArray:
         return t.view(dtype).view(*shape)
 
     def ensure(self, lo: int, hi: int) -> int:
-        """Memory behind bytes [lo, hi); returns the bytes newly mapped.  Host-synchronous, safe next to running kernels."""
+        """Memory behind bytes [lo, hi); returns the bytes newly mapped.  Host-synchronous (waits for the GPU to drain)."""
         if hi <= lo:
             return 0
-        c0, c1 = lo // CHUNK, (min(hi, self.nbytes) - 1) // CHUNK
+        c0, c1 = lo // self.chunk, (min(hi, self.nbytes) - 1) // self.chunk
         if self.have[c0:c1 + 1].all():
             return 0
         new = c_size_t()
-        _hip.check(self.lib.rc_vmm_map(self.ptr, c0 * CHUNK, (c1 - c0 + 1) * CHUNK, ctypes.byref(new)), "rc_vmm_map")
+        rc = self.lib.rc_vmm_map(self.ptr, c0 * self.chunk, (c1 - c0 + 1) * self.chunk, ctypes.byref(new))
+        if rc != 0 and self.trim():          # out of memory with released arrays still holding theirs: give that back, try again
+            rc = self.lib.rc_vmm_map(self.ptr, c0 * self.chunk, (c1 - c0 + 1) * self.chunk, ctypes.byref(new))
+        _hip.check(rc, "rc_vmm_map")
         self.have[c0:c1 + 1] = True
         self.mapped_bytes += int(new.value)
         return int(new.value)
+
+    @classmethod
+    def has_parked(cls, nbytes: int, device, chunk: int = CHUNK) -> bool:
+        nb = (int(nbytes) + chunk - 1) // chunk * chunk
+        return bool(cls._parked.get((nb, chunk, torch.device(device).index)))
+
+    def park(self):
+        """The owner is done with the array (it has synchronised and dropped its tensors).  Address range and memory are kept for
+        the next array of the same shape -- successive forests of one benchmark or evaluation are that -- instead of being
+        unmapped and mapped again; `trim` really releases them."""
+        if self.ptr:
+            self._parked.setdefault((self.nbytes, self.chunk, self.device.index), []).append(self)
+
+    @classmethod
+    def trim(cls) -> int:
+        """Releases every parked array (memory and address range); returns how many."""
+        n = 0
+        for arrs in cls._parked.values():
+            while arrs:
+                arrs.pop().close()
+                n += 1
+        return n
 
     def close(self):
         """Gives memory and address range back.  The caller has synchronised with every kernel that used the array and holds no
         tensor of it any more."""
         if self.ptr:
-            _hip.check(self.lib.rc_vmm_release(self.ptr), "rc_vmm_release")
-            self.ptr = 0
-
-    def __del__(self):
-        try:
-            if self.ptr:
-                torch.cuda.synchronize()
-                self.close()
-        except Exception:   # noqa: BLE001 -- interpreter shutdown
-            pass
+            ptr, self.ptr = self.ptr, 0
+            _hip.check(self.lib.rc_vmm_release(ptr), "rc_vmm_release")

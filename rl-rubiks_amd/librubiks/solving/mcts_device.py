@@ -100,7 +100,12 @@ class MCTSForest:
     # node records of at least this many bytes: the per-node arrays are mapped on demand (None: never).  RUBIKS_VMM_MIN_GB
     # overrides it for a process (0 = every forest, "never" = none): A/B runs and diagnosis.
     VMM_MIN_BYTES = (lambda v: 1 << 30 if v is None else None if v == "never" else int(float(v) * (1 << 30)))(os.environ.get("RUBIKS_VMM_MIN_GB"))
-    GROW_ROWS = 8192          # rows a tree's mapping grows by (8 192 node records = one 2 MiB chunk)
+    # Rows a planted tree starts with, and the factor its mapping grows by when it gets near them (then every tree that is past
+    # 70 % of its rows grows in the same step): a map call returns only when the GPU has drained, so growth comes in few, large
+    # steps -- a depth-20 tree ends at 12-14 k nodes on average and never grows at all.
+    GROW_ROWS = 16384
+    GROW_FACTOR = 2.0
+    BIG_CHUNKS_FROM = 96 << 30   # node records of this many bytes and more arrive in 8 MiB chunks (32 768 records) instead of 2 MiB
 
     def __init__(self, n_trees: int, capacity: int, max_path: int = 4096, device=None, _results_only: bool = False, vmm: bool = None):
         """vmm: per-node arrays as reserved address ranges with memory mapped behind the rows in use (`grow`); None = by size."""
@@ -132,6 +137,14 @@ class MCTSForest:
             "ring_len": ((B, RING_K), torch.int32), "phase": ((B,), torch.int32),
         }
         self._ranges = {}     # name -> (VmmArray, bytes per row) of the arrays mapped on demand
+        if self.vmm:
+            # the arrays a finished forest of the same shape has left behind are taken over as they are (addresses and memory);
+            # a forest of another shape first gives all such memory back
+            sizes = [(rows * int(np.prod(shape[1:], dtype=np.int64)) * torch.empty(0, dtype=dt).element_size(), self._chunk_for(rows, shape, dt))
+                     for name, (shape, dt) in per_node.items() if name != "nbr"]
+            if not all(VmmArray.has_parked(nb, dev, ch) for nb, ch in sizes):
+                torch.cuda.synchronize()
+                VmmArray.trim()
         for name, (shape, dt) in per_node.items():
             if name == ("node" if _results_only else "nbr"):
                 continue      # a search forest keeps nbr as a field of the node record, a results-only forest as a plain array
@@ -139,7 +152,7 @@ class MCTSForest:
                 t = z((1,) + shape[1:], dt)   # arrays that turning finished trees into results never touches: one row, so that pointers are valid
             elif self.vmm:    # no memory yet, and none of these arrays needs clearing: a node's rows are written when it is created
                 bpr = int(np.prod(shape[1:], dtype=np.int64)) * torch.empty(0, dtype=dt).element_size()
-                arr = VmmArray(rows * bpr, dev)
+                arr = VmmArray(rows * bpr, dev, chunk=self._chunk_for(rows, shape, dt))
                 self._ranges[name] = (arr, bpr)
                 t = arr.tensor(dt, shape)
             else:
@@ -205,14 +218,19 @@ class MCTSForest:
         self._graphs = {}          # (G, c, max_states, level budget) -> captured iteration
         self._graph_pool = None    # one memory pool for all of them: they never run concurrently
 
+    @classmethod
+    def _chunk_for(cls, rows: int, shape, dt) -> int:
+        bpr = int(np.prod(shape[1:], dtype=np.int64)) * torch.empty(0, dtype=dt).element_size()
+        return (8 << 20) if rows * NODE_WORDS * 4 >= cls.BIG_CHUNKS_FROM and bpr >= 16 else (2 << 20)
+
     # ---- memory behind the rows (forests mapped on demand) ---------------------------------------------
     def ensure_rows(self, trees: np.ndarray, rows: np.ndarray) -> int:
-        """Memory behind rows 0 .. rows[i] - 1 of tree trees[i] in every per-node array (never less than a tree already has; in
-        steps of GROW_ROWS); the kernels learn of it in stream order.  Returns the bytes newly mapped.  No-op without vmm."""
+        """Memory behind rows 0 .. rows[i] - 1 of tree trees[i] in every per-node array (never less than a tree already has);
+        the kernels learn of it in stream order.  Returns the bytes newly mapped.  No-op without vmm."""
         if not self.vmm:
             return 0
         trees = np.asarray(trees, dtype=np.int64).reshape(-1)
-        want = np.minimum(self.C + 1, (np.asarray(rows, dtype=np.int64).reshape(-1) + self.GROW_ROWS - 1) // self.GROW_ROWS * self.GROW_ROWS)
+        want = np.minimum(self.C + 1, np.asarray(rows, dtype=np.int64).reshape(-1))
         more = want > self.mapped_host[trees]
         if not more.any():
             return 0
@@ -228,14 +246,24 @@ class MCTSForest:
     def grow(self, n_nodes: np.ndarray, steps_ahead: int):
         """The host's look at the trees: `n_nodes` (host array, [B]) are node counts at some point of the stream, and up to
         `steps_ahead` iterations may run beyond that point before the next look (a tree gains at most 12 nodes per iteration).
-        Maps what those iterations can reach."""
+        If a tree can reach the end of its rows in that time, it -- and with it every tree past 70 % of its rows: mapping drains
+        the GPU, so it should be rare -- gets GROW_FACTOR times the rows."""
         self.nodes_seen = np.asarray(n_nodes, dtype=np.int64).copy()
-        if self.vmm:
-            self.ensure_rows(np.arange(self.B), self.nodes_seen + N_ACT * (steps_ahead + 1) + 2)
+        if not self.vmm:
+            return
+        have = self.mapped_host.astype(np.int64)
+        need = self.nodes_seen + N_ACT * (steps_ahead + 1) + 2
+        must = need > have
+        if not must.any():
+            return
+        soon = must | (self.nodes_seen > 0.7 * have)
+        trees = np.flatnonzero(soon & (have < self.C + 1))
+        self.ensure_rows(trees, np.maximum(need[trees], (have[trees] * self.GROW_FACTOR).astype(np.int64)))
 
     def _grow_now(self):
         """Direct steppers (tests, tools) have no MCTSRun looking after the mapping: a synchronising look, 256 iterations ahead."""
         self.grow(self.n_nodes.cpu().numpy(), 256)
+        self.ensure_rows(np.arange(self.B), np.full(self.B, min(self.GROW_ROWS, self.C + 1)))
         self._steps_covered = 256
 
     def ensure_bfs(self, trees: np.ndarray = None):
@@ -262,11 +290,11 @@ class MCTSForest:
                 if hasattr(self, name):
                     delattr(self, name)
             self.bfs = None
-            for arr, _ in self._ranges.values():
-                arr.close()
+            for arr, _ in self._ranges.values():     # kept for the next forest of this shape (VmmArray.park); VmmArray.trim() releases
+                arr.park()
             if getattr(self, "_ranges_bfs", None) is not None:
-                self._ranges_bfs.close()
-            self._ranges = None
+                self._ranges_bfs.park()
+            self._ranges, self._ranges_bfs = None, None
 
     def __del__(self):
         try:
