@@ -901,6 +901,15 @@ def step_rooflines(engine, agent, roots, args, name):
     return phases, roofline, group, roofline_input, rows
 
 
+def release_node_stores():
+    """Between leg families: the address ranges and memory that finished forests have left for a successor of their shape
+    (librubiks/_vmm.py) are given back, so the next family starts from an empty card."""
+    from librubiks._vmm import VmmArray
+    torch.cuda.synchronize()
+    VmmArray.trim()
+    torch.cuda.empty_cache()
+
+
 def draw_scrambles(n_config, n_pool, depth, slice_rank, slice_world):
     """
     Synthetic inputs of one rank.  The first n_config * world games are the reference's scramble stream (np.random.seed(0),
@@ -1072,6 +1081,7 @@ def main():
         del engine, agent
         torch.cuda.empty_cache()
     del pool_roots
+    release_node_stores()
 
     # ---- BASELINE configs[2]: A* ------------------------------------------------------------------------------------------
     astar = {}
@@ -1096,6 +1106,7 @@ def main():
             del engine, agent
             torch.cuda.empty_cache()
         del c_roots, c_pool
+        release_node_stores()
 
     # ---- BASELINE configs[3]: data generation of an ADI rollout ---------------------------------------------------------------
     adi = {}

@@ -100,11 +100,15 @@ class MCTSForest:
     # node records of at least this many bytes: the per-node arrays are mapped on demand (None: never).  RUBIKS_VMM_MIN_GB
     # overrides it for a process (0 = every forest, "never" = none): A/B runs and diagnosis.
     VMM_MIN_BYTES = (lambda v: 1 << 30 if v is None else None if v == "never" else int(float(v) * (1 << 30)))(os.environ.get("RUBIKS_VMM_MIN_GB"))
-    # Rows a planted tree starts with, and the factor its mapping grows by when it gets near them (then every tree that is past
-    # 70 % of its rows grows in the same step): a map call returns only when the GPU has drained, so growth comes in few, large
-    # steps -- a depth-20 tree ends at 12-14 k nodes on average and never grows at all.
+    # Rows a planted tree starts with (a depth-20 tree ends at 12-14 k nodes on average and never grows at all), and how its
+    # mapping grows when it gets near them: by GROW_FACTOR, at most GROW_STEP rows at a time.  A map call returns only when the
+    # GPU has drained, so in forests whose iterations are short (<= PREGROW_TREES trees) every tree past 70 % of its rows grows
+    # in the same step as the one that has to; in large forests an iteration takes milliseconds, a drained queue is nothing
+    # against that, and only the trees that have to grow do (8 192 trees x one chunk too many would be 67 GB).
     GROW_ROWS = 16384
     GROW_FACTOR = 2.0
+    GROW_STEP = 32768
+    PREGROW_TREES = 2048
     BIG_CHUNKS_FROM = 96 << 30   # node records of this many bytes and more arrive in 8 MiB chunks (32 768 records) instead of 2 MiB
 
     def __init__(self, n_trees: int, capacity: int, max_path: int = 4096, device=None, _results_only: bool = False, vmm: bool = None):
@@ -246,8 +250,7 @@ class MCTSForest:
     def grow(self, n_nodes: np.ndarray, steps_ahead: int):
         """The host's look at the trees: `n_nodes` (host array, [B]) are node counts at some point of the stream, and up to
         `steps_ahead` iterations may run beyond that point before the next look (a tree gains at most 12 nodes per iteration).
-        If a tree can reach the end of its rows in that time, it -- and with it every tree past 70 % of its rows: mapping drains
-        the GPU, so it should be rare -- gets GROW_FACTOR times the rows."""
+        A tree that can reach the end of its rows in that time gets more (see GROW_ROWS)."""
         self.nodes_seen = np.asarray(n_nodes, dtype=np.int64).copy()
         if not self.vmm:
             return
@@ -256,9 +259,10 @@ class MCTSForest:
         must = need > have
         if not must.any():
             return
-        soon = must | (self.nodes_seen > 0.7 * have)
+        soon = must | (self.nodes_seen > 0.7 * have) if self.B <= self.PREGROW_TREES else must
         trees = np.flatnonzero(soon & (have < self.C + 1))
-        self.ensure_rows(trees, np.maximum(need[trees], (have[trees] * self.GROW_FACTOR).astype(np.int64)))
+        step = np.minimum((have[trees] * self.GROW_FACTOR).astype(np.int64), have[trees] + self.GROW_STEP)
+        self.ensure_rows(trees, np.maximum(need[trees], step))
 
     def _grow_now(self):
         """Direct steppers (tests, tools) have no MCTSRun looking after the mapping: a synchronising look, 256 iterations ahead."""
