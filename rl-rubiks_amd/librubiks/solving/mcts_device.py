@@ -109,7 +109,9 @@ class MCTSForest:
     GROW_FACTOR = 2.0
     GROW_STEP = 32768
     PREGROW_TREES = 2048
-    BIG_CHUNKS_FROM = 96 << 30   # node records of this many bytes and more arrive in 8 MiB chunks (32 768 records) instead of 2 MiB
+    # Chunks: 2 MiB (8 192 node records).  A map call costs ~15 us per 1 000 chunks the process has mapped already, so forests
+    # whose node records reserve this many bytes and more take 4 MiB chunks for the records and 8 MiB for the keys.
+    BIG_CHUNKS_FROM = 96 << 30
 
     def __init__(self, n_trees: int, capacity: int, max_path: int = 4096, device=None, _results_only: bool = False, vmm: bool = None):
         """vmm: per-node arrays as reserved address ranges with memory mapped behind the rows in use (`grow`); None = by size."""
@@ -120,13 +122,18 @@ class MCTSForest:
         dev = device or torch.device("cuda", torch.cuda.current_device())
         B, C = int(n_trees), int(capacity)
         assert B > 0 and 13 <= C < (1 << 24) and 2 <= max_path <= 4096   # 32-bit buffer offsets inside a tree: < 2^24 nodes
+        if vmm is None:
+            vmm = self.VMM_MIN_BYTES is not None and B * (C + 1) * NODE_WORDS * 4 >= self.VMM_MIN_BYTES
+        self.vmm = bool(vmm)
+        if self.vmm and not _results_only:
+            # every tree's node records start on a chunk boundary (rows per tree rounded up to whole chunks: address space, not
+            # memory), so the first rows of a tree cost one chunk, not the two a straddling range would
+            per_chunk = self._chunk_for(B * (C + 1), (0, NODE_WORDS), torch.int32) // (NODE_WORDS * 4)
+            C = min((1 << 24) - 1, (C + per_chunk) // per_chunk * per_chunk - 1)
         self.B, self.C, self.max_path, self.device = B, C, max_path, dev
         self.hash_size = 1 << int(np.ceil(np.log2(2 * (C + 1))))
         z = lambda shape, dt: torch.zeros(shape, dtype=dt, device=dev)   # noqa: E731
         rows = B * (C + 1)
-        if vmm is None:
-            vmm = self.VMM_MIN_BYTES is not None and rows * NODE_WORDS * 4 >= self.VMM_MIN_BYTES
-        self.vmm = bool(vmm)
         self.results_only = _results_only
         per_node = {   # [B][capacity + 1] rows each
             "keys": ((rows, 4), torch.int32), "node": ((rows, NODE_WORDS), torch.int32), "nbr": ((rows, N_ACT), torch.int32),
@@ -225,7 +232,9 @@ class MCTSForest:
     @classmethod
     def _chunk_for(cls, rows: int, shape, dt) -> int:
         bpr = int(np.prod(shape[1:], dtype=np.int64)) * torch.empty(0, dtype=dt).element_size()
-        return (8 << 20) if rows * NODE_WORDS * 4 >= cls.BIG_CHUNKS_FROM and bpr >= 16 else (2 << 20)
+        if rows * NODE_WORDS * 4 < cls.BIG_CHUNKS_FROM or bpr < 16:
+            return 2 << 20
+        return (4 << 20) if bpr >= NODE_WORDS * 4 else (8 << 20)
 
     # ---- memory behind the rows (forests mapped on demand) ---------------------------------------------
     def ensure_rows(self, trees: np.ndarray, rows: np.ndarray) -> int:
