@@ -433,11 +433,11 @@ __device__ __forceinline__ LaneEval lane_eval(float c32, const u32 (&n)[kA], con
     int sum = 0;
 #pragma unroll
     for (int a = 0; a < kA; ++a) sum += (int)n[a];
-    const float sq = __builtin_amdgcn_sqrtf((float)sum);
+    const float csq = c32 * __builtin_amdgcn_sqrtf((float)sum);   // c sqrt(sum N), once per node
     LaneEval e;
 #pragma unroll
     for (int a = 0; a < kA; ++a) {
-        e.u[a] = c32 * __uint_as_float(p[a]) * sq * __builtin_amdgcn_rcpf((float)(1 + (int)n[a]));
+        e.u[a] = __uint_as_float(p[a]) * csq * __builtin_amdgcn_rcpf((float)(1 + (int)n[a]));
         e.w[a] = __uint_as_float(w[a]);
     }
     return e;
@@ -468,41 +468,39 @@ __device__ __forceinline__ int lane_pick(const LaneEval &e, u64 cnt5, bool &cert
     certain = ok;
     return arg;
 }
-// The two picks every re-decided level needs -- best0 (no loss) and best1 (one loss on best0) -- sharing their scores: the second
-// pick differs from the first in ONE entry, so it is a second argmax over the same array instead of a second evaluation.
-// Same arithmetic, entry for entry, as lane_pick(e, 0, c0) followed by lane_pick(e, 1 << 5 b0, c1).
+// The two picks every re-decided level needs -- best0 (no loss) and best1 (one loss on best0) -- from ONE pass over the twelve
+// scores: the three largest scores (a min / max cascade), the actions of the two largest, the largest magnitude and the sum of
+// the scores (NaN detector).  best1 differs from best0 in one entry, so it is either best0 itself (its score less 100 still
+// leads) or the runner-up.  Acceptance is the rule of lane_pick made one-sided: the winner must lead the next score by more than
+// kPuctEps x twice the LARGEST magnitude of the node (>= the two magnitudes lane_pick adds), so whatever is accepted here
+// lane_pick accepts too, with the same winner; ties, near ties, NaNs and infinities of opposite sign come back uncertain and
+// are re-decided in float64.  (score of best0 with its loss = best - 100: one rounding more than u + (w - 100), far inside the
+// margin, which is then taken on magnitudes + 100.)  ~190 VALU instructions per level less than two full argmax passes.
 __device__ __forceinline__ void lane_pick2(const LaneEval &e, int &b0, bool &c0, int &b1, bool &c1) {
-    float sc[kA], mg[kA];
-    float best = -INFINITY, mbest = 0.f;
-    int arg = 0;
-    bool ok = true;
+    float best = -INFINITY, second = -INFINITY, third = -INFINITY, mmax = 0.f, acc = 0.f;
+    int arg = 0, arg2 = 0;
 #pragma unroll
     for (int a = 0; a < kA; ++a) {
-        sc[a] = e.u[a] + e.w[a];
-        mg[a] = fabsf(e.u[a]) + fabsf(e.w[a]);
-        ok &= sc[a] == sc[a];
-        if (sc[a] > best) { best = sc[a]; arg = a; mbest = mg[a]; }
+        const float sc = e.u[a] + e.w[a];
+        mmax = fmaxf(mmax, fabsf(e.u[a]) + fabsf(e.w[a]));
+        acc += sc;
+        const bool lead = sc > best, runner = sc > second;     // first maximum keeps its place on ties (which are uncertain anyway)
+        arg2 = lead ? arg : runner ? a : arg2;
+        arg = lead ? a : arg;
+        const float t1 = fminf(sc, best);
+        best = fmaxf(best, sc);
+        const float t2 = fminf(t1, second);
+        second = fmaxf(second, t1);
+        third = fmaxf(third, t2);
     }
-    bool ok0 = ok;
-#pragma unroll
-    for (int a = 0; a < kA; ++a) ok0 &= (a == arg) | (best - sc[a] > kPuctEps * (mg[a] + mbest));
-    b0 = arg, c0 = ok0;
-    // one virtual loss on b0
-    float best1 = -INFINITY, mbest1 = 0.f;
-    int arg1 = 0;
-    bool ok1 = true;
-#pragma unroll
-    for (int a = 0; a < kA; ++a) {
-        const bool hit = a == arg;
-        const float s1 = hit ? e.u[a] + (e.w[a] - 100.0f) : sc[a];
-        const float m1 = hit ? mg[a] + 100.0f : mg[a];
-        sc[a] = s1, mg[a] = m1;
-        ok1 &= s1 == s1;
-        if (s1 > best1) { best1 = s1; arg1 = a; mbest1 = m1; }
-    }
-#pragma unroll
-    for (int a = 0; a < kA; ++a) ok1 &= (a == arg1) | (best1 - sc[a] > kPuctEps * (mg[a] + mbest1));
-    b1 = arg1, c1 = ok1;
+    const bool finite = acc == acc;                              // a NaN score (or +inf and -inf) poisons the sum
+    b0 = arg;
+    c0 = finite & (best - second > kPuctEps * 2.f * mmax);
+    const float lost = best - 100.0f;                            // best0 carrying one virtual loss
+    const bool stays = lost > second;
+    b1 = stays ? arg : arg2;
+    const float lead1 = stays ? lost - second : second - fmaxf(third, lost);
+    c1 = finite & (lead1 > kPuctEps * 2.f * (mmax + 100.0f));
 }
 __device__ __forceinline__ void cnt5_add(u64 &cnt5, bool &overflow, u32 a) {
     overflow |= ((u32)(cnt5 >> (5 * a)) & 31u) >= 30u;

@@ -12,7 +12,8 @@ from ctypes import c_char_p, c_int, c_size_t, c_void_p
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(os.path.dirname(_HERE), "lib", "librubiks_hip.so")
+# RUBIKS_HIP_LIB: another build of the same library (same-box A/B of kernel changes); it must export the same ABI
+LIB_PATH = os.environ.get("RUBIKS_HIP_LIB") or os.path.join(os.path.dirname(_HERE), "lib", "librubiks_hip.so")
 
 P, SZ, I = c_void_p, c_size_t, c_int
 
