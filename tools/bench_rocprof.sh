@@ -1,9 +1,30 @@
-# The driver's bench command under rocprofv3 --kernel-trace --stats -> profiles-ready summaries (run on the GPU box through gpurun).
-#   bash tools/bench_rocprof.sh <tag> [extra bench.py arguments]
-# writes gpurun_out/<tag>_bench_under_rocprof.json (the stdout line), <tag>_bench_detail_under_rocprof.json and <tag>_bench_kernel_stats.csv
-tag=${1:-rX}; shift
+# rocprofv3 passes whose summaries are committed under profiles/ (run on the GPU box through gpurun):
+#   bash tools/bench_rocprof.sh <tag> bench [bench.py arguments]   the driver's bench command under --kernel-trace --stats
+#        -> gpurun_out/<tag>_bench_under_rocprof.json (the stdout line), <tag>_bench_detail_under_rocprof.json, <tag>_bench_kernel_stats.csv
+#   bash tools/bench_rocprof.sh <tag> timeline [f32s|bf16]         kernel trace of configs[1] searched to completion -> per-step timelines
+#        at four points of the launch-size ladder -> gpurun_out/<tag>_step_timelines_<dtype>.txt, <tag>_solve_run_<dtype>.json
+#   bash tools/bench_rocprof.sh <tag> select_pmc                   SQ instruction / wait counters of the tree kernel in the steady-state pool
+#        -> gpurun_out/<tag>_select_pmc.txt
+#   bash tools/bench_rocprof.sh <tag> env_traffic                  FETCH_SIZE / WRITE_SIZE passes (separate) of the environment kernels at 2^24
+#        states -> gpurun_out/<tag>_env_pmc_traffic.json
+tag=${1:-rX}; mode=${2:-bench}; shift; shift
 R=${GRAFT_REPO_ROOT:-/root/repo}
-cd /tmp && export TMPDIR=/tmp && rocprofv3 --kernel-trace --stats -d /tmp/prof_$tag -o bench -- python3 $R/bench.py --steps 20 --warmup 5 --no-cpu-baseline --detail $R/gpurun_out/${tag}_bench_detail_under_rocprof.json "$@" > $R/gpurun_out/${tag}_bench_under_rocprof.json 2> $R/gpurun_out/${tag}_bench_under_rocprof.err
-cd $R
-db=$(find /tmp/prof_$tag -name "*.db" | head -1)
-python3 tools/rocprof_summary.py kernels "$db" gpurun_out/${tag}_bench_kernel_stats.csv 100
+O=$R/gpurun_out
+cd /tmp && export TMPDIR=/tmp
+case $mode in
+bench)
+  rocprofv3 --kernel-trace --stats -d /tmp/prof_$tag -o bench -- python3 $R/bench.py --steps 20 --warmup 5 --no-cpu-baseline --detail $O/${tag}_bench_detail_under_rocprof.json "$@" > $O/${tag}_bench_under_rocprof.json 2> $O/${tag}_bench_under_rocprof.err
+  python3 $R/tools/rocprof_summary.py kernels "$(find /tmp/prof_$tag -name '*.db' | head -1)" $O/${tag}_bench_kernel_stats.csv 100 ;;
+timeline)
+  dt=${1:-f32s}
+  rocprofv3 --kernel-trace --output-format csv -d /tmp/prof_tl_$tag -- python3 $R/tools/search_probe.py solve --dtype $dt --out $O/${tag}_solve_run_$dt.json > $O/${tag}_timeline.log 2>&1
+  f=$(find /tmp/prof_tl_$tag -name '*kernel_trace.csv' | head -1)
+  for s in -400 -1500 -3000 -4500; do echo "=== steps from $s"; python3 $R/tools/rocprof_summary.py timeline $f $s 150; done > $O/${tag}_step_timelines_$dt.txt ;;
+select_pmc)
+  rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_WAIT_INST_ANY SQ_INSTS_SALU SQ_BUSY_CYCLES SQ_WAVE_CYCLES --output-format csv -d /tmp/prof_pmc_$tag -- python3 $R/tools/search_probe.py window bf16 20 > $O/${tag}_select_pmc.log 2>&1
+  python3 $R/tools/rocprof_summary.py pmc "$(find /tmp/prof_pmc_$tag -name '*counter_collection.csv' | head -1)" k_mcts_select > $O/${tag}_select_pmc.txt ;;
+env_traffic)
+  rocprofv3 --pmc FETCH_SIZE --output-format csv -d /tmp/prof_f_$tag -- python3 $R/tools/env_bench.py 24 > $O/${tag}_env_fetch.log 2>&1
+  rocprofv3 --pmc WRITE_SIZE --output-format csv -d /tmp/prof_w_$tag -- python3 $R/tools/env_bench.py 24 > $O/${tag}_env_write.log 2>&1
+  python3 $R/tools/rocprof_summary.py traffic "$(find /tmp/prof_f_$tag -name '*counter_collection.csv' | head -1)" "$(find /tmp/prof_w_$tag -name '*counter_collection.csv' | head -1)" $O/${tag}_env_pmc_traffic.json 24 ;;
+esac
