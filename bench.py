@@ -55,8 +55,10 @@ MFMA_BF16_PEAK_TFLOPS = 2500.0   # dense bf16
 MFMA_F32_PEAK_TFLOPS = 157.3
 # `traffic` of roofline_env is NOT measured inside this run: it is the stored figure of separate rocprofv3 --pmc passes
 # (FETCH_SIZE / WRITE_SIZE, gfx950 corrections applied by tools/rocprof_summary.py traffic) of the same launches at 2^24 states
-PMC_FILE = "r2_env_pmc_traffic.json" if os.path.exists(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles",
-                                                                  "r2_env_pmc_traffic.json")) else "r1b_env_pmc_traffic.json"
+_PROFILES = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles")
+# the most recent measurement on the env kernels as they are (round 4 re-measured them; they have not changed since round 2)
+PMC_FILE = next((f for f in ("r4k_env_pmc_traffic.json", "r2_env_pmc_traffic.json", "r1b_env_pmc_traffic.json") if os.path.exists(os.path.join(_PROFILES, f))),
+                "r4k_env_pmc_traffic.json")
 GEMM_PMC_FILE = "r3_split_gemm_traffic.json"   # the hidden-layer kernel that runs today (k_split_gemm<2, 4, 11, 4, ...>), re-measured in round 3
 PMC_SOURCE = f"stored PMC figure: profiles/{PMC_FILE} (separate rocprofv3 --pmc passes of these launches, not this run)"
 

@@ -19,7 +19,7 @@ timeline)
   dt=${1:-f32s}
   rocprofv3 --kernel-trace --output-format csv -d /tmp/prof_tl_$tag -- python3 $R/tools/search_probe.py solve --dtype $dt --out $O/${tag}_solve_run_$dt.json > $O/${tag}_timeline.log 2>&1
   f=$(find /tmp/prof_tl_$tag -name '*kernel_trace.csv' | head -1)
-  for s in -400 -1500 -3000 -4500; do echo "=== steps from $s"; python3 $R/tools/rocprof_summary.py timeline $f $s 150; done > $O/${tag}_step_timelines_$dt.txt ;;
+  for s in -400 -1500 -3000 -4500; do echo "=== steps from $s"; python3 $R/tools/rocprof_summary.py timeline $f $s 150 1; done > $O/${tag}_step_timelines_$dt.txt ;;
 select_pmc)
   rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_WAIT_INST_ANY SQ_INSTS_SALU SQ_BUSY_CYCLES SQ_WAVE_CYCLES --output-format csv -d /tmp/prof_pmc_$tag -- python3 $R/tools/search_probe.py window bf16 20 > $O/${tag}_select_pmc.log 2>&1
   python3 $R/tools/rocprof_summary.py pmc "$(find /tmp/prof_pmc_$tag -name '*counter_collection.csv' | head -1)" k_mcts_select > $O/${tag}_select_pmc.txt ;;

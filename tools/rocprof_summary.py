@@ -8,7 +8,7 @@ Summaries of rocprofv3 output, as committed under profiles/ (run where the profi
                                                per launch of the environment kernels, gfx950 corrections applied
                                                (MI355X_MICROARCH.md, HBM: counters in KiB; FETCH_SIZE reports half the bytes of a
                                                wide coalesced streaming read -> doubled; WRITE_SIZE exact for 16-B-per-lane stores)
-  timeline <kernel_trace.csv> [first_step] [n] --kernel-trace --output-format csv of a search: per lock-step iteration (a step ends
+  timeline <kernel_trace.csv> [first_step] [n] [dump] --kernel-trace --output-format csv of a search: per lock-step iteration (a step ends
                                                with its tree kernel) the period, busy time per kernel and idle gaps on the step's
                                                queue (first_step < 0: counted from the end of the trace)
 """
@@ -85,8 +85,8 @@ def _short(name):
     return name[:40]
 
 
-def timeline(path, first=2000, count=200):
-    first, count = int(first), int(count)
+def timeline(path, first=2000, count=200, dump=0):
+    first, count, dump = int(first), int(count), int(dump)
     rows = list(csv.DictReader(open(path)))
     k = sorted((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r["Kernel_Name"], r.get("Queue_Id", "0")) for r in rows)
     starts = [i + 1 for i, e in enumerate(k) if "k_mcts_select" in e[2]]   # a step = the launches behind the previous tree kernel up to and including this one
@@ -114,6 +114,10 @@ def timeline(path, first=2000, count=200):
         if prev_end is not None and nxt[0] > prev_end:
             gaps[prev_name + " -> next step"] += (nxt[0] - prev_end) / 1e3
     n = len(sel) - 1
+    if dump:      # the launches of the first selected step, one per line: offset from the step's start, duration, queue, grid
+        t0 = k[sel[0]][0]
+        for e in k[sel[0]:sel[1] + 1]:
+            print(f"    +{(e[0] - t0) / 1e3:8.1f} us  {(e[1] - e[0]) / 1e3:8.1f} us  queue {e[3]:>3}  {_short(e[2])}")
     print(f"steps {first}..{first + n}: period {period:.1f} us")
     for title, d, top in (("busy on the step queue", busy, 99), ("gaps on the step queue", gaps, 12), ("other queues", other, 8)):
         print(f"{title} (us/step):")
