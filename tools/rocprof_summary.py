@@ -100,13 +100,17 @@ def timeline(path, first=2000, count=200, dump=0):
     main_q = k[sel[0]][3]
     period = (k[sel[-1]][0] - k[sel[0]][0]) / (len(sel) - 1) / 1e3
     busy, other, gaps = collections.defaultdict(float), collections.defaultdict(float), collections.defaultdict(float)
+    worst = collections.defaultdict(lambda: [0.0, 0])      # per edge: the largest single gap and how many exceeded 20 us
     for a, b in zip(sel[:-1], sel[1:]):
         prev_end, prev_name = None, None
         for e in k[a:b]:
             if e[3] == main_q:
                 busy[_short(e[2])] += (e[1] - e[0]) / 1e3
                 if prev_end is not None and e[0] > prev_end:
-                    gaps[prev_name + " -> " + _short(e[2])] += (e[0] - prev_end) / 1e3
+                    g = (e[0] - prev_end) / 1e3
+                    gaps[prev_name + " -> " + _short(e[2])] += g
+                    w = worst[prev_name + " -> " + _short(e[2])]
+                    w[0], w[1] = max(w[0], g), w[1] + (g > 20.0)
                 prev_end, prev_name = max(e[1], prev_end or 0), _short(e[2])
             else:
                 other[_short(e[2])] += (e[1] - e[0]) / 1e3
@@ -122,7 +126,8 @@ def timeline(path, first=2000, count=200, dump=0):
     for title, d, top in (("busy on the step queue", busy, 99), ("gaps on the step queue", gaps, 12), ("other queues", other, 8)):
         print(f"{title} (us/step):")
         for name, v in sorted(d.items(), key=lambda x: -x[1])[:top]:
-            print(f"  {v / n:8.1f}  {name}")
+            extra = f"   (largest {worst[name][0]:.0f} us, {worst[name][1]} of {n} steps above 20 us)" if d is gaps and name in worst else ""
+            print(f"  {v / n:8.1f}  {name}{extra}")
         if d is not other:
             print(f"  {sum(d.values()) / n:8.1f}  total")
 
