@@ -105,7 +105,7 @@ class MCTSForest:
     # GPU has drained, so in forests whose iterations are short (<= PREGROW_TREES trees) every tree past 70 % of its rows grows
     # in the same step as the one that has to; in large forests an iteration takes milliseconds, a drained queue is nothing
     # against that, and only the trees that have to grow do (8 192 trees x one chunk too many would be 67 GB).
-    GROW_ROWS = 16384
+    GROW_ROWS = 16384          # (forests of <= PREGROW_TREES trees: twice that -- 8 GB for 1 024 trees -- so that few trees ever grow)
     GROW_FACTOR = 2.0
     GROW_STEP = 32768
     PREGROW_TREES = 2048
@@ -273,10 +273,14 @@ class MCTSForest:
         step = np.minimum((have[trees] * self.GROW_FACTOR).astype(np.int64), have[trees] + self.GROW_STEP)
         self.ensure_rows(trees, np.maximum(need[trees], step))
 
+    def _first_rows(self) -> int:
+        """Rows a planted tree starts with."""
+        return min(self.C + 1, self.GROW_ROWS * (2 if self.B <= self.PREGROW_TREES else 1))
+
     def _grow_now(self):
         """Direct steppers (tests, tools) have no MCTSRun looking after the mapping: a synchronising look, 256 iterations ahead."""
         self.grow(self.n_nodes.cpu().numpy(), 256)
-        self.ensure_rows(np.arange(self.B), np.full(self.B, min(self.GROW_ROWS, self.C + 1)))
+        self.ensure_rows(np.arange(self.B), np.full(self.B, self._first_rows()))
         self._steps_covered = 256
 
     def ensure_bfs(self, trees: np.ndarray = None):
@@ -478,7 +482,7 @@ class MCTSForest:
         one = bool(self.fused_step and max_states is not None)
         if self.vmm:   # a root and its children need rows before the kernel runs; the first GROW_ROWS rows of every planted tree
             which = np.arange(self.B) if slots is None else (slots_host if slots_host is not None else slots.cpu().numpy())
-            self.ensure_rows(which, np.full(len(which), self.GROW_ROWS))
+            self.ensure_rows(which, np.full(len(which), self._first_rows()))
             self.nodes_seen[which] = 0
         if slots is None:
             self._one_launch = one
