@@ -382,11 +382,6 @@ typedef struct rc_mcts {
      * RUNNING, `expanded` stays 0, its iteration count does not advance) and tries again in the next one: the host maps ahead
      * of the trees' growth, the kernels never touch a row that is not there. */
     const int32_t *mapped_rows;
-    /* rc_mcts_step* on more than 512 listed trees: 0 = one launch, 256 threads per tree; > 0 = two launches side by side -- trees
-     * whose pending descent path has more than deep_levels levels get 1 024 threads (and a CU) each on a second stream, the others
-     * 256 -- because a launch waits for its deepest tree (a 1 000-level descent is four rounds of everything that is one lane per
-     * level at 256 threads, one at 1 024).  Same trees either way. */
-    uint32_t deep_levels;
 } rc_mcts_t;
 
 /* sizeof(rc_mcts_t) as the library was compiled: a binding that mirrors the struct (ctypes, cgo, JNI) checks its own

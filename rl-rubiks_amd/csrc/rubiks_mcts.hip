@@ -584,11 +584,7 @@ __device__ __forceinline__ u32 sel_hash(int node) { return ((u32)node * 0x9E3779
 // rc_mcts_step* gives a tree 512 / 1 024 threads there -- the parallel parts (staging, re-validation: one lane per path level)
 // of a 1 200-level descent take two rounds per thread instead of five.
 // LW: waves that check a line together (1: wave 0 alone, 64 levels per round; 4: waves 0-3, 256 levels per round -- see "line round").
-// SEL (full forests, rc_mcts_step*): a launch waits for its deepest tree, and with 256 threads a 1 000-level descent is four
-// rounds of everything that is one lane per level.  So a full forest is served by TWO launches that run side by side: SEL 1 takes
-// the trees whose pending path has at most rc_mcts_t::deep_levels levels (256 threads each, four per CU), SEL 2 the few deep ones
-// with 1 024 threads and four-wave line rounds -- each tree exactly one of them, decided by path_len before anything is written.
-template <int MODE, bool FUSE = false, int NT = kBlock, int LW = 1, int SEL = 0>
+template <int MODE, bool FUSE = false, int NT = kBlock, int LW = 1>
 __global__ __launch_bounds__(NT) void k_mcts_select(rc_mcts_t m, double c, u32 level_budget, const void *__restrict__ probs_or_head,
                                                       const float *__restrict__ values, size_t ld, bool head_bf16, u32 max_states) {
     __shared__ u32 s_lut[FUSE ? sizeof(kTables.lut) / 4 : 1];
@@ -614,7 +610,6 @@ __global__ __launch_bounds__(NT) void k_mcts_select(rc_mcts_t m, double c, u32 l
     const int ti = tree_of(m, slot);
     if (ti < 0) return;
     const u32 t = (u32)ti;
-    if (SEL != 0 && (SEL == 2) != (m.path_len[t] > (int)m.deep_levels)) return;   // the other launch serves this tree
     const bool running = m.status[t] == RC_MCTS_RUNNING;
     const bool backup = MODE > 0 && m.expanded[t];   // uniform over the workgroup
     if (!running && !backup) return;
@@ -1413,52 +1408,6 @@ static int check_mcts(const rc_mcts_t *m, bool results_only_ok = false) {
     return RC_OK;
 }
 
-// Full forests (more than 512 listed trees) with rc_mcts_t::deep_levels set: two launches side by side (see SEL at k_mcts_select),
-// the deep trees' first and on a stream of its own, joined before anything that follows on `stream` (events: capturable).
-struct StepFork {
-    hipStream_t side = nullptr;
-    hipEvent_t fork = nullptr, join = nullptr;
-};
-static StepFork *step_fork() {
-    static thread_local StepFork forks[16];
-    int dev = 0;
-    if (hipGetDevice(&dev) != hipSuccess) return nullptr;
-    StepFork &f = forks[dev & 15];
-    if (!f.side) {
-        if (hipStreamCreateWithFlags(&f.side, hipStreamNonBlocking) != hipSuccess) return nullptr;
-        if (hipEventCreateWithFlags(&f.fork, hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&f.join, hipEventDisableTiming) != hipSuccess)
-            return nullptr;
-    }
-    return &f;
-}
-
-template <int MODE>
-static int launch_step(const rc_mcts_t *m, const void *probs_or_head, const float *values, size_t ld, bool head_bf16, double c,
-                       uint32_t level_budget, uint32_t max_states, hipStream_t stream) {
-    const unsigned g = mcts_grid(m);
-#define RC_STEP(NT_, LW_, SEL_, STREAM_)                                                                                                    \
-    hipLaunchKernelGGL((k_mcts_select<MODE, true, NT_, LW_, SEL_>), dim3(g), dim3(NT_), 0, STREAM_, *m, c, level_budget, probs_or_head, values, ld, \
-                       head_bf16, max_states)
-    const unsigned nt = step_threads(g);
-    const bool four = line_waves(g) == 4;
-    if (nt == 256 && m->deep_levels > 0 && g > 512) {
-        StepFork *f = step_fork();
-        RC_REQUIRE(f != nullptr, RC_ERR_NODEVICE);
-        if (hipError_t e = hipEventRecord(f->fork, stream); e != hipSuccess) return hip_rc(e);
-        if (hipError_t e = hipStreamWaitEvent(f->side, f->fork, 0); e != hipSuccess) return hip_rc(e);
-        RC_STEP(1024, 4, 2, f->side);           // the deep trees: a CU each
-        if (hipError_t e = hipEventRecord(f->join, f->side); e != hipSuccess) return hip_rc(e);
-        RC_STEP(256, 1, 1, stream);             // everybody else
-        if (hipError_t e = hipStreamWaitEvent(stream, f->join, 0); e != hipSuccess) return hip_rc(e);
-        return launch_status();
-    }
-    if (nt == 1024) { if (four) RC_STEP(1024, 4, 0, stream); else RC_STEP(1024, 1, 0, stream); }
-    else if (nt == 512) { if (four) RC_STEP(512, 4, 0, stream); else RC_STEP(512, 1, 0, stream); }
-    else { if (four) RC_STEP(256, 4, 0, stream); else RC_STEP(256, 1, 0, stream); }
-#undef RC_STEP
-    return launch_status();
-}
-
 extern "C" {
 
 size_t rc_mcts_struct_bytes(void) { return sizeof(rc_mcts_t); }
@@ -1574,7 +1523,22 @@ int rc_mcts_step(const rc_mcts_t *m, const float *probs, const float *values, do
     if (int rc = check_mcts(m)) return rc;
     RC_REQUIRE(probs && values, RC_ERR_NULL);
     RC_REQUIRE(max_states > 0, RC_ERR_RANGE);
-    return launch_step<1>(m, (const void *)probs, values, (size_t)0, false, c, level_budget, max_states, (hipStream_t)stream);
+    const unsigned g = mcts_grid(m);
+#define RC_STEP(NT_)                                                                                                                        \
+    do {                                                                                                                                    \
+        if (line_waves(g) == 4)                                                                                                              \
+            hipLaunchKernelGGL((k_mcts_select<1, true, NT_, 4>), dim3(g), dim3(NT_), 0, (hipStream_t)stream, *m, c, level_budget,            \
+                               (const void *)probs, values, (size_t)0, false, max_states);                                                  \
+        else                                                                                                                                \
+            hipLaunchKernelGGL((k_mcts_select<1, true, NT_, 1>), dim3(g), dim3(NT_), 0, (hipStream_t)stream, *m, c, level_budget,            \
+                               (const void *)probs, values, (size_t)0, false, max_states);                                                  \
+    } while (0)
+    const unsigned nt = step_threads(g);
+    if (nt == 1024) RC_STEP(1024);
+    else if (nt == 512) RC_STEP(512);
+    else RC_STEP(256);
+#undef RC_STEP
+    return launch_status();
 }
 
 int rc_mcts_step_head(const rc_mcts_t *m, const void *head, size_t ld, int head_is_bf16, double c, uint32_t level_budget,
@@ -1582,7 +1546,22 @@ int rc_mcts_step_head(const rc_mcts_t *m, const void *head, size_t ld, int head_
     if (int rc = check_mcts(m)) return rc;
     RC_REQUIRE(head != nullptr, RC_ERR_NULL);
     RC_REQUIRE(ld >= (size_t)kActions + 1 && max_states > 0, RC_ERR_RANGE);
-    return launch_step<2>(m, head, (const float *)nullptr, ld, head_is_bf16 != 0, c, level_budget, max_states, (hipStream_t)stream);
+    const unsigned g = mcts_grid(m);
+#define RC_STEP(NT_)                                                                                                                        \
+    do {                                                                                                                                    \
+        if (line_waves(g) == 4)                                                                                                              \
+            hipLaunchKernelGGL((k_mcts_select<2, true, NT_, 4>), dim3(g), dim3(NT_), 0, (hipStream_t)stream, *m, c, level_budget, head,      \
+                               (const float *)nullptr, ld, head_is_bf16 != 0, max_states);                                                  \
+        else                                                                                                                                \
+            hipLaunchKernelGGL((k_mcts_select<2, true, NT_, 1>), dim3(g), dim3(NT_), 0, (hipStream_t)stream, *m, c, level_budget, head,      \
+                               (const float *)nullptr, ld, head_is_bf16 != 0, max_states);                                                  \
+    } while (0)
+    const unsigned nt = step_threads(g);
+    if (nt == 1024) RC_STEP(1024);
+    else if (nt == 512) RC_STEP(512);
+    else RC_STEP(256);
+#undef RC_STEP
+    return launch_status();
 }
 
 }  // extern "C"

@@ -37,7 +37,7 @@ class _McStruct(Structure):   # mirrors rc_mcts_t (include/rubiks_hip.h)
                [(name, c_void_p) for name in ("child_idx", "new_mask", "expanded", "select_stats", "bfs", "short_act",
                                               "short_len", "rec")] + \
                [("ring_k", c_uint32)] + [(name, c_void_p) for name in ("ring_node", "ring_act", "ring_len", "phase", "active")] + \
-               [("n_active", c_uint32), ("unc_list_cap", c_uint32), ("mapped_rows", c_void_p), ("deep_levels", c_uint32)]
+               [("n_active", c_uint32), ("unc_list_cap", c_uint32), ("mapped_rows", c_void_p)]
 
 
 _hip.register({
@@ -99,9 +99,6 @@ def rungs(n_trees: int) -> list:
 class MCTSForest:
     # node records of at least this many bytes: the per-node arrays are mapped on demand (None: never).  RUBIKS_VMM_MIN_GB
     # overrides it for a process (0 = every forest, "never" = none): A/B runs and diagnosis.
-    # full forests: trees whose pending descent is deeper than this many levels are served by a second, concurrent launch with 1 024
-    # threads each (rc_mcts_t::deep_levels; 0 = one launch for all).  RUBIKS_DEEP_LEVELS overrides it for a process (A/B).
-    DEEP_LEVELS = int(os.environ.get("RUBIKS_DEEP_LEVELS", "512"))
     VMM_MIN_BYTES = (lambda v: 1 << 30 if v is None else None if v == "never" else int(float(v) * (1 << 30)))(os.environ.get("RUBIKS_VMM_MIN_GB"))
     # Rows a planted tree starts with (a depth-20 tree ends at 12-14 k nodes on average and never grows at all), and how its
     # mapping grows when it gets near them: by GROW_FACTOR, at most GROW_STEP rows at a time.  A map call returns only when the
@@ -225,7 +222,6 @@ class MCTSForest:
         s.active, s.n_active = self.active_buf.data_ptr(), B
         s.unc_list_cap = 128
         s.mapped_rows = self.mapped_rows.data_ptr() if self.vmm else None
-        s.deep_levels = self.DEEP_LEVELS
         self.struct = s
         self.engine = None
         self._net_fp = None
