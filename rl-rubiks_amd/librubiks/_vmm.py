@@ -39,16 +39,15 @@ class VmmArray:
 
     _parked = {}   # (nbytes, chunk, device index) -> released arrays, memory still mapped: the next array of that shape takes one over
 
-    def __new__(cls, nbytes: int, device, chunk: int = CHUNK):
+    @classmethod
+    def take(cls, nbytes: int, device, chunk: int = CHUNK) -> "VmmArray":
+        """An array of this shape: one that a finished owner has parked (same address range, its chunks still mapped), else a
+        new reservation."""
         nb = (int(nbytes) + chunk - 1) // chunk * chunk
         free = cls._parked.get((nb, chunk, torch.device(device).index))
-        if free:
-            return free.pop()
-        return super().__new__(cls)
+        return free.pop() if free else cls(nbytes, device, chunk)
 
     def __init__(self, nbytes: int, device, chunk: int = CHUNK):
-        if getattr(self, "ptr", 0):      # taken over from the park: same address range, same chunks mapped
-            return
         self.lib = _hip.lib()
         self.device = torch.device(device)
         self.chunk = int(chunk)

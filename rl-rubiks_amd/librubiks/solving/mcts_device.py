@@ -163,7 +163,7 @@ class MCTSForest:
                 t = z((1,) + shape[1:], dt)   # arrays that turning finished trees into results never touches: one row, so that pointers are valid
             elif self.vmm:    # no memory yet, and none of these arrays needs clearing: a node's rows are written when it is created
                 bpr = int(np.prod(shape[1:], dtype=np.int64)) * torch.empty(0, dtype=dt).element_size()
-                arr = VmmArray(rows * bpr, dev, chunk=self._chunk_for(rows, shape, dt))
+                arr = VmmArray.take(rows * bpr, dev, chunk=self._chunk_for(rows, shape, dt))
                 self._ranges[name] = (arr, bpr)
                 t = arr.tensor(dt, shape)
             else:
@@ -288,7 +288,7 @@ class MCTSForest:
         if self.bfs is None:
             rows = self.B * (self.C + 1)
             if self.vmm:
-                self._ranges_bfs = VmmArray(rows * 8, self.device)
+                self._ranges_bfs = VmmArray.take(rows * 8, self.device)
                 self.bfs = self._ranges_bfs.tensor(torch.int32, (rows, 2))
             else:
                 self.bfs = torch.zeros((rows, 2), dtype=torch.int32, device=self.device)
