@@ -96,6 +96,28 @@ def rungs(n_trees: int) -> list:
     return out
 
 
+def growth_plan(have: np.ndarray, seen: np.ndarray, steps_ahead: int, max_rows: int, pregrow: bool, factor: float = 2.0,
+                step: int = 32768):
+    """
+    Which trees get more rows, and how many (host logic of the on-demand node store, `MCTSForest.grow`).
+    have[t]: rows of tree t with memory behind them; seen[t]: its node count at the host's last look; up to `steps_ahead`
+    iterations (12 new nodes each at most) run before the next look.  Nothing happens until some tree could reach the end of its
+    rows in that time; then that tree -- and, if `pregrow`, every tree past 70 % of its rows: a map call drains the GPU, so growth
+    steps should be few -- goes to max(what it can reach, min(factor x its rows, its rows + step)), never beyond max_rows.
+    Returns (tree indices, rows wanted).
+    """
+    have = np.asarray(have, dtype=np.int64)
+    seen = np.asarray(seen, dtype=np.int64)
+    need = np.minimum(max_rows, seen + N_ACT * (steps_ahead + 1) + 2)
+    must = need > have
+    if not must.any():
+        return np.zeros(0, dtype=np.int64), np.zeros(0, dtype=np.int64)
+    soon = (must | (seen > 0.7 * have)) if pregrow else must
+    trees = np.flatnonzero(soon & (have < max_rows))
+    grown = np.minimum((have[trees] * factor).astype(np.int64), have[trees] + step)
+    return trees, np.minimum(max_rows, np.maximum(need[trees], grown))
+
+
 class MCTSForest:
     # node records of at least this many bytes: the per-node arrays are mapped on demand (None: never).  RUBIKS_VMM_MIN_GB
     # overrides it for a process (0 = every forest, "never" = none): A/B runs and diagnosis.
@@ -263,15 +285,10 @@ class MCTSForest:
         self.nodes_seen = np.asarray(n_nodes, dtype=np.int64).copy()
         if not self.vmm:
             return
-        have = self.mapped_host.astype(np.int64)
-        need = self.nodes_seen + N_ACT * (steps_ahead + 1) + 2
-        must = need > have
-        if not must.any():
-            return
-        soon = must | (self.nodes_seen > 0.7 * have) if self.B <= self.PREGROW_TREES else must
-        trees = np.flatnonzero(soon & (have < self.C + 1))
-        step = np.minimum((have[trees] * self.GROW_FACTOR).astype(np.int64), have[trees] + self.GROW_STEP)
-        self.ensure_rows(trees, np.maximum(need[trees], step))
+        trees, rows = growth_plan(self.mapped_host, self.nodes_seen, steps_ahead, self.C + 1, self.B <= self.PREGROW_TREES,
+                                  self.GROW_FACTOR, self.GROW_STEP)
+        if len(trees):
+            self.ensure_rows(trees, rows)
 
     def _first_rows(self) -> int:
         """Rows a planted tree starts with."""
