@@ -53,6 +53,8 @@ def test_the_plan_keeps_a_growing_tree_ahead_of_its_nodes():
     while n + 12 < C1:
         seen_then = n                                   # the host sees the count of one round ago ...
         for _ in range(look_every):
+            if n + 12 >= C1:
+                break                                   # the tree has reached its capacity: it ends (EXHAUSTED), nothing waits
             assert n + 12 < have[0], "an expansion would have had to wait"
             n += 12
             steps += 1
