@@ -112,13 +112,14 @@ def scarce_rows(monkeypatch):
     from librubiks import _vmm
     from librubiks.solving import mcts_device as md
     made = []
-    init = _vmm.VmmArray.__init__
+    take = _vmm.VmmArray.take.__func__
 
-    def counting(self, *a, **k):
-        init(self, *a, **k)
-        made.append(self)
+    def counting(cls, *a, **k):          # every array a forest asks for, new or taken over from a finished forest of the same shape
+        arr = take(cls, *a, **k)
+        made.append(arr)
+        return arr
 
-    monkeypatch.setattr(_vmm.VmmArray, "__init__", counting)
+    monkeypatch.setattr(_vmm.VmmArray, "take", classmethod(counting))
     monkeypatch.setattr(md.MCTSForest, "VMM_MIN_BYTES", 0)
     monkeypatch.setattr(md.MCTSForest, "GROW_ROWS", 16)
     return made
