@@ -178,16 +178,26 @@ class MCTSForest:
             if not all(VmmArray.has_parked(nb, dev, ch) for nb, ch in sizes):
                 torch.cuda.synchronize()
                 VmmArray.trim()
+            try:
+                for name, (shape, dt) in per_node.items():
+                    if name != ("node" if _results_only else "nbr") and not (_results_only and name not in _RESULT_NODE):
+                        bpr = int(np.prod(shape[1:], dtype=np.int64)) * torch.empty(0, dtype=dt).element_size()
+                        self._ranges[name] = (VmmArray.take(rows * bpr, dev, chunk=self._chunk_for(rows, shape, dt)), bpr)
+            except _hip.RubiksHipError as e:
+                # a runtime without HIP virtual memory management (or out of address space): the forest is allocated up front,
+                # as in rounds 1-3 -- which fails by itself, loudly, if that does not fit
+                import warnings
+                warnings.warn(f"MCTSForest: node rows cannot be reserved on demand ({e}); allocating {rows * 285 / 1e9:.0f} GB up front", RuntimeWarning)
+                for arr, _ in self._ranges.values():
+                    arr.close()
+                self._ranges, self.vmm = {}, False
         for name, (shape, dt) in per_node.items():
             if name == ("node" if _results_only else "nbr"):
                 continue      # a search forest keeps nbr as a field of the node record, a results-only forest as a plain array
             if _results_only and name not in _RESULT_NODE:
                 t = z((1,) + shape[1:], dt)   # arrays that turning finished trees into results never touches: one row, so that pointers are valid
             elif self.vmm:    # no memory yet, and none of these arrays needs clearing: a node's rows are written when it is created
-                bpr = int(np.prod(shape[1:], dtype=np.int64)) * torch.empty(0, dtype=dt).element_size()
-                arr = VmmArray.take(rows * bpr, dev, chunk=self._chunk_for(rows, shape, dt))
-                self._ranges[name] = (arr, bpr)
-                t = arr.tensor(dt, shape)
+                t = self._ranges[name][0].tensor(dt, shape)
             else:
                 t = z(shape, dt)
             setattr(self, name, t)
