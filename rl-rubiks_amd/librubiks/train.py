@@ -42,18 +42,31 @@ def average_gradients(net: torch.nn.Module):
 class GradBuckets:
     """
     Data-parallel gradient averaging overlapped with backward.  The parameters' `.grad` tensors are views into a few
-    flat buckets (no gather / scatter copies); a bucket's all_reduce is launched asynchronously the moment
+    flat buckets (no gather / scatter copies); a bucket's exchange is launched asynchronously the moment
     backward has accumulated its last gradient, so it runs on RCCL's stream while autograd is still computing the
     gradients of the earlier layers.  Buckets are filled in the order backward produces gradients (last layer
-    first).  Sizing for xGMI: the eight GPUs of a node are fully connected point to point, RCCL's ring moves
-    2 (W-1)/W of a bucket over one ~150 GB/s link, so the 50 MB of fp32 gradients of fc_small cost ~0.6 ms per step
-    at W = 8; buckets of ~16 MB keep the per-call latency (~20 us) negligible while the first one starts after
+    first); ~16 MB each keeps the per-call latency (~20 us) negligible while the first one starts after
     the two head layers, i.e. under the backward of the three large trunk GEMMs.
+
+    exchange (the eight GPUs of a node are fully connected point to point, 7 xGMI links x ~150 GB/s each):
+      "ring"    one all_reduce per bucket: RCCL's ring moves 2 (W-1)/W of a bucket over ONE link (~0.6 ms per step for the 50 MB
+                of fp32 gradients of fc_small at W = 8);
+      "direct"  reduce-scatter and all-gather over all links at once: an all_to_all_single hands rank j everybody's j-th shard
+                (each rank sends (W-1)/W of the bucket, a W-th over each link), rank j adds them -- one fixed order, so every rank
+                ends with bit-identical gradients -- and an all_gather_into_tensor returns the sums; the first half runs under
+                backward, the second is issued in wait();
+      "auto"    direct on RCCL with at least four ranks, ring otherwise.
+    Neither form has been timed on xGMI (no multi-GPU box was available to this build); both are tested on gloo.
     `wait()` = every bucket reduced and divided by the world size; `zero()` replaces optimizer.zero_grad().
     """
 
-    def __init__(self, net: torch.nn.Module, bucket_bytes: int = 16 << 20):
-        self.world = dist.get_world_size() if (dist.is_available() and dist.is_initialized()) else 1
+    def __init__(self, net: torch.nn.Module, bucket_bytes: int = 16 << 20, exchange: str = "auto"):
+        on = dist.is_available() and dist.is_initialized()
+        self.world = dist.get_world_size() if on else 1
+        assert exchange in ("auto", "ring", "direct")
+        if exchange == "auto":
+            exchange = "direct" if on and dist.get_backend() == "nccl" and self.world >= 4 else "ring"
+        self.direct = exchange == "direct" and self.world > 1
         params = [p for p in net.parameters() if p.requires_grad]
         self.flats, self.bucket_of, self.sizes = [], {}, []
         group, nbytes = [], 0
@@ -67,7 +80,9 @@ class GradBuckets:
         if group:
             groups.append(group)
         for b, group in enumerate(groups):
-            flat = torch.zeros(sum(p.numel() for p in group), dtype=group[0].dtype, device=group[0].device)
+            n = sum(p.numel() for p in group)
+            n = -(-n // self.world) * self.world     # whole shards (the padding stays zero)
+            flat = torch.zeros(n, dtype=group[0].dtype, device=group[0].device)
             off = 0
             for p in group:
                 p.grad = flat[off:off + p.numel()].view_as(p)
@@ -75,16 +90,23 @@ class GradBuckets:
                 self.bucket_of[p] = b
             self.flats.append(flat)
             self.sizes.append(len(group))
+        self.recvs = [torch.empty_like(f) for f in self.flats] if self.direct else []
         self.left = list(self.sizes)
-        self.works = []
+        self.works = []                             # (bucket, work handle of its first collective)
         self.hooks = [p.register_post_accumulate_grad_hook(self._ready) for p in params]
         self.bytes = sum(f.numel() * f.element_size() for f in self.flats)
+
+    def _launch(self, b: int):
+        if self.direct:      # shard j of everybody's bucket -> rank j
+            self.works.append((b, dist.all_to_all_single(self.recvs[b], self.flats[b], async_op=True)))
+        else:
+            self.works.append((b, dist.all_reduce(self.flats[b], op=dist.ReduceOp.SUM, async_op=True)))
 
     def _ready(self, p):
         b = self.bucket_of[p]
         self.left[b] -= 1
         if self.left[b] == 0 and self.world > 1:
-            self.works.append(dist.all_reduce(self.flats[b], op=dist.ReduceOp.SUM, async_op=True))
+            self._launch(b)
 
     def zero(self):
         for f in self.flats:
@@ -99,10 +121,16 @@ class GradBuckets:
         if self.world > 1:
             for b, left in enumerate(self.left):
                 if left > 0:
-                    self.works.append(dist.all_reduce(self.flats[b], op=dist.ReduceOp.SUM, async_op=True))
+                    self._launch(b)
                     self.left[b] = 0
-        for w in self.works:
+        gathers = []
+        for b, w in self.works:
             w.wait()
+            if self.direct:   # this rank's shard of the sum (ranks added in one fixed order), then back to everybody
+                shard = self.recvs[b].view(self.world, -1).sum(0)
+                gathers.append((shard, dist.all_gather_into_tensor(self.flats[b], shard, async_op=True)))
+        for _, g in gathers:      # (the shards live until their gathers have run)
+            g.wait()
         self.works = []
         if self.world > 1:
             for f in self.flats:

@@ -117,14 +117,15 @@ def test_sharded_search_batch_two_ranks():
             assert full[k] == whole[k].tolist()
 
 
-def _bucket_worker(rank, world, port, q):
+def _bucket_worker(rank, world, port, exchange, q):
     import torch
     init_gloo(rank, world, port)
     from librubiks.train import GradBuckets
     torch.manual_seed(0)
     net = torch.nn.Sequential(torch.nn.Linear(6, 40), torch.nn.ReLU(), torch.nn.Linear(40, 30), torch.nn.ReLU(),
                               torch.nn.Linear(30, 2))
-    buckets = GradBuckets(net, bucket_bytes=200)      # three buckets, one per Linear layer (last layer first)
+    buckets = GradBuckets(net, bucket_bytes=200, exchange=exchange)      # three buckets, one per Linear layer (last layer first)
+    assert buckets.direct == (exchange == "direct") and all(f.numel() % world == 0 for f in buckets.flats)
     out = []
     for step in range(3):                             # a second step: zero() really resets, hooks fire again
         buckets.zero()
@@ -143,11 +144,13 @@ def _bucket_worker(rank, world, port, q):
     dist.destroy_process_group()
 
 
-def test_bucketed_async_gradient_average():
-    """GradBuckets: gradients live in flat buckets, every bucket is all-reduced during backward, result = mean over ranks."""
+@pytest.mark.parametrize("world,exchange", [(2, "auto"), (2, "direct"), (3, "direct")])
+def test_bucketed_async_gradient_average(world, exchange):
+    """GradBuckets: gradients live in flat buckets, every bucket's exchange starts during backward, result = mean over ranks --
+    by one all_reduce per bucket ("auto" on gloo = ring) or by the direct form (all_to_all_single of shards, local sum,
+    all_gather_into_tensor: what uses all xGMI links at once; three ranks: buckets padded to whole shards)."""
     import torch
-    world = 2
-    got = run_ranks(_bucket_worker, world, lambda r, port, q: (r, world, port, q), timeout=120)
+    got = run_ranks(_bucket_worker, world, lambda r, port, q: (r, world, port, exchange, q), timeout=120)
     assert got[0][1] == got[1][1] >= 3 and got[0][2] and got[1][2]
     for step in range(3):
         # reference: the same two local backward passes in this process, averaged by hand
@@ -165,6 +168,7 @@ def test_bucketed_async_gradient_average():
             assert launched == got[r][1] - (step == 2)        # every bucket that got its gradients was reduced inside backward
             for i, m in enumerate(mean):
                 assert np.allclose(np.array(reduced[i]), m, rtol=1e-6, atol=1e-7)
+        assert all(got[r][3][step][1] == got[0][3][step][1] for r in range(world))     # bit-identical on every rank
 
 
 def _dying_worker(rank, world, port, how, q):
