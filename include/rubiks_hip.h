@@ -245,13 +245,6 @@ typedef struct rc_split_layer {
     int32_t *range_flag;        /* optional */
     int products;               /* rc_split_layer_f16: 0 / 3 = the three products of the split layer; 1 = ONE f16 product of a [n_rows][k]
                                  * and w [n_out][k] as they are (the input layer: a = [onehot | 2^-11 onehot], w = [W_hi | W_lo], k = 960) */
-    int32_t *tile_counters;     /* optional, with out_partials: one zero-initialised int per output tile (>= 1 024 of them is always
-                                 * enough).  The K chunks of a tile then finish the layer themselves: whichever workgroup stores its
-                                 * partial last (an atomic count per tile) sums the tile's partials in the order p = 0, 1, ... exactly
-                                 * as rc_split_reduce_f16 does, applies bias / residual / activation / post_* and writes out_hi_lo or
-                                 * out_f32 (one of them must be given, with bias) -- no separate reduce launch.  Bit-identical to
-                                 * out_partials + rc_split_reduce_f16; the counters are left at zero.  For 2 .. 4 chunks (a tile's
-                                 * finisher reads them all from L2); not more than one launch at a time may use a counter array. */
 } rc_split_layer_t;
 size_t rc_split_layer_struct_bytes(void);
 int rc_split_layer_f16(const rc_split_layer_t *layer, rc_stream_t stream);

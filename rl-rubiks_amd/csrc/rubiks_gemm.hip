@@ -52,9 +52,6 @@ struct GemmArgs {
                                             // Linear because a skip connection reads its output as well
     int *flag;                   // kOutHalves: OR-ed with 1 when an output leaves IEEE half's range (|y| > 65504 or not finite)
     u32 S;                       // kPartials: number of K chunks (workgroups per tile)
-    int *counters;               // kPartials, optional: per-tile arrival counts -> the last chunk of a tile finishes the layer (fin_*)
-    void *fin_hl, *fin_f32;      // ... into [M][2N] halves or [M][N] fp32
-    u32 n_corr;                  // ... leading chunks that hold correction products only
     u32 P;                       // products of the f16 kinds: 3 = the split layer (a hi | lo, w lo | hi | hi), 1 = a [M][K] x w [N][K] as they are
 };
 constexpr float kHalfMax = 65504.0f;
@@ -205,8 +202,8 @@ __global__ __launch_bounds__(WM *WN * 64) void k_split_gemm(GemmArgs g) {
             }
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
-                if (KIND != kPartials && ACT == RC_ACT_RELU) y[e] = fmaxf(y[e], 0.f);
-                if (KIND != kPartials && ACT == RC_ACT_ELU) y[e] = y[e] > 0.f ? y[e] : g.alpha * expm1_neg(y[e]);
+                if (ACT == RC_ACT_RELU) y[e] = fmaxf(y[e], 0.f);
+                if (ACT == RC_ACT_ELU) y[e] = y[e] > 0.f ? y[e] : g.alpha * expm1_neg(y[e]);
             }
             if (KIND != kPartials && g.post_scale) {
                 const float4 ps = *reinterpret_cast<const float4 *>(g.post_scale + col), pt = *reinterpret_cast<const float4 *>(g.post_shift + col);
@@ -236,79 +233,6 @@ __global__ __launch_bounds__(WM *WN * 64) void k_split_gemm(GemmArgs g) {
         }
     }
     if (KIND == kOutHalves && g.flag && out_of_range) atomicOr(g.flag, 1);
-    if (KIND == kPartials && g.counters) {
-        // The tile's chunks finish the layer themselves.  Every thread's partial stores are made visible device-wide, then ONE
-        // atomic per workgroup counts the arrival; whoever arrives last reads all S partials back (from L2: they were just
-        // written) and runs rc_split_reduce_f16's arithmetic on its own lanes' outputs: ordered sum p = 0, 1, ..., the 2^-11 scaling
-        // in front of chunk n_corr, bias, skip connection, activation (expm1f, as the reduce kernel), post affine, re-split.
-        __shared__ int s_last;
-        __threadfence();
-        __syncthreads();
-        if (tid == 0) s_last = atomicAdd(&g.counters[wg], 1) == (int)g.S - 1;
-        __syncthreads();
-        if (!s_last) return;
-        if (tid == 0) g.counters[wg] = 0;     // ready for the next launch (stream-ordered behind this one)
-        __threadfence();                      // acquire: the other chunks' partials, not stale lines
-        bool oor = false;
-        const float *pbase = reinterpret_cast<const float *>(g.out);
-#pragma unroll
-        for (int m = 0; m < MR; ++m) {
-            const size_t row = row0 + wr * MR * 16 + m * 16 + fr;
-            if (row >= g.M) continue;
-#pragma unroll
-            for (int n = 0; n < NR; ++n) {
-                const u32 col = cbase + 16 * n;
-                float y[4] = {0.f, 0.f, 0.f, 0.f};
-                for (u32 p = 0; p < g.S; ++p) {
-                    if (p == g.n_corr) {
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) y[e] *= (1.0f / kSplitScale);
-                    }
-                    const f32x4 v = *reinterpret_cast<const f32x4 *>(pbase + ((size_t)p * g.M + row) * (size_t)g.N + col);
-                    y[0] += v[0], y[1] += v[1], y[2] += v[2], y[3] += v[3];
-                }
-                if (g.n_corr >= g.S) {
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) y[e] *= (1.0f / kSplitScale);
-                }
-                const float4 bv = *reinterpret_cast<const float4 *>(g.bias + col);
-                y[0] += bv.x, y[1] += bv.y, y[2] += bv.z, y[3] += bv.w;
-                if (g.res) {
-                    const unsigned char *rrow = g.res + row * ((size_t)g.N * 4);
-                    const uint2 rh = *reinterpret_cast<const uint2 *>(rrow + col * 2), rl = *reinterpret_cast<const uint2 *>(rrow + ((size_t)g.N + col) * 2);
-                    const u32 hw[2] = {rh.x, rh.y}, lw[2] = {rl.x, rl.y};
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        const float hi = (float)__builtin_bit_cast(_Float16, (unsigned short)(hw[e >> 1] >> (16 * (e & 1))));
-                        const float lo = (float)__builtin_bit_cast(_Float16, (unsigned short)(lw[e >> 1] >> (16 * (e & 1))));
-                        y[e] += hi + lo * (1.0f / kSplitScale);
-                    }
-                }
-#pragma unroll
-                for (int e = 0; e < 4; ++e)
-                    y[e] = ACT == RC_ACT_RELU ? fmaxf(y[e], 0.f) : ACT == RC_ACT_ELU ? (y[e] > 0.f ? y[e] : g.alpha * expm1f(y[e])) : y[e];
-                if (g.post_scale) {
-                    const float4 ps = *reinterpret_cast<const float4 *>(g.post_scale + col), pt = *reinterpret_cast<const float4 *>(g.post_shift + col);
-                    y[0] = y[0] * ps.x + pt.x, y[1] = y[1] * ps.y + pt.y, y[2] = y[2] * ps.z + pt.z, y[3] = y[3] * ps.w + pt.w;
-                }
-                if (g.fin_f32)
-                    *reinterpret_cast<float4 *>(reinterpret_cast<float *>(g.fin_f32) + row * (size_t)g.N + col) = make_float4(y[0], y[1], y[2], y[3]);
-                if (g.fin_hl) {
-                    float hi[4], lo[4];
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        oor |= !(fabsf(y[e]) <= kHalfMax);
-                        hi[e] = round_to_half_f32(y[e]);
-                        lo[e] = (y[e] - hi[e]) * kSplitScale;
-                    }
-                    unsigned char *orow = reinterpret_cast<unsigned char *>(g.fin_hl) + row * ((size_t)g.N * 4);
-                    *reinterpret_cast<uint2 *>(orow + col * 2) = make_uint2(pack_half2(hi[0], hi[1]), pack_half2(hi[2], hi[3]));
-                    *reinterpret_cast<uint2 *>(orow + ((size_t)g.N + col) * 2) = make_uint2(pack_half2(lo[0], lo[1]), pack_half2(lo[2], lo[3]));
-                }
-            }
-        }
-        if (g.fin_hl && g.flag && oor) atomicOr(g.flag, 1);
-    }
 }
 
 // The same tile with the two wave rows (waves 0-3 / 4-7: one of each per SIMD) running half a phase apart: a K-step is four
@@ -597,13 +521,11 @@ static int layer_args(const rc_split_layer_t *L, GemmArgs &g) {
     g.post_shift = L->post_shift;
     g.flag = L->range_flag;
     g.S = 1;
-    g.counters = nullptr, g.fin_hl = nullptr, g.fin_f32 = nullptr, g.n_corr = 0;
     RC_REQUIRE(L->products == 0 || L->products == 1 || L->products == 3, RC_ERR_RANGE);
     g.P = L->products == 1 ? 1u : 3u;
     return RC_OK;
 }
 
-extern "C" int rc_split_layer_corr_chunks(size_t k, int k_splits);
 extern "C" size_t rc_split_layer_struct_bytes(void) { return sizeof(rc_split_layer_t); }
 
 extern "C" int rc_split_layer_f16(const rc_split_layer_t *L, rc_stream_t stream) {
@@ -612,22 +534,13 @@ extern "C" int rc_split_layer_f16(const rc_split_layer_t *L, rc_stream_t stream)
     if (L->n_rows == 0) return RC_OK;
     hipStream_t s = (hipStream_t)stream;
     const int outs = (L->out_hi_lo != nullptr) + (L->out_f32 != nullptr) + (L->out_partials != nullptr);
-    RC_REQUIRE(L->out_bf16 == nullptr && (L->tile_counters ? (L->out_partials && outs == 2) : outs == 1), RC_ERR_NULL);
-    if (L->out_partials) {   // K cut into k_splits chunks, raw accumulators
+    RC_REQUIRE(outs == 1 && L->out_bf16 == nullptr, RC_ERR_NULL);
+    if (L->out_partials) {   // K cut into k_splits chunks, raw accumulators: no epilogue inputs
         const u32 S = (u32)L->k_splits, nk_all = g.P * g.K / 64;
         RC_REQUIRE(L->k_splits >= 2 && L->k_splits <= 32 && nk_all % S == 0 && nk_all / S >= 2 && (L->tile == 0 || L->tile == 1 || L->tile == 3) &&
                        L->n_out % (L->tile == 3 ? 128 : 256) == 0, RC_ERR_RANGE);
         g.out = (void *)L->out_partials;
         g.S = S;
-        if (L->tile_counters) {   // ... and the last chunk of every tile finishes the layer (no rc_split_reduce_f16 launch)
-            RC_REQUIRE(L->bias != nullptr && aligned16(L->tile_counters), RC_ERR_NULL);
-            RC_REQUIRE(L->k_splits <= 4 && g.P == 3 && ceil_div(L->n_rows, (size_t)352) * (L->n_out / (L->tile == 3 ? 128 : 256)) <= 1024, RC_ERR_RANGE);
-            const int nc = rc_split_layer_corr_chunks(L->k, L->k_splits);
-            RC_REQUIRE(nc >= 0, RC_ERR_RANGE);
-            g.counters = L->tile_counters, g.fin_hl = (void *)L->out_hi_lo, g.fin_f32 = (void *)L->out_f32, g.n_corr = (u32)nc;
-            if (L->tile == 3) return dispatch_split_gemm<2, 4, 11, 2, kPartials>(g, L->activation, s);
-            return dispatch_split_gemm<2, 4, 11, 4, kPartials>(g, L->activation, s);
-        }
         g.bias = nullptr;
         if (L->tile == 3) return launch_split_gemm<2, 4, 11, 2, RC_ACT_NONE, kPartials>(g, s);   // 352 x 128 tiles: small batches
         return launch_split_gemm<2, 4, 11, 4, RC_ACT_NONE, kPartials>(g, s);

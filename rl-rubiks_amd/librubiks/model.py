@@ -452,7 +452,7 @@ class _SplitLayer(ctypes.Structure):   # mirrors rc_split_layer_t (include/rubik
                                                "out_partials", "out_bf16")] + \
                [(n, ctypes.c_size_t) for n in ("n_rows", "n_out", "k")] + \
                [("activation", ctypes.c_int), ("alpha", ctypes.c_float), ("tile", ctypes.c_int), ("k_splits", ctypes.c_int),
-                ("range_flag", ctypes.c_void_p), ("products", ctypes.c_int), ("tile_counters", ctypes.c_void_p)]
+                ("range_flag", ctypes.c_void_p), ("products", ctypes.c_int)]
 
 
 def _ptr(t):
@@ -518,7 +518,6 @@ class SplitF32Net:
         self._model, self._fallback = model, None
         self._zeros = {layer[1].shape[0]: torch.zeros(layer[1].shape[0], dtype=torch.float32, device=self.device)
                        for layer in self.layers + self.value_layers if layer[0] == "hid"}
-        self._tile_counters = torch.zeros(1024, dtype=torch.int32, device=self.device)   # rc_split_layer_t::tile_counters (self-resetting)
 
     def overflowed(self) -> bool:
         """True if an activation left half range since the last call (reads and clears the device flag: synchronises)."""
@@ -558,7 +557,6 @@ class SplitF32Net:
             self._opts[id(out[-1])] = LayerOpts(o.save, o.add, None if o.post is None else tuple(t.float().contiguous() for t in o.post))
         return out
 
-    finish_in_kernel = True   # layers whose K loop is cut into 2 .. 4 chunks finish themselves (the tile's last chunk sums the partials): no reduce launch
     small_batch_cut = True   # False: the K loop is cut (in two) only from 96 whole-K tiles up, smaller batches go to the library (A/B switch)
     fused_hidden = True   # hidden layers as one kernel each (rc_split_gemm_f16) where its tile fills the chip
     fused_head = True     # last activation + output layer in one pass (rc_head_split_f32) behind a hidden layer that came as partials
@@ -717,25 +715,8 @@ class SplitF32Net:
                     # chunk, ~one per CU), raw fp32 partials; the first n_corr hold correction products only (still scaled by 2^11)
                     _, tile, chunks = plan
                     part = torch.empty((chunks, n, w), dtype=torch.float32, device=a.device)
-                    n_corr = _hip.lib().rc_split_layer_corr_chunks(K, chunks)
-                    pair_for_head = head_ok and chunks == 2 and n_corr == 1      # the head kernel takes (c, c_corr) as they are
-                    if self.finish_in_kernel and chunks <= 4 and not pair_for_head:
-                        # few chunks: the last of a tile's workgroups sums them and writes the layer's output itself (bias, skip,
-                        # activation, re-split) -- rc_split_reduce_f16's arithmetic bit for bit, without its launch and re-read
-                        out = torch.empty((n, w if last_hidden else 2 * w), dtype=torch.float32 if last_hidden else torch.float16, device=a.device)
-                        _layer_call("rc_split_layer_f16", a=a, w=W3, bias=b, residual=res, post_scale=post[0] if post else None,
-                                    post_shift=post[1] if post else None, n_rows=n, n_out=w, k=K, activation=code, alpha=alpha,
-                                    out_partials=part, out_hi_lo=None if last_hidden else out, out_f32=out if last_hidden else None,
-                                    k_splits=chunks, tile=tile, range_flag=self.range_flag, tile_counters=self._tile_counters)
-                        if head_ok:
-                            o16 = torch.empty((n, 16), dtype=torch.float32, device=a.device)
-                            _hip.check(_hip.lib().rc_head_split_f32(out.data_ptr(), None, 1.0 / SPLIT_SCALE, n, w, self._zero_bias(w).data_ptr(), 0, alpha,
-                                                                    nxt[1].data_ptr(), nxt[2].data_ptr(), nxt[1].shape[0], o16.data_ptr(),
-                                                                    _hip.stream_ptr()), "rc_head_split_f32")
-                            return o16[:, :nxt[1].shape[0]]
-                        a = out
-                        continue
                     _layer_call("rc_split_layer_f16", a=a, w=W3, n_rows=n, n_out=w, k=K, out_partials=part, k_splits=chunks, tile=tile)
+                    n_corr = _hip.lib().rc_split_layer_corr_chunks(K, chunks)
                 if head_ok:
                     # activation + the skinny output layer in one pass: the fp32 activations are never written (rc_head_split_f32)
                     out = torch.empty((n, 16), dtype=torch.float32, device=a.device)

@@ -661,37 +661,6 @@ def test_split_engine_small_batches_run_the_cut_kernel():
     assert not eng.overflowed()
 
 
-@pytest.mark.parametrize("arch", ["fc_small", "res_small"])
-def test_layers_that_finish_in_kernel_equal_the_reduce_kernel_bit_for_bit(arch):
-    """Layers whose K loop is cut into 2 .. 4 chunks finish themselves: the workgroup that stores a tile's last partial sums the
-    partials and applies bias / skip connection / activation / post affine / re-split (rc_split_layer_t::tile_counters).  Same
-    arithmetic in the same order as out_partials + rc_split_reduce_f16, so the whole forward must agree BIT FOR BIT with the engine
-    that launches the reduce kernel -- at every row count whose plan has 2 .. 4 chunks, twice in a row (the counters reset
-    themselves), with ragged row counts, and on a residual net (skip connection + post-activation affine in the finisher)."""
-    from librubiks import cube
-    from librubiks.model import F32_SPLIT, Model, ModelConfig, make_inference_net
-    torch.manual_seed(5)
-    np.random.seed(5)
-    net = _res_model(batchnorm=True) if arch == "res_small" else Model.create(ModelConfig(architecture="fc_small")).eval().cuda()
-    eng = make_inference_net(net, F32_SPLIT)
-    used = 0
-    for rows in (2816, 3000, 4224, 5632, 5633, 7040, 11264):
-        plans = [eng._layer_plan(rows, eng.layers, i) for i in range(1, len(eng.layers) - 1)]
-        used += sum(isinstance(p, tuple) and p[2] <= 4 for p in plans)
-        cubes, _, _ = cube.scramble_batch(rows, 25, True)
-        out = {}
-        for mode in (False, True, True):
-            eng.finish_in_kernel = mode
-            out.setdefault(mode, []).append((eng.head_cubes(cubes).clone(), eng.value_cubes(cubes).clone()))
-        eng.finish_in_kernel = True
-        (h0, v0), = out[False]
-        for h, v in out[True]:
-            assert torch.equal(h, h0) and torch.equal(v, v0), (rows, plans)
-        assert int(eng._tile_counters.abs().sum().item()) == 0
-    assert used >= 6, used          # the finishing form was what ran
-    assert not eng.overflowed()
-
-
 def test_layer_request_one_product_and_the_input_layer_on_it():
     """rc_split_layer_t.products = 1: the GEMM kernel as ONE f16 product of a [n][k] and w [n_out][k] (fp32 accumulation, the split
     epilogue) against float64; then the input layer of the split engine both ways -- fused one-hot kernel / explicit one-hot operand on
