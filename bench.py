@@ -59,7 +59,7 @@ _PROFILES = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles")
 # the most recent measurement on the env kernels as they are (round 4 re-measured them; they have not changed since round 2)
 PMC_FILE = next((f for f in ("r4k_env_pmc_traffic.json", "r2_env_pmc_traffic.json", "r1b_env_pmc_traffic.json") if os.path.exists(os.path.join(_PROFILES, f))),
                 "r4k_env_pmc_traffic.json")
-GEMM_PMC_FILE = "r3_split_gemm_traffic.json"   # the hidden-layer kernel that runs today (k_split_gemm<2, 4, 11, 4, ...>), re-measured in round 3
+GEMM_PMC_FILE = "r4_split_gemm_traffic.json"   # the hidden-layer kernel that runs today (k_split_gemm<2, 4, 11, 4, 2, 0>), re-measured in round 4
 PMC_SOURCE = f"stored PMC figure: profiles/{PMC_FILE} (separate rocprofv3 --pmc passes of these launches, not this run)"
 
 
