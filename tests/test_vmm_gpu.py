@@ -191,3 +191,48 @@ def test_config2_at_the_reference_cap_keeps_a_fraction_mapped():
         assert res.solved.mean() > 0.97
     # the rows of every tree that were mapped cover what the tree reached, and not the whole capacity
     assert (forest.mapped_host >= np.minimum(cap + 1, forest.nodes_seen + 1)).all() and forest.mapped_host.mean() < 0.25 * cap
+
+
+def test_config5_share_on_large_chunks_equals_the_oracle_on_sampled_trees():
+    """One GPU's share of BASELINE configs[4] -- 8 192 concurrent depth-24 trees -- on a forest whose node records reserve 105 GB
+    (capacity 50 000): the store then takes 4 MiB chunks for the records and 8 MiB for the keys, at addresses aligned by hand
+    inside the reservation (csrc/rubiks_vmm.hip).  Searched with max_states 13 000 at production precision; sixteen trees spread
+    over the forest (first, last, chunk neighbours) are replayed through the oracle on their own recorded network outputs: nodes,
+    neighbours, N, W, L, P, V and the action queues must be the oracle's."""
+    from librubiks import cube
+    from librubiks.model import F32_SPLIT, Model
+    from librubiks.solving.agents import MCTS
+    from librubiks.solving import mcts_device as md
+    import test_search_edge_gpu as edge
+    if not os.path.isdir(WEIGHTS):
+        pytest.skip("needs the trained weights")
+    net = Model.load(WEIGHTS).eval()
+    np.random.seed(11)
+    B, cap = 8192, 13_000
+    cubes, _, _ = cube.scramble_batch(B, 24, True)
+    states = cubes.numpy()
+    agent = MCTS(net, c=0.6, search_graph=True, net_dtype=F32_SPLIT)
+    agent.prepare(B, 50_000)                                    # the forest the search below runs in (capacity within 4 x its budget)
+    forest = agent.forest
+    chunks = {name: arr.chunk for name, (arr, _) in forest._ranges.items()}
+    assert forest.vmm and forest.bytes_reserved() > 100e9 and chunks["node"] == 4 << 20 and chunks["keys"] == 8 << 20 and chunks["V"] == 2 << 20
+    assert (forest.C + 1) % ((4 << 20) // 256) == 0            # every tree starts on a chunk boundary
+    res = agent.search_batch(cubes, None, cap, compact=False)
+    assert agent.forest is forest and (res.nodes <= cap).all() and res.solved.mean() > 0.5
+    assert forest.bytes_mapped() < 0.5 * forest.bytes_reserved()
+    for t in (0, 1, 2, 3, 511, 512, 2047, 2048, 4095, 4096, 6000, 7000, 8188, 8189, 8190, 8191):
+        tree = forest.tree_arrays(t)
+        n = tree["n"]
+        table = {tree["states"][i].tobytes(): (tree["P"][i].astype(np.float32), np.float32(tree["V"][i])) for i in range(1, n + 1)}
+        ref = oa.MCTS(edge._TableNet(table), c=0.6, search_graph=True)
+        before = {}
+        complete = ref._complete_graph
+
+        def recording_complete(ref=ref, before=before, complete=complete):
+            before["neighbors"] = ref.neighbors.copy()          # the device tree is read after its graph completion ran in place
+            complete()
+
+        ok = ref.search(states[t], cap)
+        assert bool(res.solved[t]) == ok and res.nodes[t] == len(ref) == n, f"tree {t}"
+        assert list(res.queues[t]) == list(ref.action_queue) and res.iterations[t] == ref.iterations, f"tree {t}"
+        edge._compare(tree, ref, n)
