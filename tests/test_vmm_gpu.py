@@ -196,7 +196,7 @@ def test_config2_at_the_reference_cap_keeps_a_fraction_mapped():
 def test_config5_share_on_large_chunks_equals_the_oracle_on_sampled_trees():
     """One GPU's share of BASELINE configs[4] -- 8 192 concurrent depth-24 trees -- on a forest whose node records reserve 105 GB
     (capacity 50 000): the store then takes 4 MiB chunks for the records and 8 MiB for the keys, at addresses aligned by hand
-    inside the reservation (csrc/rubiks_vmm.hip).  Searched with max_states 13 000 at production precision; sixteen trees spread
+    inside the reservation (csrc/rubiks_vmm.hip).  Searched with max_states 17 000 at production precision; twelve trees spread
     over the forest (first, last, chunk neighbours) are replayed through the oracle on their own recorded network outputs: nodes,
     neighbours, N, W, L, P, V and the action queues must be the oracle's."""
     from librubiks import cube
@@ -208,7 +208,7 @@ def test_config5_share_on_large_chunks_equals_the_oracle_on_sampled_trees():
         pytest.skip("needs the trained weights")
     net = Model.load(WEIGHTS).eval()
     np.random.seed(11)
-    B, cap = 8192, 13_000
+    B, cap = 8192, 17_000
     cubes, _, _ = cube.scramble_batch(B, 24, True)
     states = cubes.numpy()
     agent = MCTS(net, c=0.6, search_graph=True, net_dtype=F32_SPLIT)
@@ -220,7 +220,7 @@ def test_config5_share_on_large_chunks_equals_the_oracle_on_sampled_trees():
     res = agent.search_batch(cubes, None, cap, compact=False)
     assert agent.forest is forest and (res.nodes <= cap).all() and res.solved.mean() > 0.5
     assert forest.bytes_mapped() < 0.5 * forest.bytes_reserved()
-    for t in (0, 1, 2, 3, 511, 512, 2047, 2048, 4095, 4096, 6000, 7000, 8188, 8189, 8190, 8191):
+    for t in (0, 1, 2, 511, 512, 2048, 4095, 4096, 7000, 8189, 8190, 8191):
         tree = forest.tree_arrays(t)
         n = tree["n"]
         table = {tree["states"][i].tobytes(): (tree["P"][i].astype(np.float32), np.float32(tree["V"][i])) for i in range(1, n + 1)}
