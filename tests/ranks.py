@@ -40,6 +40,8 @@ def _entry(target, rank, args, q, err_path):
         err.write(tb)
         try:
             q.put((_ERROR, rank, tb))
+            q.close()
+            q.join_thread()           # the queue's feeder thread has written the report before the process goes
         finally:
             os._exit(1)
 
