@@ -34,7 +34,7 @@
 extern "C" {
 #endif
 
-#define RC_ABI_VERSION 6
+#define RC_ABI_VERSION 7
 
 #define RC_OK 0
 #define RC_ERR_NULL (-1)      /* required pointer is NULL */
@@ -462,6 +462,7 @@ int rc_vmm_reserve(size_t bytes, size_t chunk_bytes, void **out_base);
 int rc_vmm_map(void *base, size_t offset, size_t bytes, size_t *out_new_bytes);
 int rc_vmm_mapped_bytes(void *base, size_t *out_bytes);
 int rc_vmm_release(void *base);
+int rc_vmm_retired_bytes(size_t *out_bytes);   /* address space of released ranges kept reserved: never mapped twice */
 
 /* ---- batched weighted A*: B independent problems, N expansions each per iteration --------------
  *

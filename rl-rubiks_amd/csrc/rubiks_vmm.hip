@@ -26,9 +26,12 @@ struct Range {
     std::vector<hipMemGenericAllocationHandle_t> handles;   // one per chunk
     std::vector<char> mapped;
     size_t mapped_bytes = 0;
+    bool ever_mapped = false;
 };
 std::mutex g_mu;
 std::unordered_map<void *, Range> g_ranges;
+size_t g_retired_bytes = 0;                    // address space of released ranges that stays reserved (see rc_vmm_release)
+constexpr size_t kRetireBudget = 32ull << 40;   // of the 128 TiB a process has
 
 // One allocation per chunk, every chunk at an address that is a multiple of the chunk size.  Measured on MI355X / ROCm 7.2
 // (profiles/r4_vmm_raw_probe.txt, r4_vmm_raw_probe2.txt): hipMemSetAccess returns hipErrorInvalidValue for a piece whose virtual
@@ -42,6 +45,24 @@ std::unordered_map<void *, Range> g_ranges;
 int failed(hipError_t e) {
     (void)hipGetLastError();
     return hip_rc(e);
+}
+
+// hipMemUnmap does not make the GPU forget its translations of the unmapped addresses (ROCm 7.2 / MI355X, tools/vmm_remap_probe.hip,
+// profiles/r4_vmm_remap_probe.txt): memory mapped LATER at such an address -- in the same reservation, or in a new one that was
+// handed the freed addresses again -- is read and written through the stale translations by part of the chip (9 of 9 rounds with
+// wrong data; 0 of 9 at addresses never mapped before, and 0 of 9 at the addresses of a hipFree'd block).  An ordinary
+// hipMalloc + hipFree after the unmaps cures it in the probe (0 of 9): hipFree's own unmapping is announced to the GPU, and that
+// announcement covers everything.  rc_vmm_release does that AND keeps the range's addresses reserved for good, so that neither a
+// later reservation nor hipMalloc can be handed them: either measure alone passes the probe, address space is not scarce.
+void forget_translations() {
+    void *blk = nullptr;
+    if (hipMalloc(&blk, 2u << 20) != hipSuccess) {
+        (void)hipGetLastError();
+        return;
+    }
+    (void)hipMemset(blk, 0, 2u << 20);
+    (void)hipDeviceSynchronize();
+    (void)hipFree(blk);
 }
 
 hipMemAllocationProp device_prop(int device) {
@@ -117,6 +138,7 @@ int rc_vmm_map(void *base, size_t offset, size_t bytes, size_t *out_new_bytes) {
         }
         r.handles[c] = h;
         r.mapped[c] = 1;
+        r.ever_mapped = true;
         r.mapped_bytes += run;
         if (out_new_bytes) *out_new_bytes += run;
     }
@@ -132,7 +154,16 @@ int rc_vmm_mapped_bytes(void *base, size_t *out_bytes) {
     return RC_OK;
 }
 
-// Unmaps and releases everything, then frees the address range.  The caller has synchronised with every kernel that uses it.
+int rc_vmm_retired_bytes(size_t *out_bytes) {
+    RC_REQUIRE(out_bytes != nullptr, RC_ERR_NULL);
+    std::lock_guard<std::mutex> lock(g_mu);
+    *out_bytes = g_retired_bytes;
+    return RC_OK;
+}
+
+// Unmaps and releases the memory.  The caller has synchronised with every kernel that uses the range.  The ADDRESSES of a range
+// that had memory mapped are retired, not freed (see forget_translations): nothing is ever mapped at them again.  Only once
+// kRetireBudget of address space has been retired are ranges freed for reuse, relying on forget_translations alone.
 int rc_vmm_release(void *base) {
     RC_REQUIRE(base != nullptr, RC_ERR_NULL);
     std::lock_guard<std::mutex> lock(g_mu);
@@ -146,7 +177,12 @@ int rc_vmm_release(void *base) {
         if (hipError_t err = hipMemUnmap(static_cast<char *>(base) + c * r.chunk, r.chunk); err != hipSuccess && rc == RC_OK) rc = failed(err);
         if (hipError_t err = hipMemRelease(r.handles[c]); err != hipSuccess && rc == RC_OK) rc = failed(err);
     }
-    if (hipError_t err = hipMemAddressFree(r.raw, r.raw_bytes); err != hipSuccess && rc == RC_OK) rc = failed(err);
+    if (r.ever_mapped) forget_translations();
+    if (r.ever_mapped && g_retired_bytes + r.raw_bytes <= kRetireBudget) {
+        g_retired_bytes += r.raw_bytes;
+    } else if (hipError_t err = hipMemAddressFree(r.raw, r.raw_bytes); err != hipSuccess && rc == RC_OK) {
+        rc = failed(err);
+    }
     g_ranges.erase(it);
     return rc;
 }

@@ -21,6 +21,7 @@ _hip.register({
     "rc_vmm_map": [c_void_p, c_size_t, c_size_t, POINTER(c_size_t)],
     "rc_vmm_mapped_bytes": [c_void_p, POINTER(c_size_t)],
     "rc_vmm_release": [c_void_p],
+    "rc_vmm_retired_bytes": [POINTER(c_size_t)],
 })
 
 
@@ -83,6 +84,13 @@ class VmmArray:
         return int(new.value)
 
     @classmethod
+    def retired_bytes(cls) -> int:
+        """Address space of closed arrays that stays reserved so that nothing is mapped there again."""
+        out = c_size_t()
+        _hip.check(_hip.lib().rc_vmm_retired_bytes(ctypes.byref(out)), "rc_vmm_retired_bytes")
+        return int(out.value)
+
+    @classmethod
     def has_parked(cls, nbytes: int, device, chunk: int = CHUNK) -> bool:
         nb = (int(nbytes) + chunk - 1) // chunk * chunk
         return bool(cls._parked.get((nb, chunk, torch.device(device).index)))
@@ -105,8 +113,10 @@ class VmmArray:
         return n
 
     def close(self):
-        """Gives memory and address range back.  The caller has synchronised with every kernel that used the array and holds no
-        tensor of it any more."""
+        """Gives the memory back.  The caller has synchronised with every kernel that used the array and holds no tensor of it
+        any more.  The address range is retired, not reused: on this platform memory mapped at an address that was mapped before
+        is not coherent (rc_vmm_release, tools/vmm_remap_probe.hip) -- which is also why arrays are parked rather than closed
+        wherever a successor of the same shape is likely."""
         if self.ptr:
             ptr, self.ptr = self.ptr, 0
             _hip.check(self.lib.rc_vmm_release(ptr), "rc_vmm_release")

@@ -333,7 +333,7 @@ class MCTS(DeepAgent):
     # ---- batched search --------------------------------------------------------------------------
     def _forest_for(self, n_trees: int, capacity: int) -> md.MCTSForest:
         f = self.forest
-        if f is None or f.B != n_trees or f.C < capacity or f.C > 4 * capacity:
+        if f is None or f.B != n_trees or f.C < capacity or f.C_asked > 4 * capacity:
             self.forest = None
             torch.cuda.empty_cache()
             f = self.forest = md.MCTSForest(n_trees, capacity, self.max_path)

@@ -143,6 +143,7 @@ class MCTSForest:
                                       "here: rebuild the library (make -C rl-rubiks_amd)")
         dev = device or torch.device("cuda", torch.cuda.current_device())
         B, C = int(n_trees), int(capacity)
+        self.C_asked = C            # C below may be rounded up to whole chunks per tree
         assert B > 0 and 13 <= C < (1 << 24) and 2 <= max_path <= 4096   # 32-bit buffer offsets inside a tree: < 2^24 nodes
         if vmm is None:
             vmm = self.VMM_MIN_BYTES is not None and B * (C + 1) * NODE_WORDS * 4 >= self.VMM_MIN_BYTES

@@ -301,7 +301,7 @@ def test_one_launch_search_stopped_midway_ends_on_completed_iterations(net_gpu):
             ta, tb = a.forest.tree_arrays(t), b.forest.tree_arrays(t)
             assert ta["n"] == tb["n"]
             for k in ("states", "neighbors", "P", "V", "W", "N", "L", "leaves"):
-                assert np.array_equal(ta[k], tb[k]), (t, k)
+                assert np.array_equal(ta[k][1:], tb[k][1:]), (t, k)   # row 0 is no node: padded launch rows are written there
             if t % 8 == 0:
                 ref = oa.MCTS(onet, c=0.6, search_graph=False)
                 ref.search(states[t], cap, max_iterations=S)

@@ -101,7 +101,7 @@ def test_leaf_with_all_children_known(net_gpu):
         unseen = [k for k in range(12) if kids[k].tobytes() not in ref.indices]
         assert len(unseen) >= 10
         p, v = onet(kids[unseen])
-        base, n = t * (C + 1), len(ref)
+        base, n = t * (forest.C + 1), len(ref)      # forest.C: an on-demand forest rounds its rows per tree up
         table = forest.hash[t].cpu().numpy()
         for i, k in enumerate(unseen):
             idx = n + 1 + i

@@ -7,6 +7,9 @@ behind the rows in use.  What must hold:
   * searches on forests mapped on demand -- also with so little mapped ahead that trees have to WAIT for their rows (the
     kernels' `mapped_rows` guard) -- build the reference's trees node for node: the exact-tree tests of the continuous
     batching path (refill, narrowing, results forest) and of the deep production trees are repeated in that mode;
+  * an address is mapped at most once: on this platform memory mapped where other memory was mapped before is not coherent
+    (tools/vmm_remap_probe.hip), so closed arrays retire their addresses -- a forest of one shape followed by a forest of
+    another builds exact trees, which it did not while freed ranges were handed out again;
   * BASELINE configs[1] at the reference's max_states = 175 000 (1 024 x 175 001 rows reserved = 46 GB of node records)
     keeps less than 20 GB mapped.
 """
@@ -54,6 +57,80 @@ def test_vmm_array_maps_on_demand():
     del t
     arr.close()
     assert arr.ptr == 0 and torch.cuda.mem_get_info()[0] > free0 - (1 << 30)
+
+
+def test_addresses_of_a_closed_array_are_never_mapped_again():
+    """hipMemUnmap leaves stale translations on the GPU (tools/vmm_remap_probe.hip: 9 of 9 rounds with wrong data at addresses
+    mapped a second time): rc_vmm_release keeps the addresses of a range that had memory reserved for good.  Arrays of the
+    sizes that provoke the runtime into handing the same addresses back, written by one kernel shape and read by others."""
+    from librubiks._vmm import CHUNK, VmmArray
+    dev = torch.device("cuda", 0)
+    g = torch.Generator(device="cuda").manual_seed(0)
+    seen = []                                                      # (lo, hi) of every range that ever had memory
+    retired0 = VmmArray.retired_bytes()
+    expect_retired = 0
+    for r in range(6):
+        chunks = 8 + 4 * (r % 3)
+        for part in (1, 2, 2):                                     # one array, then two of half the size
+            n = chunks // part
+            arr = VmmArray(n * CHUNK, dev)
+            assert all(arr.ptr + arr.nbytes <= lo or hi <= arr.ptr for lo, hi in seen), "addresses that had memory were handed out again"
+            seen.append((arr.ptr, arr.ptr + arr.nbytes))
+            arr.ensure(0, arr.nbytes)
+            rows = arr.nbytes // 256
+            t = arr.tensor(torch.int32, (rows, 64))
+            want = (torch.arange(rows, device=dev, dtype=torch.int32) * 7 + 1000 * r + part).view(-1, 1).expand(rows, 64)
+            t.copy_(want)
+            t[1::3] += 1
+            exp = want.clone()
+            exp[1::3] += 1
+            idx = torch.randint(0, rows, (1 << 16,), device=dev, generator=g)
+            assert torch.equal(t.index_select(0, idx), exp.index_select(0, idx)) and torch.equal(t.flip(0), exp.flip(0))
+            assert torch.equal(t.cpu(), exp.cpu())
+            del t
+            torch.cuda.synchronize()
+            arr.close()
+            expect_retired += arr.nbytes
+    assert VmmArray.retired_bytes() - retired0 == expect_retired
+    never = VmmArray(4 * CHUNK, dev)                               # a range that never had memory is simply freed
+    never.close()
+    assert VmmArray.retired_bytes() - retired0 == expect_retired
+
+
+def test_a_forest_after_a_forest_of_another_shape_builds_exact_trees(standin_net, monkeypatch):
+    """The sequence that exposed the stale translations: a search on one forest, then a forest of another shape (the first
+    one's arrays cannot be taken over, their memory is given back), stepped in the three-phase form -- planting, expansion and
+    descent are different kernels with different grids, so they met different translations of the same address.  Every tree
+    must be the oracle's after each of the first iterations."""
+    from librubiks.cube import DeviceCubes
+    from librubiks.model import GenericNet
+    from librubiks.solving import mcts_device as md
+    from librubiks.solving.agents import MCTS
+    monkeypatch.setattr(md.MCTSForest, "VMM_MIN_BYTES", 0)          # every forest on demand, whatever its size
+    net = standin_net.cuda()
+    onet = oa.TorchNet(net, device="cuda")
+    for round_, (n_a, cap_a, n_b, cap_b) in enumerate([(8, 20000, 6, 400), (40, 9000, 5, 700), (3, 30000, 12, 300)]):
+        first = MCTS(net, c=0.6, search_graph=True, net_dtype=torch.float32)
+        first.search_batch(_roots(n_a, 20, 60 + round_), None, cap_a)          # to the cap: every tree's rows get memory
+        assert first.forest.vmm
+        del first
+        states = _roots(n_b, 15, 70 + round_)
+        forest = md.MCTSForest(n_b, cap_b)
+        assert forest.vmm
+        forest.set_net(GenericNet(net), torch.float32)
+        forest.reset(DeviceCubes.from_numpy(states))
+        warm = 9
+        for _ in range(warm + 1):                                   # a tree's first iteration (its root's) takes two steps
+            forest.step(0.6, cap_b, use_graph=False)
+        torch.cuda.synchronize()
+        for t in range(n_b):
+            ref = oa.MCTS(onet, c=0.6, search_graph=False)
+            assert not ref.search(states[t], cap_b, max_iterations=warm)
+            tree, n = forest.tree_arrays(t), len(ref)
+            assert tree["n"] == n, (round_, t)
+            assert np.array_equal(tree["neighbors"][:n + 1], ref.neighbors[:n + 1]) and np.array_equal(tree["N"][:n + 1], ref.N[:n + 1])
+            assert np.array_equal(tree["states"][1:n + 1], ref.states[1:n + 1]) and np.array_equal(tree["W"][1:n + 1], ref.W[1:n + 1])
+        forest.close()
 
 
 def _roots(n, depth, seed):
