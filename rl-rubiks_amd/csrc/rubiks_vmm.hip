@@ -177,7 +177,13 @@ int rc_vmm_release(void *base) {
         if (hipError_t err = hipMemUnmap(static_cast<char *>(base) + c * r.chunk, r.chunk); err != hipSuccess && rc == RC_OK) rc = failed(err);
         if (hipError_t err = hipMemRelease(r.handles[c]); err != hipSuccess && rc == RC_OK) rc = failed(err);
     }
-    if (r.ever_mapped) forget_translations();
+    if (r.ever_mapped) {   // on the range's device, whichever is current
+        int current = r.device;
+        (void)hipGetDevice(&current);
+        if (current != r.device) (void)hipSetDevice(r.device);
+        forget_translations();
+        if (current != r.device) (void)hipSetDevice(current);
+    }
     if (r.ever_mapped && g_retired_bytes + r.raw_bytes <= kRetireBudget) {
         g_retired_bytes += r.raw_bytes;
     } else if (hipError_t err = hipMemAddressFree(r.raw, r.raw_bytes); err != hipSuccess && rc == RC_OK) {
