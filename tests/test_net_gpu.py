@@ -700,3 +700,55 @@ def test_layer_request_one_product_and_the_input_layer_on_it():
     assert float((val(on_gemm) - val(fused)).abs().max()) < 1e-6
     del eng.gemm_input_rows
     assert not eng.overflowed()
+
+
+def test_engines_at_every_launch_size_of_a_narrowing_search():
+    """
+    The layer plan of the engines depends on the row count (own kernels on whole tiles, K cut in 2 .. 32 chunks + reduce for small
+    batches, the library chain in between: DESIGN.md 3.3), and a narrowing search walks through all of them: every rung of a
+    1 024-tree forest (11 rows per tree), plus the row counts either side of every plan boundary and a few odd ones.  At each size
+    the split engine must stay within 1.25 x the fp32 module's own error against float64 (its contract), the bf16 engine within
+    2 % of the largest output, and padding rows must not leak: the first n rows of a larger launch equal the rows of the
+    n-row launch to fp32 rounding.
+    """
+    import copy
+    import os
+    from conftest import ROOT
+    from librubiks import cube
+    from librubiks.cube.device import DeviceCubes
+    from librubiks.model import F32_SPLIT, Model, ModelConfig, make_inference_net
+    from librubiks.solving.mcts_device import rungs
+    torch.manual_seed(0)
+    np.random.seed(0)
+    wdir = os.path.join(ROOT, "weights", "fc_small_r1")
+    net = Model.load(wdir).eval() if os.path.isdir(wdir) else Model.create(ModelConfig()).eval()
+    ref64 = copy.deepcopy(net).double()
+    split, bf16 = make_inference_net(net, F32_SPLIT), make_inference_net(net, torch.bfloat16)
+    sizes = sorted({11 * r for r in rungs(1024)} | {1, 2, 11, 12, 351, 352, 353, 703, 704, 705, 1407, 1408, 1409, 2815, 2816, 2817,
+                                                      4097, 5631, 5632, 5633, 11263, 11265, 12288, 20000})
+    cubes, _, _ = cube.scramble_batch(max(sizes), 30, True)
+    oh = cubes.as_oh(torch.float32)
+    with torch.no_grad():
+        p64, v64 = ref64(oh.double())
+        p32, v32 = net(oh)
+    v64, v32 = v64.reshape(-1), v32.reshape(-1)
+    scale = max(1.0, float(p64.abs().max()), float(v64.abs().max()))
+    worst = {"split": 0.0, "bf16": 0.0, "fp32": 0.0}
+    for n in sizes:
+        e_f32 = max(float((p32[:n].double() - p64[:n]).abs().max()), float((v32[:n].double() - v64[:n]).abs().max()))
+        for name, eng in (("split", split), ("bf16", bf16)):
+            p, v = eng.forward_cubes(DeviceCubes(cubes.soa, n))        # the first n states of the same SoA
+            assert p.shape == (n, 12) and v.shape == (n,), (name, n)
+            e = max(float((p.double() - p64[:n]).abs().max()), float((v.double() - v64[:n]).abs().max()))
+            worst[name] = max(worst[name], e)
+            if name == "split":
+                assert not eng.overflowed() and e <= 1.25 * e_f32 + 2e-7 * scale, (n, e, e_f32)
+            else:
+                assert e <= 2e-2 * scale, (n, e)        # bf16: 2^-8 per rounding, five layers
+        worst["fp32"] = max(worst["fp32"], e_f32)
+        # a column window in the middle of the SoA (what a forest's rows are for A*): same rows, same numbers to fp32 rounding
+        if 16 <= n <= max(sizes) // 2:
+            off = n // 2 // 16 * 16                      # windows start on a multiple of 16 states
+            vw = split.value_cubes(cubes, None, off, n)
+            assert float((vw.double() - v64[off:off + n]).abs().max()) <= 1.25 * float((v32[off:off + n].double() - v64[off:off + n]).abs().max()) + 2e-7 * scale, n
+    print(f"{len(sizes)} launch sizes, |out| <= {scale:.2f}: worst max |err| vs float64: split {worst['split']:.2e}, fp32 module {worst['fp32']:.2e}, bf16 {worst['bf16']:.2e}")
