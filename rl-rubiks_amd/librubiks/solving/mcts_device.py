@@ -135,6 +135,21 @@ class MCTSForest:
     # whose node records reserve this many bytes and more take 4 MiB chunks for the records and 8 MiB for the keys.
     BIG_CHUNKS_FROM = 96 << 30
 
+    @classmethod
+    def on_demand_pays(cls, n_trees: int, capacity: int) -> bool:
+        """Whether a forest of this shape is mapped on demand.  Memory arrives a chunk (2 MiB = 8 192 node records) at a time and
+        every tree's records start on a chunk boundary, a planted tree starts with `_first_rows` rows, and a map call costs more
+        the more chunks are mapped: trees whose whole capacity is not at least twice their first rows gain nothing (8 192 trees x
+        10 000 nodes: 23 GB allocated up front, 36 GB mapped at the first plant; 65 536 trees x 200 nodes: 3.7 GB against one chunk
+        per tree = 137 GB and half a minute of map calls) -- those, and forests under VMM_MIN_BYTES, are allocated up front.
+        VMM_MIN_BYTES = 0 (tests, RUBIKS_VMM_MIN_GB=0) means every forest."""
+        if cls.VMM_MIN_BYTES is None:
+            return False
+        if cls.VMM_MIN_BYTES == 0:
+            return True
+        first = cls.GROW_ROWS * (2 if n_trees <= cls.PREGROW_TREES else 1)
+        return n_trees * (capacity + 1) * NODE_WORDS * 4 >= cls.VMM_MIN_BYTES and capacity + 1 >= 2 * first
+
     def __init__(self, n_trees: int, capacity: int, max_path: int = 4096, device=None, _results_only: bool = False, vmm: bool = None):
         """vmm: per-node arrays as reserved address ranges with memory mapped behind the rows in use (`grow`); None = by size."""
         self.lib = _hip.lib()
@@ -146,7 +161,7 @@ class MCTSForest:
         self.C_asked = C            # C below may be rounded up to whole chunks per tree
         assert B > 0 and 13 <= C < (1 << 24) and 2 <= max_path <= 4096   # 32-bit buffer offsets inside a tree: < 2^24 nodes
         if vmm is None:
-            vmm = self.VMM_MIN_BYTES is not None and B * (C + 1) * NODE_WORDS * 4 >= self.VMM_MIN_BYTES
+            vmm = self.on_demand_pays(B, C)
         self.vmm = bool(vmm)
         if self.vmm and not _results_only:
             # every tree's node records start on a chunk boundary (rows per tree rounded up to whole chunks: address space, not

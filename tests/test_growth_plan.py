@@ -64,3 +64,18 @@ def test_the_plan_keeps_a_growing_tree_ahead_of_its_nodes():
             have[0] = rows[0]
             grows += 1
     assert have[0] == C1 and grows <= 6                 # 32 768 -> 65 536 -> 98 304 -> 131 072 -> 163 840 -> 175 001
+
+
+def test_on_demand_only_where_it_pays():
+    """The automatic choice (MCTSForest.on_demand_pays): large forests of trees much larger than their first rows; forests of many
+    small trees are allocated up front (one chunk per tree would cost far more than their whole capacity)."""
+    from librubiks.solving.mcts_device import MCTSForest as F
+    if F.VMM_MIN_BYTES != 1 << 30:
+        import pytest
+        pytest.skip("RUBIKS_VMM_MIN_GB overrides the choice in this process")
+    assert F.on_demand_pays(1024, 175000) and F.on_demand_pays(8192, 175000) and F.on_demand_pays(8192, 50000)
+    assert not F.on_demand_pays(8192, 10000)        # 23 GB up front, 36 GB if every tree started with its 16 384 first rows
+    assert not F.on_demand_pays(65536, 200)         # 3.7 GB up front, a chunk per tree would be 137 GB
+    assert not F.on_demand_pays(1024, 50000)        # forests of <= 2 048 trees start with 32 768 rows per tree: most of 50 000
+    assert not F.on_demand_pays(16, 175000)         # under 1 GB
+    assert F.on_demand_pays(2048, 70000)
