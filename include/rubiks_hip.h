@@ -296,7 +296,7 @@ int rc_adi_targets(const float *values, const uint8_t *child_solved, const uint8
 
 typedef struct rc_mcts {
     uint32_t n_trees;    /* B */
-    uint32_t capacity;   /* largest node index per tree */
+    uint32_t capacity;   /* largest node index per tree; capacity + 1 < 2^24 (32-bit byte offsets into a tree's 256-byte records) */
     uint32_t hash_size;  /* slots per tree, power of two, >= 2 * (capacity + 1) */
     uint32_t max_path;   /* descent buffer length per tree (2 .. 4096) */
     uint32_t rows_per_tree; /* network rows reserved per tree and iteration: 11 (see child_soa) */

@@ -515,13 +515,13 @@ struct TreeBufs {
     __amdgpu_buffer_rsrc_t N, nbr, P, W, rec;
 };
 __device__ __forceinline__ TreeBufs tree_bufs(const rc_mcts_t &m, size_t base) {
-    const int rows = (int)((m.capacity + 1) * kRow);
+    const u32 rows = (m.capacity + 1) * (u32)kRow;   // words; x 4 bytes must stay below 2^32: capacity + 1 < 2^24 (check_mcts)
     TreeBufs b;
-    b.N = __builtin_amdgcn_make_buffer_rsrc((void *)(m.N + base * kRow), 0, rows * 4, kRsrcFlags);
-    b.nbr = __builtin_amdgcn_make_buffer_rsrc((void *)(m.nbr + base * kRow), 0, rows * 4, kRsrcFlags);
-    b.P = __builtin_amdgcn_make_buffer_rsrc((void *)(m.P + base * kRow), 0, rows * 4, kRsrcFlags);
-    b.W = __builtin_amdgcn_make_buffer_rsrc((void *)(m.W + base * kRow), 0, rows * 4, kRsrcFlags);
-    b.rec = __builtin_amdgcn_make_buffer_rsrc((void *)(reinterpret_cast<uint4 *>(m.rec) + base * kRowRec), 0, rows * 4,
+    b.N = __builtin_amdgcn_make_buffer_rsrc((void *)(m.N + base * kRow), 0, (int)(rows * 4u), kRsrcFlags);
+    b.nbr = __builtin_amdgcn_make_buffer_rsrc((void *)(m.nbr + base * kRow), 0, (int)(rows * 4u), kRsrcFlags);
+    b.P = __builtin_amdgcn_make_buffer_rsrc((void *)(m.P + base * kRow), 0, (int)(rows * 4u), kRsrcFlags);
+    b.W = __builtin_amdgcn_make_buffer_rsrc((void *)(m.W + base * kRow), 0, (int)(rows * 4u), kRsrcFlags);
+    b.rec = __builtin_amdgcn_make_buffer_rsrc((void *)(reinterpret_cast<uint4 *>(m.rec) + base * kRowRec), 0, (int)(rows * 4u),
                                               kRsrcFlags);
     return b;
 }
@@ -1389,7 +1389,7 @@ static int check_mcts(const rc_mcts_t *m, bool results_only_ok = false) {
                RC_ERR_NULL);
     RC_REQUIRE(m->n_trees > 0 && m->capacity >= 13 && m->max_path >= 2 && m->max_path <= (uint32_t)kMaxPath, RC_ERR_RANGE);
     // the kernels address a tree's node records through 32-bit buffer resources: (capacity + 1) * 256 bytes must stay below 2^32
-    RC_REQUIRE(m->capacity < (1u << 24), RC_ERR_RANGE);
+    RC_REQUIRE(m->capacity + 1 < (1u << 24), RC_ERR_RANGE);   // a tree's node records are addressed by 32-bit byte offsets (tree_bufs)
     RC_REQUIRE(m->active == nullptr || (m->n_active >= 1 && m->n_active <= m->n_trees), RC_ERR_RANGE);
     RC_REQUIRE((m->hash_size & (m->hash_size - 1)) == 0 && m->hash_size >= 2 * (m->capacity + 1), RC_ERR_RANGE);
     RC_REQUIRE(aligned16(m->keys) && aligned16(m->rec) && aligned16(m->child_soa) && (m->child_stride & 15u) == 0, RC_ERR_ALIGN);

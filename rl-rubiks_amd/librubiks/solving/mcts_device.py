@@ -80,6 +80,8 @@ _NODE_FIELDS = {"N": (0, 12, torch.int32), "W": (12, 24, torch.float32), "rec": 
                 "P": (32, 44, torch.float32), "nbr": (44, 56, torch.int32)}
 
 
+MAX_CAPACITY = (1 << 24) - 2   # nodes per tree: capacity + 1 rows of 256 bytes, addressed by 32-bit byte offsets (rc_mcts_t, tree_bufs)
+
 RUNG_RATIO = 0.95   # measured on configs[1] to completion, same box: 0.8 1.772 s, 0.9 1.735, 0.93 1.715, 0.95 1.710, 0.97 1.703 (profiles/r3_rung_ratio_ab.txt)
 
 
@@ -159,7 +161,7 @@ class MCTSForest:
         dev = device or torch.device("cuda", torch.cuda.current_device())
         B, C = int(n_trees), int(capacity)
         self.C_asked = C            # C below may be rounded up to whole chunks per tree
-        assert B > 0 and 13 <= C < (1 << 24) and 2 <= max_path <= 4096   # 32-bit buffer offsets inside a tree: < 2^24 nodes
+        assert B > 0 and 13 <= C <= MAX_CAPACITY and 2 <= max_path <= 4096, f"capacity {C}: 13 .. {MAX_CAPACITY} (32-bit byte offsets inside a tree's node records)"
         if vmm is None:
             vmm = self.on_demand_pays(B, C)
         self.vmm = bool(vmm)
@@ -167,7 +169,7 @@ class MCTSForest:
             # every tree's node records start on a chunk boundary (rows per tree rounded up to whole chunks: address space, not
             # memory), so the first rows of a tree cost one chunk, not the two a straddling range would
             per_chunk = self._chunk_for(B * (C + 1), (0, NODE_WORDS), torch.int32) // (NODE_WORDS * 4)
-            C = min((1 << 24) - 1, (C + per_chunk) // per_chunk * per_chunk - 1)
+            C = min(MAX_CAPACITY, (C + per_chunk) // per_chunk * per_chunk - 1)
         self.B, self.C, self.max_path, self.device = B, C, max_path, dev
         self.hash_size = 1 << int(np.ceil(np.log2(2 * (C + 1))))
         z = lambda shape, dt: torch.zeros(shape, dtype=dt, device=dev)   # noqa: E731
