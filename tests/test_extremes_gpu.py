@@ -77,3 +77,50 @@ def test_one_tree_with_the_largest_capacity():
     ref.search(states[0], cap, max_iterations=200)
     assert len(ref) == n and ref.iterations == res.iterations[0]
     _compare(tree, ref, n)
+
+
+def test_environment_kernels_beyond_2_to_the_31_states():
+    """multi_rotate, is_solved and the AoS <-> SoA transposes on 2^31 + 4 096 + 5 cube states (43 GB per SoA: element indices pass
+    2^32 inside a plane, state indices pass 2^31): windows at the start, either side of 2^31 and at the ragged end against the
+    oracle; the whole array through a property -- every action followed by its inverse gives the input back."""
+    from librubiks import cube
+    from librubiks.cube.device import DeviceCubes
+    n = (1 << 31) + 4096 + 5
+    if torch.cuda.mem_get_info()[0] < 150e9:
+        pytest.skip("needs 150 GB of free HBM")
+    np.random.seed(6)
+    block = 1 << 20
+    base, _, _ = cube.scramble_batch(block, 30, True)
+    big = DeviceCubes.empty(n)
+    for lo in range(0, n, block):
+        w = min(block, n - lo)
+        big.soa[:, lo:lo + w] = base.soa[:, :w]
+    g = torch.Generator(device="cuda").manual_seed(1)
+    actions = torch.randint(0, 12, ((n + 15) // 16 * 16,), dtype=torch.uint8, device="cuda", generator=g)
+    out = big.multi_rotate(actions)
+    windows = [0, (1 << 31) - 2048, n - 4096 - 5]
+    for lo in windows:
+        w = min(4096 + 5, n - lo)
+        src = big.soa[:, lo:lo + w].T.contiguous().cpu().numpy()
+        got = out.soa[:, lo:lo + w].T.contiguous().cpu().numpy()
+        assert np.array_equal(got, oc.multi_rotate_actions(src, actions[lo:lo + w].cpu().numpy())), lo
+    back = out.multi_rotate(actions ^ 1)                       # the inverse of action a is a ^ 1
+    for lo in range(0, n, 1 << 28):
+        hi = min(n, lo + (1 << 28))
+        assert torch.equal(back.soa[:, lo:hi], big.soa[:, lo:hi]), lo
+    del back
+    # is_solved: plant solved cubes at chosen places, the flags must find exactly those
+    solved = torch.from_numpy(oc.get_solved().astype(np.int8)).cuda()
+    where = [0, 12345, (1 << 31) - 1, 1 << 31, (1 << 31) + 17, n - 1]
+    for i in where:
+        out.soa[:, i] = solved
+    flags = out.is_solved()
+    mask, count = out.solved_mask()
+    assert int(count.item()) == len(where)
+    for i in where:
+        assert (int(mask[i // 64].item()) >> (i % 64)) & 1
+    assert sum(int(flags[lo:lo + (1 << 28)].sum().item()) for lo in range(0, n, 1 << 28)) == len(where) and all(bool(flags[i].item()) for i in where)
+    # the ragged end through the transposes
+    aos = out.to_aos()
+    assert aos.shape == (n, 20) and np.array_equal(aos[n - 3:].cpu().numpy(), out.soa[:, n - 3:n].T.cpu().numpy())
+    assert np.array_equal(aos[(1 << 31) - 2:(1 << 31) + 2].cpu().numpy(), out.soa[:, (1 << 31) - 2:(1 << 31) + 2].T.cpu().numpy())
