@@ -124,3 +124,29 @@ def test_environment_kernels_beyond_2_to_the_31_states():
     aos = out.to_aos()
     assert aos.shape == (n, 20) and np.array_equal(aos[n - 3:].cpu().numpy(), out.soa[:, n - 3:n].T.cpu().numpy())
     assert np.array_equal(aos[(1 << 31) - 2:(1 << 31) + 2].cpu().numpy(), out.soa[:, (1 << 31) - 2:(1 << 31) + 2].T.cpu().numpy())
+
+
+def test_astar_on_32768_problems_and_on_one_problem_with_a_large_open_list(standin_net):
+    """Batched A* at the ends of its shape range, stand-in net (exact arithmetic), sampled problems against the oracle:
+    32 768 problems at once (8 expansions each per iteration), and ONE problem with 1 000 expansions per iteration and
+    3 000 000 node slots."""
+    from librubiks.solving.agents import AStar
+    net = standin_net.cuda()
+    onet = oa.TorchNet(net, device="cuda")
+    np.random.seed(12)
+    B = 32768
+    states = np.array([oc.scramble(1 + i % 9, True)[0] for i in range(512)])
+    states = np.tile(states, (B // 512, 1))
+    res = AStar(net, lambda_=0.3, expansions=8, net_dtype=torch.float32).search_batch(states, None, 400)
+    assert res.nodes.shape == (B,) and 0.2 < res.solved.mean() < 1.0
+    for b in (0, 1, 511, 512, 16383, 16384, B - 2, B - 1):
+        ref = oa.AStar(onet, lambda_=0.3, expansions=8)
+        ok = ref.search(states[b], 400)
+        assert bool(res.solved[b]) == ok and res.nodes[b] == len(ref) and list(res.queues[b]) == list(ref.action_queue), b
+    assert np.array_equal(res.nodes[:512], res.nodes[512:1024]) and np.array_equal(res.lengths[:512], res.lengths[-512:])   # equal problems, equal ends
+    one = np.array([oc.scramble(40, True)[0]])
+    res = AStar(net, lambda_=0.1, expansions=1000, net_dtype=torch.float32).search_batch(one, None, 3_000_000)
+    ref = oa.AStar(onet, lambda_=0.1, expansions=1000)
+    ok = ref.search(one[0], 3_000_000, max_iterations=None)
+    assert bool(res.solved[0]) == ok and res.nodes[0] == len(ref) and list(res.queues[0]) == list(ref.action_queue)
+    assert res.nodes[0] > 100_000 or ok
