@@ -144,11 +144,12 @@ def _bucket_worker(rank, world, port, exchange, q):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world,exchange", [(2, "auto"), (2, "direct"), (3, "direct")])
+@pytest.mark.parametrize("world,exchange", [(2, "auto"), (2, "direct"), (3, "direct"), (8, "direct")])
 def test_bucketed_async_gradient_average(world, exchange):
     """GradBuckets: gradients live in flat buckets, every bucket's exchange starts during backward, result = mean over ranks --
     by one all_reduce per bucket ("auto" on gloo = ring) or by the direct form (all_to_all_single of shards, local sum,
-    all_gather_into_tensor: what uses all xGMI links at once; three ranks: buckets padded to whole shards)."""
+    all_gather_into_tensor: what uses all xGMI links at once; three ranks: buckets padded to whole shards; eight: the rank count of a node,
+    where "auto" picks this form on RCCL)."""
     import torch
     got = run_ranks(_bucket_worker, world, lambda r, port, q: (r, world, port, exchange, q), timeout=120)
     assert got[0][1] == got[1][1] >= 3 and got[0][2] and got[1][2]
