@@ -47,8 +47,9 @@ def _worker(rank, world, port, n_games, q):
     dist.destroy_process_group()
 
 
-def test_two_rank_gather_uneven():
-    n_games, world = 37, 2
+@pytest.mark.parametrize("n_games,world", [(37, 2), (37, 8), (5, 8)])
+def test_gather_of_uneven_shards(n_games, world):
+    """Two ranks, the eight of a node (uneven shards), and more ranks than games (some shards are empty)."""
     got = run_ranks(_worker, world, lambda r, port, q: (r, world, port, n_games, q), timeout=120)
     g = np.arange(n_games)
     for rank, full, summary in got:
@@ -57,7 +58,7 @@ def test_two_rank_gather_uneven():
         assert full["lengths"] == np.where(g % 3 == 0, g % 11, -1).tolist()
         assert summary["games"] == n_games and summary["nodes"] == int((100 + g).sum())
         assert abs(summary["nodes_per_sec"] - (100 + g).sum() / 2.0) < 1e-6
-    assert got[0][2] == got[1][2]
+    assert all(g[2] == got[0][2] for g in got)
 
 
 def _grad_worker(rank, world, port, q):
@@ -105,13 +106,15 @@ def _search_worker(rank, world, port, states, q):
     dist.destroy_process_group()
 
 
-def test_sharded_search_batch_two_ranks():
-    """Every rank ends with the results of ALL games, equal to the single-process search."""
+@pytest.mark.parametrize("world,n_games", [(2, 41), (8, 41), (8, 3)])
+def test_sharded_search_batch_on_several_ranks(world, n_games):
+    """Every rank ends with the results of ALL games, equal to the single-process search (eight ranks; more ranks than games)."""
     from librubiks.solving.sharding import sharded_search_batch
     rng = np.random.default_rng(0)
-    states = rng.integers(0, 24, size=(41, 20)).astype(np.int8)
+    states = rng.integers(0, 24, size=(n_games, 20)).astype(np.int8)
     whole = sharded_search_batch(_ToyAgent(), states, None, 100)      # no process group: plain search
-    got = run_ranks(_search_worker, 2, lambda r, port, q: (r, 2, port, states, q), timeout=120)
+    got = run_ranks(_search_worker, world, lambda r, port, q: (r, world, port, states, q), timeout=180)
+    assert len(got) == world
     for _, full in got:
         for k in ("solved", "lengths", "nodes"):
             assert full[k] == whole[k].tolist()
