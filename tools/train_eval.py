@@ -1,12 +1,12 @@
 """
 End-to-end experiment on one MI355X: train fc_small by Autodidactic Iteration with the device-resident
 data path (reference settings of configs/main_train.ini, scaled by wall-clock budget), then evaluate
-the batched agents on the trained weights and cross-check a subset of games against the restated
-reference agents (oracle/) driven by the same weights.
+the batched agents on the trained weights.  (The game-by-game cross-check of the fp32 agents against the restated
+reference agents on the trained weights is a test: tests/test_evaluation_gpu.py.)
 
     python tools/train_eval.py --minutes 12 --out gpurun_out/train_eval
 
-Writes <out>/results.json (losses, timings, solve rates by depth and agent, parity subset) and
+Writes <out>/results.json (losses, timings, solve rates by depth and agent) and
 <out>/model/{model.pt,config.json} in the reference's checkpoint layout.
 """
 import argparse
@@ -32,7 +32,6 @@ def main():
     ap.add_argument("--eval-games", type=int, default=256)
     ap.add_argument("--eval-depths", default="4,8,12,16,20")
     ap.add_argument("--max-states", type=int, default=20000)
-    ap.add_argument("--parity-games", type=int, default=12)
     ap.add_argument("--out", default="gpurun_out/train_eval")
     ap.add_argument("--load", default=None, help="skip training and load this model directory")
     args = ap.parse_args()
@@ -125,32 +124,6 @@ def main():
         del agent
         torch.cuda.empty_cache()
 
-    # ---- parity subset: the restated reference agents (oracle) on the same weights, game by game ---------
-    from oracle import agents as oa
-    from oracle import cube as oc
-    onet = oa.TorchNet(net, device="cuda")
-    parity = {}
-    for name, make_prod, make_ref, cap in (
-        ("MCTS", lambda: MCTS(net, c=0.6, search_graph=True, net_dtype=torch.float32), lambda: oa.MCTS(onet, 0.6, True), 3000),
-        ("AStar", lambda: AStar(net, lambda_=0.2, expansions=20, net_dtype=torch.float32), lambda: oa.AStar(onet, 0.2, 20), 3000),
-    ):
-        rows = []
-        for d in depths:
-            np.random.seed(1000 + d)
-            states = np.array([oc.scramble(d, True)[0] for _ in range(args.parity_games)])
-            res = make_prod().search_batch(states, None, cap)
-            same_solved = same_len = same_nodes = 0
-            for g, s in enumerate(states):
-                ref = make_ref()
-                ok = ref.search(s, cap)
-                same_solved += int(ok == bool(res.solved[g]))
-                same_len += int((len(ref.action_queue) if ok else -1) == res.lengths[g])
-                same_nodes += int(len(ref) == res.nodes[g])
-            rows.append({"depth": d, "games": args.parity_games, "same_solved": same_solved, "same_length": same_len,
-                         "same_node_count": same_nodes, "gpu_solved": int(res.solved.sum())})
-        parity[name] = rows
-        print("parity", name, rows, flush=True)
-    results["parity_vs_oracle_fp32"] = parity
     with open(os.path.join(args.out, "results.json"), "w") as f:
         json.dump(results, f, indent=1)
     print("wrote", os.path.join(args.out, "results.json"))
