@@ -98,14 +98,17 @@ class Model(nn.Module):
         super().__init__()
         self.config, self.log = config, logger
         trunk_out = config.shared_sizes[-1]
+        # Construction order = the reference's (model.py:117-129, 256-264): trunk, policy head, value head, THEN the residual
+        # blocks appended to the trunk -- the order in which the initialisers draw from torch's generator, so that a seeded
+        # `Model.create` has the reference's parameters bit for bit (tests/test_model.py, tests/golden/model_golden.npz).
         self.shared_net = nn.Sequential(*self._stack([OH_WIDTH, *config.shared_sizes], last_is_output=False))
+        self.policy_net = nn.Sequential(*self._stack([trunk_out, *config.part_sizes, N_ACTIONS], last_is_output=True))
+        self.value_net = nn.Sequential(*self._stack([trunk_out, *config.part_sizes, 1], last_is_output=True))
         if config.architecture.startswith("res"):
             assert trunk_out == config.res_size
             for i in range(config.res_blocks):
                 self.shared_net.add_module(f"resblock{i}",
                                            NonConvResBlock(config.res_size, config.activation_function, config.batchnorm))
-        self.policy_net = nn.Sequential(*self._stack([trunk_out, *config.part_sizes, N_ACTIONS], last_is_output=True))
-        self.value_net = nn.Sequential(*self._stack([trunk_out, *config.part_sizes, 1], last_is_output=True))
 
     @staticmethod
     def create(config: ModelConfig, logger=NullLogger()):

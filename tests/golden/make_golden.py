@@ -4,7 +4,7 @@ Generates the golden fixtures under tests/golden/ by IMPORTING THE REFERENCE (pe
 Run only in the build container, where the reference is mounted read-only:
 
     cd /tmp && PYTHONDONTWRITEBYTECODE=1 MPLBACKEND=Agg PYTHONPATH=/root/reference \
-        python /root/repo/tests/golden/make_golden.py [cube] [bfs] [bfs_cut] [agents] [adi] [simple]
+        python /root/repo/tests/golden/make_golden.py [cube] [bfs] [bfs_cut] [agents] [adi] [simple] [model]
 
 The fixtures are DATA (inputs + the reference's outputs).  No reference source travels with them.
 The GPU box never runs this script (it has no /root/reference); it only reads the committed files.
@@ -147,6 +147,63 @@ def make_bfs_cut():
                         seen=np.array([r[3] for r in rows]), queues=np.array([r[4] for r in rows]))
     print("bfs_cut_golden.npz:", len(rows), "searches,", sum(r[2] for r in rows), "solved")
 
+def make_model():
+    """
+    The reference's own `Model` (librubiks/model.py:106-161, ResNet :250-264), imported: for every architecture x batchnorm
+    the ordered (key, shape, dtype) list of `Model.create(ModelConfig(...)).state_dict()` under `torch.manual_seed(0)`, a
+    SHA-256 per tensor of that state_dict (the parameters themselves are 50-200 MB), and the module's eval-mode outputs on
+    the 256 golden `oh_in` states, in fp32 as the reference runs them and from the same module cast to float64.  For the
+    batchnorm variants additionally: three train-mode forwards (256 states each) so that the BatchNorm statistics are not
+    the initial ones, the statistics, and the eval-mode outputs behind them.
+    """
+    import hashlib
+    import torch
+    from librubiks import cube
+    from librubiks.model import Model, ModelConfig
+    g = np.load(os.path.join(OUT, "cube_golden.npz"))
+    oh_eval = cube.as_oh(g["oh_in"]).cpu()
+    oh_train = [cube.as_oh(g["mr_in"][256 * i:256 * (i + 1)]).cpu() for i in (1, 2, 3)]
+    fx, meta = {}, {}
+
+    def outputs(net, tag):
+        net.eval()
+        with torch.no_grad():
+            p, v = net(oh_eval)
+            net64 = Model.create(net.config).double()
+            net64.load_state_dict({k: (t.double() if t.is_floating_point() else t) for k, t in net.state_dict().items()})
+            net64.eval()
+            p64, v64 = net64(oh_eval.double())
+        assert p.dtype == torch.float32 and p.shape == (256, 12) and v.shape == (256, 1)
+        fx[f"{tag}_p32"], fx[f"{tag}_v32"] = p.numpy(), v.numpy()
+        fx[f"{tag}_p64"], fx[f"{tag}_v64"] = p64.numpy(), v64.numpy()
+
+    for arch in ("fc_small", "fc_big", "res_small", "res_big"):
+        for bn in (True, False):
+            name = f"{arch}_bn{int(bn)}"
+            torch.manual_seed(0)
+            net = Model.create(ModelConfig(architecture=arch, batchnorm=bn))
+            assert net.training                       # a fresh module is in train mode (agents call .eval(), agents.py:53)
+            sd = net.state_dict()
+            meta[name] = {"keys": [[k, list(t.shape), str(t.dtype)] for k, t in sd.items()],
+                          "sha256": {k: hashlib.sha256(t.contiguous().numpy().tobytes()).hexdigest() for k, t in sd.items()},
+                          "n_params": int(sum(p.numel() for p in net.parameters())),
+                          "repr": repr(net)}
+            outputs(net, f"{name}_fresh")
+            if bn:
+                net.train()
+                with torch.no_grad():
+                    for x in oh_train:
+                        net(x)
+                for k, t in net.state_dict().items():
+                    if "running_" in k or "num_batches" in k:
+                        fx[f"{name}_stat_{k}"] = t.numpy().copy()
+                outputs(net, f"{name}_trained_stats")
+            print(name, meta[name]["n_params"], "parameters,", len(sd), "tensors")
+    fx["meta_json"] = np.array(json.dumps(meta))
+    fx["torch_version"] = np.array(torch.__version__)
+    np.savez_compressed(os.path.join(OUT, "model_golden.npz"), **fx)
+    print("model_golden.npz:", len(fx), "arrays,", os.path.getsize(os.path.join(OUT, "model_golden.npz")), "bytes")
+
 
 if __name__ == "__main__":
     what = sys.argv[1:] or ["cube", "bfs", "bfs_cut", "agents", "adi", "simple"]
@@ -166,3 +223,5 @@ if __name__ == "__main__":
     if "adi" in what:
         from make_golden_agents import make_adi
         make_adi()
+    if "model" in what:
+        make_model()

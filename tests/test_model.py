@@ -119,3 +119,82 @@ def test_reference_model_tests_restated(tmp_path):
     # value-only / policy-only calls (model.py:131-141)
     m = Model(ModelConfig()).eval()
     assert m(x, policy=True, value=False).shape == (2, 12) and m(x, policy=False, value=True).shape == (2, 1)
+
+
+# ------------------------------------------------------------------------------------------------
+# a11 pinned against the REFERENCE's Model (tests/golden/model_golden.npz, written by make_golden.py `model`
+# from the imported reference, librubiks/model.py:106-161 and :250-264)
+# ------------------------------------------------------------------------------------------------
+import hashlib   # noqa: E402
+import json      # noqa: E402
+import os        # noqa: E402
+
+import pytest    # noqa: E402
+
+_GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+MODEL_CASES = [(a, b) for a in ("fc_small", "fc_big", "res_small", "res_big") for b in (True, False)]
+
+
+def golden_model_inputs():
+    """One-hot of the 256 golden `oh_in` states and of the three train-mode batches (states 256..1023 of `mr_in`)."""
+    g = np.load(os.path.join(_GOLDEN, "cube_golden.npz"))
+
+    def oh(states):
+        out = np.zeros((len(states), 480), dtype=np.float32)
+        out[np.repeat(np.arange(len(states)), 20), (24 * np.arange(20) + states).ravel()] = 1   # cube.py:265-277
+        return torch.from_numpy(out)
+    assert np.array_equal(np.nonzero(oh(g["oh_in"]).numpy())[1].reshape(256, 20), g["oh_cols"])
+    return oh(g["oh_in"]), [oh(g["mr_in"][256 * i:256 * (i + 1)]) for i in (1, 2, 3)]
+
+
+def seeded_reference_model(arch, bn, fx=None, trained_stats=False):
+    """The build's Model under the reference's seed; with `trained_stats` the BatchNorm statistics of the fixture loaded."""
+    torch.manual_seed(0)
+    net = Model.create(ModelConfig(architecture=arch, batchnorm=bn))
+    if trained_stats:
+        pre = f"{arch}_bn1_stat_"
+        net.load_state_dict({k[len(pre):]: torch.from_numpy(fx[k]) for k in fx.files if k.startswith(pre)}, strict=False)
+    return net
+
+
+@pytest.mark.parametrize("arch,bn", MODEL_CASES)
+def test_model_is_the_references_module(arch, bn):
+    """Same ordered state_dict (key, shape, dtype), same parameters bit for bit under the same seed, same module tree, and
+    the same function: eval-mode outputs in float64 to 1e-10 and in fp32 to 2e-6 x |out| (fp32 summation order differs
+    between BLAS builds and thread counts, nothing else may), fresh and behind three train-mode forwards."""
+    fx = np.load(os.path.join(_GOLDEN, "model_golden.npz"))
+    meta = json.loads(str(fx["meta_json"]))[f"{arch}_bn{int(bn)}"]
+    assert str(fx["torch_version"]) == torch.__version__      # initialisers are only promised per torch build
+    net = seeded_reference_model(arch, bn)
+    assert net.training
+    sd = net.state_dict()
+    assert [[k, list(t.shape), str(t.dtype)] for k, t in sd.items()] == meta["keys"]
+    assert sum(p.numel() for p in net.parameters()) == meta["n_params"]
+    for k, t in sd.items():
+        assert hashlib.sha256(t.contiguous().numpy().tobytes()).hexdigest() == meta["sha256"][k], k
+    # module tree (layer order Linear -> ELU -> BatchNorm1d, model.py:150-159); the reference's residual class is `ResNet`
+    assert repr(net).split("\n", 1)[1] == meta["repr"].split("\n", 1)[1]
+    oh_eval, oh_train = golden_model_inputs()
+    name = f"{arch}_bn{int(bn)}"
+
+    def check(net, tag):
+        net.eval()
+        with torch.no_grad():
+            p, v = net(oh_eval)
+            p64, v64 = net.double()(oh_eval.double())
+            net.float()
+        assert p.dtype == torch.float32 and v.shape == (256, 1)
+        for got, want in ((p64, fx[f"{tag}_p64"]), (v64, fx[f"{tag}_v64"])):
+            assert np.abs(got.numpy() - want).max() <= 1e-10 * max(1.0, np.abs(want).max())
+        for got, want in ((p, fx[f"{tag}_p32"]), (v, fx[f"{tag}_v32"])):
+            assert np.abs(got.numpy() - want).max() <= 2e-6 * max(1.0, np.abs(want).max())
+    check(net, f"{name}_fresh")
+    if bn:
+        net.train()
+        with torch.no_grad():
+            for x in oh_train:
+                net(x)
+        for k, t in net.state_dict().items():
+            if "running_" in k or "num_batches" in k:
+                assert np.allclose(t.numpy(), fx[f"{name}_stat_{k}"], rtol=1e-5, atol=1e-7), k
+        check(seeded_reference_model(arch, bn, fx, trained_stats=True), f"{name}_trained_stats")

@@ -752,3 +752,56 @@ def test_engines_at_every_launch_size_of_a_narrowing_search():
             vw = split.value_cubes(cubes, None, off, n)
             assert float((vw.double() - v64[off:off + n]).abs().max()) <= 1.25 * float((v32[off:off + n].double() - v64[off:off + n]).abs().max()) + 2e-7 * scale, n
     print(f"{len(sizes)} launch sizes, |out| <= {scale:.2f}: worst max |err| vs float64: split {worst['split']:.2e}, fp32 module {worst['fp32']:.2e}, bf16 {worst['bf16']:.2e}")
+
+
+@pytest.mark.parametrize("arch,bn,stats", [("fc_small", True, "trained_stats"), ("fc_small", True, "fresh"), ("fc_small", False, "fresh"),
+                                           ("res_small", True, "trained_stats"), ("fc_big", True, "trained_stats")])
+def test_engines_against_outputs_of_the_references_model(arch, bn, stats):
+    """
+    a11 against the REFERENCE: tests/golden/model_golden.npz holds what the imported reference `Model` (librubiks/model.py:106-161)
+    returns on the 256 golden `oh_in` states under torch.manual_seed(0) -- fp32 as the reference runs it, and the same module in
+    float64.  The build's Model has those parameters bit for bit (tests/test_model.py checks the hashes on the CPU; here again on the
+    state_dict that feeds the engines), and every engine is held to the fixture:
+      SplitF32Net   max |err| vs the reference's float64 outputs <= 1.25 x the error of the reference's OWN fp32 outputs (+1e-7)
+      fp32 chain    rtol = atol = 1e-4 against the reference's fp32 outputs
+      bf16          atol 3e-2 on logits and values of magnitude <= 1 (glorot weights)
+    """
+    import hashlib
+    import json
+    import os
+    from conftest import GOLDEN
+    from test_model import seeded_reference_model
+    from librubiks.cube import DeviceCubes
+    from librubiks.model import F32_SPLIT, InferenceNet, SplitF32Net, make_inference_net
+    fx = np.load(os.path.join(GOLDEN, "model_golden.npz"))
+    name = f"{arch}_bn{int(bn)}"
+    meta = json.loads(str(fx["meta_json"]))[name]
+    net = seeded_reference_model(arch, bn, fx, trained_stats=(stats == "trained_stats"))
+    for k, t in net.state_dict().items():
+        if stats == "fresh" or not ("running_" in k or "num_batches" in k):
+            assert hashlib.sha256(t.cpu().contiguous().numpy().tobytes()).hexdigest() == meta["sha256"][k], k
+    net = net.cuda().eval()
+    states = np.load(os.path.join(GOLDEN, "cube_golden.npz"))["oh_in"]
+    cubes = DeviceCubes.from_numpy(states)
+    oh = cubes.as_oh(torch.float32)
+    tag = f"{name}_{stats}"
+    p32, v32, p64, v64 = (fx[f"{tag}_{k}"] for k in ("p32", "v32", "p64", "v64"))
+    e_ref32 = max(np.abs(p32 - p64).max(), np.abs(v32 - v64).max())
+    err = lambda got, want: float(np.abs(got.double().cpu().numpy().reshape(want.shape) - want).max())   # noqa: E731
+    # the module itself on the GPU (torch's fp32 GEMMs): the function the fixture pins
+    with torch.no_grad():
+        pm, vm = net(oh)
+    assert err(pm, p32) <= 1e-4 and err(vm, v32) <= 1e-4
+    split = make_inference_net(net, F32_SPLIT)
+    assert isinstance(split, SplitF32Net)
+    for p, v in (split.forward_cubes(cubes), split(oh)):
+        e = max(err(p, p64), err(v, v64))
+        print(f"{tag}: split engine {e:.3e}, the reference's fp32 forward {e_ref32:.3e} from its float64 forward")
+        assert e <= 1.25 * e_ref32 + 1e-7
+    assert err(split.value_cubes(cubes), v64) <= 1.25 * e_ref32 + 1e-7
+    f32 = InferenceNet(net, torch.float32)
+    for p, v in ((f32.forward_cubes(cubes), f32(oh)) if f32.supports_cubes else (f32(oh),)):
+        assert np.allclose(p.cpu().numpy(), p32, rtol=1e-4, atol=1e-4) and np.allclose(v.cpu().numpy().reshape(-1, 1), v32, rtol=1e-4, atol=1e-4)
+    bf = make_inference_net(net, torch.bfloat16)
+    p, v = bf.forward_cubes(cubes)
+    assert err(p.float(), p32) <= 3e-2 and err(v.float(), v32) <= 3e-2
