@@ -401,6 +401,30 @@ LEG_DTYPE = {   # leg name -> the arithmetic the network computes in (`dtype` of
 }
 
 
+def replay_solutions(roots_np, res, what):
+    """
+    Every game reported solved: its action queue has the reported length and, walked from the game's scramble through the
+    library's own `cube.multi_rotate` (one call per move index over the games still moving), ends on the solved state
+    (`cube.multi_is_solved`).  Outside every timed region.  A mismatch ends the benchmark: a solve rate is checked, not reported.
+    """
+    from librubiks import cube
+    idx = np.flatnonzero(np.asarray(res.solved))
+    if not len(idx):
+        return {"games_reported_solved": 0, "solutions_replayed_to_solved": 0}
+    lens = np.array([len(res.queues[i]) for i in idx])
+    if not np.array_equal(lens, np.asarray(res.lengths)[idx]):
+        raise RuntimeError(f"{what}: a reported solution length is not its action queue's")
+    cur = np.ascontiguousarray(roots_np[idx]).copy()
+    for d in range(int(lens.max())):
+        live = np.flatnonzero(lens > d)
+        faces, dirs = cube.indices_to_actions(np.array([res.queues[idx[i]][d] for i in live], dtype=np.int64))
+        cur[live] = cube.multi_rotate(cur[live], faces, dirs)
+    ok = int(np.asarray(cube.multi_is_solved(cur)).sum())
+    if ok != len(idx):
+        raise RuntimeError(f"{what}: {len(idx) - ok} of {len(idx)} reported solutions do not end on the solved state")
+    return {"games_reported_solved": int(len(idx)), "solutions_replayed_to_solved": ok}
+
+
 def run_leg(name, model, pool_roots, config_roots, args, world, coll_device, trees, cap, window_only=False, full_warm=True):
     """
     One network precision: steady-state window of K steps on the continuously refilled pool, the whole pool to
@@ -476,7 +500,8 @@ def run_leg(name, model, pool_roots, config_roots, args, world, coll_device, tre
         res = run.finish()
         torch.cuda.synchronize()
         pool_seconds = time.perf_counter() - t_pool
-        pool = {"games": int(run.n_games), "slots": trees, "nodes": int(res.nodes.sum()), "seconds": round(pool_seconds, 3),
+        pool_check = replay_solutions(pool_roots.numpy(), res, f"{name} pool run")
+        pool = {"games": int(run.n_games), "slots": trees, "nodes": int(res.nodes.sum()), "seconds": round(pool_seconds, 3), **pool_check,
                 "nodes_per_sec": round(float(res.nodes.sum()) / pool_seconds, 1), "solve_rate": float(res.solved.mean()),
                 "iterations": int(run.it), **{k: (round(v, 4) if isinstance(v, float) else v) for k, v in run.stats.items() if k != "iterations"}}
     del run
@@ -494,7 +519,8 @@ def run_leg(name, model, pool_roots, config_roots, args, world, coll_device, tre
         rtc_seconds = time.perf_counter() - t1
         local = {"nodes": full.nodes, "solved": full.solved, "lengths": full.lengths}
         rtc = {"seconds": rtc_seconds, "nodes": int(full.nodes.sum()), "iterations": int(full.iterations.max()),
-               "launch_sizes": int(agent.refill_stats.get("compactions", 0)) + 1}
+               "launch_sizes": int(agent.refill_stats.get("compactions", 0)) + 1,
+               "check": replay_solutions(config_roots.numpy(), full, f"{name} run to completion")}
     forest_gb = {"hbm_behind_the_forest_gb": round(agent.forest.bytes_allocated() / 1e9, 2), "mapped_on_demand": bool(agent.forest.vmm),
                  "node_rows_reserved_gb": round(agent.forest.bytes_reserved() / 1e9, 2)}
     stats = torch.tensor([seconds, float(nodes), float(steps_done), rtc["seconds"] if rtc else 0.0,
@@ -529,6 +555,7 @@ def run_leg(name, model, pool_roots, config_roots, args, world, coll_device, tre
             "ci95": float(1.959963984540054 * np.sqrt(p * (1 - p) / total)),
             "mean_solution_length": float(np.mean(g["lengths"][g["solved"].astype(bool)])) if np.any(g["solved"]) else None,
             "lock_step_iterations_rank0": rtc["iterations"], "launch_sizes_rank0": rtc["launch_sizes"],
+            **{k + "_rank0": v for k, v in rtc["check"].items()},
             "seconds_incl_prepare_rank0": round(rtc["seconds"] + prepare_seconds, 3),
             "warm_up": "forest allocated and HIP graphs of every launch size captured before (MCTS.prepare), then "
                        + ("the same search once, untimed" if full_warm else "30 iterations of it, untimed"),
@@ -635,6 +662,7 @@ def astar_leg(name, model, roots, args, world, coll_device):
         torch.cuda.synchronize()
         solve_s = time.perf_counter() - t1
         local = {"nodes": res.nodes, "solved": res.solved, "lengths": res.lengths}
+        solve_check = replay_solutions(roots.numpy(), res, f"{name} A* solve run")
     stats = torch.tensor([seconds, float(nodes), solve_s if local else 0.0], dtype=torch.float64, device=coll_device)
     if world > 1:
         mx, sm = stats.clone(), stats.clone()
@@ -651,7 +679,8 @@ def astar_leg(name, model, roots, args, world, coll_device):
         out["solve_run"] = {"games": int(total_games), "max_states_per_problem": cap, "nodes": int(np.sum(g["nodes"])), "seconds": round(solve_s, 3),
                             "states_per_sec": round(float(np.sum(g["nodes"])) / solve_s, 1), "solve_rate": p,
                             "ci95": float(1.959963984540054 * np.sqrt(p * (1 - p) / total_games)),
-                            "mean_solution_length": float(np.mean(g["lengths"][g["solved"].astype(bool)])) if np.any(g["solved"]) else None}
+                            "mean_solution_length": float(np.mean(g["lengths"][g["solved"].astype(bool)])) if np.any(g["solved"]) else None,
+                            **{k + "_rank0": v for k, v in solve_check.items()}}
     del agent, batch
     torch.cuda.empty_cache()
     return out
@@ -884,15 +913,14 @@ def step_rooflines(engine, agent, roots, args, name):
                     "traffic": None, "flops_per_launch": f1, "ms_per_launch": phases["gemm_hidden1"]}
     if fused:
         H = eng._fused_first[4]
-        mode = eng._fused_first[5]
-        mfma = mode in (2, 4, 5)
-        kname = ("rc_first_layer_mfma2_bf16" if mode == 5 else "rc_first_layer_mfma_bf16") + (" (one-hot x W1 on the matrix cores, one-hot fragments generated from the cube codes, "
-                 "W1 slice in LDS, + bias + ELU)") if mfma else "rc_first_layer_bf16 (one-hot x W1 as 20-row gather-sum from LDS + bias + ELU)"
+        is_half = bool(eng._fused_first[5])
+        kname = ("rc_first_layer_mfma_bf16 (one-hot x W1 on the matrix cores, one-hot fragments generated from the cube codes, "
+                 "W1 slice in LDS, + bias + ELU)")
         f_in = 2 * 480 * H * rows
         tf_in = f_in / (phases["input_layer"] * 1e-3) / 1e12
         nbytes = (20 + 2 * H) * rows
-        roofline_input = {"kernel": kname, "table": {0: "bf16", 1: "f16", 2: "bf16", 3: "f16 pairs", 4: "f16", 5: "f16, two tiles per wave"}[mode],
-                          "bound": "mfma" if mfma else "lds", "achieved": round(tf_in, 1), "peak": MFMA_BF16_PEAK_TFLOPS,
+        roofline_input = {"kernel": kname, "weights": "f16" if is_half else "bf16",
+                          "bound": "mfma", "achieved": round(tf_in, 1), "peak": MFMA_BF16_PEAK_TFLOPS,
                           "unit": "TFLOP/s", "frac": round(tf_in / MFMA_BF16_PEAK_TFLOPS, 4), "flops_per_launch": f_in,
                           "traffic": None, "ms_per_launch": phases["input_layer"], "algorithmic_bytes": nbytes,
                           "note": "dense-equivalent flops of the 480-wide one-hot product; the kernel is bound by feeding the MFMAs "
@@ -1025,8 +1053,8 @@ def main():
     ap.add_argument("--level-budget", default="auto",
                     help="new tree levels a PUCT descent may walk per step before it is suspended (0 = strict lock step; "
                          "auto = the agent's default: a budget while scrambles are waiting for a slot, none for the tail)")
-    ap.add_argument("--first-layer-table", default="auto", choices=["auto", "f16", "f16pair", "bf16", "mfma", "mfma16", "mfma16x2", "onehot"],
-                    help="bf16 engine's input layer: fused gather-sum with an f16 / bf16 table, or the one-hot GEMM")
+    ap.add_argument("--first-layer-table", default="auto", choices=["auto", "onehot"],
+                    help="bf16 engine's input layer: the fused matrix-core kernel from the cube codes, or the explicit one-hot + library GEMM")
     ap.add_argument("--as-rank", default=None, metavar="R/W",
                     help="single process, no process group: take rank R's share of a W-rank run's scrambles (tests compare "
                          "the ranks of a distributed run with these)")

@@ -34,7 +34,7 @@
 extern "C" {
 #endif
 
-#define RC_ABI_VERSION 7
+#define RC_ABI_VERSION 8
 
 #define RC_OK 0
 #define RC_ERR_NULL (-1)      /* required pointer is NULL */
@@ -122,34 +122,20 @@ int rc_sequence_states(const uint8_t *moves, int8_t *out_soa, size_t games, size
                        int with_solved, size_t stride_out, rc_stream_t stream);
 
 /* ---- network input layer fused with the one-hot encoding ------------------------------------------
- * out[i][c] = act( bias[c] + sum_j w1t[24 j + s[i][j]][c] )   (bf16 out, fp32 accumulation)
+ * out[i][c] = act( bias[c] + sum_j W1[c][24 j + s[i][j]] )   (bf16 out, fp32 accumulation)
  * = activation(Linear(480, H)(as_oh(states))) of the reference (librubiks/cube/cube.py:265-277 feeding
- * the first nn.Linear of librubiks/model.py:123-127,150-157) without materialising the one-hot
- * matrix: a one-hot row has exactly 20 ones, so the product is a 20-row gather-sum of W1^T.
- *   w1t : [480][H] row-major 16-bit table (the Linear weight transposed): bf16, or IEEE f16 when
- *         table_is_f16 != 0 (11 mantissa bits instead of 8; one v_fma_mix_f32 converts and adds);
- *         table_is_f16 == 2 additionally adds PAIRS of table rows in half precision first (v_pk_add_f16)
+ * the first nn.Linear of librubiks/model.py:123-127,150-157) on the matrix cores, without materialising the
+ * one-hot matrix: the one-hot A-fragments of v_mfma_f32_32x32x16_{f16,bf16} are generated in registers from the
+ * cube codes and a 128-column slice of W1 is resident in LDS as the B operand.
+ *   w1  : [H][480] row-major = the nn.Linear weight as stored, IEEE half if table_is_f16 != 0 (11 mantissa bits:
+ *         the default whenever every weight fits half's range), else bf16
  *   bias: float[H], out: bf16 [n][H];  H: multiple of 128;  activation: 0 = none, 1 = ReLU, 2 = ELU(alpha)
- * Algorithmic HBM bytes per state: 20 in + 2 H out (W1^T is 0.96 H KB, L2-resident). */
+ * Algorithmic HBM bytes per state: 20 in + 2 H out (W1 is 0.96 H KB, L2-resident). */
 #define RC_ACT_NONE 0
 #define RC_ACT_RELU 1
 #define RC_ACT_ELU 2
-int rc_first_layer_bf16(const int8_t *soa, size_t n, size_t stride, const uint16_t *w1t, const float *bias,
-                        uint16_t *out, size_t H, int activation, float alpha, int table_is_f16, rc_stream_t stream);
-/* The same layer on the matrix cores: out = act(as_oh(s) @ W1^T + bias) with the one-hot A-fragments of
- * v_mfma_f32_32x32x16_bf16 generated in registers from the cube codes (the one-hot matrix never exists in
- * memory) and a 128-column slice of W1 resident in LDS as the B operand.
- *   w1: bf16 (or IEEE half if table_is_f16 != 0: v_mfma_f32_32x32x16_f16) [H][480] row-major = the nn.Linear
- *   weight as stored; other arguments as above. */
 int rc_first_layer_mfma_bf16(const int8_t *soa, size_t n, size_t stride, const uint16_t *w1, const float *bias,
                              uint16_t *out, size_t H, int activation, float alpha, int table_is_f16, rc_stream_t stream);
-
-/* The same layer with 64 output columns per workgroup and two 32-state tiles per wave sharing every W1 fragment read from
- * LDS (the structure of rc_first_layer_split_f16 with one table).  Measured 55.7 us against 50.5 us for the kernel above
- * at 11 264 x 4096, so the bf16 engine keeps the kernel above; selectable as first_layer_table="mfma16x2".
- * w1_half: IEEE half [H][480] row-major, H % 64 == 0 (61 KiB of LDS: no attribute call needed). */
-int rc_first_layer_mfma2_bf16(const int8_t *soa, size_t n, size_t stride, const uint16_t *w1_half, const float *bias,
-                              uint16_t *out, size_t H, int activation, float alpha, rc_stream_t stream);
 
 /* In-place ReLU / ELU(alpha) of a contiguous bf16 tensor of n elements (n % 8 == 0): the activation pass between
  * two library GEMMs (model.py:150-157: Linear -> activation), 16 bytes per lane.  4 B of HBM traffic per element. */

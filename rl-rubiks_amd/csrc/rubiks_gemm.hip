@@ -13,8 +13,7 @@
 //
 // Schedule (k_split_gemm): one barrier per K-step; per 16-row fragment of activations two ds_read_b128 and eight MFMAs, and
 // behind the MFMAs of the first fragments the wave issues its LDS-DMA pieces of the NEXT stage two at a time -- in the shadow
-// of the matrix cores and of the SIMD's other wave, early enough to land before the next barrier.  k_split_gemm_pp is the
-// variant with the two wave rows running half a phase apart (measured 8 % slower, kept for comparison as tile 4).
+// of the matrix cores and of the SIMD's other wave, early enough to land before the next barrier.
 //
 // Data movement: both operands are K-contiguous ([rows][K] halves), staged global -> LDS by global_load_lds_dwordx4 in
 // 64-deep K-steps (128-byte LDS rows, two stages).  LDS-DMA writes lane-linear, so the bank swizzle is applied to the
@@ -235,242 +234,6 @@ __global__ __launch_bounds__(WM *WN * 64) void k_split_gemm(GemmArgs g) {
     if (KIND == kOutHalves && g.flag && out_of_range) atomicOr(g.flag, 1);
 }
 
-// The same tile with the two wave rows (waves 0-3 / 4-7: one of each per SIMD) running half a phase apart: a K-step is four
-// phases, one per block of three 16-row fragments, each {LDS reads + LDS-DMA issue | barrier | MFMAs | barrier}; the second
-// wave row enters the loop one barrier late, so on every SIMD one wave issues MFMAs while the other reads its next
-// fragments and stages the next K-step.  2 x 4 waves only.
-//   global barrier index (row 0 counts 8 per K-step s, row 1 is one behind):
-//     row 0: R_p in (8s+2p-1, 8s+2p), MFMA_p in (8s+2p, 8s+2p+1);   row 1: R_p in (8s+2p, 8s+2p+1), MFMA_p in (8s+2p+1, 8s+2p+2)
-//   stage s+1 goes into the buffer last read in step s-1: row 1's reads R_3(s-1) retire after barrier 8s-1, so row 0 issues its
-//   LDS-DMA in R_1, R_2 (after 8s+1) and row 1 in R_0, R_1 (after 8s); both wait vmcnt(0) before barrier 8s+7, which every
-//   wave passes before its first read of stage s+1.
-// KIND: kOutHalves / kOutF32 = the split layer (f16 operands, three products), kBf16 = a plain bf16 layer (one product, bf16 out),
-// kPartials = the split layer with its K loop cut in two: twice the workgroups, each walks one half of the 3K / 64 K-steps and
-// stores its raw fp32 accumulators into out[half][M][N] (no bias, no activation).  Half 0 holds correction products only, half
-// 1 the rest of them (scaled by 2^-11 inside, as always) plus the main product, so y = act(out[1] + 2^-11 out[0] + bias) --
-// exactly what rc_head_split_f32 / rc_split_act_f16 compute from (c, c_corr).  For layers too narrow to fill the chip with
-// 352 x 256 tiles (the 2048 -> 1024 layer: 128 tiles).
-template <int MR, int NR, int ACT, int KIND>
-__global__ __launch_bounds__(512) void k_split_gemm_pp(GemmArgs g) {
-    constexpr int WM = 2, WN = 4;
-    using T = GemmTile<WM, WN, MR, NR>;
-    constexpr int kBlk = 3, kPhases = (MR + kBlk - 1) / kBlk;
-    static_assert(kPhases == 4, "four phases per K-step");
-    extern __shared__ __attribute__((aligned(1024))) unsigned char lds[];
-    const u32 tid = threadIdx.x, lane = tid & 63;
-    const u32 wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const u32 wr = wave / WN, wc = wave % WN;
-
-    const u32 nwg = gridDim.x, nn = g.N / T::BN;
-    const u32 xcd = blockIdx.x % 8, q = nwg / 8, r8 = nwg % 8;
-    const u32 wg_all = (xcd < r8 ? xcd * (q + 1) : r8 * (q + 1) + (xcd - r8) * q) + blockIdx.x / 8;
-    const u32 n_tiles = KIND == kPartials ? nwg / g.S : nwg;
-    const u32 half = wg_all / n_tiles, wg = wg_all % n_tiles;   // kPartials: K chunk `half` of S; the first n_tiles workgroups of the (XCD-ordered) grid walk chunk 0
-    const u32 tm = wg / nn, tn = wg % nn;
-    const size_t row0 = (size_t)tm * T::BM;
-    const u32 col0 = tn * T::BN;
-    const bool one = KIND == kBf16 || g.P == 1;   // one product: a is [M][K], w is [N][K]
-    const u32 K = g.K, lda = (one ? 1 : 2) * K * 2, ldw = (one ? 1 : 3) * K * 2;   // bytes
-    const u32 last_row = (u32)(g.M - 1 - row0);
-
-    // LDS-DMA piece p = i * 8 + wave covers stage rows 8 p .. 8 p + 7 (activation rows first, then weight rows); lane l moves
-    // the 16-byte chunk (l & 7) ^ swizzle(row) of row 8 p + (l >> 3).  64 | rows per i, so the swizzle does not depend on i.
-    const u32 r_lane = wave * 8 + (lane >> 3), c_lane = ((lane & 7) ^ ((r_lane >> 1) & 7)) * 16;
-    const unsigned char *a_tile = g.a + row0 * lda;
-    const unsigned char *w_tile = g.w + (size_t)col0 * ldw;
-
-    constexpr int kHalf = (T::PPW + 1) / 2;
-    auto stage_part = [&](u32 ks, u32 buf, int lo, int hi) {   // this wave's pieces lo .. hi - 1 of stage ks
-        const u32 kk = ks * 64, a_col = (one || kk < 2 * K) ? kk : kk - 2 * K;
-        const unsigned char *ab = a_tile + a_col * 2, *wb = w_tile + kk * 2;
-        unsigned char *dst = lds + buf * T::STAGE;
-        u32 rl = r_lane, cl = c_lane;
-        asm volatile("" : "+v"(rl), "+v"(cl));   // keeps the per-piece addresses out of registers between K-steps (hoisted, they spill)
-#pragma unroll
-        for (int i = 0; i < T::PPW; ++i) {
-            if (i < lo || i >= hi) continue;
-            const u32 p = i * T::WAVES + wave;
-            if (p < (u32)T::PIECES) {
-                const u32 R = i * 64 + rl;
-                const unsigned char *src = p < (u32)(T::BM / 8) ? ab + (min(R, last_row) * lda + cl) : wb + ((R - T::BM) * ldw + cl);
-                __builtin_amdgcn_global_load_lds((glb_void *)src, (lds_void *)(dst + p * 1024), 16, 0, 0);
-            }
-        }
-    };
-
-    const u32 fr = lane & 15, fq = lane >> 4, swz = fr >> 1;
-    u32 x_off[2], w_off[2];
-#pragma unroll
-    for (int kh = 0; kh < 2; ++kh) {
-        const u32 c = ((fq + 4 * kh) ^ swz) * 16;
-        x_off[kh] = (wr * MR * 16 + fr) * kGemmRowBytes + c;
-        w_off[kh] = T::A_BYTES + (wc * NR * 16 + fr) * kGemmRowBytes + c;
-    }
-
-    f32x4 acc[MR][NR];
-#pragma unroll
-    for (int m = 0; m < MR; ++m)
-#pragma unroll
-        for (int n = 0; n < NR; ++n) acc[m][n] = f32x4{0.f, 0.f, 0.f, 0.f};
-
-    const u32 nk_all = (one ? 1 : 3) * K / 64, scale_step = one ? 0xFFFFFFFFu : 2 * K / 64;
-    const u32 ks0 = KIND == kPartials ? half * (nk_all / g.S) : 0u, nk = KIND == kPartials ? ks0 + nk_all / g.S : nk_all;
-    stage_part(ks0, 0, 0, T::PPW);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();
-    if (wr == 1) __builtin_amdgcn_s_barrier();   // the half-phase stagger
-
-    f16x8 wf[NR][2], xf[kBlk][2];
-    for (u32 ks = ks0; ks < nk; ++ks) {
-        const unsigned char *s = lds + ((ks - ks0) & 1) * T::STAGE;
-        const bool more = ks + 1 < nk;
-        const u32 nbuf = (ks + 1 - ks0) & 1;
-#pragma unroll
-        for (int ph = 0; ph < kPhases; ++ph) {
-            // ---- R_ph: fragments of this phase, and this wave's share of the next stage
-            if (ph == 0) {
-#pragma unroll
-                for (int n = 0; n < NR; ++n)
-#pragma unroll
-                    for (int kh = 0; kh < 2; ++kh) wf[n][kh] = *reinterpret_cast<const f16x8 *>(s + w_off[kh] + n * 16 * kGemmRowBytes);
-            }
-#pragma unroll
-            for (int j = 0; j < kBlk; ++j)
-                if (ph * kBlk + j < MR) {
-#pragma unroll
-                    for (int kh = 0; kh < 2; ++kh)
-                        xf[j][kh] = *reinterpret_cast<const f16x8 *>(s + x_off[kh] + (ph * kBlk + j) * 16 * kGemmRowBytes);
-                }
-            if (more) {
-                if (wr == 1) {
-                    if (ph == 0) stage_part(ks + 1, nbuf, 0, kHalf);
-                    if (ph == 1) stage_part(ks + 1, nbuf, kHalf, T::PPW);
-                } else {
-                    if (ph == 1) stage_part(ks + 1, nbuf, 0, kHalf);
-                    if (ph == 2) stage_part(ks + 1, nbuf, kHalf, T::PPW);
-                }
-            }
-            if (ph == kPhases - 1 && wr == 1) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            __builtin_amdgcn_sched_barrier(0);
-            __builtin_amdgcn_s_barrier();
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            __builtin_amdgcn_sched_barrier(0);
-            // ---- MFMA_ph
-            if (ph == 0 && ks == scale_step) {
-#pragma unroll
-                for (int m = 0; m < MR; ++m)
-#pragma unroll
-                    for (int n = 0; n < NR; ++n) acc[m][n] *= (1.0f / kSplitScale);
-            }
-            __builtin_amdgcn_s_setprio(1);
-#pragma unroll
-            for (int j = 0; j < kBlk; ++j)
-                if (ph * kBlk + j < MR) {
-#pragma unroll
-                    for (int kh = 0; kh < 2; ++kh)
-#pragma unroll
-                        for (int n = 0; n < NR; ++n)
-                            acc[ph * kBlk + j][n] = KIND == kBf16 ? __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, wf[n][kh]), __builtin_bit_cast(bf16x8, xf[j][kh]), acc[ph * kBlk + j][n], 0, 0, 0)
-                                                                  : __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[n][kh], xf[j][kh], acc[ph * kBlk + j][n], 0, 0, 0);
-                }
-            __builtin_amdgcn_s_setprio(0);
-            if (ph == kPhases - 1 && wr == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            __builtin_amdgcn_sched_barrier(0);
-            __builtin_amdgcn_s_barrier();
-            __builtin_amdgcn_sched_barrier(0);
-        }
-    }
-    if (wr == 0) __builtin_amdgcn_s_barrier();
-
-    const u32 cbase = col0 + wc * NR * 16 + 4 * fq;
-    float4 b4[NR];
-    bool out_of_range = false;
-#pragma unroll
-    for (int n = 0; n < NR; ++n) b4[n] = KIND == kPartials ? make_float4(0.f, 0.f, 0.f, 0.f) : *reinterpret_cast<const float4 *>(g.bias + cbase + 16 * n);
-#pragma unroll
-    for (int m = 0; m < MR; ++m) {
-        const size_t row = row0 + wr * MR * 16 + m * 16 + fr;
-        if (row >= g.M) continue;
-#pragma unroll
-        for (int n = 0; n < NR; ++n) {
-            float y[4] = {acc[m][n][0] + b4[n].x, acc[m][n][1] + b4[n].y, acc[m][n][2] + b4[n].z, acc[m][n][3] + b4[n].w};
-            const u32 col = cbase + 16 * n;
-            if (KIND != kPartials && g.res) {   // skip connection: the block's input, in the activations' own format
-                if (KIND == kBf16) {
-                    const uint2 r2 = *reinterpret_cast<const uint2 *>(g.res + (row * (size_t)g.N + col) * 2);
-                    y[0] += __uint_as_float(r2.x << 16), y[1] += __uint_as_float(r2.x & 0xffff0000u);
-                    y[2] += __uint_as_float(r2.y << 16), y[3] += __uint_as_float(r2.y & 0xffff0000u);
-                } else {
-                    const unsigned char *rrow = g.res + row * ((size_t)g.N * 4);
-                    const uint2 rh = *reinterpret_cast<const uint2 *>(rrow + col * 2), rl = *reinterpret_cast<const uint2 *>(rrow + ((size_t)g.N + col) * 2);
-                    const u32 hw[2] = {rh.x, rh.y}, lw[2] = {rl.x, rl.y};
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        const float hi = (float)__builtin_bit_cast(_Float16, (unsigned short)(hw[e >> 1] >> (16 * (e & 1))));
-                        const float lo = (float)__builtin_bit_cast(_Float16, (unsigned short)(lw[e >> 1] >> (16 * (e & 1))));
-                        y[e] += hi + lo * (1.0f / kSplitScale);
-                    }
-                }
-            }
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                if (ACT == RC_ACT_RELU) y[e] = fmaxf(y[e], 0.f);
-                if (ACT == RC_ACT_ELU) y[e] = y[e] > 0.f ? y[e] : g.alpha * expm1_neg(y[e]);
-            }
-            if (KIND != kPartials && g.post_scale) {
-                const float4 ps = *reinterpret_cast<const float4 *>(g.post_scale + col), pt = *reinterpret_cast<const float4 *>(g.post_shift + col);
-                y[0] = y[0] * ps.x + pt.x, y[1] = y[1] * ps.y + pt.y, y[2] = y[2] * ps.z + pt.z, y[3] = y[3] * ps.w + pt.w;
-            }
-            if (KIND == kPartials) {
-                float *orow = reinterpret_cast<float *>(g.out) + ((size_t)half * g.M + row) * (size_t)g.N;
-                *reinterpret_cast<float4 *>(orow + col) = make_float4(y[0], y[1], y[2], y[3]);
-            } else if (KIND == kBf16) {
-                unsigned char *orow = reinterpret_cast<unsigned char *>(g.out) + row * ((size_t)g.N * 2);
-                *reinterpret_cast<uint2 *>(orow + col * 2) = make_uint2(pack_bf16(y[0], y[1]), pack_bf16(y[2], y[3]));
-            } else if (KIND == kOutHalves) {
-                float hi[4], lo[4];
-#pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    out_of_range |= !(fabsf(y[e]) <= kHalfMax);   // hi would be +-inf (or y is NaN): the caller falls back to fp32
-                    hi[e] = round_to_half_f32(y[e]);
-                    lo[e] = (y[e] - hi[e]) * kSplitScale;
-                }
-                unsigned char *orow = reinterpret_cast<unsigned char *>(g.out) + row * ((size_t)g.N * 4);
-                *reinterpret_cast<uint2 *>(orow + col * 2) = make_uint2(pack_half2(hi[0], hi[1]), pack_half2(hi[2], hi[3]));
-                *reinterpret_cast<uint2 *>(orow + ((size_t)g.N + col) * 2) = make_uint2(pack_half2(lo[0], lo[1]), pack_half2(lo[2], lo[3]));
-            } else {
-                float *orow = reinterpret_cast<float *>(g.out) + row * (size_t)g.N;
-                *reinterpret_cast<float4 *>(orow + col) = make_float4(y[0], y[1], y[2], y[3]);
-            }
-        }
-    }
-    if (KIND == kOutHalves && g.flag && out_of_range) atomicOr(g.flag, 1);
-}
-
-template <int MR, int NR, int ACT, int KIND> static int launch_split_gemm_pp(const GemmArgs &g, hipStream_t s) {
-    using T = GemmTile<2, 4, MR, NR>;
-    static std::atomic<unsigned long long> attr_set{0};
-    int dev = 0;
-    (void)hipGetDevice(&dev);
-    if (!((attr_set.load(std::memory_order_acquire) >> (dev & 63)) & 1ull)) {
-        hipError_t e = hipFuncSetAttribute((const void *)k_split_gemm_pp<MR, NR, ACT, KIND>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                           T::LDS_BYTES);
-        if (e != hipSuccess) return hip_rc(e);
-        attr_set.fetch_or(1ull << (dev & 63), std::memory_order_release);
-    }
-    const u32 grid = (u32)(ceil_div((size_t)g.M, (size_t)T::BM) * (g.N / T::BN)) * (KIND == kPartials ? g.S : 1u);
-    hipLaunchKernelGGL((k_split_gemm_pp<MR, NR, ACT, KIND>), dim3(grid), dim3(T::THREADS), T::LDS_BYTES, s, g);
-    return launch_status();
-}
-
-template <int MR, int NR, int KIND> static int dispatch_split_gemm_pp(const GemmArgs &g, int act, hipStream_t s) {
-#define RC_GEMM_ACT(ACT) launch_split_gemm_pp<MR, NR, ACT, KIND>(g, s)
-    if (act == RC_ACT_ELU) return RC_GEMM_ACT(RC_ACT_ELU);
-    if (act == RC_ACT_RELU) return RC_GEMM_ACT(RC_ACT_RELU);
-    return RC_GEMM_ACT(RC_ACT_NONE);
-#undef RC_GEMM_ACT
-}
-
 template <int WM, int WN, int MR, int NR, int ACT, int KIND> static int launch_split_gemm(const GemmArgs &g, hipStream_t s) {
     using T = GemmTile<WM, WN, MR, NR>;
     static std::atomic<unsigned long long> attr_set{0};   // per device: the attribute belongs to the function ON A DEVICE
@@ -545,21 +308,19 @@ extern "C" int rc_split_layer_f16(const rc_split_layer_t *L, rc_stream_t stream)
         if (L->tile == 3) return launch_split_gemm<2, 4, 11, 2, RC_ACT_NONE, kPartials>(g, s);   // 352 x 128 tiles: small batches
         return launch_split_gemm<2, 4, 11, 4, RC_ACT_NONE, kPartials>(g, s);
     }
-    RC_REQUIRE(L->bias != nullptr && L->k_splits <= 1 && L->tile >= 0 && L->tile <= 4, RC_ERR_RANGE);
+    RC_REQUIRE(L->bias != nullptr && L->k_splits <= 1 && L->tile >= 0 && L->tile <= 3, RC_ERR_RANGE);
     g.out = L->out_hi_lo ? (void *)L->out_hi_lo : (void *)L->out_f32;
     const bool split = L->out_hi_lo != nullptr;
     int tile = L->tile;
     // tile 0: choose -- the 352 x 256 tile when it fills the chip, else 352 x 128, else 176 x 128
     const size_t row_tiles = ceil_div(L->n_rows, (size_t)352);
     if (tile == 0) tile = (L->n_out % 256 == 0 && row_tiles * (L->n_out / 256) >= 192) ? 1 : (row_tiles * (L->n_out / 128) >= 192) ? 3 : 2;
-    RC_REQUIRE((tile != 1 && tile != 4) || L->n_out % 256 == 0, RC_ERR_RANGE);
+    RC_REQUIRE(tile != 1 || L->n_out % 256 == 0, RC_ERR_RANGE);
     const int activation = L->activation;
     if (tile == 1)   // 352 x 256
         return split ? dispatch_split_gemm<2, 4, 11, 4, kOutHalves>(g, activation, s) : dispatch_split_gemm<2, 4, 11, 4, kOutF32>(g, activation, s);
     if (tile == 3)   // 352 x 128
         return split ? dispatch_split_gemm<2, 4, 11, 2, kOutHalves>(g, activation, s) : dispatch_split_gemm<2, 4, 11, 2, kOutF32>(g, activation, s);
-    if (tile == 4)   // 352 x 256, the staggered-wave-row schedule (kept for comparison: measured 8 % slower)
-        return split ? dispatch_split_gemm_pp<11, 4, kOutHalves>(g, activation, s) : dispatch_split_gemm_pp<11, 4, kOutF32>(g, activation, s);
     return split ? dispatch_split_gemm<1, 4, 11, 2, kOutHalves>(g, activation, s) : dispatch_split_gemm<1, 4, 11, 2, kOutF32>(g, activation, s);   // 176 x 128
 }
 

@@ -1,7 +1,7 @@
 // Network-side kernels that touch cube states: the input layer of the policy/value MLP fused with
-// the one-hot encoding.  as_oh(states) @ W1^T is a 20-row gather-sum because a one-hot row has
-// exactly 20 ones; doing it from an LDS-resident slice of W1^T removes the (n x 480) one-hot matrix,
-// the K = 480 GEMM and the separate bias + activation pass.
+// the one-hot encoding (the one-hot A fragments of the MFMAs are generated from the cube codes, so the (n x 480) one-hot
+// matrix, the K = 480 GEMM and the separate bias + activation pass never exist), the fused head kernels, the
+// activation / reduce passes of the split engine and the ADI target kernel.
 #include <atomic>
 
 #include "rubiks_common.h"
@@ -9,10 +9,6 @@
 
 namespace rubiks {
 
-constexpr int kFLCols = 128;                  // output columns per workgroup: one LDS bank row (256 B) of bf16
-constexpr int kFLThreads = 1024;              // 16 waves = 4 per SIMD (LDS allows one workgroup per CU); 64 row slots x 16 chunks of 8 columns
-constexpr int kFLRowSlots = kFLThreads / 16;  // rows produced per pass
-constexpr int kFLChunkRows = 512;             // rows whose table indices are staged at a time
 constexpr int kOH = 480;
 
 __device__ __forceinline__ float act_apply(float x, int act, float alpha) {
@@ -21,113 +17,6 @@ __device__ __forceinline__ float act_apply(float x, int act, float alpha) {
     return x;
 }
 
-
-template <int ACT, int F16>   // F16: 0 bf16 table, 1 f16 table, 2 f16 table with pairs of rows added in f16 first
-__global__ __launch_bounds__(kFLThreads) __attribute__((amdgpu_waves_per_eu(4, 4))) void k_first_layer(const u8 *__restrict__ soa, size_t n, size_t stride,
-                                                            const uint4 *__restrict__ w1t, const float *__restrict__ bias,
-                                                            uint4 *__restrict__ out, u32 H, u32 rows_per_block, float alpha) {
-    extern __shared__ __attribute__((aligned(256))) unsigned char lds[];
-    uint4 *wslice = reinterpret_cast<uint4 *>(lds);                                    // [480][16] x 16 B
-    unsigned short *sidx = reinterpret_cast<unsigned short *>(lds + kOH * kFLCols * 2);   // [kFLChunkRows][20]
-    const u32 tid = threadIdx.x;
-    const u32 col_tiles = H / kFLCols;
-    const u32 ct = blockIdx.x % col_tiles, rg = blockIdx.x / col_tiles;
-    const size_t row_lo = (size_t)rg * rows_per_block;
-    if (row_lo >= n) return;
-    const size_t row_hi = (row_lo + rows_per_block < n) ? row_lo + rows_per_block : n;
-
-    // W1^T[:, 128 ct .. 128 ct + 127] -> LDS: row k is one 256-byte bank row, so a ds_read_b128 of
-    // chunk c of ANY row hits bank quad c: 16 lanes reading the 16 chunks of a row never conflict.
-    const u32 h16 = H / 8;   // 16-byte chunks per global row
-    for (u32 i = tid; i < kOH * 16; i += kFLThreads) wslice[i] = w1t[(size_t)(i >> 4) * h16 + ct * 16 + (i & 15)];
-
-    const u32 slot = tid >> 4, chunk = tid & 15;
-    float *sbias = reinterpret_cast<float *>(lds + kOH * kFLCols * 2 + kFLChunkRows * kPlanes * 2);   // [128]
-    if (tid < kFLCols) sbias[tid] = bias[ct * kFLCols + tid];
-
-    for (size_t c0 = row_lo; c0 < row_hi; c0 += kFLChunkRows) {
-        const u32 crow = (u32)((row_hi - c0 < (size_t)kFLChunkRows) ? row_hi - c0 : kFLChunkRows);
-        __syncthreads();   // previous chunk's readers are done (and wslice is complete on the first pass)
-        {   // stage the chunk's table indices: all of a thread's byte loads are issued before the first is used
-            constexpr int kPer = kPlanes * kFLChunkRows / kFLThreads;   // 10 planes per thread
-            const u32 rr = tid % kFLChunkRows, j0 = tid / kFLChunkRows;
-            u32 code[kPer];
-#pragma unroll
-            for (int t = 0; t < kPer; ++t) {
-                const u32 j = j0 + t * (kFLThreads / kFLChunkRows);
-                code[t] = (rr < crow) ? soa[(size_t)j * stride + c0 + rr] : 0;
-            }
-#pragma unroll
-            for (int t = 0; t < kPer; ++t) {
-                const u32 j = j0 + t * (kFLThreads / kFLChunkRows);
-                const u32 idx = 24u * j + (code[t] & 31u);
-                sidx[rr * kPlanes + j] = (unsigned short)(idx < (u32)kOH ? idx : kOH - 1);
-            }
-        }
-        __syncthreads();
-        uint4 *out_c = out + c0 * h16;
-#pragma unroll 1
-        for (u32 r = slot; r < crow; r += kFLRowSlots) {
-            const u32 *ridx = reinterpret_cast<const u32 *>(sidx + r * kPlanes);   // 20 u16 = 10 dwords (row stride 40 B)
-            // table rows are requested kFLBatch at a time before any is consumed: the LDS latency is paid
-            // 20 / kFLBatch times per output chunk instead of 20 times
-            float acc[8];
-            {
-                const float4 b0 = reinterpret_cast<const float4 *>(sbias)[2 * chunk], b1 = reinterpret_cast<const float4 *>(sbias)[2 * chunk + 1];
-                acc[0] = b0.x; acc[1] = b0.y; acc[2] = b0.z; acc[3] = b0.w;
-                acc[4] = b1.x; acc[5] = b1.y; acc[6] = b1.z; acc[7] = b1.w;
-            }
-            u32 kk[kPlanes];
-#pragma unroll
-            for (int jj = 0; jj < kPlanes / 2; ++jj) {
-                const u32 two = ridx[jj];
-                kk[2 * jj] = (two & 0xffffu) * 16 + chunk;
-                kk[2 * jj + 1] = (two >> 16) * 16 + chunk;
-            }
-            constexpr int kFLBatch = F16 ? 10 : 5;   // table rows requested from LDS before any is consumed (register budget)
-#pragma unroll
-            for (int q = 0; q < kPlanes / kFLBatch; ++q) {
-                uint4 w[kFLBatch];
-#pragma unroll
-                for (int j = 0; j < kFLBatch; ++j) w[j] = wslice[kk[q * kFLBatch + j]];
-                __builtin_amdgcn_sched_barrier(0);   // keep the batch's loads ahead of its adds, and the batches apart
-                if (F16 == 2) {   // two table rows meet in one packed f16 add (half the conversions): 3 instructions per 4 terms
-#pragma unroll
-                    for (int j = 0; j < kFLBatch; j += 2) {
-                        const u32 wa[4] = {w[j].x, w[j].y, w[j].z, w[j].w}, wb[4] = {w[j + 1].x, w[j + 1].y, w[j + 1].z, w[j + 1].w};
-#pragma unroll
-                        for (int d = 0; d < 4; ++d) {
-                            u32 t;
-                            asm volatile("v_pk_add_f16 %0, %1, %2" : "=v"(t) : "v"(wa[d]), "v"(wb[d]));
-                            asm volatile("v_fma_mix_f32 %0, %1, 1.0, %0 op_sel:[0,0,0] op_sel_hi:[1,0,0]" : "+v"(acc[2 * d]) : "v"(t));
-                            asm volatile("v_fma_mix_f32 %0, %1, 1.0, %0 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "+v"(acc[2 * d + 1]) : "v"(t));
-                        }
-                    }
-                } else {
-#pragma unroll
-                for (int j = 0; j < kFLBatch; ++j) {
-                    const u32 ww[4] = {w[j].x, w[j].y, w[j].z, w[j].w};
-#pragma unroll
-                    for (int d = 0; d < 4; ++d) {
-                        if (F16) {   // f16 table: v_fma_mix_f32 converts a half and adds it in ONE instruction (h * 1.0 + acc, exact)
-                            asm volatile("v_fma_mix_f32 %0, %1, 1.0, %0 op_sel:[0,0,0] op_sel_hi:[1,0,0]" : "+v"(acc[2 * d]) : "v"(ww[d]));
-                            asm volatile("v_fma_mix_f32 %0, %1, 1.0, %0 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "+v"(acc[2 * d + 1]) : "v"(ww[d]));
-                        } else {     // bf16 table: bf16 -> f32 is a 16-bit shift / mask, then a plain f32 add
-                            acc[2 * d] += __uint_as_float(ww[d] << 16);
-                            acc[2 * d + 1] += __uint_as_float(ww[d] & 0xffff0000u);
-                        }
-                    }
-                }
-                }
-                __builtin_amdgcn_sched_barrier(0);
-            }
-#pragma unroll
-            for (int e = 0; e < 8; ++e) acc[e] = act_apply(acc[e], ACT, alpha);
-            out_c[r * h16 + ct * 16 + chunk] =
-                make_uint4(pack_bf16(acc[0], acc[1]), pack_bf16(acc[2], acc[3]), pack_bf16(acc[4], acc[5]), pack_bf16(acc[6], acc[7]));
-        }
-    }
-}
 
 // =================================================================================================
 // Input layer on the matrix cores.
@@ -684,15 +573,13 @@ __global__ __launch_bounds__(kBlock) void k_head_split(const float4 *__restrict_
 constexpr int kSpCols = 64;
 constexpr int kSpSub = 2;   // 32-state tiles a wave holds at once (they share every B fragment read from LDS); 3 / 4 measured slower
 
-
-// SPLIT = false: the same kernel as the bf16 engine's input layer (one table, W1 in IEEE half; bf16 output [n][H]).
-template <int ACT, bool SPLIT>
+template <int ACT>
 __global__ __launch_bounds__(kMfWaves * kWave) void k_first_layer_split(const u8 *__restrict__ soa, size_t n, size_t stride,
                                                                       const uint4 *__restrict__ w_hi, const uint4 *__restrict__ w_lo,
                                                                       const float *__restrict__ bias, u32 *__restrict__ out, u32 H,
                                                                       u32 rows_per_block, float alpha, int *__restrict__ range_flag) {
     extern __shared__ __attribute__((aligned(256))) unsigned char lds[];
-    constexpr int kTables = SPLIT ? 2 : 1;
+    constexpr int kTables = 2;
     bool out_of_range = false;
     unsigned char *wslice = lds;                                                       // [kTables][64 slots][976 B]
     const u32 tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
@@ -704,7 +591,7 @@ __global__ __launch_bounds__(kMfWaves * kWave) void k_first_layer_split(const u8
     const size_t row_hi = (row_lo + rows_per_block < n) ? row_lo + rows_per_block : n;
     {   // 2 x 64 columns x 60 chunks of 16 B = 7 680 chunks / 512 threads = 15 per thread.  Column g of the slice goes to slot
         // (g % 2) * 32 + g / 2: MFMA column tile c, lane r owns column 2 r + c.
-        constexpr int kBatch = 5, kPer = kTables * kSpCols * 60 / (kMfWaves * kWave) / kBatch * kBatch;   // 15 or 5 (+ a tail of 2.5)
+        constexpr int kBatch = 5, kPer = kTables * kSpCols * 60 / (kMfWaves * kWave) / kBatch * kBatch;   // 15
 #pragma unroll
         for (int b0 = 0; b0 < kPer; b0 += kBatch) {
             uint4 tmp[kBatch];
@@ -720,11 +607,7 @@ __global__ __launch_bounds__(kMfWaves * kWave) void k_first_layer_split(const u8
                 *reinterpret_cast<uint4 *>(wslice + (tbl * kSpCols + slot) * kMfPitch + (j % 60) * 16) = tmp[t];
             }
         }
-        for (u32 i = tid + kPer * (kMfWaves * kWave); i < (u32)(kTables * kSpCols * 60); i += kMfWaves * kWave) {   // what kBatch left over
-            const u32 tbl = i / (kSpCols * 60), j = i % (kSpCols * 60), g = j / 60, slot = (g & 1) * 32 + (g >> 1);
-            *reinterpret_cast<uint4 *>(wslice + (tbl * kSpCols + slot) * kMfPitch + (j % 60) * 16) =
-                (tbl ? w_lo : w_hi)[(size_t)(ct * kSpCols + j / 60) * 60 + j % 60];
-        }
+        static_assert(kPer * kMfWaves * kWave == kTables * kSpCols * 60, "the staging loop covers the slices exactly");
     }
     if (tid < 9 * kTables) {
         u32 w[4] = {0, 0, 0, 0};
@@ -811,8 +694,8 @@ __global__ __launch_bounds__(kMfWaves * kWave) void k_first_layer_split(const u8
                 for (int c = 0; c < 2; ++c) b_cur[c] = b_nxt[c];
             }
         }
-        // epilogue: activation, then the lane's columns 2 r, 2 r + 1 of one state as one 4-byte store: bf16 pair, or -- split --
-        // the pair of hi halves and the pair of lo halves into the [hi | lo] row of the state (row pitch 2 H halves)
+        // epilogue: activation, then the lane's columns 2 r, 2 r + 1 of one state as two 4-byte stores: the pair of hi halves and
+        // the pair of lo halves into the [hi | lo] row of the state (row pitch 2 H halves)
 #pragma unroll
         for (int u = 0; u < kSpSub; ++u)
 #pragma unroll
@@ -822,27 +705,19 @@ __global__ __launch_bounds__(kMfWaves * kWave) void k_first_layer_split(const u8
 #pragma unroll
                 for (int c = 0; c < 2; ++c) {
                     const float x = acc[u][c][i];
-                    if (SPLIT) {
-                        y[c] = ACT == RC_ACT_RELU ? fmaxf(x, 0.f) : ACT == RC_ACT_ELU ? (x > 0.f ? x : alpha * expm1_neg(x)) : x;
-                        hi[c] = round_to_half_f32(y[c]);
-                        lo[c] = (y[c] - hi[c]) * kSplitScale;
-                        out_of_range |= row < n && !(fabsf(y[c]) <= 65504.0f);
-                    } else {
-                        y[c] = act_apply(x, ACT, alpha);
-                    }
+                    y[c] = ACT == RC_ACT_RELU ? fmaxf(x, 0.f) : ACT == RC_ACT_ELU ? (x > 0.f ? x : alpha * expm1_neg(x)) : x;
+                    hi[c] = round_to_half_f32(y[c]);
+                    lo[c] = (y[c] - hi[c]) * kSplitScale;
+                    out_of_range |= row < n && !(fabsf(y[c]) <= 65504.0f);
                 }
                 if (row < n && row < row_hi) {
-                    if (SPLIT) {
-                        u32 *orow = out + row * H;   // 2 H halves = H dwords per row
-                        orow[(ct * kSpCols) / 2 + r] = pack_half2(hi[0], hi[1]);
-                        orow[H / 2 + (ct * kSpCols) / 2 + r] = pack_half2(lo[0], lo[1]);
-                    } else {
-                        out[row * (H / 2) + (ct * kSpCols) / 2 + r] = pack_bf16(y[0], y[1]);
-                    }
+                    u32 *orow = out + row * H;   // 2 H halves = H dwords per row
+                    orow[(ct * kSpCols) / 2 + r] = pack_half2(hi[0], hi[1]);
+                    orow[H / 2 + (ct * kSpCols) / 2 + r] = pack_half2(lo[0], lo[1]);
                 }
             }
     }
-    if (SPLIT && range_flag && out_of_range) atomicOr(range_flag, 1);
+    if (range_flag && out_of_range) atomicOr(range_flag, 1);
 }
 
 extern "C" int rc_oh_split_f16(const int8_t *soa, size_t n, size_t stride, uint16_t *out, rc_stream_t stream) {
@@ -951,43 +826,18 @@ extern "C" int rc_first_layer_split_flag_f16(const int8_t *soa, size_t n, size_t
         int dev_ = 0;                                                                                                 \
         (void)hipGetDevice(&dev_);                                                                                    \
         if (!((attr_set.load(std::memory_order_acquire) >> (dev_ & 63)) & 1ull)) {                                     \
-            hipError_t e = hipFuncSetAttribute((const void *)k_first_layer_split<ACT, true>, hipFuncAttributeMaxDynamicSharedMemorySize, \
+            hipError_t e = hipFuncSetAttribute((const void *)k_first_layer_split<ACT>, hipFuncAttributeMaxDynamicSharedMemorySize, \
                                                (int)lds_bytes);                                                       \
             if (e != hipSuccess) return hip_rc(e);                                                                    \
             attr_set.fetch_or(1ull << (dev_ & 63), std::memory_order_release);                                        \
         }                                                                                                             \
-        hipLaunchKernelGGL((k_first_layer_split<ACT, true>), grid, block, lds_bytes, s, (const u8 *)soa, n, stride, (const uint4 *)w_hi, \
+        hipLaunchKernelGGL((k_first_layer_split<ACT>), grid, block, lds_bytes, s, (const u8 *)soa, n, stride, (const uint4 *)w_hi, \
                            (const uint4 *)w_lo, bias, (u32 *)out_hi_lo, (u32)H, rows_per_block, alpha, (int *)range_flag); \
     } while (0)
     if (activation == RC_ACT_ELU) RC_LAUNCH_SP(RC_ACT_ELU);
     else if (activation == RC_ACT_RELU) RC_LAUNCH_SP(RC_ACT_RELU);
     else RC_LAUNCH_SP(RC_ACT_NONE);
 #undef RC_LAUNCH_SP
-    return launch_status();
-}
-
-extern "C" int rc_first_layer_mfma2_bf16(const int8_t *soa, size_t n, size_t stride, const uint16_t *w1_half, const float *bias,
-                                         uint16_t *out, size_t H, int activation, float alpha, rc_stream_t stream) {
-    if (n == 0) return RC_OK;
-    RC_CHECK_SOA(soa, n, stride);
-    RC_REQUIRE(w1_half && bias && out, RC_ERR_NULL);
-    RC_REQUIRE(aligned16(w1_half) && aligned16(out), RC_ERR_ALIGN);
-    RC_REQUIRE(H >= (size_t)kSpCols && H % kSpCols == 0 && activation >= RC_ACT_NONE && activation <= RC_ACT_ELU, RC_ERR_RANGE);
-    const u32 col_tiles = (u32)(H / kSpCols);
-    u32 row_groups = (256 + col_tiles - 1) / col_tiles;
-    constexpr u32 kRowsPerPass = kMfWaves * kSpSub * kMfTile;
-    u32 rows_per_block = (u32)round_up(ceil_div(n, row_groups), kRowsPerPass);
-    row_groups = (u32)ceil_div(n, rows_per_block);
-    const size_t lds_bytes = (size_t)kSpCols * kMfPitch + 9 * 16;
-    const dim3 grid(col_tiles * row_groups), block(kMfWaves * kWave);
-    hipStream_t s = (hipStream_t)stream;
-#define RC_LAUNCH_M2(ACT)                                                                                             \
-    hipLaunchKernelGGL((k_first_layer_split<ACT, false>), grid, block, lds_bytes, s, (const u8 *)soa, n, stride,     \
-                       (const uint4 *)w1_half, (const uint4 *)w1_half, bias, (u32 *)out, (u32)H, rows_per_block, alpha, (int *)nullptr)
-    if (activation == RC_ACT_ELU) RC_LAUNCH_M2(RC_ACT_ELU);
-    else if (activation == RC_ACT_RELU) RC_LAUNCH_M2(RC_ACT_RELU);
-    else RC_LAUNCH_M2(RC_ACT_NONE);
-#undef RC_LAUNCH_M2
     return launch_status();
 }
 
@@ -1002,54 +852,3 @@ extern "C" int rc_adi_targets(const float *values, const uint8_t *child_solved, 
                        state_solved, n, depth, win_reward, fix_mode, (long long *)policy_target, value_target);
     return launch_status();
 }
-
-
-extern "C" int rc_first_layer_bf16(const int8_t *soa, size_t n, size_t stride, const uint16_t *w1t, const float *bias,
-                                   uint16_t *out, size_t H, int activation, float alpha, int table_is_f16, rc_stream_t stream) {
-    if (n == 0) return RC_OK;
-    RC_CHECK_SOA(soa, n, stride);
-    RC_REQUIRE(w1t && bias && out, RC_ERR_NULL);
-    RC_REQUIRE(aligned16(w1t) && aligned16(out), RC_ERR_ALIGN);
-    RC_REQUIRE(H >= kFLCols && H % kFLCols == 0 && activation >= RC_ACT_NONE && activation <= RC_ACT_ELU, RC_ERR_RANGE);
-    const u32 col_tiles = (u32)(H / kFLCols);
-    // LDS (120 KiB slice + 20 KiB indices) allows one workgroup per CU: one wave of 256 workgroups, so
-    // that every W1 slice is staged once per row group
-    u32 row_groups = (256 + col_tiles - 1) / col_tiles;
-    u32 rows_per_block = (u32)round_up(ceil_div(n, row_groups), kFLRowSlots);
-    if (rows_per_block < 64) rows_per_block = 64;
-    row_groups = (u32)ceil_div(n, rows_per_block);
-    const size_t lds_bytes = (size_t)kOH * kFLCols * 2 + (size_t)kFLChunkRows * kPlanes * 2 + kFLCols * sizeof(float);
-    const dim3 grid(col_tiles * row_groups), block(kFLThreads);
-    hipStream_t s = (hipStream_t)stream;
-    const u8 *in = (const u8 *)soa;
-    const uint4 *w = (const uint4 *)w1t;
-    uint4 *o = (uint4 *)out;
-#define RC_LAUNCH_FL(ACT, F16)                                                                                     \
-    do {                                                                                                           \
-        /* per device and thread-safe: the attribute belongs to the function ON A DEVICE (one process may drive several) */ \
-        static std::atomic<unsigned long long> attr_set{0};                                                        \
-        int dev_ = 0;                                                                                              \
-        (void)hipGetDevice(&dev_);                                                                                 \
-        if (!((attr_set.load(std::memory_order_acquire) >> (dev_ & 63)) & 1ull)) {                                  \
-            hipError_t e = hipFuncSetAttribute((const void *)k_first_layer<ACT, F16>,                               \
-                                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);        \
-            if (e != hipSuccess) return hip_rc(e);                                                                 \
-            attr_set.fetch_or(1ull << (dev_ & 63), std::memory_order_release);                                     \
-        }                                                                                                          \
-        hipLaunchKernelGGL((k_first_layer<ACT, F16>), grid, block, lds_bytes, s, in, n, stride, w, bias, o, (u32)H, \
-                           rows_per_block, alpha);                                                                 \
-    } while (0)
-#define RC_LAUNCH_FL_ACT(F16)                                       \
-    do {                                                            \
-        if (activation == RC_ACT_ELU) RC_LAUNCH_FL(RC_ACT_ELU, F16); \
-        else if (activation == RC_ACT_RELU) RC_LAUNCH_FL(RC_ACT_RELU, F16); \
-        else RC_LAUNCH_FL(RC_ACT_NONE, F16);                        \
-    } while (0)
-    if (table_is_f16 == 2) RC_LAUNCH_FL_ACT(2);
-    else if (table_is_f16) RC_LAUNCH_FL_ACT(1);
-    else RC_LAUNCH_FL_ACT(0);
-#undef RC_LAUNCH_FL_ACT
-#undef RC_LAUNCH_FL
-    return launch_status();
-}
-

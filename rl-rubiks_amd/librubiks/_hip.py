@@ -52,9 +52,7 @@ SIGNATURES = {
     "rc_head_split_f32": [P, P, ctypes.c_float, SZ, SZ, P, I, ctypes.c_float, P, P, SZ, P, P],
     "rc_head_bf16": [P, SZ, SZ, P, P, SZ, P, I, ctypes.c_float, P],
     "rc_adi_targets": [P, P, P, SZ, SZ, ctypes.c_float, I, P, P, P],
-    "rc_first_layer_bf16": [P, SZ, SZ, P, P, P, SZ, I, ctypes.c_float, I, P],
     "rc_first_layer_mfma_bf16": [P, SZ, SZ, P, P, P, SZ, I, ctypes.c_float, I, P],
-    "rc_first_layer_mfma2_bf16": [P, SZ, SZ, P, P, P, SZ, I, ctypes.c_float, P],
 }
 _RESTYPES = {"rc_error_string": c_char_p, "rc_split_layer_struct_bytes": c_size_t}
 

@@ -284,31 +284,20 @@ class InferenceNet:
         model.train(was_training)
         self.dtype, self.device = dtype, device
         self.flops_per_state = 2 * sum(W.shape[0] * W.shape[1] for W, _, _ in self.layers)
-        # Input layer fused with the one-hot encoding (csrc/rubiks_net.hip): needs bf16 and H % 128 == 0
+        # Input layer fused with the one-hot encoding on the matrix cores (csrc/rubiks_net.hip): needs bf16 and H % 128 == 0.
+        # The Linear weight as stored, in IEEE half when every weight fits its range (11 mantissa bits, closer to fp32 than bf16;
+        # v_mfma_f32_32x32x16_f16), in bf16 otherwise (checkpoints without BatchNorm / with `he` init / early in training).
         W1, b1, act1 = self.layers[0]
         self._fused_first = None
+        assert first_layer_table in ("auto", "onehot"), first_layer_table
         if dtype == torch.bfloat16 and W1.is_cuda and W1.shape[0] % 128 == 0 and W1.shape[1] == OH_WIDTH \
                 and first_layer_table != "onehot":
             code = 0 if act1 is None else 1 if isinstance(act1, nn.ReLU) else 2
-            # 16-bit table for the gather-sum, built from the fp32 folded weights: IEEE f16 when every
-            # weight fits its range (11 mantissa bits, i.e. closer to fp32 than bf16, and the kernel
-            # converts + adds in one v_fma_mix_f32), bf16 otherwise
             W1_full = layers[0][0].to(device)
             half_ok = bool(torch.isfinite(W1_full).all()) and float(W1_full.abs().max()) < 3.0e4
-            # mode: 0 / 1 gather-sum with a bf16 / f16 table, 3 f16 table with pairs of rows added in f16 first,
-            #       2 / 4 matrix-core variant with the Linear weight as stored in bf16 / f16
-            #       5 matrix-core variant with 64 columns per workgroup and two tiles per wave sharing the W1 fragments (f16
-            #         weights; "mfma16x2"): measured 55.7 us against 50.5 us for mode 4 at 11 264 rows, so not the default
-            if first_layer_table in ("mfma", "mfma16", "mfma16x2") or (first_layer_table == "auto" and half_ok):
-                use_f16 = first_layer_table != "mfma" and half_ok
-                two_tiles = use_f16 and first_layer_table == "mfma16x2" and W1.shape[0] % 64 == 0
-                table, mode = W1_full.to(torch.float16 if use_f16 else torch.bfloat16).contiguous(), 5 if two_tiles else 4 if use_f16 else 2
-            else:
-                use_f16 = first_layer_table in ("f16", "f16pair") and half_ok
-                table = W1_full.t().to(torch.float16 if use_f16 else torch.bfloat16).contiguous()
-                mode = (1 if first_layer_table == "f16" else 3) if use_f16 else 0
+            table = W1_full.to(torch.float16 if half_ok else torch.bfloat16).contiguous()
             self._fused_first = (table, layers[0][1].to(device).float().contiguous(), code,
-                                 float(getattr(act1, "alpha", 1.0)), W1.shape[0], mode)
+                                 float(getattr(act1, "alpha", 1.0)), W1.shape[0], half_ok)
 
     @property
     def input_dtype(self):
@@ -340,18 +329,9 @@ class InferenceNet:
             cubes = _CubeWindow(cubes.soa.data_ptr() + lo, n, cubes.stride)
         if out is None:
             out = torch.empty((cubes.n, H), dtype=torch.bfloat16, device=w1t.device)
-        if is_f16 == 5:
-            _hip.check(_hip.lib().rc_first_layer_mfma2_bf16(_soa_ptr(cubes), cubes.n, cubes.stride, w1t.data_ptr(), b1.data_ptr(),
-                                                            out.data_ptr(), H, code, alpha, _hip.stream_ptr()), "rc_first_layer_mfma2_bf16")
-            return out
-        if is_f16 in (2, 4):
-            _hip.check(_hip.lib().rc_first_layer_mfma_bf16(_soa_ptr(cubes), cubes.n, cubes.stride, w1t.data_ptr(),
-                                                           b1.data_ptr(), out.data_ptr(), H, code, alpha, int(is_f16 == 4),
-                                                           _hip.stream_ptr()), "rc_first_layer_mfma_bf16")
-            return out
-        _hip.check(_hip.lib().rc_first_layer_bf16(_soa_ptr(cubes), cubes.n, cubes.stride, w1t.data_ptr(),
-                                                  b1.data_ptr(), out.data_ptr(), H, code, alpha, 2 if is_f16 == 3 else is_f16,
-                                                  _hip.stream_ptr()), "rc_first_layer_bf16")
+        _hip.check(_hip.lib().rc_first_layer_mfma_bf16(_soa_ptr(cubes), cubes.n, cubes.stride, w1t.data_ptr(),
+                                                       b1.data_ptr(), out.data_ptr(), H, code, alpha, int(is_f16),
+                                                       _hip.stream_ptr()), "rc_first_layer_mfma_bf16")
         return out
 
     def _fused_head_ok(self) -> bool:

@@ -122,7 +122,7 @@ def test_config3_astar_4096_problems():
     np.random.seed(0)
     cubes, _, _ = cube.scramble_batch(4096, 20, True)
     states = cubes.numpy()
-    cap, N = 50_000, 100
+    cap, N = 175_000, 100      # the cap of the bench's solve run = the reference's default max_states (runeval.py:42-44)
     res = AStar(_net(), lambda_=0.2, expansions=N).search_batch(cubes, None, cap)
     assert res.nodes.shape == (4096,) and (res.nodes <= cap).all()
     for b in np.flatnonzero(res.solved):
@@ -130,7 +130,7 @@ def test_config3_astar_4096_problems():
     for b in np.flatnonzero(~res.solved):
         assert res.nodes[b] + 12 * N > cap                        # the budget rule (agents.py:236)
     if os.path.isdir(WEIGHTS):
-        assert res.solved.mean() > 0.8
+        assert res.solved.mean() > 0.99      # the bench line reports 100 % at this cap (93.6 % at 50 000)
 
 
 def test_config4_adi_batch_16384(standin_net):
