@@ -526,7 +526,11 @@ def run_leg(name, model, pool_roots, config_roots, args, world, coll_device, tre
     stats = torch.tensor([seconds, float(nodes), float(steps_done), rtc["seconds"] if rtc else 0.0,
                           float(pool["nodes"]) if pool else 0.0, float(pool["seconds"]) if pool else 0.0],
                          dtype=torch.float64, device=coll_device)
+    rank_values = [round(nodes / seconds, 1)]           # every rank's own window: its nodes / its seconds
     if world > 1:
+        every = [torch.zeros_like(stats) for _ in range(world)]
+        dist.all_gather(every, stats)
+        rank_values = [round(float(e[1]) / float(e[0]), 1) for e in every]
         mx, sm = stats.clone(), stats.clone()
         dist.all_reduce(mx, op=dist.ReduceOp.MAX)
         dist.all_reduce(sm, op=dist.ReduceOp.SUM)
@@ -538,7 +542,7 @@ def run_leg(name, model, pool_roots, config_roots, args, world, coll_device, tre
            "nodes_in_window": nodes, "steps_timed": steps_done, "prep_iterations_untimed": prep_iters, "result_flushes_in_window": flushes_in_window,
            "refills_in_window": refills_in_window, "running_trees_rank0": running_in_window,
            "mean_descent_depth_rank0": round(mean_path, 1), "max_states_per_tree": cap,
-           "prepare_seconds_rank0": round(prepare_seconds, 3), "forest_rank0": forest_gb}
+           "prepare_seconds_rank0": round(prepare_seconds, 3), "forest_rank0": forest_gb, "rank_values": rank_values}
     if pool:
         out["pool_run"] = dict(pool, nodes=pool_nodes, seconds=round(pool_s, 3), nodes_per_sec=round(pool_nodes / pool_s, 1),
                                games=int(pool["games"]) * world,
@@ -639,14 +643,14 @@ def astar_leg(name, model, roots, args, world, coll_device):
             ms = event_ms(lambda: _hip.check(batch.lib.rc_split_gemm_f16(a.data_ptr(), W3.data_ptr(), b.data_ptr(), rows, Nd, Kd, code, alpha,
                                                                          o.data_ptr(), None, 0, _hip.stream_ptr()), "rc_split_gemm_f16"), 5)[0]
             fl = 3 * 2 * rows * Nd * Kd
-            kname = f"rc_split_gemm_f16 [{rows} x {3 * Kd}] x [{3 * Kd} x {Nd}] f16 products + bias + ELU + re-split: first hidden layer of A*'s value network"
+            kname = f"rc_split_gemm_f16 [{rows}x{3 * Kd}]x[{3 * Kd}x{Nd}] f16 MFMA +bias+ELU+re-split: hidden layer 1 of A*'s value network"
         else:
             x1 = eng.first_layer(batch.new_states, None, 0, rows)
             Wt, bt, _ = eng.value_layers[1]
             Kd, Nd = int(Wt.shape[1]), int(Wt.shape[0])
             ms = event_ms(lambda: torch.addmm(bt, x1, Wt.t()), 5)[0]
             fl = 2 * rows * Nd * Kd
-            kname = f"hidden GEMM [{rows} x {Kd}] x [{Kd} x {Nd}] + bias, bf16 MFMA via hipBLASLt: first hidden layer of A*'s value network"
+            kname = f"hidden GEMM [{rows}x{Kd}]x[{Kd}x{Nd}] + bias, bf16 MFMA via hipBLASLt: hidden layer 1 of A*'s value network"
         roof = {"kernel": kname, "bound": "mfma", "achieved": round(fl / (ms * 1e-3) / 1e12, 1), "peak": peak, "unit": "TFLOP/s",
                 "frac": round(fl / (ms * 1e-3) / 1e12 / peak, 4), "flops_per_launch": fl, "ms_per_launch": round(ms, 4), "traffic": None,
                 "note": "HIP events on the launch stream; the tree-side kernels (pop_expand: per-problem heap pops + 12 children + hash "
@@ -777,7 +781,7 @@ def adi_leg(name, model, args, world, coll_device):
         ms = event_ms(lambda: _hip.check(lib.rc_split_gemm_f16(a.data_ptr(), W3.data_ptr(), b.data_ptr(), rows, Nd, Kd, code, alpha, o.data_ptr(), None, 0,
                                                                _hip.stream_ptr()), "rc_split_gemm_f16"), 5)[0]
         fl = 3 * 2 * rows * Nd * Kd
-        kname = f"rc_split_gemm_f16 [{rows} x {3 * Kd}] x [{3 * Kd} x {Nd}] f16 products + bias + ELU + re-split: first hidden layer of the ADI value network"
+        kname = f"rc_split_gemm_f16 [{rows}x{3 * Kd}]x[{3 * Kd}x{Nd}] f16 MFMA +bias+ELU+re-split: hidden layer 1 of the ADI value network"
         flops_state = 3 * 2 * sum(int(l[1].shape[0]) * int(l[1].shape[1]) for l in eng.value_layers)
     else:
         x1 = eng.first_layer(kids, None, 0, rows)
@@ -785,7 +789,7 @@ def adi_leg(name, model, args, world, coll_device):
         Kd, Nd = int(Wt.shape[1]), int(Wt.shape[0])
         ms = event_ms(lambda: torch.addmm(bt, x1, Wt.t()), 5)[0]
         fl = 2 * rows * Nd * Kd
-        kname = f"hidden GEMM [{rows} x {Kd}] x [{Kd} x {Nd}] + bias, bf16 MFMA via hipBLASLt: first hidden layer of the ADI value network"
+        kname = f"hidden GEMM [{rows}x{Kd}]x[{Kd}x{Nd}] + bias, bf16 MFMA via hipBLASLt: hidden layer 1 of the ADI value network"
         flops_state = 2 * sum(int(Wt.shape[0]) * int(Wt.shape[1]) for Wt, _, _ in eng.value_layers)
     tf = fl / (ms * 1e-3) / 1e12
     res["roofline"] = {"kernel": kname, "bound": "mfma", "achieved": round(tf, 1), "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s",
@@ -816,6 +820,67 @@ def cpu_adi(model, games=64, depth=32):
     return {"value": round(reps * games * depth / dt, 1), "unit": "states/s", "cores": torch.get_num_threads(), "kind": "port",
             "sample": f"{reps} x oracle.train.adi_traindata({games} games x {depth} moves = {games * depth} states, {12 * games * depth} substates), "
                       f"NumPy cube ops + torch CPU fp32 value network, {dt:.1f} s"}
+
+
+def preflight(rank, world, local_rank, backend, device_index, coll_device, need_gb):
+    """
+    Everything the N-rank run relies on, checked before any leg starts; a failure is ONE rank-tagged line on stderr and a
+    non-zero exit of that rank (the launcher then ends the others): the device this rank is bound to (RCCL: GPU index =
+    LOCAL_RANK), free HBM against the largest leg's reservation, and -- on the run's own process group and tensors of the sizes the
+    legs use -- a float64 `all_reduce` (SUM and MAX) of a known vector, the `all_gather` of per-game results, and the
+    `all_to_all_single` + `all_gather_into_tensor` pair of one 16 MB `GradBuckets` bucket.  Returns a dict for the result file.
+    """
+    def fail(what):
+        print(f"[bench preflight] rank {rank}/{world} (local rank {local_rank}, device {device_index}, backend {backend}): {what}",
+              file=sys.stderr, flush=True)
+        sys.exit(3)
+
+    out = {"backend": backend, "device_index": device_index}
+    if backend == "nccl" and device_index != local_rank:
+        fail(f"bound to GPU {device_index}, expected LOCAL_RANK {local_rank}")
+    if torch.cuda.current_device() != device_index:
+        fail(f"torch's current device is {torch.cuda.current_device()}")
+    free, total = torch.cuda.mem_get_info(device_index)
+    out["free_hbm_gb"], out["need_hbm_gb"] = round(free / 1e9, 1), need_gb
+    if free < need_gb * 1e9:
+        fail(f"{free / 1e9:.1f} GB of HBM free, the largest leg needs ~{need_gb} GB (another process on this GPU?)")
+    from librubiks import _hip
+    try:
+        _hip.lib()
+    except Exception as e:   # noqa: BLE001
+        fail(f"librubiks_hip.so: {e!r}")
+    if world > 1:
+        try:
+            v = torch.arange(4, dtype=torch.float64, device=coll_device) + rank
+            sm, mx = v.clone(), v.clone()
+            dist.all_reduce(sm, op=dist.ReduceOp.SUM)
+            dist.all_reduce(mx, op=dist.ReduceOp.MAX)
+            want = torch.arange(4, dtype=torch.float64) * world + world * (world - 1) / 2
+            if not torch.equal(sm.cpu(), want) or not torch.equal(mx.cpu(), torch.arange(4, dtype=torch.float64) + world - 1):
+                fail(f"all_reduce of a known vector returned {sm.tolist()} / {mx.tolist()}")
+            from librubiks.solving.sharding import gather_results
+            games = 8
+            g = gather_results({"nodes": np.full(games, rank, dtype=np.int64), "solved": np.ones(games, dtype=bool),
+                                "lengths": np.full(games, 20 + rank, dtype=np.int64)}, games * world, device=coll_device)
+            if not np.array_equal(g["nodes"], np.repeat(np.arange(world), games)) or not np.array_equal(g["lengths"], 20 + np.repeat(np.arange(world), games)):
+                fail("gather_results did not return every rank's slice in rank order")
+            n = (16 << 20) // 4 // world * world             # one GradBuckets bucket (fp32), whole shards
+            send = torch.full((n,), float(rank + 1), device=coll_device)
+            recv = torch.empty_like(send)
+            dist.all_to_all_single(recv, send)
+            shard = recv.view(world, -1).sum(0)
+            back = torch.empty_like(send)
+            dist.all_gather_into_tensor(back, shard)
+            if float(back.min()) != world * (world + 1) / 2 or float(back.max()) != world * (world + 1) / 2:
+                fail(f"all_to_all_single + all_gather_into_tensor of a bucket returned {float(back.min())} .. {float(back.max())}")
+            torch.cuda.synchronize()
+            dist.barrier()
+        except SystemExit:
+            raise
+        except Exception as e:   # noqa: BLE001
+            fail(f"collective failed: {e!r}")
+        out["collectives"] = "all_reduce SUM/MAX (f64), gather_results, all_to_all_single + all_gather_into_tensor (16 MB): ok"
+    return out
 
 
 def step_rooflines(engine, agent, roots, args, name):
@@ -872,7 +937,9 @@ def step_rooflines(engine, agent, roots, args, name):
             gemm_traffic = stored["traffic_bytes"]
             gemm_traffic_src = (f"stored PMC figure: profiles/{GEMM_PMC_FILE} (separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of "
                                 f"{stored['kernel']}, gfx950 corrections applied; algorithmic bytes 310 MB)")
-        roofline = {"kernel": (f"rc_split_gemm_f16 (own MFMA kernel, 352 x 256 tiles), first hidden layer: [{rows} x {3 * W1[1]}] x [{3 * W1[1]} x {W1[0]}] "
+        roofline = {"kernel_short": (f"rc_split_gemm_f16 352x256 tiles, hidden layer 1: [{rows}x{3 * W1[1]}]x[{3 * W1[1]}x{W1[0]}] f16 MFMA, f32 acc, +bias+ELU+re-split"
+                                     if own else f"hidden layer 1 of the split engine via hipBLASLt: f16 GEMMs [{rows}x{3 * W1[1]}]x[{3 * W1[1]}x{W1[0]}], fp32 out"),
+                    "kernel": (f"rc_split_gemm_f16 (own MFMA kernel, 352 x 256 tiles), first hidden layer: [{rows} x {3 * W1[1]}] x [{3 * W1[1]} x {W1[0]}] "
                                f"f16 products (hi.lo, lo.hi, hi.hi) in one fp32 accumulator + bias + ELU + re-split") if own else
                               (f"first hidden layer of the split engine via hipBLASLt: f16 GEMMs [{rows} x {W1[1]}] x [{W1[1]} x {W1[0]}] (hi.hi) and "
                                f"[{rows} x {2 * W1[1]}] x [{2 * W1[1]} x {W1[0]}] (hi.lo + lo.hi), fp32 out"),
@@ -908,7 +975,8 @@ def step_rooflines(engine, agent, roots, args, name):
         W1 = phases.pop("gemm_hidden1_weight")
         f1 = 2 * W1[0] * W1[1] * rows
         tf1 = f1 / (phases["gemm_hidden1"] * 1e-3) / 1e12
-        roofline = {"kernel": f"hidden GEMM [{rows} x {W1[1]}] x [{W1[1]} x {W1[0]}] + bias, {lib_name}: the dominant kernel of a step",
+        roofline = {"kernel_short": f"hidden GEMM [{rows}x{W1[1]}]x[{W1[1]}x{W1[0]}] + bias, {'bf16' if name == 'bf16' else 'fp32'} MFMA via hipBLASLt: dominant kernel of a step",
+                    "kernel": f"hidden GEMM [{rows} x {W1[1]}] x [{W1[1]} x {W1[0]}] + bias, {lib_name}: the dominant kernel of a step",
                     "bound": "mfma", "achieved": round(tf1, 1), "peak": peak, "unit": "TFLOP/s", "frac": round(tf1 / peak, 4),
                     "traffic": None, "flops_per_launch": f1, "ms_per_launch": phases["gemm_hidden1"]}
     if fused:
@@ -1055,6 +1123,9 @@ def main():
                          "auto = the agent's default: a budget while scrambles are waiting for a slot, none for the tail)")
     ap.add_argument("--first-layer-table", default="auto", choices=["auto", "onehot"],
                     help="bf16 engine's input layer: the fused matrix-core kernel from the cube codes, or the explicit one-hot + library GEMM")
+    ap.add_argument("--preflight", action="store_true",
+                    help="run only the preflight (device binding, free HBM, the collectives the legs use) and print its one-line result; "
+                         "with more than one rank the preflight always runs before the first leg")
     ap.add_argument("--as-rank", default=None, metavar="R/W",
                     help="single process, no process group: take rank R's share of a W-rank run's scrambles (tests compare "
                          "the ranks of a distributed run with these)")
@@ -1079,10 +1150,22 @@ def main():
     backend, device_index, coll_device = pick_backend(os.environ, torch.cuda.device_count(), local_rank)
     torch.cuda.set_device(device_index)
     if world > 1:
+        import datetime
+        limit = datetime.timedelta(minutes=10)      # a rank that never arrives fails the others instead of hanging them
         if backend == "nccl":
-            dist.init_process_group("nccl", device_id=torch.device("cuda", device_index))
+            dist.init_process_group("nccl", device_id=torch.device("cuda", device_index), timeout=limit)
         else:
-            dist.init_process_group(backend)
+            dist.init_process_group(backend, timeout=limit)
+    pre = None
+    if world > 1 or args.preflight:
+        need_gb = 190 if "config5" in extra and args.config5_max_states >= 100000 else 90
+        pre = preflight(rank, world, local_rank, backend, device_index, coll_device, need_gb)
+        if args.preflight:
+            if rank == 0:
+                print(json.dumps({"preflight": "ok", "n_gpus": world, **pre}), flush=True)
+            if world > 1:
+                dist.destroy_process_group()
+            return
 
     from librubiks.model import Model, ModelConfig
 
@@ -1191,14 +1274,40 @@ def main():
             summary[f"config5_share_{name}_run_to_completion"] = rtc_of(leg)["nodes_per_sec"]
             summary[f"config5_share_{name}_solve_rate"] = rtc_of(leg)["solve_rate"]
             summary[f"config5_share_{name}_forest_gb"] = leg["forest_rank0"]["hbm_behind_the_forest_gb"]
+    # ---- the scaling curve, without post-processing: a one-GPU run leaves its value next to the script (SCALE_REF); an N-GPU run
+    # of the same workload on the same checkout divides by it.  null when no such record exists (or the workload differs).
+    workload_key = {"trees": args.trees, "depth": args.depth, "max_states": args.solve_max_states, "leg": legs[0], "pool_factor": args.pool_factor,
+                    "steps": args.steps, "warmup": args.warmup}
+    ref_path = os.path.join(ROOT, SCALE_REF)
+    efficiency, efficiency_note = None, "one GPU: this run IS the reference of the curve"
+    if world == 1 and not args.as_rank:
+        try:
+            with open(ref_path, "w") as f:
+                json.dump({"value": head["value"], "workload": workload_key, "gpu": torch.cuda.get_device_name(device_index)}, f)
+        except OSError:
+            pass
+    elif world > 1:
+        efficiency_note = f"no one-GPU record of this workload ({SCALE_REF}) next to bench.py: run --gpus 1 first on this checkout"
+        if os.path.exists(ref_path):
+            ref = json.load(open(ref_path))
+            if ref.get("workload") == workload_key and ref.get("value"):
+                efficiency = round(head["value"] / (world * ref["value"]), 4)
+                efficiency_note = f"value / ({world} x {ref['value']}), the one-GPU value this checkout's last --gpus 1 run of the same workload left in {SCALE_REF}"
+            else:
+                efficiency_note = f"{SCALE_REF} holds another workload ({ref.get('workload')})"
+    weights_short = os.path.relpath(args.weights, ROOT) if os.path.isdir(args.weights) else "random-init"
     result = {
         "metric": "MCTS node expansions/sec, depth-20 scrambles", "value": head["value"],
         "unit": "node expansions/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-        "ms_per_step": head["ms_per_step"], "higher_is_better": True, "scaling": "weak", "scaling_measured": False,
+        "ms_per_step": head["ms_per_step"], "higher_is_better": True, "scaling": "weak", "scaling_measured": world > 1,
+        "rank_values": head.get("rank_values"), "efficiency": efficiency, "efficiency_note": efficiency_note,
         "vs_baseline": None, "dtype": head["dtype"], "data": "synthetic",
         "config": {"workload": f"{args.trees} concurrent depth-{args.depth} MCTS trees per GPU (c=0.6, graph search, max_states "
                                f"{args.solve_max_states}), slots refilled from a pool of {args.pool_factor} x {args.trees} scrambles "
                                f"per GPU; {model.config.architecture} net, weights: {weights_note}",
+                   # (the driver's record keeps 120 characters of a string: the line carries the *_short forms, the detail file both)
+                   "workload_short": f"{args.trees} depth-{args.depth} MCTS trees/GPU, c=0.6, graph search, max_states {args.solve_max_states}, "
+                                     f"pool {args.pool_factor}x{args.trees}, {model.config.architecture} {weights_short}",
                    "trees_per_gpu": args.trees, "pool_scrambles_per_gpu": per_rank, "select_level_budget": args.level_budget,
                    "scramble_depth": args.depth, "max_states": args.solve_max_states, "parallelism": f"scramble-sharded x{world}",
                    "scrambles": "configs' own games: the reference's stream (np.random.seed(0), scramble(depth, True)), rank r owns games "
@@ -1206,6 +1315,7 @@ def main():
                    "timed_region": "K lock-step iterations of the stationary pool (harvest + refill included) between barrier + synchronize; "
                                    "prep (until 2 x trees scrambles have been started) and warm-up untimed; result flushes (graph completion + "
                                    "BFS of 256 finished trees on a side stream) fall where they fall: results.result_flushes_in_window",
+                   "timed_region_short": "K lock-step steps of the stationary pool between barrier+synchronize; prep and warm-up untimed",
                    "results": summary},
         "value_note": f"headline = the '{legs[0]}' leg: the reference's network arithmetic is fp32 (librubiks/model.py:131-141); f32s reaches "
                       "fp32 accuracy with three f16 MFMA products per layer (error against float64 within 1.25 x the fp32 forward's, "
@@ -1213,7 +1323,9 @@ def main():
         "value_run_to_completion": summary["value_run_to_completion"],
         "value_pool_run": summary["value_pool_run"],
         "solve_rate": summary["solve_rate"],
-        "scaling_note": "no multi-GPU curve has been measured yet (no SCALE record): the N > 1 path is covered by two-rank tests only",
+        "scaling_note": ("this line is one point of the curve: value = all ranks' nodes / max-over-ranks seconds; rank_values = every rank's own rate"
+                         if world > 1 else "no multi-GPU curve has been measured by the build (gpurun hands out one GPU); N > 1 is covered by gloo tests"),
+        "preflight": pre,
         "legs": results,
     }
     if astar:
@@ -1257,6 +1369,7 @@ def main():
         dist.destroy_process_group()
 
 
+SCALE_REF = "bench_scale_ref.json"   # left by a one-GPU run: the denominator of `efficiency` in the N-GPU runs that follow on the same checkout
 LINE_LIMIT = 8000   # bytes of the final stdout line: the driver's record keeps the last 8 KB of output and parses the line from there
 
 
@@ -1274,21 +1387,23 @@ def compact_line(full, detail_name="bench_detail.json"):
     """
     cfg = full["config"]
     line = {k: full[k] for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
-                                 "scaling_measured", "vs_baseline", "data") if k in full}
+                                 "scaling_measured", "rank_values", "efficiency", "vs_baseline", "data") if k in full}
     line["dtype"] = _short(full["dtype"], 96)
-    line["config"] = {"workload": _short(cfg["workload"], 420), "trees_per_gpu": cfg.get("trees_per_gpu"), "max_states": cfg.get("max_states"),
-                      "scramble_depth": cfg.get("scramble_depth"), "parallelism": cfg.get("parallelism"),
-                      "timed_region": _short(cfg.get("timed_region", ""), 330), "results": dict(cfg.get("results") or {})}
+    line["config"] = {"workload": _short(cfg.get("workload_short") or cfg["workload"], STR_LIMIT), "trees_per_gpu": cfg.get("trees_per_gpu"),
+                      "max_states": cfg.get("max_states"), "scramble_depth": cfg.get("scramble_depth"), "parallelism": cfg.get("parallelism"),
+                      "timed_region": _short(cfg.get("timed_region_short") or cfg.get("timed_region", ""), STR_LIMIT),
+                      "results": dict(cfg.get("results") or {})}
     roof = full.get("roofline") or {}
     keep = ("kernel", "bound", "achieved", "peak", "unit", "frac", "traffic", "algorithmic_bytes", "flops_per_launch", "ms_per_launch", "ms",
             "fp32_equivalent_tflops")
-    line["roofline"] = {k: (_short(roof[k], 200) if k == "kernel" else roof[k]) for k in keep if k in roof}
+    line["roofline"] = {k: (_short(roof.get("kernel_short") or roof[k], STR_LIMIT) if k == "kernel" else roof[k]) for k in keep if k in roof}
     for sub in ("env_multi_rotate_2p24", "astar_dominant_kernel", "adi_dominant_kernel", "adi_env"):
         if sub in roof:
-            line["roofline"][sub] = {k: (_short(v, 140) if isinstance(v, str) else v) for k, v in roof[sub].items() if k in keep}
+            line["roofline"][sub] = {k: (_short(roof[sub].get("kernel_short") or v, STR_LIMIT) if isinstance(v, str) else v)
+                                     for k, v in roof[sub].items() if k in keep}
     cpu = full.get("cpu_baseline")
     if cpu:
-        line["cpu_baseline"] = {k: (_short(cpu[k], 220) if k == "sample" else cpu[k])
+        line["cpu_baseline"] = {k: (_short(cpu.get("sample_short") or cpu[k], STR_LIMIT) if k == "sample" else cpu[k])
                                 for k in ("value", "unit", "cores", "host_cpus", "kind", "sample", "env_ops", "bfs_config1", "adi") if k in cpu}
     line["detail"] = detail_name
     dropped = []
@@ -1306,7 +1421,20 @@ def compact_line(full, detail_name="bench_detail.json"):
         dropped.append(f"config.results: the last {n_cut} scalars")
     if dropped:
         line["dropped_to_detail"] = dropped
-    return line
+    return _clip_strings(line)
+
+
+STR_LIMIT = 120   # characters of a string the driver's record keeps: longer descriptions live in the detail file
+
+
+def _clip_strings(x):
+    if isinstance(x, str):
+        return _short(x, STR_LIMIT)
+    if isinstance(x, dict):
+        return {k: _clip_strings(v) for k, v in x.items()}
+    if isinstance(x, list):
+        return [_clip_strings(v) for v in x]
+    return x
 
 
 def emit(full, detail_path):

@@ -442,13 +442,29 @@ int rc_mcts_copy_trees(const rc_mcts_t *src, const rc_mcts_t *dst, const int32_t
  * only the nodes a search creates.  rc_vmm_reserve reserves an address range of the array's full size, rc_vmm_map puts memory
  * behind [offset, offset + bytes) of it, chunk by chunk (chunk_bytes: a multiple of 2 MiB; a chunk already mapped is left
  * alone); addresses never change, so structs, kernels and captured graphs are unaffected.  rc_vmm_map is host-synchronous and
- * may be called while kernels work on other parts of the range.  rc_vmm_release: after the caller has synchronised. */
+ * may be called while kernels work on other parts of the range (*out_new_bytes = bytes it added, also when it fails part of
+ * the way).  rc_vmm_release: after the caller has synchronised; unmaps, flushes the GPU's translations and puts the address
+ * range on the idle list of its size class (reservations are whole powers of two), where the next rc_vmm_reserve of that class
+ * finds it: rc_vmm_retired_bytes = address space idle on those lists, bounded by one range per class and live overlap.
+ * Diagnosis: every call is recorded (the last 512 events in memory; all of them, flushed line by line, in the file the
+ * environment variable RUBIKS_VMM_LOG names, "stderr" = stderr); rc_vmm_dump writes the live ranges with their mapped chunk runs,
+ * the idle ranges and the recent events as text (at most cap - 1 characters; *out_needed = full length incl. NUL);
+ * rc_vmm_classify says what an address -- that of a GPU memory access fault, say -- is to the library at this moment;
+ * rc_vmm_chunk_map copies the per-chunk "has memory" flags of a range. */
+#define RC_VMM_ADDR_UNKNOWN 0    /* not inside any reservation of this library */
+#define RC_VMM_ADDR_MAPPED 1     /* live range, memory behind the chunk */
+#define RC_VMM_ADDR_UNMAPPED 2   /* live range, NO memory behind the chunk: a row touched before it was mapped */
+#define RC_VMM_ADDR_SLACK 3      /* live reservation, outside the range handed out (alignment slack, rest of the size class) */
+#define RC_VMM_ADDR_IDLE 4       /* a released range waiting for reuse: nothing mapped */
 int rc_vmm_granularity(size_t *out_bytes);
 int rc_vmm_reserve(size_t bytes, size_t chunk_bytes, void **out_base);
 int rc_vmm_map(void *base, size_t offset, size_t bytes, size_t *out_new_bytes);
 int rc_vmm_mapped_bytes(void *base, size_t *out_bytes);
+int rc_vmm_chunk_map(void *base, uint8_t *out_flags, size_t cap, size_t *out_chunks);
 int rc_vmm_release(void *base);
-int rc_vmm_retired_bytes(size_t *out_bytes);   /* address space of released ranges kept reserved: never mapped twice */
+int rc_vmm_retired_bytes(size_t *out_bytes);
+int rc_vmm_classify(const void *addr, int *out_kind, void **out_base, size_t *out_offset);
+int rc_vmm_dump(char *out, size_t cap, size_t *out_needed);
 
 /* ---- batched weighted A*: B independent problems, N expansions each per iteration --------------
  *

@@ -8,7 +8,24 @@
 // chunk (a multiple of the allocation granularity, 2 MiB on MI355X) as the trees grow.  Addresses never change, so the kernels,
 // the rc_mcts_t struct and every captured HIP graph stay as they are; the host maps ahead of the trees' growth at the points
 // where it already looks at their node counts (MCTSRun.round).
+//
+// Address space is handed out in SIZE CLASSES (powers of two) and comes back: a released range is unmapped, the GPU's
+// translations are flushed (forget_translations), and the range waits on its class's free list for the next reservation of that
+// class -- a process that cycles through forests of many shapes holds at most one idle range per class and live overlap, not one
+// per forest it ever built (rc_vmm_retired_bytes stops growing after the first cycle).
+//
+// Every reservation, map, release and reuse is recorded: the last kEvents in memory (rc_vmm_dump), all of them appended to the file
+// RUBIKS_VMM_LOG names ("stderr" = the process's stderr), flushed line by line so that the record survives the abort that follows a
+// GPU memory access fault; rc_vmm_classify / tools/vmm_classify.py say what a faulting address was at that moment (memory behind
+// it / a reserved row without memory / a released range / never ours).
+#include <cinttypes>
+#include <cstdarg>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <map>
 #include <mutex>
+#include <string>
 #include <unordered_map>
 #include <vector>
 
@@ -20,18 +37,59 @@ namespace {
 
 struct Range {
     size_t bytes = 0, chunk = 0;
-    void *raw = nullptr;      // what hipMemAddressReserve returned (the range handed out starts at the next multiple of `chunk`)
+    void *raw = nullptr;      // the reservation (a whole size class); the range handed out starts at the next multiple of `chunk`
     size_t raw_bytes = 0;
     int device = 0;
+    uint32_t uses = 0;        // times this address range has been handed out (1 = fresh addresses)
     std::vector<hipMemGenericAllocationHandle_t> handles;   // one per chunk
     std::vector<char> mapped;
     size_t mapped_bytes = 0;
-    bool ever_mapped = false;
 };
+struct Idle {                 // a released reservation waiting on its class's free list: nothing mapped, translations flushed
+    void *raw;
+    size_t raw_bytes;
+    int device;
+    uint32_t uses;
+};
+struct Event {
+    uint64_t seq;
+    char op;                  // A the reservation behind the R / U that follows (base = its first address), R range handed out on fresh
+                              // addresses, U on an idle reservation of the class, M map, X release (unmap), I reservation put on the idle
+                              // list, F its address space freed instead, E a HIP call failed
+    uintptr_t base;
+    size_t a, b;              // A: raw bytes, 0;  R/U: bytes, chunk (rc = uses);  M: offset, bytes of the range that have memory behind them
+                              // after the call (from offset on; chunk multiples);  X: mapped bytes given back, raw bytes;  I/F: raw bytes, uses;
+                              // E: offset, bytes
+    int rc;
+};
+
 std::mutex g_mu;
 std::unordered_map<void *, Range> g_ranges;
-size_t g_retired_bytes = 0;                    // address space of released ranges that stays reserved (see rc_vmm_release)
-constexpr size_t kRetireBudget = 32ull << 40;   // of the 128 TiB a process has
+std::multimap<std::pair<int, size_t>, Idle> g_idle;      // (device, raw bytes) -> idle reservations
+size_t g_retired_bytes = 0;                               // address space on the idle lists
+constexpr size_t kRetireBudget = 32ull << 40;             // of the 128 TiB a process has: beyond it released ranges are freed
+constexpr size_t kMinChunk = 2u << 20;
+constexpr int kEvents = 512;
+Event g_events[kEvents];
+uint64_t g_seq = 0;
+FILE *g_log = nullptr;
+bool g_log_checked = false;
+
+void record(char op, const void *base, size_t a, size_t b, int rc) {   // g_mu held
+    Event &e = g_events[g_seq % kEvents];
+    e = Event{g_seq, op, reinterpret_cast<uintptr_t>(base), a, b, rc};
+    ++g_seq;
+    if (!g_log_checked) {
+        g_log_checked = true;
+        const char *path = std::getenv("RUBIKS_VMM_LOG");
+        if (path && *path) g_log = std::strcmp(path, "stderr") == 0 ? stderr : std::fopen(path, "a");
+        if (g_log) std::fprintf(g_log, "# rubiks vmm log: seq op base a b rc  (A raw_bytes 0 | R/U bytes chunk uses | M offset covered | X mapped raw | I/F raw uses | E offset bytes)\n");
+    }
+    if (g_log) {
+        std::fprintf(g_log, "%" PRIu64 " %c 0x%" PRIxPTR " %zu %zu %d\n", e.seq, e.op, e.base, e.a, e.b, e.rc);
+        std::fflush(g_log);
+    }
+}
 
 // One allocation per chunk, every chunk at an address that is a multiple of the chunk size.  Measured on MI355X / ROCm 7.2
 // (profiles/r4_vmm_raw_probe.txt, r4_vmm_raw_probe2.txt): hipMemSetAccess returns hipErrorInvalidValue for a piece whose virtual
@@ -42,18 +100,19 @@ constexpr size_t kRetireBudget = 32ull << 40;   // of the 128 TiB a process has
 // queued before it: large forests take larger chunks, and the host maps in few, large steps (MCTSForest.grow).
 // A failed HIP call leaves its code as the thread's "last error", which the next hipGetLastError() of anybody -- torch checks it
 // after every launch -- would report as its own: read it away.
-int failed(hipError_t e) {
+int failed(hipError_t e, const void *base = nullptr, size_t a = 0, size_t b = 0) {
     (void)hipGetLastError();
+    record('E', base, a, b, hip_rc(e));
     return hip_rc(e);
 }
 
 // hipMemUnmap does not make the GPU forget its translations of the unmapped addresses (ROCm 7.2 / MI355X, tools/vmm_remap_probe.hip,
-// profiles/r4_vmm_remap_probe.txt): memory mapped LATER at such an address -- in the same reservation, or in a new one that was
-// handed the freed addresses again -- is read and written through the stale translations by part of the chip (9 of 9 rounds with
-// wrong data; 0 of 9 at addresses never mapped before, and 0 of 9 at the addresses of a hipFree'd block).  An ordinary
-// hipMalloc + hipFree after the unmaps cures it in the probe (0 of 9): hipFree's own unmapping is announced to the GPU, and that
-// announcement covers everything.  rc_vmm_release does that AND keeps the range's addresses reserved for good, so that neither a
-// later reservation nor hipMalloc can be handed them: either measure alone passes the probe, address space is not scarce.
+// profiles/r4_vmm_remap_probe.txt, profiles/r5_vmm_remap_probe.txt): memory mapped LATER at such an address -- in the same reservation,
+// or in a new one that was handed the freed addresses again -- is read and written through the stale translations by part of the
+// chip (9 of 9 rounds with wrong data; 0 of 9 at addresses never mapped before, and 0 of 9 at the addresses of a hipFree'd
+// block).  An ordinary hipMalloc + hipFree after the unmaps cures it (0 wrong rounds with it, in every run of the probe): hipFree's
+// own unmapping is announced to the GPU, and that announcement covers everything.  rc_vmm_release does that before a range goes to
+// the idle list, so by the time an address is mapped a second time no translation of its first life is left.
 void forget_translations() {
     void *blk = nullptr;
     if (hipMalloc(&blk, 2u << 20) != hipSuccess) {
@@ -73,6 +132,21 @@ hipMemAllocationProp device_prop(int device) {
     return prop;
 }
 
+size_t size_class(size_t need) {   // the power of two >= need (>= 4 MiB)
+    size_t c = 4u << 20;
+    while (c < need) c <<= 1;
+    return c;
+}
+
+void append(std::string &s, const char *fmt, ...) {
+    char line[256];
+    va_list ap;
+    va_start(ap, fmt);
+    std::vsnprintf(line, sizeof line, fmt, ap);
+    va_end(ap);
+    s += line;
+}
+
 }  // namespace
 
 extern "C" {
@@ -88,25 +162,37 @@ int rc_vmm_granularity(size_t *out_bytes) {
 int rc_vmm_reserve(size_t bytes, size_t chunk_bytes, void **out_base) {
     RC_REQUIRE(out_base != nullptr, RC_ERR_NULL);
     *out_base = nullptr;
-    constexpr size_t kMin = 2u << 20;
-    RC_REQUIRE(bytes > 0 && chunk_bytes >= kMin && (chunk_bytes & (chunk_bytes - 1)) == 0 && chunk_bytes <= (1u << 30), RC_ERR_RANGE);
+    RC_REQUIRE(bytes > 0 && bytes <= (1ull << 46) && chunk_bytes >= kMinChunk && (chunk_bytes & (chunk_bytes - 1)) == 0 && chunk_bytes <= (1u << 30),
+               RC_ERR_RANGE);
     Range r;
     r.chunk = chunk_bytes;
     r.bytes = (bytes + chunk_bytes - 1) / chunk_bytes * chunk_bytes;
-    r.raw_bytes = r.bytes + (chunk_bytes > kMin ? chunk_bytes : 0);
+    r.raw_bytes = size_class(r.bytes + (chunk_bytes > kMinChunk ? chunk_bytes : 0));
+    std::lock_guard<std::mutex> lock(g_mu);
     if (hipError_t e = hipGetDevice(&r.device); e != hipSuccess) return failed(e);
-    if (hipError_t e = hipMemAddressReserve(&r.raw, r.raw_bytes, kMin, nullptr, 0); e != hipSuccess) return failed(e);
+    auto idle = g_idle.find({r.device, r.raw_bytes});
+    if (idle != g_idle.end()) {            // an idle reservation of this class: its addresses again (flushed when it was released)
+        r.raw = idle->second.raw;
+        r.uses = idle->second.uses + 1;
+        g_retired_bytes -= r.raw_bytes;
+        g_idle.erase(idle);
+    } else {
+        if (hipError_t e = hipMemAddressReserve(&r.raw, r.raw_bytes, kMinChunk, nullptr, 0); e != hipSuccess) return failed(e, nullptr, r.raw_bytes, chunk_bytes);
+        r.uses = 1;
+    }
     void *base = reinterpret_cast<void *>((reinterpret_cast<uintptr_t>(r.raw) + chunk_bytes - 1) / chunk_bytes * chunk_bytes);
     r.handles.assign(r.bytes / chunk_bytes, hipMemGenericAllocationHandle_t{});
     r.mapped.assign(r.bytes / chunk_bytes, 0);
-    std::lock_guard<std::mutex> lock(g_mu);
+    record('A', r.raw, r.raw_bytes, 0, RC_OK);
+    record(r.uses == 1 ? 'R' : 'U', base, r.bytes, chunk_bytes, (int)r.uses);
     g_ranges.emplace(base, std::move(r));
     *out_base = base;
     return RC_OK;
 }
 
 // Backs [offset, offset + bytes) of the range with physical memory (chunks already mapped are left alone).  Host-synchronous;
-// kernels running on other parts of the range are not disturbed.  *out_new_bytes: physical bytes this call added.
+// kernels running on other parts of the range are not disturbed.  *out_new_bytes: physical bytes this call added -- also when it
+// fails part of the way (the chunks mapped until then stay mapped).
 int rc_vmm_map(void *base, size_t offset, size_t bytes, size_t *out_new_bytes) {
     if (out_new_bytes) *out_new_bytes = 0;
     RC_REQUIRE(base != nullptr, RC_ERR_NULL);
@@ -121,28 +207,36 @@ int rc_vmm_map(void *base, size_t offset, size_t bytes, size_t *out_new_bytes) {
     hipMemAccessDesc access = {};
     access.location = prop.location;
     access.flags = hipMemAccessFlagsProtReadWrite;
-    for (size_t c = c0; c <= c1; ++c) {
-        if (r.mapped[c]) continue;
+    size_t added = 0, done = c0;   // chunks c0 .. done - 1 have memory behind them when the loop ends
+    int rc = RC_OK;
+    for (size_t c = c0; c <= c1 && rc == RC_OK; ++c) {
+        if (r.mapped[c]) {
+            done = c + 1;
+            continue;
+        }
         const size_t run = r.chunk;
         hipMemGenericAllocationHandle_t h{};
-        if (hipError_t err = hipMemCreate(&h, run, &prop, 0); err != hipSuccess) return failed(err);
         char *at = static_cast<char *>(base) + c * r.chunk;
-        if (hipError_t err = hipMemMap(at, run, 0, h, 0); err != hipSuccess) {
+        if (hipError_t err = hipMemCreate(&h, run, &prop, 0); err != hipSuccess) {
+            rc = failed(err, base, c * r.chunk, run);
+        } else if (hipError_t err = hipMemMap(at, run, 0, h, 0); err != hipSuccess) {
             (void)hipMemRelease(h);
-            return failed(err);
-        }
-        if (hipError_t err = hipMemSetAccess(at, run, &access, 1); err != hipSuccess) {
+            rc = failed(err, base, c * r.chunk, run);
+        } else if (hipError_t err = hipMemSetAccess(at, run, &access, 1); err != hipSuccess) {
             (void)hipMemUnmap(at, run);
             (void)hipMemRelease(h);
-            return failed(err);
+            rc = failed(err, base, c * r.chunk, run);
+        } else {
+            r.handles[c] = h;
+            r.mapped[c] = 1;
+            r.mapped_bytes += run;
+            added += run;
+            done = c + 1;
         }
-        r.handles[c] = h;
-        r.mapped[c] = 1;
-        r.ever_mapped = true;
-        r.mapped_bytes += run;
-        if (out_new_bytes) *out_new_bytes += run;
     }
-    return RC_OK;
+    if (out_new_bytes) *out_new_bytes = added;
+    if (added) record('M', base, c0 * r.chunk, (done - c0) * r.chunk, rc);
+    return rc;
 }
 
 int rc_vmm_mapped_bytes(void *base, size_t *out_bytes) {
@@ -154,6 +248,21 @@ int rc_vmm_mapped_bytes(void *base, size_t *out_bytes) {
     return RC_OK;
 }
 
+// Per chunk of the range: 1 = memory behind it.  out_flags: [n_chunks] bytes, or NULL to ask for the count alone.
+int rc_vmm_chunk_map(void *base, uint8_t *out_flags, size_t cap, size_t *out_chunks) {
+    RC_REQUIRE(base != nullptr && out_chunks != nullptr, RC_ERR_NULL);
+    std::lock_guard<std::mutex> lock(g_mu);
+    auto it = g_ranges.find(base);
+    RC_REQUIRE(it != g_ranges.end(), RC_ERR_RANGE);
+    const Range &r = it->second;
+    *out_chunks = r.mapped.size();
+    if (out_flags) {
+        RC_REQUIRE(cap >= r.mapped.size(), RC_ERR_RANGE);
+        std::memcpy(out_flags, r.mapped.data(), r.mapped.size());
+    }
+    return RC_OK;
+}
+
 int rc_vmm_retired_bytes(size_t *out_bytes) {
     RC_REQUIRE(out_bytes != nullptr, RC_ERR_NULL);
     std::lock_guard<std::mutex> lock(g_mu);
@@ -161,9 +270,9 @@ int rc_vmm_retired_bytes(size_t *out_bytes) {
     return RC_OK;
 }
 
-// Unmaps and releases the memory.  The caller has synchronised with every kernel that uses the range.  The ADDRESSES of a range
-// that had memory mapped are retired, not freed (see forget_translations): nothing is ever mapped at them again.  Only once
-// kRetireBudget of address space has been retired are ranges freed for reuse, relying on forget_translations alone.
+// Unmaps and releases the memory.  The caller has synchronised with every kernel that uses the range.  The address range goes to
+// the idle list of its size class (after forget_translations, so that nothing of its mappings is left in the GPU when the next
+// reservation of the class maps memory there); only beyond kRetireBudget of idle address space is it freed instead.
 int rc_vmm_release(void *base) {
     RC_REQUIRE(base != nullptr, RC_ERR_NULL);
     std::lock_guard<std::mutex> lock(g_mu);
@@ -174,23 +283,105 @@ int rc_vmm_release(void *base) {
     const size_t n = r.mapped.size();
     for (size_t c = 0; c < n; ++c) {
         if (!r.mapped[c]) continue;
-        if (hipError_t err = hipMemUnmap(static_cast<char *>(base) + c * r.chunk, r.chunk); err != hipSuccess && rc == RC_OK) rc = failed(err);
-        if (hipError_t err = hipMemRelease(r.handles[c]); err != hipSuccess && rc == RC_OK) rc = failed(err);
+        if (hipError_t err = hipMemUnmap(static_cast<char *>(base) + c * r.chunk, r.chunk); err != hipSuccess && rc == RC_OK) rc = failed(err, base, c * r.chunk, r.chunk);
+        if (hipError_t err = hipMemRelease(r.handles[c]); err != hipSuccess && rc == RC_OK) rc = failed(err, base, c * r.chunk, r.chunk);
     }
-    if (r.ever_mapped) {   // on the range's device, whichever is current
+    record('X', base, r.mapped_bytes, r.raw_bytes, rc);
+    if (r.mapped_bytes) {   // chunks are only ever unmapped here: a range without memory now never had any.  On the range's device, whichever is current
         int current = r.device;
         (void)hipGetDevice(&current);
         if (current != r.device) (void)hipSetDevice(r.device);
         forget_translations();
         if (current != r.device) (void)hipSetDevice(current);
     }
-    if (r.ever_mapped && g_retired_bytes + r.raw_bytes <= kRetireBudget) {
+    if (g_retired_bytes + r.raw_bytes <= kRetireBudget) {
+        g_idle.insert({{r.device, r.raw_bytes}, Idle{r.raw, r.raw_bytes, r.device, r.uses}});
         g_retired_bytes += r.raw_bytes;
-    } else if (hipError_t err = hipMemAddressFree(r.raw, r.raw_bytes); err != hipSuccess && rc == RC_OK) {
-        rc = failed(err);
+        record('I', r.raw, r.raw_bytes, r.uses, RC_OK);
+    } else {
+        hipError_t err = hipMemAddressFree(r.raw, r.raw_bytes);
+        if (err != hipSuccess && rc == RC_OK) rc = failed(err, r.raw, 0, r.raw_bytes);
+        record('F', r.raw, r.raw_bytes, r.uses, hip_rc(err));
     }
     g_ranges.erase(it);
     return rc;
+}
+
+// What `addr` is to this library right now.  *out_base / *out_offset: the range it lies in (its handed-out base; offset may be
+// negative-as-size_t for the alignment slack in front of the base) or 0.
+//   RC_VMM_ADDR_UNKNOWN   not inside any reservation of this library (live or idle)
+//   RC_VMM_ADDR_MAPPED    a live range, the chunk has memory behind it
+//   RC_VMM_ADDR_UNMAPPED  a live range, no memory behind the chunk: a row that was touched before it was mapped
+//   RC_VMM_ADDR_SLACK     a live reservation, outside the range handed out (alignment slack / the rest of the size class)
+//   RC_VMM_ADDR_IDLE      a released range waiting for reuse: nothing is mapped there
+int rc_vmm_classify(const void *addr, int *out_kind, void **out_base, size_t *out_offset) {
+    RC_REQUIRE(out_kind != nullptr, RC_ERR_NULL);
+    const uintptr_t a = reinterpret_cast<uintptr_t>(addr);
+    if (out_base) *out_base = nullptr;
+    if (out_offset) *out_offset = 0;
+    *out_kind = RC_VMM_ADDR_UNKNOWN;
+    std::lock_guard<std::mutex> lock(g_mu);
+    for (const auto &kv : g_ranges) {
+        const Range &r = kv.second;
+        const uintptr_t raw = reinterpret_cast<uintptr_t>(r.raw), base = reinterpret_cast<uintptr_t>(kv.first);
+        if (a < raw || a >= raw + r.raw_bytes) continue;
+        if (out_base) *out_base = kv.first;
+        if (out_offset) *out_offset = a - base;
+        *out_kind = (a < base || a >= base + r.bytes) ? RC_VMM_ADDR_SLACK : r.mapped[(a - base) / r.chunk] ? RC_VMM_ADDR_MAPPED : RC_VMM_ADDR_UNMAPPED;
+        return RC_OK;
+    }
+    for (const auto &kv : g_idle) {
+        const uintptr_t raw = reinterpret_cast<uintptr_t>(kv.second.raw);
+        if (a < raw || a >= raw + kv.second.raw_bytes) continue;
+        if (out_base) *out_base = kv.second.raw;
+        if (out_offset) *out_offset = a - raw;
+        *out_kind = RC_VMM_ADDR_IDLE;
+        return RC_OK;
+    }
+    return RC_OK;
+}
+
+// Text description of the node store's state: live ranges (with their mapped chunk runs), idle ranges per class, the last events.
+// Writes at most cap - 1 characters + NUL into out (may be NULL); *out_needed = the full length incl. NUL.
+int rc_vmm_dump(char *out, size_t cap, size_t *out_needed) {
+    std::string s;
+    {
+        std::lock_guard<std::mutex> lock(g_mu);
+        append(s, "rubiks vmm: %zu live ranges, %zu idle (%zu bytes of address space), %" PRIu64 " events\n", g_ranges.size(), g_idle.size(),
+               g_retired_bytes, g_seq);
+        for (const auto &kv : g_ranges) {
+            const Range &r = kv.second;
+            append(s, "live base=0x%" PRIxPTR " bytes=%zu chunk=%zu raw=0x%" PRIxPTR " raw_bytes=%zu device=%d uses=%u mapped_bytes=%zu chunks:",
+                   reinterpret_cast<uintptr_t>(kv.first), r.bytes, r.chunk, reinterpret_cast<uintptr_t>(r.raw), r.raw_bytes, r.device, r.uses, r.mapped_bytes);
+            size_t runs = 0;
+            for (size_t c = 0; c < r.mapped.size();) {
+                if (!r.mapped[c]) {
+                    ++c;
+                    continue;
+                }
+                size_t e = c;
+                while (e < r.mapped.size() && r.mapped[e]) ++e;
+                if (++runs <= 64) append(s, " %zu-%zu", c, e - 1);
+                c = e;
+            }
+            append(s, runs > 64 ? " ... (%zu runs)\n" : "\n", runs);
+        }
+        for (const auto &kv : g_idle)
+            append(s, "idle raw=0x%" PRIxPTR " raw_bytes=%zu device=%d uses=%u\n", reinterpret_cast<uintptr_t>(kv.second.raw), kv.second.raw_bytes,
+                   kv.second.device, kv.second.uses);
+        const uint64_t first = g_seq > (uint64_t)kEvents ? g_seq - kEvents : 0;
+        for (uint64_t q = first; q < g_seq; ++q) {
+            const Event &e = g_events[q % kEvents];
+            append(s, "event %" PRIu64 " %c 0x%" PRIxPTR " %zu %zu %d\n", e.seq, e.op, e.base, e.a, e.b, e.rc);
+        }
+    }
+    if (out_needed) *out_needed = s.size() + 1;
+    if (out && cap) {
+        const size_t n = s.size() < cap - 1 ? s.size() : cap - 1;
+        std::memcpy(out, s.data(), n);
+        out[n] = 0;
+    }
+    return RC_OK;
 }
 
 }  // extern "C"

@@ -335,6 +335,9 @@ class MCTS(DeepAgent):
         f = self.forest
         if f is None or f.B != n_trees or f.C < capacity or f.C_asked > 4 * capacity:
             self.forest = None
+            if f is not None:
+                f.close()             # node store mapped on demand: parked for the next forest of that shape (not left to __del__)
+                del f
             torch.cuda.empty_cache()
             f = self.forest = md.MCTSForest(n_trees, capacity, self.max_path)
         f.set_net(self._search_net(), self.net_dtype)   # every search: `net` may have been trained or replaced since the last one
@@ -447,7 +450,9 @@ class MCTSRun:
         forest.set_active(None)
         self.plant_states = self.cap_states if one_launch else None   # one-launch iterations: roots expanded by the plant itself
         forest.plant(None, roots, 0, self.plant_states)       # the first S scrambles; the others move in as trees finish
-        forest._steps_covered = 2 * agent.sync_every          # (a planted tree has rows for its first ~680 iterations)
+        # iterations that may be queued before the host has looked at the node counts: what a planted tree's first rows cover
+        # (16 384 rows: its first ~1 360 iterations), so that a long `sync_every` cannot make trees sit out behind the kernel's guard
+        forest._steps_covered = min(2 * agent.sync_every, max(1, (forest._first_rows() - 14) // 12))
         self.owner = np.arange(S)          # game index of every slot; -1 once its result has been taken and nobody moved in
         self.stale_until = np.full(S, -1)  # snapshots up to this index predate the tree that now lives in the slot
         self.next_game = S

@@ -343,20 +343,33 @@ class MCTSForest:
                 base = int(t) * (self.C + 1)
                 self._ranges_bfs.ensure(base * 8, (base + int(self.nodes_seen[t]) + 2) * 8)
 
+    _deferred = []   # ranges of forests collected while a HIP graph was being captured: parked by the next close() outside a capture
+
     def close(self):
-        """Returns the mapped memory (forests mapped on demand; others free theirs with their tensors).  Synchronises."""
-        if self.vmm and self._ranges is not None:
-            torch.cuda.synchronize()
-            self._graphs, self._graph_pool = {}, None
-            for name in list(self._ranges) + list(_NODE_FIELDS):
-                if hasattr(self, name):
-                    delattr(self, name)
-            self.bfs = None
-            for arr, _ in self._ranges.values():     # kept for the next forest of this shape (VmmArray.park); VmmArray.trim() releases
-                arr.park()
-            if getattr(self, "_ranges_bfs", None) is not None:
-                self._ranges_bfs.park()
-            self._ranges, self._ranges_bfs = None, None
+        """Hands the node store on (forests mapped on demand; others free theirs with their tensors): the arrays are parked for the
+        next forest of this shape (`VmmArray.park`; `VmmArray.trim()` releases parked memory).  Synchronises -- except while a HIP
+        graph is being captured on this thread (a forest may be garbage-collected at any point, and a synchronisation would break
+        the capture): the ranges then wait in `_deferred`.  Agents close the forests they drop themselves (`MCTS._forest_for`);
+        `__del__` is the safety net."""
+        ranges = getattr(self, "_ranges", None)
+        if not getattr(self, "vmm", False) or ranges is None:
+            return
+        self._graphs, self._graph_pool = {}, None
+        for name in list(ranges) + list(_NODE_FIELDS):
+            if hasattr(self, name):
+                delattr(self, name)
+        self.bfs = None
+        arrays = [arr for arr, _ in ranges.values()]
+        if getattr(self, "_ranges_bfs", None) is not None:
+            arrays.append(self._ranges_bfs)
+        self._ranges, self._ranges_bfs = None, None
+        if torch.cuda.is_current_stream_capturing():
+            MCTSForest._deferred.extend(arrays)
+            return
+        torch.cuda.synchronize()
+        arrays, MCTSForest._deferred = MCTSForest._deferred + arrays, []
+        for arr in arrays:
+            arr.park()
 
     def __del__(self):
         try:
@@ -364,7 +377,7 @@ class MCTSForest:
         except Exception as e:   # noqa: BLE001 -- nothing to raise into; but a failed release must not pass unseen
             try:
                 import sys
-                print(f"MCTSForest: releasing the node store failed: {e!r}", file=sys.stderr)
+                print(f"MCTSForest: handing the node store on failed: {e!r}", file=sys.stderr)
             except Exception:   # noqa: BLE001 -- interpreter shutdown
                 pass
 

@@ -55,7 +55,9 @@ class GradBuckets:
                 (each rank sends (W-1)/W of the bucket, a W-th over each link), rank j adds them -- one fixed order, so every rank
                 ends with bit-identical gradients -- and an all_gather_into_tensor returns the sums; the first half runs under
                 backward, the second is issued in wait();
-      "auto"    direct on RCCL with at least four ranks, ring otherwise.
+      "auto"    ring.  The direct form is OPT-IN (`exchange="direct"`): it has run on gloo (2, 3, 8 ranks) and on a one-rank RCCL
+                group, never between GPUs, and it doubles the gradient buffers (`recvs`); it becomes the default on RCCL only once
+                an 8-GPU run has shown it bit-identical across ranks and faster than the ring.
     Neither form has been timed on xGMI (no multi-GPU box was available to this build); both are tested on gloo.
     `wait()` = every bucket reduced and divided by the world size; `zero()` replaces optimizer.zero_grad().
     """
@@ -65,7 +67,7 @@ class GradBuckets:
         self.world = dist.get_world_size() if on else 1
         assert exchange in ("auto", "ring", "direct")
         if exchange == "auto":
-            exchange = "direct" if on and dist.get_backend() == "nccl" and self.world >= 4 else "ring"
+            exchange = "ring"
         self.direct = exchange == "direct" and self.world > 1
         params = [p for p in net.parameters() if p.requires_grad]
         self.flats, self.bucket_of, self.sizes = [], {}, []

@@ -56,6 +56,30 @@ def test_line_is_small_and_complete():
         assert bulky not in back
     assert "boundary_calls" not in cpu
     assert "dropped_to_detail" not in back
+    # the driver's record keeps 120 characters of a string: nothing in the line is longer (long forms live in the detail file)
+    def strings(x):
+        if isinstance(x, str):
+            yield x
+        elif isinstance(x, dict):
+            for v in x.values():
+                yield from strings(v)
+        elif isinstance(x, list):
+            for v in x:
+                yield from strings(v)
+    assert max(len(t) for t in strings(back)) <= bench.STR_LIMIT == 120
+
+
+def test_short_forms_are_what_the_line_carries():
+    full = _full()
+    full["config"]["workload_short"] = "1024 depth-20 MCTS trees/GPU, c=0.6, graph search, max_states 175000, pool 8x1024, fc_small weights/fc_small_r1"
+    full["config"]["timed_region_short"] = "K lock-step steps of the stationary pool between barrier+synchronize; prep and warm-up untimed"
+    full["roofline"]["kernel_short"] = "rc_split_gemm_f16 352x256 tiles, hidden layer 1: [11264x12288]x[12288x2048] f16 MFMA, f32 acc, +bias+ELU+re-split"
+    full.update(rank_values=[1.0, 2.0], efficiency=0.97)
+    line = bench.compact_line(full)
+    assert line["config"]["workload"] == full["config"]["workload_short"] and len(line["config"]["workload"]) <= 120
+    assert line["config"]["timed_region"] == full["config"]["timed_region_short"]
+    assert line["roofline"]["kernel"] == full["roofline"]["kernel_short"] and not line["roofline"]["kernel"].endswith("...")
+    assert line["rank_values"] == [1.0, 2.0] and line["efficiency"] == 0.97
 
 
 def test_line_stays_under_the_limit_whatever_the_result_holds():

@@ -102,6 +102,24 @@ def _bench_line(args, env_extra, launcher=(), detail=None):
     return line, full
 
 
+def test_bench_preflight_alone():
+    """`bench.py --gpus 2 --preflight`: device binding, free HBM and every collective the legs use, on two gloo ranks sharing the
+    GPU; prints one line and runs no leg.  A rank that cannot meet a requirement ends with a rank-tagged message and code 3."""
+    import json
+    import subprocess
+    import sys
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")}
+    env["RUBIKS_DIST_BACKEND"] = "gloo"
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--preflight"], env=env, capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stderr[-2000:]
+    line = json.loads([ln for ln in out.stdout.splitlines() if ln.startswith("{")][-1])
+    assert line["preflight"] == "ok" and line["n_gpus"] == 2 and line["collectives"].endswith("ok")
+    # RCCL with two ranks on ONE GPU: pick_backend refuses before anything hangs
+    env["RUBIKS_DIST_BACKEND"] = "nccl"
+    bad = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--preflight"], env=env, capture_output=True, text=True, timeout=300)
+    assert bad.returncode != 0 and not [ln for ln in bad.stdout.splitlines() if ln.startswith("{")]
+
+
 def test_bench_two_ranks_aggregate_their_shares():
     """
     bench.py for N = 2, both ways it can be started: under torch.distributed.run (one process per rank, RANK / WORLD_SIZE in
@@ -132,7 +150,13 @@ def test_bench_two_ranks_aggregate_their_shares():
     pool = two["legs"]["bf16"]["pool_run"]
     assert pool["games"] == 2 * 96 and pool["nodes"] == sum(x["legs"]["bf16"]["pool_run"]["nodes"] for x in shares)
     assert two["legs"]["bf16"]["steps_timed"] == 6 and two["value"] > 0
-    assert two["config"]["parallelism"] == "scramble-sharded x2" and two["scaling_measured"] is False
+    assert two["config"]["parallelism"] == "scramble-sharded x2" and two["scaling_measured"] is True and shares[0]["scaling_measured"] is False
+    # every rank's own rate is on the line, the preflight ran before the first leg, and the efficiency field is there (a number
+    # only when a one-GPU run of the same workload left its value next to bench.py)
+    assert len(line["rank_values"]) == 2 and all(v > 0 for v in line["rank_values"]) and line["value"] <= sum(line["rank_values"]) * 1.001
+    assert two["preflight"]["backend"] == "gloo" and two["preflight"]["collectives"].endswith("ok") and two["preflight"]["free_hbm_gb"] > 90
+    assert "efficiency" in line and (line["efficiency"] is None or 0 < line["efficiency"] < 2) and shares[0]["efficiency"] is None
+    assert max(len(v) for v in (line["config"]["workload"], line["config"]["timed_region"], line["roofline"].get("kernel", ""))) <= 120
     # the self-launched run searched the same games to the same trees
     ap = two_plain["legs"]["bf16"]
     assert ap["run_to_completion"]["nodes"] == a["nodes"] and ap["run_to_completion"]["solve_rate"] == a["solve_rate"]

@@ -7,9 +7,13 @@ behind the rows in use.  What must hold:
   * searches on forests mapped on demand -- also with so little mapped ahead that trees have to WAIT for their rows (the
     kernels' `mapped_rows` guard) -- build the reference's trees node for node: the exact-tree tests of the continuous
     batching path (refill, narrowing, results forest) and of the deep production trees are repeated in that mode;
-  * an address is mapped at most once: on this platform memory mapped where other memory was mapped before is not coherent
-    (tools/vmm_remap_probe.hip), so closed arrays retire their addresses -- a forest of one shape followed by a forest of
-    another builds exact trees, which it did not while freed ranges were handed out again;
+  * an address is mapped again only behind a flush of the GPU's translations: on this platform memory mapped where other memory
+    was mapped before is otherwise not coherent (tools/vmm_remap_probe.hip), so rc_vmm_release flushes and keeps the address
+    range for the next reservation of its size class -- a forest of one shape followed by a forest of another builds exact
+    trees (it did not while freed ranges were handed out again unflushed), data written in an address range's second and
+    third life is read back exactly by other kernel shapes, and the idle address space stops growing after the first cycle
+    through a set of shapes;
+  * rc_vmm_classify / rc_vmm_dump / RUBIKS_VMM_LOG say what an address is to the node store (what a GPU fault report needs);
   * BASELINE configs[1] at the reference's max_states = 175 000 (1 024 x 175 001 rows reserved = 46 GB of node records)
     keeps less than 20 GB mapped.
 """
@@ -59,27 +63,38 @@ def test_vmm_array_maps_on_demand():
     assert arr.ptr == 0 and torch.cuda.mem_get_info()[0] > free0 - (1 << 30)
 
 
-def test_addresses_of_a_closed_array_are_never_mapped_again():
+def test_released_addresses_come_back_clean_and_idle_address_space_is_bounded(tmp_path):
     """hipMemUnmap leaves stale translations on the GPU (tools/vmm_remap_probe.hip: 9 of 9 rounds with wrong data at addresses
-    mapped a second time): rc_vmm_release keeps the addresses of a range that had memory reserved for good.  Arrays of the
-    sizes that provoke the runtime into handing the same addresses back, written by one kernel shape and read by others."""
-    from librubiks._vmm import CHUNK, VmmArray
+    mapped a second time, 0 with an ordinary hipMalloc + hipFree in between): rc_vmm_release flushes, then keeps the address range
+    on the idle list of its size class, and the next reservation of the class maps memory there again.  A process cycling through
+    20 array shapes three times: (1) every array's data -- written by one kernel shape, read by three others -- is exact in the
+    range's first, second and third life; (2) from the second cycle on every reservation is a reused one; (3) the idle address
+    space (rc_vmm_retired_bytes) does not grow after the first cycle and is bounded by the classes' sizes; (4) rc_vmm_classify
+    names what an address is at each point of an array's life, rc_vmm_dump lists the range."""
+    from librubiks import _vmm
+    from librubiks._vmm import CHUNK, VmmArray, class_bytes
     dev = torch.device("cuda", 0)
+    torch.cuda.synchronize()
+    VmmArray.trim()
     g = torch.Generator(device="cuda").manual_seed(0)
-    seen = []                                                      # (lo, hi) of every range that ever had memory
+    shapes = [(3 + 7 * i + (i % 3) * 40, CHUNK if i % 4 else 2 * CHUNK) for i in range(20)]      # (chunks asked, chunk size): 20 shapes, 8 classes
     retired0 = VmmArray.retired_bytes()
-    expect_retired = 0
-    for r in range(6):
-        chunks = 8 + 4 * (r % 3)
-        for part in (1, 2, 2):                                     # one array, then two of half the size
-            n = chunks // part
-            arr = VmmArray(n * CHUNK, dev)
-            assert all(arr.ptr + arr.nbytes <= lo or hi <= arr.ptr for lo, hi in seen), "addresses that had memory were handed out again"
-            seen.append((arr.ptr, arr.ptr + arr.nbytes))
-            arr.ensure(0, arr.nbytes)
-            rows = arr.nbytes // 256
+    after_cycle, lives = [], {}
+    for cycle in range(3):
+        for i, (n, chunk) in enumerate(shapes):
+            arr = VmmArray(n * chunk, dev, chunk)
+            assert arr.nbytes == class_bytes(n * chunk, chunk) >= n * chunk
+            lives[arr.ptr] = lives.get(arr.ptr, 0) + 1
+            if cycle:
+                assert lives[arr.ptr] >= 2, "a reservation after the first cycle did not reuse an idle range of its class"
+            mapped = n * chunk                                       # the part the 'forest' uses; the rest of the class stays unmapped
+            arr.ensure(0, mapped)
+            assert _vmm.classify(arr.ptr + mapped - 1)[0] == "mapped" and _vmm.classify(arr.ptr + 5)[:2] == ("mapped", arr.ptr)
+            if arr.nbytes > mapped:
+                assert _vmm.classify(arr.ptr + mapped)[0] == "unmapped"     # reserved, no memory: what a guard miss would touch
+            rows = mapped // 256
             t = arr.tensor(torch.int32, (rows, 64))
-            want = (torch.arange(rows, device=dev, dtype=torch.int32) * 7 + 1000 * r + part).view(-1, 1).expand(rows, 64)
+            want = (torch.arange(rows, device=dev, dtype=torch.int32) * 7 + 1000 * cycle + i).view(-1, 1).expand(rows, 64)
             t.copy_(want)
             t[1::3] += 1
             exp = want.clone()
@@ -87,19 +102,58 @@ def test_addresses_of_a_closed_array_are_never_mapped_again():
             idx = torch.randint(0, rows, (1 << 16,), device=dev, generator=g)
             assert torch.equal(t.index_select(0, idx), exp.index_select(0, idx)) and torch.equal(t.flip(0), exp.flip(0))
             assert torch.equal(t.cpu(), exp.cpu())
+            assert f"base=0x{arr.ptr:x}" in _vmm.dump()
+            ptr = arr.ptr
             del t
             torch.cuda.synchronize()
             arr.close()
-            expect_retired += arr.nbytes
-    assert VmmArray.retired_bytes() - retired0 == expect_retired
-    never = VmmArray(4 * CHUNK, dev)                               # a range that never had memory is simply freed
-    never.close()
-    assert VmmArray.retired_bytes() - retired0 == expect_retired
+            assert _vmm.classify(ptr)[0] == "idle"
+        after_cycle.append(VmmArray.retired_bytes() - retired0)
+    assert after_cycle[0] > 0 and after_cycle[1] == after_cycle[0] and after_cycle[2] == after_cycle[0], after_cycle
+    classes = {(class_bytes(n * c, c) + (c if c > CHUNK else 0)) for n, c in shapes}
+    assert after_cycle[0] <= sum(classes)                          # one idle range per class (arrays lived one at a time)
+    assert max(lives.values()) >= 3
+    assert _vmm.classify(1 << 20)[0] == "unknown"
+    text = _vmm.dump()
+    assert "idle raw=" in text and "event" in text and " U 0x" in text      # reuse events are on record
+
+
+def test_vmm_log_replays_to_the_librarys_own_classification(tmp_path):
+    """RUBIKS_VMM_LOG: the event file of a process (flushed line by line: it survives the abort behind a GPU fault) replayed by
+    tools/vmm_classify.py gives, for addresses in every state, what rc_vmm_classify said inside the process."""
+    import json
+    import subprocess
+    import sys
+    log = tmp_path / "vmm.log"
+    code = f"""
+import json, sys, torch
+sys.path[:0] = [{ROOT!r}, {os.path.join(ROOT, "rl-rubiks_amd")!r}]
+from librubiks import _vmm
+from librubiks._vmm import CHUNK, VmmArray
+dev = torch.device("cuda", 0)
+a = VmmArray(40 * CHUNK, dev); a.ensure(3 * CHUNK, 9 * CHUNK)
+b = VmmArray(10 * CHUNK, dev, 2 * CHUNK); b.ensure(0, 4 * CHUNK)
+c = VmmArray(12 * CHUNK, dev); c.ensure(0, CHUNK); pc = c.ptr; torch.cuda.synchronize(); c.close()
+d = VmmArray(5 * CHUNK, dev)
+probes = [a.ptr, a.ptr + 3 * CHUNK, a.ptr + 9 * CHUNK - 1, a.ptr + 9 * CHUNK, a.ptr + 63 * CHUNK, b.ptr + CHUNK, b.ptr + 4 * CHUNK, b.ptr - 1,
+          pc, pc + 11 * CHUNK, d.ptr, 1 << 20]
+print(json.dumps([[p, _vmm.classify(p)[0]] for p in probes]))
+"""
+    env = dict(os.environ, RUBIKS_VMM_LOG=str(log))
+    p = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=300)
+    assert p.returncode == 0, p.stderr[-2000:]
+    inside = json.loads(p.stdout.strip().splitlines()[-1])
+    assert {k for _, k in inside} >= {"mapped", "unmapped", "idle", "unknown"}
+    for addr, kind in inside:
+        q = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "vmm_classify.py"), str(log), hex(addr)], capture_output=True, text=True, timeout=60)
+        assert q.returncode == 0, q.stderr[-2000:]
+        assert q.stdout.split()[1] == kind, (hex(addr), kind, q.stdout)
 
 
 def test_a_forest_after_a_forest_of_another_shape_builds_exact_trees(standin_net, monkeypatch):
     """The sequence that exposed the stale translations: a search on one forest, then a forest of another shape (the first
-    one's arrays cannot be taken over, their memory is given back), stepped in the three-phase form -- planting, expansion and
+    one's arrays cannot be taken over: their memory is given back, and their ADDRESS RANGES are what the second forest's
+    reservations of the same size classes get), stepped in the three-phase form -- planting, expansion and
     descent are different kernels with different grids, so they met different translations of the same address.  Every tree
     must be the oracle's after each of the first iterations."""
     from librubiks.cube import DeviceCubes
