@@ -57,6 +57,22 @@ def classify(addr: int):
     return ADDR_KINDS[int(kind.value)], int(base.value or 0), int(off.value)
 
 
+def zeros_or_trim(shape, dtype, device, fill=None) -> torch.Tensor:
+    """torch.zeros / torch.full for the large up-front allocations of the search stores (forests allocated up front, A* batches):
+    torch's caching allocator cannot see the HBM that parked node stores hold, so on an out-of-memory error that memory is given
+    back (`VmmArray.trim`, after a synchronise) and the allocation is tried once more."""
+    make = (lambda: torch.zeros(shape, dtype=dtype, device=device)) if fill is None else (lambda: torch.full(shape, fill, dtype=dtype, device=device))
+    try:
+        return make()
+    except torch.OutOfMemoryError:
+        if not VmmArray.parked_bytes():
+            raise
+        torch.cuda.synchronize(device)
+        VmmArray.trim()
+        torch.cuda.empty_cache()
+        return make()
+
+
 class _Span:
     """What torch.as_tensor reads a device pointer from."""
 

@@ -423,6 +423,10 @@ class InferenceNet:
 _PLAIN = LayerOpts()
 SPLIT_SCALE = 2.0 ** 11
 F32_SPLIT = "f32_split"   # `net_dtype` value selecting SplitF32Net
+# ... and SplitF32Net(deterministic=True): ONE layer plan whatever the row count, so that a state's outputs do not depend on which
+# other states share its launch -- a game searched alone, in a batch, on fewer slots or in a narrowed forest builds the same tree bit
+# for bit (agents: `MCTS(..., deterministic=True)`).  Costs throughput at both ends of the row-count range.
+F32_SPLIT_DET = "f32_split_deterministic"
 HALF_MAX = 65504.0
 
 
@@ -485,8 +489,13 @@ class SplitF32Net:
     input_dtype = torch.float32
     supports_cubes = True
 
-    def __init__(self, model: Model, device=None):
+    DET_CHUNKS = 4    # deterministic mode: every hidden layer's K loop is cut into this many chunks (2 where 3 k / 64 is not a multiple of 4)
+
+    def __init__(self, model: Model, device=None, deterministic: bool = False):
         ref = InferenceNet(model, dtype=torch.float64, device=device, first_layer_table="onehot")
+        self.deterministic = bool(deterministic)
+        if self.deterministic:
+            self.dtype = F32_SPLIT_DET
         self.device = ref.device
         self._opts = {}
         self.layers, self.value_layers = self._split(ref.layers, ref._opts), self._split(ref.value_layers, ref._opts)
@@ -549,6 +558,16 @@ class SplitF32Net:
         (the same kernel with its K loop cut into chunks + rc_split_reduce_f16), or 'library' (two hipBLASLt GEMMs + reduce / the fused head)."""
         Wh = layers[i][1]
         N, K = Wh.shape
+        if self.deterministic:
+            # one summation order for every launch: the K-cut form with a FIXED chunk count (partials summed in order by
+            # rc_split_reduce_f16).  A row's partials do not depend on the tile or on the other rows (every tile walks its chunk of K in
+            # the same order), so the tile may still follow the row count: 352 x 256 once that fills a quarter of the chip.
+            steps = 3 * K // 64
+            chunks = self.DET_CHUNKS if steps % self.DET_CHUNKS == 0 and steps // self.DET_CHUNKS >= 2 else 2
+            if K % 64 or N % 128 or steps % chunks or steps // chunks < 2:
+                raise SplitRangeError(f"deterministic mode needs layers the own kernel takes (k % 128 == 0, n_out % 128 == 0), not {K} -> {N}")
+            wide = N % 256 == 0 and -(-rows // 352) * (N // 256) * chunks >= 64
+            return ("cut", 1 if wide else 3, chunks)
         if self.fused_hidden and self._fused_tile(rows, N, K):
             return "fused"
         cut = self._k_split(rows, N, K) if self.fused_hidden else None
@@ -804,9 +823,9 @@ def make_inference_net(net, dtype=torch.bfloat16):
     if isinstance(net, (InferenceNet, SplitF32Net, GenericNet)):
         return net
     if isinstance(net, Model) and net.config.architecture.split("_")[0] in ("fc", "res"):
-        if dtype == F32_SPLIT:
+        if dtype in (F32_SPLIT, F32_SPLIT_DET):
             try:
-                return SplitF32Net(net)
+                return SplitF32Net(net, deterministic=dtype == F32_SPLIT_DET)
             except SplitRangeError as e:   # the reference's fp32 forward has no such limit: run these weights on the fp32 GEMM chain
                 warnings.warn(f"SplitF32Net: {e}; using the fp32 GEMM chain for this network", RuntimeWarning)
                 return InferenceNet(net, dtype=torch.float32)

@@ -19,7 +19,7 @@ import torch
 
 from librubiks import gpu, no_grad
 from librubiks.cube.device import DeviceCubes
-from librubiks.model import F32_SPLIT, Model, net_fingerprint
+from librubiks.model import F32_SPLIT, F32_SPLIT_DET, Model, net_fingerprint
 from librubiks.solving import astar_device as ad
 from librubiks.solving import bfs_device as bd
 from librubiks.solving import mcts_device as md
@@ -298,8 +298,14 @@ class MCTS(DeepAgent):
     refill_level_budget = 0    # new levels per descent and iteration while scrambles wait for a slot (0 = no limit)
 
     def __init__(self, net, c: float, search_graph: bool, net_dtype=F32_SPLIT, use_graph: bool = True,
-                 max_path: int = 4096, sync_every: int = 16, level_budget="auto"):
+                 max_path: int = 4096, sync_every: int = 16, level_budget="auto", deterministic: bool = False):
         """
+        deterministic: bit-reproducible searches.  The default engines pick a layer plan by row count (whole-K tiles, K cut into
+        2..32 chunks), so a state's network outputs carry rounding that depends on how many states share its launch, and a near-tie
+        in a PUCT argmax can fall the other way: per-game results agree across batch shapes on > 98 % of games, not on all.  With
+        deterministic=True the split engine runs ONE plan for every row count (`SplitF32Net(deterministic=True)`): a game searched
+        alone, in a batch, on fewer `slots` or in a narrowed forest builds the same tree, bit for bit (tests/test_full_size_gpu.py).
+        It costs throughput at both ends of the row-count range: see DESIGN.md section 3.3 for the measured figures.
         max_path: longest PUCT descent a tree may make (the reference has no limit; a tree that would exceed it
         ends unsolved with status PATH_OVERFLOW).  With the ADI-trained net, 39 of 1 024 depth-20 trees needed
         more than 1 024 levels and none more than 2 048 (longest solution found: 804 moves); 4 096 is the
@@ -314,6 +320,12 @@ class MCTS(DeepAgent):
         super().__init__(net)
         self.level_budget = level_budget
         self.c, self.search_graph = float(c), bool(search_graph)
+        if deterministic:
+            if net_dtype not in (F32_SPLIT, F32_SPLIT_DET):
+                raise ValueError("deterministic=True runs on the split engine (net_dtype=F32_SPLIT): the library GEMMs of the other engines "
+                                 "choose their kernels by batch shape")
+            net_dtype = F32_SPLIT_DET
+        self.deterministic = net_dtype == F32_SPLIT_DET
         self.net_dtype, self.use_graph, self.max_path, self.sync_every = net_dtype, use_graph, max_path, sync_every
         self.forest = None
         self._last_forest = None   # the forest the last search ended in (a compacted one after `compact`)
@@ -698,8 +710,14 @@ class AStar(DeepAgent):
     `search_batch` runs one such search per scramble, all on one GPU; `search` is the batch of one.
     """
 
-    def __init__(self, net, lambda_: float, expansions: int, net_dtype=F32_SPLIT):
+    def __init__(self, net, lambda_: float, expansions: int, net_dtype=F32_SPLIT, deterministic: bool = False):
+        """deterministic: as for `MCTS` -- one layer plan of the split engine for every row count, so a problem's search does not depend
+        on which other problems share its batch."""
         super().__init__(net)
+        if deterministic:
+            if net_dtype not in (F32_SPLIT, F32_SPLIT_DET):
+                raise ValueError("deterministic=True runs on the split engine (net_dtype=F32_SPLIT)")
+            net_dtype = F32_SPLIT_DET
         self.lambda_, self.expansions, self.net_dtype = float(lambda_), int(expansions), net_dtype
         self.batch = None
         self._arrays = None

@@ -50,13 +50,14 @@ class AStarBatch:
         assert B > 0 and N > 0 and C >= 12 * N + 1
         self.B, self.C, self.N, self.device = B, C, N, dev
         self.hash_size = 1 << int(np.ceil(np.log2(2 * (C + 1))))
-        z = lambda shape, dt: torch.zeros(shape, dtype=dt, device=dev)   # noqa: E731
+        from librubiks._vmm import zeros_or_trim
+        z = lambda shape, dt: zeros_or_trim(shape, dt, dev)   # noqa: E731  (parked MCTS node stores are given back if HBM runs out)
         rows = B * (C + 1)
         self.keys = z((rows, 4), torch.int32)
         self.G = z((rows,), torch.int32)
         self.parents = z((rows,), torch.int32)
         self.parent_actions = z((rows,), torch.uint8)
-        self.claim = torch.full((rows,), INT_MAX, dtype=torch.int32, device=dev)
+        self.claim = zeros_or_trim((rows,), torch.int32, dev, fill=INT_MAX)
         self.hash = z((B, self.hash_size), torch.int32)
         self.heap_cost = z((rows,), torch.float64)
         self.heap_idx = z((rows,), torch.int32)

@@ -19,7 +19,7 @@ import numpy as np
 import torch
 
 from librubiks import _hip
-from librubiks._vmm import VmmArray
+from librubiks._vmm import VmmArray, zeros_or_trim
 from librubiks.cube.device import DeviceCubes
 from librubiks.model import make_inference_net, net_fingerprint
 
@@ -172,7 +172,7 @@ class MCTSForest:
             C = min(MAX_CAPACITY, (C + per_chunk) // per_chunk * per_chunk - 1)
         self.B, self.C, self.max_path, self.device = B, C, max_path, dev
         self.hash_size = 1 << int(np.ceil(np.log2(2 * (C + 1))))
-        z = lambda shape, dt: torch.zeros(shape, dtype=dt, device=dev)   # noqa: E731
+        z = lambda shape, dt: zeros_or_trim(shape, dt, dev)   # noqa: E731  (parked node stores of other shapes are given back if HBM runs out)
         rows = B * (C + 1)
         self.results_only = _results_only
         per_node = {   # [B][capacity + 1] rows each

@@ -116,6 +116,37 @@ def test_config2_mcts_1024_trees():
     assert abs(int(pooled.nodes.sum()) - int(res.nodes.sum())) < 0.05 * int(res.nodes.sum())
 
 
+def test_deterministic_mode_is_bit_reproducible_across_batch_shapes():
+    """`MCTS(..., deterministic=True)`: one layer plan of the split engine for every row count, so BASELINE configs[1] searched as
+    one batch, on half the slots (continuous batching + narrowing) and -- for a sample of games -- alone gives the same trees:
+    nodes, iterations, solution queues equal game for game, bit for bit (the default engines promise > 98 % of games)."""
+    from librubiks import cube
+    from librubiks.solving.agents import MCTS
+    if not os.path.isdir(WEIGHTS):
+        pytest.skip("needs the trained weights")
+    np.random.seed(0)
+    cubes, _, _ = cube.scramble_batch(1024, 20, True)
+    states = cubes.numpy()
+    cap = 175_000
+    mk = lambda: MCTS(_net(), c=0.6, search_graph=True, deterministic=True)   # noqa: E731
+    res = mk().search_batch(cubes, None, cap)
+    pooled = mk().search_batch(cubes, None, cap, slots=512)
+    assert res.solved.mean() > 0.99
+    for name in ("nodes", "solved", "lengths", "iterations"):
+        assert np.array_equal(getattr(res, name), getattr(pooled, name)), name
+    assert all(list(res.queues[t]) == list(pooled.queues[t]) for t in range(1024))
+    for t in np.flatnonzero(res.solved)[:64]:
+        assert _replay_ok(states[t], res.queues[t])
+    few = np.array([0, 1, 17, 511, 1023])
+    small = mk().search_batch(states[few], None, cap)                       # five games in a forest of five
+    alone = mk()
+    for i, t in enumerate(few):
+        assert small.nodes[i] == res.nodes[t] and list(small.queues[i]) == list(res.queues[t])
+    assert alone.search(states[17], None, cap) == bool(res.solved[17]) and len(alone) == res.nodes[17] and list(alone.action_queue) == list(res.queues[17])
+    with pytest.raises(ValueError):
+        MCTS(_net(), c=0.6, search_graph=True, net_dtype=torch.bfloat16, deterministic=True)
+
+
 def test_config3_astar_4096_problems():
     from librubiks import cube
     from librubiks.solving.agents import AStar

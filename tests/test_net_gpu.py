@@ -807,3 +807,43 @@ def test_engines_against_outputs_of_the_references_model(arch, bn, stats):
     bf = make_inference_net(net, torch.bfloat16)
     p, v = bf.forward_cubes(cubes)
     assert err(p.float(), p32) <= 3e-2 and err(v.float(), v32) <= 3e-2
+
+
+def test_deterministic_split_engine_gives_a_state_the_same_outputs_in_every_launch():
+    """SplitF32Net(deterministic=True): the K-cut form with a fixed chunk count at every row count.  The same 352 states evaluated
+    inside launches of 352 ... 11 264 rows (every layer-plan boundary of the default engine lies in between), at different row
+    offsets, as policy + value and as value only, return bit-identical numbers; and they are as close to float64 as the default
+    engine's (<= 1.25 x the fp32 module's error)."""
+    import copy
+    import os
+    from conftest import ROOT
+    from librubiks import cube
+    from librubiks.cube import DeviceCubes
+    from librubiks.model import F32_SPLIT_DET, Model, ModelConfig, SplitF32Net, make_inference_net
+    wdir = os.path.join(ROOT, "weights", "fc_small_r1")
+    torch.manual_seed(0)
+    net = Model.load(wdir).eval() if os.path.isdir(wdir) else Model.create(ModelConfig()).eval()
+    eng = make_inference_net(net, F32_SPLIT_DET)
+    assert isinstance(eng, SplitF32Net) and eng.deterministic and eng.dtype == F32_SPLIT_DET
+    np.random.seed(5)
+    cubes, _, _ = cube.scramble_batch(11264, 25, True)
+    states = cubes.numpy()
+    base = states[:352]
+    want_p, want_v = eng.forward_cubes(DeviceCubes.from_numpy(base))
+    want_val = eng.value_cubes(DeviceCubes.from_numpy(base))     # the value head alone (A*): its own layers, its own -- equally fixed -- sums
+    assert float((want_val - want_v).abs().max()) <= 4e-6 * float(want_v.abs().max())
+    for rows, at in ((352, 0), (368, 16), (1056, 352), (1408, 1056), (2816, 0), (4224, 2464), (5632, 5280), (6336, 352), (11264, 10912), (11264, 0)):
+        batch = states[:rows].copy()
+        batch[at:at + 352] = base
+        p, v = eng.forward_cubes(DeviceCubes.from_numpy(batch))
+        assert torch.equal(p[at:at + 352], want_p) and torch.equal(v[at:at + 352], want_v), (rows, at)
+        assert torch.equal(eng.value_cubes(DeviceCubes.from_numpy(batch))[at:at + 352], want_val), (rows, at)
+    one_p, one_v = eng.forward_cubes(DeviceCubes.from_numpy(base[:1]))
+    assert torch.equal(one_p, want_p[:1]) and torch.equal(one_v, want_v[:1])
+    oh = DeviceCubes.from_numpy(states[:4096]).as_oh(torch.float32)
+    with torch.no_grad():
+        p64, v64 = copy.deepcopy(net).double()(oh.double())
+        p32, v32 = net(oh)
+    pd, vd = eng.forward_cubes(DeviceCubes.from_numpy(states[:4096]))
+    err = lambda a, b: float((a.double() - b).abs().max())   # noqa: E731
+    assert max(err(pd, p64), err(vd, v64.reshape(-1))) <= 1.25 * max(err(p32, p64), err(v32.reshape(-1), v64.reshape(-1))) + 1e-7

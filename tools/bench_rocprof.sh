@@ -7,6 +7,9 @@
 #        -> gpurun_out/<tag>_select_pmc.txt
 #   bash tools/bench_rocprof.sh <tag> env_traffic                  FETCH_SIZE / WRITE_SIZE passes (separate) of the environment kernels at 2^24
 #        states -> gpurun_out/<tag>_env_pmc_traffic.json
+#   bash tools/bench_rocprof.sh <tag> gemm_pmc                     matrix-pipe duty cycle of the hidden-layer kernel: SQ_VALU_MFMA_BUSY_CYCLES, SQ_BUSY_CYCLES,
+#        wave / wait / LDS counters over tools/split_gemm_fused_probe.py at 11 264 rows (the program itself behind `--`)
+#        -> gpurun_out/<tag>_split_gemm_pmc.txt
 tag=${1:-rX}; mode=${2:-bench}; shift; shift
 R=${GRAFT_REPO_ROOT:-/root/repo}
 O=$R/gpurun_out
@@ -23,6 +26,12 @@ timeline)
 select_pmc)
   rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_WAIT_INST_ANY SQ_INSTS_SALU SQ_BUSY_CYCLES SQ_WAVE_CYCLES --output-format csv -d /tmp/prof_pmc_$tag -- python3 $R/tools/search_probe.py window bf16 20 > $O/${tag}_select_pmc.log 2>&1
   python3 $R/tools/rocprof_summary.py pmc "$(find /tmp/prof_pmc_$tag -name '*counter_collection.csv' | head -1)" k_mcts_select > $O/${tag}_select_pmc.txt ;;
+gemm_pmc)
+  rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_WAIT_INST_LDS SQ_LDS_BANK_CONFLICT SQ_ACTIVE_INST_ANY SQ_WAIT_ANY --output-format csv -d /tmp/prof_gp_$tag -- python3 $R/tools/split_gemm_fused_probe.py --rows 11264 --shapes 4096x2048 --reps 8 > $O/${tag}_split_gemm_pmc.log 2>&1
+  python3 $R/tools/rocprof_summary.py pmc "$(find /tmp/prof_gp_$tag -name '*counter_collection.csv' | head -1)" k_split_gemm > $O/${tag}_split_gemm_pmc.txt
+  rocprofv3 --kernel-trace --stats -d /tmp/prof_gs_$tag -o g -- python3 $R/tools/split_gemm_fused_probe.py --rows 11264 --shapes 4096x2048 --reps 8 >> $O/${tag}_split_gemm_pmc.log 2>&1
+  python3 $R/tools/rocprof_summary.py kernels "$(find /tmp/prof_gs_$tag -name '*.db' | head -1)" $O/${tag}_split_gemm_kernel_stats.csv 6
+  tail -3 $O/${tag}_split_gemm_pmc.log >> $O/${tag}_split_gemm_pmc.txt ;;
 env_traffic)
   rocprofv3 --pmc FETCH_SIZE --output-format csv -d /tmp/prof_f_$tag -- python3 $R/tools/env_bench.py 24 > $O/${tag}_env_fetch.log 2>&1
   rocprofv3 --pmc WRITE_SIZE --output-format csv -d /tmp/prof_w_$tag -- python3 $R/tools/env_bench.py 24 > $O/${tag}_env_write.log 2>&1

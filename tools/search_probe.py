@@ -10,6 +10,10 @@ MCTS search probes on one MI355X with the trained weights (the programs profiles
          the program for PMC passes on the tree kernel in a full forest.
   rtc    [f32s|bf16] [reps]
          configs[1] to completion `reps` times (prepared forest, 30 warm-up iterations): seconds per run, best M nodes/s.
+  groups [f32s|bf16] [G] [games] [slots]
+         the tree kernel of one group next to the network of another: the pool searched as G independent groups (slots / G each,
+         every group on a HIP stream of its own, rounds alternating) against the one-group form, same box, a, b, a, b.  Per form:
+         the steady-state window (ms per lock-step step of all 1 024 slots) and the whole pool.
   ab     <owner.attribute> <value_a> <value_b>
          same-box A/B of a module / class attribute (e.g. mcts_device.RUNG_RATIO 0.9 0.95, model.SplitF32Net.small_batch_cut 1 0,
          agents.MCTS.sync_every via `sync_every 16 32`): variants alternate a, b, a, b in one process; per variant configs[1] to
@@ -119,6 +123,71 @@ def rtc(argv):
           f"({'mapped on demand' if agent.forest.vmm else 'allocated up front'}), env {dict((k, v) for k, v in os.environ.items() if k.startswith('RUBIKS_'))}")
 
 
+def groups(argv):
+    name, G, games = (argv[0] if argv else "f32s"), int(argv[1]) if len(argv) > 1 else 2, int(argv[2]) if len(argv) > 2 else 8192
+    CAP, SLOTS, K = 175000, int(argv[3]) if len(argv) > 3 else 1024, 40
+    np.random.seed(0)
+    pool, _, _ = cube.scramble_batch(games, 20, True)
+    states = pool.numpy()
+    model = Model.load(WEIGHTS).eval()
+
+    def one_form(g):
+        agents = [MCTS(model, c=0.6, search_graph=True, net_dtype=DT[name]) for _ in range(g)]
+        streams = [torch.cuda.Stream() for _ in range(g)] if g > 1 else [torch.cuda.current_stream()]
+        for a, st in zip(agents, streams):          # one after the other: a capture does not tolerate foreign launches
+            with torch.cuda.stream(st):
+                a.prepare(SLOTS // g, CAP)
+            torch.cuda.synchronize()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        runs = []
+        for i, (a, st) in enumerate(zip(agents, streams)):
+            with torch.cuda.stream(st):
+                runs.append(a.start_batch(states[i::g], None, CAP, slots=SLOTS // g))
+
+        def rounds(pred, max_steps=None):
+            while any(pred(r) for r in runs):
+                for r, st in zip(runs, streams):
+                    if pred(r):
+                        with torch.cuda.stream(st):
+                            r.round(max_steps)
+        rounds(lambda r: not r.done and r.next_game < min(2 * SLOTS // g + 64, r.n_games))      # slots hold trees of every age
+        torch.cuda.synchronize()
+        n0 = sum(r.nodes_now() for r in runs)
+        for r in runs:
+            r._target = r.it + K
+        torch.cuda.synchronize()
+        tw = time.perf_counter()
+        while any(not r.done and r.it < r._target for r in runs):
+            for r, st in zip(runs, streams):
+                if not r.done and r.it < r._target:
+                    with torch.cuda.stream(st):
+                        r.round(r._target - r.it)
+        torch.cuda.synchronize()
+        window_s = time.perf_counter() - tw
+        n1 = sum(r.nodes_now() for r in runs)
+        rounds(lambda r: not r.done)
+        res = []
+        for r, st in zip(runs, streams):
+            with torch.cuda.stream(st):
+                res.append(r.finish())
+        torch.cuda.synchronize()
+        total = time.perf_counter() - t0
+        nodes = sum(int(x.nodes.sum()) for x in res)
+        out = {"groups": g, "window_ms_per_step_of_all_slots": round(window_s / K * 1e3, 4), "window_nodes_per_sec": round((n1 - n0) / window_s),
+               "pool_seconds": round(total, 3), "pool_nodes_per_sec": round(nodes / total), "solved": float(np.mean(np.concatenate([x.solved for x in res]))),
+               "nodes": nodes}
+        for a in agents:
+            if a.forest is not None:
+                a.forest.close()
+        del agents, runs
+        torch.cuda.empty_cache()
+        return out
+
+    for g in (1, G, 1, G):
+        print(name, json.dumps(one_form(g)), flush=True)
+
+
 def ab(argv):
     attr, vals = argv[0], [float(v) if "." in v else int(v) for v in argv[1:3]]
     CAP = 175000
@@ -153,4 +222,4 @@ def ab(argv):
 
 
 if __name__ == "__main__":
-    {"solve": solve, "window": window, "rtc": rtc, "ab": ab}[sys.argv[1]](sys.argv[2:])
+    {"solve": solve, "window": window, "rtc": rtc, "ab": ab, "groups": groups}[sys.argv[1]](sys.argv[2:])
