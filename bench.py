@@ -411,14 +411,21 @@ def replay_solutions(roots_np, res, what):
     idx = np.flatnonzero(np.asarray(res.solved))
     if not len(idx):
         return {"games_reported_solved": 0, "solutions_replayed_to_solved": 0}
-    lens = np.array([len(res.queues[i]) for i in idx])
+    if hasattr(res.queues, "padded"):
+        acts, lens = res.queues.padded(idx)
+    else:
+        lens = np.array([len(res.queues[i]) for i in idx])
+        acts = np.full((len(idx), int(lens.max())), 255, dtype=np.uint8)
+        for o, i in enumerate(idx):
+            acts[o, :lens[o]] = list(res.queues[i])
     if not np.array_equal(lens, np.asarray(res.lengths)[idx]):
         raise RuntimeError(f"{what}: a reported solution length is not its action queue's")
-    cur = np.ascontiguousarray(roots_np[idx]).copy()
+    order = np.argsort(-lens, kind="stable")           # longest first: the games still moving at move d are a prefix
+    acts, lens, cur = acts[order], lens[order], np.ascontiguousarray(roots_np[idx][order]).copy()
     for d in range(int(lens.max())):
-        live = np.flatnonzero(lens > d)
-        faces, dirs = cube.indices_to_actions(np.array([res.queues[idx[i]][d] for i in live], dtype=np.int64))
-        cur[live] = cube.multi_rotate(cur[live], faces, dirs)
+        n_live = int(np.searchsorted(-lens, -d, side="left"))      # games with more than d moves
+        faces, dirs = cube.indices_to_actions(acts[:n_live, d].astype(np.int64))
+        cur[:n_live] = cube.multi_rotate(cur[:n_live], faces, dirs)
     ok = int(np.asarray(cube.multi_is_solved(cur)).sum())
     if ok != len(idx):
         raise RuntimeError(f"{what}: {len(idx) - ok} of {len(idx)} reported solutions do not end on the solved state")
@@ -1182,6 +1189,10 @@ def main():
         model = Model.create(ModelConfig(architecture=args.architecture)).eval()
         weights_note = f"random-init {args.architecture} (glorot, torch.manual_seed(0))"
 
+    # successive legs of one shape hand their node store on with its memory (146 GB behind the config-5 forest): the benchmark's legs are
+    # each other's successors, so nothing is released between them (the library's default keeps at most 64 GB parked between owners)
+    from librubiks._vmm import VmmArray
+    VmmArray.PARK_CAP_BYTES = max(VmmArray.PARK_CAP_BYTES, 220 << 30)
     results, extras = {}, {}
     for name in legs:
         leg, engine, agent = run_leg(name, model, pool_roots, config_roots, args, world, coll_device, args.trees, args.solve_max_states,

@@ -105,6 +105,18 @@ class QueueTable:
     def lengths(self) -> np.ndarray:
         return self._lens
 
+    def padded(self, games=None, fill: int = 255):
+        """(uint8 [len(games), longest] array of the games' action queues padded with `fill`, their lengths): the queues of many
+        games at once without building a deque per game (replaying / scoring whole result sets)."""
+        games = np.arange(len(self)) if games is None else np.asarray(games, dtype=np.int64)
+        lens = self._lens[games]
+        out = np.full((len(games), int(lens.max()) if len(games) else 0), fill, dtype=np.uint8)
+        for o, g in enumerate(games):
+            src = self._rows[g]
+            if src is not None and lens[o]:
+                out[o, :lens[o]] = src[0][src[1], :lens[o]]
+        return out, lens
+
     def __len__(self):
         return len(self._rows)
 

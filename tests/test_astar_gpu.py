@@ -123,3 +123,32 @@ def test_large_batch_throughput_sanity():
     assert (res.iterations == 4).all()
     assert (res.nodes > 1000).all() and (res.nodes <= 6000).all()
     assert res.states_per_sec > 1e5
+
+
+def test_deterministic_astar_does_not_depend_on_the_batch():
+    """`AStar(..., deterministic=True)`: one layer plan of the split engine for every row count, so a problem's search -- nodes, cost
+    order, solution -- is the same whether it is searched with 255 others, with 15 others or alone (trained weights; the default
+    engine promises this only up to the rounding that near-ties in the open list can feel)."""
+    import os
+    from conftest import ROOT
+    from librubiks import cube
+    from librubiks.model import Model
+    from librubiks.solving.agents import AStar
+    wdir = os.path.join(ROOT, "weights", "fc_small_r1")
+    if not os.path.isdir(wdir):
+        pytest.skip("needs the trained weights")
+    net = Model.load(wdir).eval()
+    np.random.seed(33)
+    cubes, _, _ = cube.scramble_batch(256, 18, True)
+    states = cubes.numpy()
+    mk = lambda: AStar(net, lambda_=0.2, expansions=50, deterministic=True)   # noqa: E731
+    big = mk().search_batch(states, None, 60_000)
+    assert big.solved.mean() > 0.9
+    part = mk().search_batch(states[64:80], None, 60_000)
+    for i in range(16):
+        assert part.nodes[i] == big.nodes[64 + i] and list(part.queues[i]) == list(big.queues[64 + i]) and part.solved[i] == big.solved[64 + i]
+    one = mk()
+    assert one.search(states[200], None, 60_000) == bool(big.solved[200]) and len(one) == big.nodes[200]
+    assert list(one.action_queue) == list(big.queues[200])
+    with pytest.raises(ValueError):
+        AStar(net, lambda_=0.2, expansions=50, net_dtype=torch.bfloat16, deterministic=True)

@@ -109,9 +109,10 @@ def test_released_addresses_come_back_clean_and_idle_address_space_is_bounded(tm
             arr.close()
             assert _vmm.classify(ptr)[0] == "idle"
         after_cycle.append(VmmArray.retired_bytes() - retired0)
-    assert after_cycle[0] > 0 and after_cycle[1] == after_cycle[0] and after_cycle[2] == after_cycle[0], after_cycle
+    # no growth after the first cycle (0 from the start when earlier work of this process already left an idle range in every class)
+    assert after_cycle[1] == after_cycle[0] and after_cycle[2] == after_cycle[0], after_cycle
     classes = {(class_bytes(n * c, c) + (c if c > CHUNK else 0)) for n, c in shapes}
-    assert after_cycle[0] <= sum(classes)                          # one idle range per class (arrays lived one at a time)
+    assert 0 <= after_cycle[0] <= sum(classes)                     # at most one idle range per class (arrays lived one at a time)
     assert max(lives.values()) >= 3
     assert _vmm.classify(1 << 20)[0] == "unknown"
     text = _vmm.dump()
