@@ -1259,6 +1259,9 @@ def main():
         "solve_rate": rtc_of(head).get("solve_rate"), "solve_rate_ci95": rtc_of(head).get("ci95"),
         "mean_solution_length": rtc_of(head).get("mean_solution_length"),
         "result_flushes_in_window": head.get("result_flushes_in_window"),
+        # solutions walked through cube.multi_rotate / multi_is_solved outside the timed regions (rank 0's games; a mismatch aborts the run)
+        "run_to_completion_solutions_replayed": rtc_of(head).get("solutions_replayed_to_solved_rank0"),
+        "pool_solutions_replayed": (head.get("pool_run") or {}).get("solutions_replayed_to_solved"),
     }
     for name in legs[1:]:
         summary[f"{name}_value"] = results[name]["value"]
@@ -1271,6 +1274,7 @@ def main():
         if "solve_run" in leg:
             summary[f"astar_{name}_solve_run_states_per_sec"] = leg["solve_run"]["states_per_sec"]
             summary[f"astar_{name}_solve_rate"] = leg["solve_run"]["solve_rate"]
+            summary[f"astar_{name}_solutions_replayed"] = leg["solve_run"].get("solutions_replayed_to_solved_rank0")
         if "roofline" in leg:
             summary[f"astar_{name}_roofline_frac"] = leg["roofline"]["frac"]
     for name, leg in adi.items():

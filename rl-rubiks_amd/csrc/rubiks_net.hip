@@ -582,7 +582,8 @@ __global__ __launch_bounds__(kMfWaves * kWave) void k_first_layer_split(const u8
     constexpr int kTables = 2;
     bool out_of_range = false;
     unsigned char *wslice = lds;                                                       // [kTables][64 slots][976 B]
-    const u32 tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const u32 tid = threadIdx.x, lane = tid & 63;
+    const u32 wave = __builtin_amdgcn_readfirstlane(tid >> 6);                         // wave-uniform: row bases and output pointers stay scalar
     uint4 *onehot = reinterpret_cast<uint4 *>(lds + kTables * kSpCols * kMfPitch);     // [kTables][9] A fragments: 1.0 / 2^-11 at position p
     const u32 col_tiles = H / kSpCols;
     const u32 ct = blockIdx.x % col_tiles, rg = blockIdx.x / col_tiles;
@@ -695,27 +696,42 @@ __global__ __launch_bounds__(kMfWaves * kWave) void k_first_layer_split(const u8
             }
         }
         // epilogue: activation, then the lane's columns 2 r, 2 r + 1 of one state as two 4-byte stores: the pair of hi halves and
-        // the pair of lo halves into the [hi | lo] row of the state (row pitch 2 H halves)
+        // the pair of lo halves into the [hi | lo] row of the state (row pitch 2 H halves = H dwords).  The kernel is bound by its
+        // VALU port, not by the matrix pipe (profiles/r3_first_layer_split_pmc.txt), so the epilogue is kept lean: wave-uniform
+        // output pointers + ONE running 32-bit offset per lane, no per-row tests when all of the wave's rows exist (every pass but a
+        // workgroup's last), branch-free ELU, the split in 5 operations per pair.
+        const size_t lim = row_hi < n ? row_hi : n;
+        u32 *o_hi = out + t0 * (size_t)H + (ct * kSpCols) / 2;    // row t0, the workgroup's first column pair
+        u32 *o_lo = o_hi + H / 2;
+        if (t0 + (size_t)kSpSub * kMfTile <= lim) {
+            u32 off = 4 * h * H + r;                                // this lane's row 4 h of the first tile, its column pair
 #pragma unroll
-        for (int u = 0; u < kSpSub; ++u)
+            for (int u = 0; u < kSpSub; ++u)
 #pragma unroll
-            for (int i = 0; i < 16; ++i) {
-                const size_t row = t0 + (size_t)u * kMfTile + (i & 3) + 8 * (i >> 2) + 4 * h;
-                float y[2], hi[2], lo[2];
-#pragma unroll
-                for (int c = 0; c < 2; ++c) {
-                    const float x = acc[u][c][i];
-                    y[c] = ACT == RC_ACT_RELU ? fmaxf(x, 0.f) : ACT == RC_ACT_ELU ? (x > 0.f ? x : alpha * expm1_neg(x)) : x;
-                    hi[c] = round_to_half_f32(y[c]);
-                    lo[c] = (y[c] - hi[c]) * kSplitScale;
-                    out_of_range |= row < n && !(fabsf(y[c]) <= 65504.0f);
+                for (int i = 0; i < 16; ++i) {
+                    const float y0 = act_value<ACT>(acc[u][0][i], alpha), y1 = act_value<ACT>(acc[u][1][i], alpha);
+                    out_of_range |= !(fabsf(y0) <= 65504.0f) || !(fabsf(y1) <= 65504.0f);
+                    const SplitPair sp = split_pair(y0, y1);
+                    o_hi[off] = sp.hi;
+                    o_lo[off] = sp.lo;
+                    off += ((i & 3) == 3 ? 5u : 1u) * H;           // rows (i & 3) + 8 (i >> 2); the next tile starts 32 rows on: 4 + 8 * 3 + 5 = 33 - 1
                 }
-                if (row < n && row < row_hi) {
-                    u32 *orow = out + row * H;   // 2 H halves = H dwords per row
-                    orow[(ct * kSpCols) / 2 + r] = pack_half2(hi[0], hi[1]);
-                    orow[H / 2 + (ct * kSpCols) / 2 + r] = pack_half2(lo[0], lo[1]);
+        } else {
+#pragma unroll
+            for (int u = 0; u < kSpSub; ++u)
+#pragma unroll
+                for (int i = 0; i < 16; ++i) {
+                    const size_t row = t0 + (size_t)u * kMfTile + (i & 3) + 8 * (i >> 2) + 4 * h;
+                    const float y0 = act_value<ACT>(acc[u][0][i], alpha), y1 = act_value<ACT>(acc[u][1][i], alpha);
+                    if (row < lim) {
+                        out_of_range |= !(fabsf(y0) <= 65504.0f) || !(fabsf(y1) <= 65504.0f);
+                        const SplitPair sp = split_pair(y0, y1);
+                        u32 *orow = out + row * H;
+                        orow[(ct * kSpCols) / 2 + r] = sp.hi;
+                        orow[H / 2 + (ct * kSpCols) / 2 + r] = sp.lo;
+                    }
                 }
-            }
+        }
     }
     if (range_flag && out_of_range) atomicOr(range_flag, 1);
 }

@@ -37,4 +37,42 @@ __device__ __forceinline__ float expm1_neg(float x) {
     return x < -0.35f ? __expf(x) - 1.0f : p * x;
 }
 
+// ELU / ReLU / identity on one value, BRANCH-FREE: both sides of expm1_neg's split are evaluated and selected (left to itself the
+// compiler wraps every __expf in a divergent branch with its own exec-mask save: 64 branch regions in an epilogue of 64 values).
+// Same values as `x > 0 ? x : alpha * expm1_neg(x)`.
+template <int ACT> __device__ __forceinline__ float act_value(float x, float alpha) {
+    if (ACT == RC_ACT_RELU) return fmaxf(x, 0.f);
+    if (ACT != RC_ACT_ELU) return x;
+    float e = __expf(x);
+    asm volatile("" : "+v"(e));   // keeps the exponential out of a conditional block
+    float p = 1.0f / 40320.0f;
+    p = fmaf(p, x, 1.0f / 5040.0f);
+    p = fmaf(p, x, 1.0f / 720.0f);
+    p = fmaf(p, x, 1.0f / 120.0f);
+    p = fmaf(p, x, 1.0f / 24.0f);
+    p = fmaf(p, x, 1.0f / 6.0f);
+    p = fmaf(p, x, 0.5f);
+    p = fmaf(p, x, 1.0f);
+    const float em1 = x < -0.35f ? e - 1.0f : p * x;
+    return x > 0.f ? x : alpha * em1;
+}
+
+// The [hi | lo] split of two adjacent values, x = hi + lo * 2^-11: hi = half(y) (round to nearest even), lo = half((y - hi) * 2^11).
+// (y - hi) * 2^11 is formed as fma(hi, -2^11, y * 2^11): both products are exact and their difference is representable, so the single
+// rounding returns exactly what the subtract-then-scale form returns; v_fma_mix_f32 reads hi straight from the packed pair (no
+// conversion back to fp32).  5 VALU operations per pair instead of 9.
+struct SplitPair {
+    u32 hi, lo;
+};
+__device__ __forceinline__ SplitPair split_pair(float y0, float y1) {
+    SplitPair s;
+    s.hi = pack_half2(y0, y1);
+    const float t0 = y0 * kSplitScale, t1 = y1 * kSplitScale, ms = -kSplitScale;
+    float l0, l1;
+    asm("v_fma_mix_f32 %0, %1, %2, %3 op_sel:[0,0,0] op_sel_hi:[1,0,0]" : "=v"(l0) : "v"(s.hi), "v"(ms), "v"(t0));
+    asm("v_fma_mix_f32 %0, %1, %2, %3 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(l1) : "v"(s.hi), "v"(ms), "v"(t1));
+    s.lo = pack_half2(l0, l1);
+    return s;
+}
+
 }  // namespace rubiks
