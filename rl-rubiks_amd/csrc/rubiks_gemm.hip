@@ -200,10 +200,7 @@ __global__ __launch_bounds__(WM *WN * 64) void k_split_gemm(GemmArgs g) {
                 }
             }
 #pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                if (ACT == RC_ACT_RELU) y[e] = fmaxf(y[e], 0.f);
-                if (ACT == RC_ACT_ELU) y[e] = y[e] > 0.f ? y[e] : g.alpha * expm1_neg(y[e]);
-            }
+            for (int e = 0; e < 4; ++e) y[e] = act_value<ACT>(y[e], g.alpha);   // branch-free (rubiks_netmath.h)
             if (KIND != kPartials && g.post_scale) {
                 const float4 ps = *reinterpret_cast<const float4 *>(g.post_scale + col), pt = *reinterpret_cast<const float4 *>(g.post_shift + col);
                 y[0] = y[0] * ps.x + pt.x, y[1] = y[1] * ps.y + pt.y, y[2] = y[2] * ps.z + pt.z, y[3] = y[3] * ps.w + pt.w;
@@ -215,16 +212,12 @@ __global__ __launch_bounds__(WM *WN * 64) void k_split_gemm(GemmArgs g) {
                 unsigned char *orow = reinterpret_cast<unsigned char *>(g.out) + row * ((size_t)g.N * 2);
                 *reinterpret_cast<uint2 *>(orow + col * 2) = make_uint2(pack_bf16(y[0], y[1]), pack_bf16(y[2], y[3]));
             } else if (KIND == kOutHalves) {
-                float hi[4], lo[4];
 #pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    out_of_range |= !(fabsf(y[e]) <= kHalfMax);   // hi would be +-inf (or y is NaN): the caller falls back to fp32
-                    hi[e] = round_to_half_f32(y[e]);
-                    lo[e] = (y[e] - hi[e]) * kSplitScale;
-                }
+                for (int e = 0; e < 4; ++e) out_of_range |= !(fabsf(y[e]) <= kHalfMax);   // hi would be +-inf (or y is NaN): the caller falls back to fp32
+                const SplitPair p01 = split_pair(y[0], y[1]), p23 = split_pair(y[2], y[3]);   // hi = half(y), lo = half((y - hi) 2^11): 5 operations per pair
                 unsigned char *orow = reinterpret_cast<unsigned char *>(g.out) + row * ((size_t)g.N * 4);
-                *reinterpret_cast<uint2 *>(orow + col * 2) = make_uint2(pack_half2(hi[0], hi[1]), pack_half2(hi[2], hi[3]));
-                *reinterpret_cast<uint2 *>(orow + ((size_t)g.N + col) * 2) = make_uint2(pack_half2(lo[0], lo[1]), pack_half2(lo[2], lo[3]));
+                *reinterpret_cast<uint2 *>(orow + col * 2) = make_uint2(p01.hi, p23.hi);
+                *reinterpret_cast<uint2 *>(orow + ((size_t)g.N + col) * 2) = make_uint2(p01.lo, p23.lo);
             } else {
                 float *orow = reinterpret_cast<float *>(g.out) + row * (size_t)g.N;
                 *reinterpret_cast<float4 *>(orow + col) = make_float4(y[0], y[1], y[2], y[3]);
