@@ -7,6 +7,8 @@
 #        -> gpurun_out/<tag>_select_pmc.txt
 #   bash tools/bench_rocprof.sh <tag> env_traffic                  FETCH_SIZE / WRITE_SIZE passes (separate) of the environment kernels at 2^24
 #        states -> gpurun_out/<tag>_env_pmc_traffic.json
+#   bash tools/bench_rocprof.sh <tag> env_stats                    kernel durations of the environment kernels at 2^24 states (tools/env_bench.py 24 under
+#        --kernel-trace --stats) -> gpurun_out/<tag>_env_kernel_stats.csv
 #   bash tools/bench_rocprof.sh <tag> gemm_pmc                     matrix-pipe duty cycle of the hidden-layer kernel: SQ_VALU_MFMA_BUSY_CYCLES, SQ_BUSY_CYCLES,
 #        wave / wait / LDS counters over tools/split_gemm_fused_probe.py at 11 264 rows (the program itself behind `--`)
 #        -> gpurun_out/<tag>_split_gemm_pmc.txt
@@ -32,6 +34,9 @@ gemm_pmc)
   rocprofv3 --kernel-trace --stats -d /tmp/prof_gs_$tag -o g -- python3 $R/tools/split_gemm_fused_probe.py --rows 11264 --shapes 4096x2048 --reps 8 >> $O/${tag}_split_gemm_pmc.log 2>&1
   python3 $R/tools/rocprof_summary.py kernels "$(find /tmp/prof_gs_$tag -name '*.db' | head -1)" $O/${tag}_split_gemm_kernel_stats.csv 6
   tail -3 $O/${tag}_split_gemm_pmc.log >> $O/${tag}_split_gemm_pmc.txt ;;
+env_stats)
+  rocprofv3 --kernel-trace --stats -d /tmp/prof_es_$tag -o env -- python3 $R/tools/env_bench.py 24 > $O/${tag}_env_bench.log 2>&1
+  python3 $R/tools/rocprof_summary.py kernels "$(find /tmp/prof_es_$tag -name '*.db' | head -1)" $O/${tag}_env_kernel_stats.csv 12 ;;
 env_traffic)
   rocprofv3 --pmc FETCH_SIZE --output-format csv -d /tmp/prof_f_$tag -- python3 $R/tools/env_bench.py 24 > $O/${tag}_env_fetch.log 2>&1
   rocprofv3 --pmc WRITE_SIZE --output-format csv -d /tmp/prof_w_$tag -- python3 $R/tools/env_bench.py 24 > $O/${tag}_env_write.log 2>&1
