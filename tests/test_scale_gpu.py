@@ -114,6 +114,12 @@ def test_bench_preflight_alone():
     assert out.returncode == 0, out.stderr[-2000:]
     line = json.loads([ln for ln in out.stdout.splitlines() if ln.startswith("{")][-1])
     assert line["preflight"] == "ok" and line["n_gpus"] == 2 and line["collectives"].endswith("ok")
+    # a requirement that cannot be met: ONE rank-tagged line per failing rank on stderr, exit code 3, no result line
+    env["RUBIKS_PREFLIGHT_NEED_GB"] = "100000"
+    short = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--preflight"], env=env, capture_output=True, text=True, timeout=300)
+    assert short.returncode == 3 and "[bench preflight] rank" in short.stderr and "GB of HBM free" in short.stderr, short.stderr[-1500:]
+    assert not [ln for ln in short.stdout.splitlines() if ln.startswith("{")]
+    del env["RUBIKS_PREFLIGHT_NEED_GB"]
     # RCCL with two ranks on ONE GPU: pick_backend refuses before anything hangs
     env["RUBIKS_DIST_BACKEND"] = "nccl"
     bad = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--preflight"], env=env, capture_output=True, text=True, timeout=300)
