@@ -549,7 +549,6 @@ class SplitF32Net:
             self._opts[id(out[-1])] = LayerOpts(o.save, o.add, None if o.post is None else tuple(t.float().contiguous() for t in o.post))
         return out
 
-    small_batch_cut = True   # False: the K loop is cut (in two) only from 96 whole-K tiles up, smaller batches go to the library (A/B switch)
     fused_hidden = True   # hidden layers as one kernel each (rc_split_gemm_f16) where its tile fills the chip
     fused_head = True     # last activation + output layer in one pass (rc_head_split_f32) behind a hidden layer that came as partials
 
@@ -571,8 +570,6 @@ class SplitF32Net:
         if self.fused_hidden and self._fused_tile(rows, N, K):
             return "fused"
         cut = self._k_split(rows, N, K) if self.fused_hidden else None
-        if cut and not self.small_batch_cut and (cut[1] != 2 or -(-rows // 352) * (N // 256) < 96):
-            cut = None
         return ("cut",) + cut if cut else "library"
 
     @staticmethod
@@ -639,7 +636,6 @@ class SplitF32Net:
     def _zero_bias(self, w: int) -> torch.Tensor:
         return self._zeros[w]   # made in __init__: never allocated (and filled) inside a graph capture
 
-    gemm_input_rows = 0   # > 0: from this many rows the input layer runs on the GEMM kernel (measured slower in whole searches: off)
     fused_input = True   # the input layer as one MFMA kernel from the cube states (rc_first_layer_split_f16) when shapes allow
 
     def _first_from_cubes(self, cubes, layers, lo: int = 0, n: int = None):
@@ -654,15 +650,6 @@ class SplitF32Net:
             assert lo % 16 == 0 and 0 <= lo and lo + n <= cubes.n
             cubes = _CubeWindow(cubes.soa.data_ptr() + lo, n, cubes.stride)
         out = torch.empty((cubes.n, 2 * H), dtype=torch.float16, device=self.device)
-        if self.gemm_input_rows and cubes.n >= self.gemm_input_rows and H % 256 == 0:
-            # the explicit one-hot operand [oh | 2^-11 oh] (21.6 MB at 11 264 rows) through the hidden layers' GEMM kernel as ONE f16 product
-            # with K = 960 (the same sums in another order, 1e-7 apart).  Off by default: faster alone from ~6 000 rows (125 -> 111 us at
-            # 11 264, profiles/r3_first_layer_gemm_probe.txt) but 2 % SLOWER in whole searches on the same box (profiles/r3_input_gemm_ab.txt)
-            oh = torch.empty((cubes.n, 2 * OH_WIDTH), dtype=torch.float16, device=self.device)
-            _hip.check(_hip.lib().rc_oh_split_f16(_soa_ptr(cubes), cubes.n, cubes.stride, oh.data_ptr(), _hip.stream_ptr()), "rc_oh_split_f16")
-            _layer_call("rc_split_layer_f16", a=oh, w=B, bias=b, n_rows=cubes.n, n_out=H, k=2 * OH_WIDTH, activation=code, alpha=alpha,
-                        out_hi_lo=out, tile=1, k_splits=1, products=1, range_flag=self.range_flag)
-            return out
         _hip.check(_hip.lib().rc_first_layer_split_flag_f16(_soa_ptr(cubes), cubes.n, cubes.stride, Wh.data_ptr(), Wl.data_ptr(), b.data_ptr(),
                                                             out.data_ptr(), H, code, alpha, self.range_flag.data_ptr(), _hip.stream_ptr()),
                    "rc_first_layer_split_flag_f16")

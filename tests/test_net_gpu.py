@@ -693,14 +693,19 @@ def test_layer_request_one_product_and_the_input_layer_on_it():
     net = Model.create(ModelConfig(architecture="fc_small")).eval().cuda()
     eng = make_inference_net(net, F32_SPLIT)
     cubes, _, _ = cube.scramble_batch(11264, 30, True)
-    assert SplitF32Net.gemm_input_rows == 0      # off by default (slower in whole searches)
     fused = eng._first_from_cubes(cubes, eng.layers)
-    eng.gemm_input_rows = 8192
-    on_gemm = eng._first_from_cubes(cubes, eng.layers)
+    # the same layer as explicit one-hot operand [oh | 2^-11 oh] (rc_oh_split_f16) x [W_hi | W_lo] through the GEMM kernel as ONE product
+    # with K = 960: an independent implementation of the fused kernel's function (the same sums in another order).  Measured 2 % slower
+    # in whole searches (profiles/r3_input_gemm_ab.txt), so the engine does not use it.
+    _, B, b0, code, alpha = eng.layers[0][:5]
+    oh = torch.empty((cubes.n, 960), dtype=torch.float16, device="cuda")
+    _hip.check(_hip.lib().rc_oh_split_f16(cubes.soa.data_ptr(), cubes.n, cubes.stride, oh.data_ptr(), _hip.stream_ptr()), "rc_oh_split_f16")
+    on_gemm = torch.empty_like(fused)
+    _layer_call("rc_split_layer_f16", a=oh, w=B, bias=b0, n_rows=cubes.n, n_out=B.shape[0], k=960, activation=code, alpha=alpha, out_hi_lo=on_gemm,
+                tile=1, k_splits=1, products=1, range_flag=eng.range_flag)
     H = fused.shape[1] // 2
     val = lambda t: t[:, :H].double() + t[:, H:].double() / 2048   # noqa: E731
     assert float((val(on_gemm) - val(fused)).abs().max()) < 1e-6
-    del eng.gemm_input_rows
     assert not eng.overflowed()
 
 

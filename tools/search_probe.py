@@ -15,7 +15,7 @@ MCTS search probes on one MI355X with the trained weights (the programs profiles
          every group on a HIP stream of its own, rounds alternating) against the one-group form, same box, a, b, a, b.  Per form:
          the steady-state window (ms per lock-step step of all 1 024 slots) and the whole pool.
   ab     <owner.attribute> <value_a> <value_b>
-         same-box A/B of a module / class attribute (e.g. mcts_device.RUNG_RATIO 0.9 0.95, model.SplitF32Net.small_batch_cut 1 0,
+         same-box A/B of a module / class attribute (e.g. mcts_device.RUNG_RATIO 0.9 0.95, model.SplitF32Net.fused_head 1 0,
          agents.MCTS.sync_every via `sync_every 16 32`): variants alternate a, b, a, b in one process; per variant configs[1] to
          completion three times and a 4 096-game pool.
 """
