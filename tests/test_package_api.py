@@ -94,3 +94,24 @@ def test_launch_size_ladder():
         assert r[-1] == (MIN_RUNG if n > MIN_RUNG else n)
     assert rungs(1024) == [1024, 960, 896, 832, 768, 704, 640, 608, 576, 544, 512, 480, 448, 416, 384, 352, 320, 288, 256, 224, 192, 160, 128, 96,
                            64, 32]
+
+
+def test_queue_table_padded_matches_the_per_game_deques():
+    """QueueTable.padded: many games' action queues as one padded array -- what bench.py's solution replay walks -- equals the deques
+    the table hands out game by game (rows from a shared array, rows set one by one, empty rows)."""
+    import numpy as np
+    from librubiks.solving.agents import QueueTable
+    acts = np.arange(40, dtype=np.uint8).reshape(4, 10) % 12
+    table = QueueTable(acts, np.array([3, 0, 10, 7]))
+    table[1] = [5, 4, 3]
+    merged = QueueTable(n=3)
+    merged.put(0, table, 2)
+    merged.put(2, table, 1)
+    for t, games in ((table, None), (table, [3, 0]), (merged, None)):
+        padded, lens = t.padded(games)
+        ids = range(len(t)) if games is None else games
+        assert padded.dtype == np.uint8 and padded.shape == (len(lens), max(lens))
+        for row, g, n in zip(padded, ids, lens):
+            assert list(row[:n]) == list(t[g]) and n == len(t[g]) and (row[n:] == 255).all()
+    empty, lens = QueueTable(n=2).padded()
+    assert empty.shape == (2, 0) and list(lens) == [0, 0]
