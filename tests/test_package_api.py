@@ -115,3 +115,45 @@ def test_queue_table_padded_matches_the_per_game_deques():
             assert list(row[:n]) == list(t[g]) and n == len(t[g]) and (row[n:] == 255).all()
     empty, lens = QueueTable(n=2).padded()
     assert empty.shape == (2, 0) and list(lens) == [0, 0]
+
+
+def test_vmm_classify_replays_an_event_log(tmp_path):
+    """tools/vmm_classify.py on a hand-written event file (the format rubiks_vmm.hip writes under RUBIKS_VMM_LOG): a live range with
+    two mapped chunks, its alignment slack, a released range on the idle list, a reused one, and addresses that were never ours."""
+    import importlib.util
+    import os
+    from conftest import ROOT
+    spec = importlib.util.spec_from_file_location("vmm_classify", os.path.join(ROOT, "tools", "vmm_classify.py"))
+    vc = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(vc)
+    MB = 1 << 20
+    log = tmp_path / "vmm.log"
+    log.write_text("\n".join([
+        "# rubiks vmm log: seq op base a b rc",
+        f"0 A 0x{0x7000_0000_0000:x} {64 * MB} 0 0",                       # reservation of 64 MiB ...
+        f"1 R 0x{0x7000_0000_0000 + 2 * MB:x} {40 * MB} {4 * MB} 1",         # ... handed out from +2 MiB on (4 MiB chunks: aligned base)
+        f"2 M 0x{0x7000_0000_0000 + 2 * MB:x} {4 * MB} {8 * MB} 0",          # chunks 1 and 2 get memory
+        f"3 A 0x{0x7100_0000_0000:x} {16 * MB} 0 0",
+        f"4 R 0x{0x7100_0000_0000:x} {16 * MB} {2 * MB} 1",
+        f"5 M 0x{0x7100_0000_0000:x} 0 {2 * MB} 0",
+        f"6 X 0x{0x7100_0000_0000:x} {2 * MB} {16 * MB} 0",                  # released ...
+        f"7 I 0x{0x7100_0000_0000:x} {16 * MB} 1 0",                         # ... onto the idle list
+        f"8 A 0x{0x7200_0000_0000:x} {8 * MB} 0 0",
+        f"9 R 0x{0x7200_0000_0000:x} {8 * MB} {2 * MB} 1",
+        f"10 X 0x{0x7200_0000_0000:x} 0 {8 * MB} 0",
+        f"11 F 0x{0x7200_0000_0000:x} {8 * MB} 1 0",                         # address space given back to the runtime
+    ]) + "\n")
+    state = vc.replay(str(log))
+    kind = lambda a: vc.classify(a, *state)[0]   # noqa: E731
+    base = 0x7000_0000_0000 + 2 * MB
+    assert kind(base) == "unmapped" and kind(base + 4 * MB) == "mapped" and kind(base + 12 * MB - 1) == "mapped" and kind(base + 12 * MB) == "unmapped"
+    assert kind(0x7000_0000_0000 + MB) == "slack" and kind(base + 40 * MB) == "slack"
+    assert kind(0x7100_0000_0000 + 5 * MB) == "idle"
+    assert kind(0x7200_0000_0000 + MB) == "unknown" and "no longer exists" in vc.classify(0x7200_0000_0000 + MB, *state)[1]
+    assert kind(0x1234_0000) == "unknown" and "never inside" in vc.classify(0x1234_0000, *state)[1]
+    # the idle range is taken again by a later reservation of its class
+    with open(log, "a") as f:
+        f.write(f"12 A 0x{0x7100_0000_0000:x} {16 * MB} 0 0\n13 U 0x{0x7100_0000_0000:x} {10 * MB} {2 * MB} 2\n14 M 0x{0x7100_0000_0000:x} {2 * MB} {2 * MB} 0\n")
+    state = vc.replay(str(log))
+    assert vc.classify(0x7100_0000_0000 + 3 * MB, *state)[0] == "mapped" and vc.classify(0x7100_0000_0000, *state)[0] == "unmapped"
+    assert vc.classify(0x7100_0000_0000 + 12 * MB, *state)[0] == "slack"
