@@ -1190,10 +1190,6 @@ def main():
         model = Model.create(ModelConfig(architecture=args.architecture)).eval()
         weights_note = f"random-init {args.architecture} (glorot, torch.manual_seed(0))"
 
-    # successive legs of one shape hand their node store on with its memory (146 GB behind the config-5 forest): the benchmark's legs are
-    # each other's successors, so nothing is released between them (the library's default keeps at most 64 GB parked between owners)
-    from librubiks._vmm import VmmArray
-    VmmArray.PARK_CAP_BYTES = max(VmmArray.PARK_CAP_BYTES, 220 << 30)
     results, extras = {}, {}
     for name in legs:
         leg, engine, agent = run_leg(name, model, pool_roots, config_roots, args, world, coll_device, args.trees, args.solve_max_states,

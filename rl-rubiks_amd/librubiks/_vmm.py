@@ -175,18 +175,30 @@ class VmmArray:
     def has_parked(cls, nbytes: int, device, chunk: int = CHUNK) -> bool:
         return any(a.asked == int(nbytes) for a in cls._parked.get((class_bytes(nbytes, chunk), chunk, torch.device(device).index), []))
 
-    def park(self):
+    def park(self, protect_from: int = None):
         """The owner is done with the array (it has synchronised and dropped its tensors).  Address range and memory are kept for
-        the next array of the same size class -- successive forests of one benchmark or evaluation -- instead of being unmapped
-        and mapped again.  Parked memory beyond PARK_CAP_BYTES is released, oldest arrays first; `trim` releases all of it."""
+        the next array of the same shape -- successive forests of one benchmark or evaluation -- instead of being unmapped and
+        mapped again.  Parked memory beyond PARK_CAP_BYTES is released, oldest arrays first -- except the arrays parked from
+        `protect_from` on (`next_park_mark()` taken before a forest parks its arrays): the forest that has just finished always
+        stays whole, whatever its size, because its successor is the likeliest next owner (releasing and re-mapping the 146 GB
+        behind a config-5-size forest costs the next search tens of seconds).  `trim` releases everything."""
         if not self.ptr:
             return
         VmmArray._park_clock += 1
         self._parked_at = VmmArray._park_clock
         self._parked.setdefault((self.nbytes, self.chunk, self.device.index), []).append(self)
         while self.parked_bytes() > self.PARK_CAP_BYTES:
-            arrs = min((a for a in self._parked.values() if a), key=lambda a: a[0]._parked_at)
-            arrs.pop(0).close()
+            old = [a for arrs in self._parked.values() for a in arrs if protect_from is None or a._parked_at < protect_from]
+            if not old:
+                break
+            victim = min(old, key=lambda a: a._parked_at)
+            self._parked[(victim.nbytes, victim.chunk, victim.device.index)].remove(victim)
+            victim.close()
+
+    @classmethod
+    def next_park_mark(cls) -> int:
+        """What `park(protect_from=...)` takes: arrays parked after this call belong to one owner and are not evicted on its behalf."""
+        return cls._park_clock + 1
 
     @classmethod
     def trim(cls) -> int:

@@ -368,8 +368,9 @@ class MCTSForest:
             return
         torch.cuda.synchronize()
         arrays, MCTSForest._deferred = MCTSForest._deferred + arrays, []
+        mark = VmmArray.next_park_mark()      # this forest's arrays stay together; older parked memory beyond the cap goes first
         for arr in arrays:
-            arr.park()
+            arr.park(protect_from=mark)
 
     def __del__(self):
         try:

@@ -368,3 +368,42 @@ def test_config5_share_on_large_chunks_equals_the_oracle_on_sampled_trees():
         assert bool(res.solved[t]) == ok and res.nodes[t] == len(ref) == n, f"tree {t}"
         assert list(res.queues[t]) == list(ref.action_queue) and res.iterations[t] == ref.iterations, f"tree {t}"
         edge._compare(tree, ref, n)
+
+
+def test_parked_memory_is_capped_but_the_store_just_finished_stays_whole(monkeypatch):
+    """VmmArray.park: HBM behind parked arrays is bounded by PARK_CAP_BYTES -- older owners' arrays are released first -- while the
+    arrays one owner parks together (`protect_from` = the mark taken before its first park) all stay, whatever they hold: the next
+    forest of that shape takes them over with their memory.  `trim` releases everything (and `take` hands out what is parked)."""
+    from librubiks._vmm import CHUNK, VmmArray
+    dev = torch.device("cuda", 0)
+    torch.cuda.synchronize()
+    VmmArray.trim()
+    monkeypatch.setattr(VmmArray, "PARK_CAP_BYTES", 8 * CHUNK)
+
+    def owner(sizes):
+        arrs = [VmmArray(n * CHUNK, dev) for n in sizes]
+        for a in arrs:
+            a.ensure(0, a.asked)
+            a.tensor(torch.int32, (a.asked // 4,)).fill_(7)
+        torch.cuda.synchronize()
+        mark = VmmArray.next_park_mark()
+        for a in arrs:
+            a.park(protect_from=mark)
+        return arrs
+
+    first = owner([6, 5])                                           # 11 chunks parked by one owner: above the cap, and kept
+    assert all(a.ptr for a in first) and VmmArray.parked_bytes() == 11 * CHUNK
+    assert VmmArray.has_parked(6 * CHUNK, dev) and VmmArray.has_parked(5 * CHUNK, dev)
+    second = owner([7, 3])                                          # the next owner: the first one's arrays go (oldest first) ...
+    assert all(a.ptr == 0 for a in first) and all(a.ptr for a in second)
+    assert VmmArray.parked_bytes() == 10 * CHUNK and not VmmArray.has_parked(6 * CHUNK, dev)
+    third = owner([2])                                              # ... until what is parked fits: 7 + 3 + 2 > 8 -> the 7 goes, 3 + 2 stay
+    assert second[0].ptr == 0 and second[1].ptr and third[0].ptr and VmmArray.parked_bytes() == 5 * CHUNK
+    again = VmmArray.take(3 * CHUNK, dev)                           # the same shape takes a parked array over, memory included
+    assert again is second[1] and again.mapped_bytes == 3 * CHUNK and VmmArray.parked_bytes() == 2 * CHUNK
+    t = again.tensor(torch.int32, (3 * CHUNK // 4,))
+    assert int(t.min().item()) == 7 and int(t.max().item()) == 7
+    del t
+    torch.cuda.synchronize()
+    again.close()
+    assert VmmArray.trim() == 1 and VmmArray.parked_bytes() == 0 and third[0].ptr == 0
