@@ -536,10 +536,7 @@ __global__ __launch_bounds__(kBlock) void k_head_split(const float4 *__restrict_
                 float y[4] = {a[u].x + corr_scale * k4[u].x + b.x, a[u].y + corr_scale * k4[u].y + b.y, a[u].z + corr_scale * k4[u].z + b.z,
                               a[u].w + corr_scale * k4[u].w + b.w};
 #pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    if (ACT == RC_ACT_RELU) y[e] = fmaxf(y[e], 0.f);
-                    if (ACT == RC_ACT_ELU) y[e] = y[e] > 0.f ? y[e] : alpha * expm1f(y[e]);
-                }
+                for (int e = 0; e < 4; ++e) y[e] = act_value<ACT>(y[e], alpha);   // branch-free; libm's expm1f cost a third of this kernel's time
                 const float4 wv4 = wf[j0 + u];
                 acc = __builtin_amdgcn_mfma_f32_16x16x4f32(y[0], wv4.x, acc, 0, 0, 0);
                 acc = __builtin_amdgcn_mfma_f32_16x16x4f32(y[1], wv4.y, acc, 0, 0, 0);
