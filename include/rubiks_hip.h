@@ -192,8 +192,7 @@ int rc_head_split_f32(const float *c, const float *c_corr, float corr_scale, siz
  * a_hi_lo: [n_rows][2 k] halves (hi | lo), as the kernels above write it;  w_lo_hi_hi: [n_out][3 k] halves, the layer's
  * weight split and laid out [W_lo | W_hi | W_hi] (the order the K loop walks: both correction products, a 2^-11 scaling of
  * the accumulator, the main product);  exactly one of out_hi_lo ([n_rows][2 n_out] halves) and out_f32 ([n_rows][n_out])
- * is non-NULL.  k % 64 == 0;  tile: 0 = choose, 1 = 352 x 256 (n_out % 256 == 0), 3 = 352 x 128, 2 = 176 x 128 (n_out % 128 == 0),
- * 4 = 352 x 256 with the two wave rows of a workgroup running half a phase apart (measured 8 % slower, kept for comparison).
+ * is non-NULL.  k % 64 == 0;  tile: 0 = choose, 1 = 352 x 256 (n_out % 256 == 0), 3 = 352 x 128, 2 = 176 x 128 (n_out % 128 == 0).
  * Every tile walks K in the same order: a row's result does not depend on the tile or on the other rows of the launch.
  * Replaces two library GEMMs + rc_split_act_f16; the fp32 partial matrices never reach HBM. */
 int rc_split_gemm_f16(const uint16_t *a_hi_lo, const uint16_t *w_lo_hi_hi, const float *bias, size_t n_rows, size_t n_out,
