@@ -311,6 +311,7 @@ def cpu_baseline(model, depth, budget_s=14.0, max_states=5000):
             "sample": f"{games} depth-{depth} scrambles x max_states={max_states}, single-tree MCTS c=0.6 "
                       f"(oracle/agents.py on NumPy + torch CPU fp32, {best[1]} torch threads picked by calibration), "
                       f"{dt:.1f} s",
+            "sample_short": f"{games} depth-{depth} scrambles, max_states {max_states}, single-tree MCTS (oracle port, torch CPU fp32, {best[1]} threads), {dt:.1f} s",
             "env_ops": cpu_env_ops(), "bfs_config1": cpu_bfs_config1(), "boundary_calls": boundary_calls()}
 
 
