@@ -1041,6 +1041,34 @@ def draw_scrambles(n_config, n_pool, depth, slice_rank, slice_world):
     return config_roots, pool_roots
 
 
+def scale_efficiency(world, value, workload_key, ref_path, write=True, gpu=""):
+    """
+    The scaling curve without post-processing: a one-GPU run leaves {value, workload} in `ref_path`; an N-GPU run of the SAME
+    workload on the same checkout returns value / (N x that value).  (efficiency, note); efficiency is None for one GPU, when
+    there is no record, or when the record is of another workload.
+    """
+    if world == 1:
+        if write:
+            try:
+                with open(ref_path, "w") as f:
+                    json.dump({"value": value, "workload": workload_key, "gpu": gpu}, f)
+            except OSError:
+                pass
+        return None, "one GPU: this run IS the reference of the curve"
+    name = os.path.basename(ref_path)
+    if not os.path.exists(ref_path):
+        return None, f"no one-GPU record of this workload ({name}) next to bench.py: run --gpus 1 first on this checkout"
+    try:
+        with open(ref_path) as f:
+            ref = json.load(f)
+    except (OSError, ValueError):
+        return None, f"{name} is unreadable"
+    if ref.get("workload") != workload_key or not ref.get("value"):
+        return None, f"{name} holds another workload ({ref.get('workload')})"
+    return round(value / (world * ref["value"]), 4), (f"value / ({world} x {ref['value']}), the one-GPU value this checkout's last --gpus 1 run of the "
+                                                      f"same workload left in {name}")
+
+
 def launch_ranks(n, argv, script=os.path.abspath(__file__)):
     """
     `python bench.py --gpus N` without a launcher (no RANK / WORLD_SIZE in the environment): this process starts the N ranks as
@@ -1291,23 +1319,8 @@ def main():
     # of the same workload on the same checkout divides by it.  null when no such record exists (or the workload differs).
     workload_key = {"trees": args.trees, "depth": args.depth, "max_states": args.solve_max_states, "leg": legs[0], "pool_factor": args.pool_factor,
                     "steps": args.steps, "warmup": args.warmup}
-    ref_path = os.path.join(ROOT, SCALE_REF)
-    efficiency, efficiency_note = None, "one GPU: this run IS the reference of the curve"
-    if world == 1 and not args.as_rank:
-        try:
-            with open(ref_path, "w") as f:
-                json.dump({"value": head["value"], "workload": workload_key, "gpu": torch.cuda.get_device_name(device_index)}, f)
-        except OSError:
-            pass
-    elif world > 1:
-        efficiency_note = f"no one-GPU record of this workload ({SCALE_REF}) next to bench.py: run --gpus 1 first on this checkout"
-        if os.path.exists(ref_path):
-            ref = json.load(open(ref_path))
-            if ref.get("workload") == workload_key and ref.get("value"):
-                efficiency = round(head["value"] / (world * ref["value"]), 4)
-                efficiency_note = f"value / ({world} x {ref['value']}), the one-GPU value this checkout's last --gpus 1 run of the same workload left in {SCALE_REF}"
-            else:
-                efficiency_note = f"{SCALE_REF} holds another workload ({ref.get('workload')})"
+    efficiency, efficiency_note = scale_efficiency(world, head["value"], workload_key, os.path.join(ROOT, SCALE_REF), write=not args.as_rank,
+                                                   gpu=torch.cuda.get_device_name(device_index))
     weights_short = os.path.relpath(args.weights, ROOT) if os.path.isdir(args.weights) else "random-init"
     result = {
         "metric": "MCTS node expansions/sec, depth-20 scrambles", "value": head["value"],

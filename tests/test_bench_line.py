@@ -161,3 +161,18 @@ def test_main_takes_the_launcher_branch_before_touching_the_gpu():
     """)
     out = subprocess.run([sys.executable, "-c", probe], env=env, capture_output=True, text=True, timeout=120)
     assert out.returncode == 0 and out.stdout.strip() == "LAUNCH 2 ['--gpus', '2', '--steps', '3']", out.stderr[-1500:]
+
+
+def test_scale_efficiency_from_the_one_gpu_record(tmp_path):
+    """`efficiency` of an N-GPU line = value / (N x the value the same checkout's one-GPU run of the same workload left behind);
+    null for one GPU, without a record, or when the record is of another workload."""
+    ref = str(tmp_path / "bench_scale_ref.json")
+    key = {"trees": 1024, "depth": 20, "max_states": 175000, "leg": "f32s", "pool_factor": 8, "steps": 20, "warmup": 5}
+    assert bench.scale_efficiency(8, 9.0e7, key, ref)[0] is None                       # nothing to divide by yet
+    eff, note = bench.scale_efficiency(1, 1.25e7, key, ref, gpu="MI355X")
+    assert eff is None and "reference" in note and json.load(open(ref))["value"] == 1.25e7
+    assert bench.scale_efficiency(8, 9.5e7, key, ref)[0] == 0.95 and bench.scale_efficiency(2, 2.5e7, key, ref)[0] == 1.0
+    assert bench.scale_efficiency(8, 9.5e7, dict(key, trees=512), ref)[0] is None      # another workload
+    assert bench.scale_efficiency(1, 1.0e7, key, ref, write=False)[0] is None and json.load(open(ref))["value"] == 1.25e7   # --as-rank runs leave no record
+    open(ref, "w").write("{not json")
+    assert bench.scale_efficiency(4, 1.0, key, ref)[0] is None
