@@ -34,7 +34,7 @@
 extern "C" {
 #endif
 
-#define RC_ABI_VERSION 8
+#define RC_ABI_VERSION 9
 
 #define RC_OK 0
 #define RC_ERR_NULL (-1)      /* required pointer is NULL */
@@ -276,14 +276,15 @@ int rc_adi_targets(const float *values, const uint8_t *child_solved, const uint8
 #define RC_MCTS_RUNNING 0
 #define RC_MCTS_SOLVED 1        /* a child of the expanded leaf is the solved cube (agents.py:540-543) */
 #define RC_MCTS_EXHAUSTED 2     /* len + 12 > max_states (agents.py:476) or node capacity reached */
-#define RC_MCTS_PATH_OVERFLOW 3 /* PUCT descent longer than max_path (treated as unsolved) */
+#define RC_MCTS_PATH_OVERFLOW 3 /* a PUCT descent reached max_path levels: the path store is exhausted (the reference has no limit,
+                                 * agents.py:575-595; max_path is a resource bound the caller chooses, not a search parameter) */
 #define RC_MCTS_ROOT_SOLVED 4   /* the scramble itself is solved (agents.py:468) */
 
 typedef struct rc_mcts {
     uint32_t n_trees;    /* B */
     uint32_t capacity;   /* largest node index per tree; capacity + 1 < 2^24 (32-bit byte offsets into a tree's 256-byte records) */
     uint32_t hash_size;  /* slots per tree, power of two, >= 2 * (capacity + 1) */
-    uint32_t max_path;   /* descent buffer length per tree (2 .. 4096) */
+    uint32_t max_path;   /* levels the path store can hold per tree (>= 2; see "descent path" below): a whole number of path blocks */
     uint32_t rows_per_tree; /* network rows reserved per tree and iteration: 11 (see child_soa) */
     uint32_t node_words;    /* 32-bit words between consecutive nodes in N / W / P / nbr / rec: RC_MCTS_NODE_WORDS.  A forest that
                              * only waits for rc_mcts_complete_graph / rc_mcts_shorten (finished trees) may instead pass 12 with
@@ -315,8 +316,13 @@ typedef struct rc_mcts {
     int32_t *iterations;
     int32_t *path_len;   /* number of nodes on the current descent path, root included */
     int32_t *pending;    /* 0, or (carried action + 2) of a descent that rc_mcts_select suspended at its level budget */
-    int32_t *path_node;  /* [B][max_path] indices_visited (agents.py:581,592) */
-    uint8_t *path_act;   /* [B][max_path] actions_taken   (agents.py:582,593) */
+    /* The descent path (agents.py:581-582,592-593) has no length limit in the reference.  The path arrays path_node / path_act /
+     * path_next / short_act are therefore BLOCKED: level k of tree t is element
+     *     ((k >> path_block_log2) * B + t) << path_block_log2  |  (k & (2^path_block_log2 - 1)),
+     * i.e. [max_path >> path_block_log2][B][2^path_block_log2] -- block 0 is the dense [B][block] array a shallow tree lives in,
+     * and deeper blocks can be address space that gets memory only for the trees that go that deep (path_rows). */
+    int32_t *path_node;  /* indices_visited (agents.py:581,592) */
+    uint8_t *path_act;   /* actions_taken   (agents.py:582,593) */
     /* per iteration staging */
     int8_t *child_soa;   /* [20][child_stride]: network input: the NEW children of tree t's leaf, packed in child order at
                           * columns 11 t + rank.  A non-root leaf always has a known child (its parent), so 11 rows
@@ -331,7 +337,7 @@ typedef struct rc_mcts {
                               line-following rounds << 16 | levels they appended */
     /* optional, only needed by rc_mcts_shorten (may be NULL otherwise) */
     int32_t *bfs;        /* [B][capacity + 1][2] scratch: {claim, parent << 4 | action} */
-    uint8_t *short_act;  /* [B][max_path] shortened action queue of every solved tree */
+    uint8_t *short_act;  /* (blocked like path_act) shortened action queue of every solved tree; never longer than the tree's last path */
     int32_t *short_len;  /* [B] its length, -1 where no shortened queue was produced */
     /* per node: the 16-byte walk record, owned by the kernels (words 24-27 of the node record):
      *   uint32 {neighbour through best0, neighbour through best1, best0 | best1 << 8 | leaf << 16, 0}
@@ -343,8 +349,8 @@ typedef struct rc_mcts {
      * a descent many levels at a time.  Path number s (= the tree's iteration count when it was walked) lives in slot
      * s % ring_k; zero-initialised by the caller, owned by the kernels.  ring_k: a power of two, 1 .. 64. */
     uint32_t ring_k;
-    int32_t *ring_node;  /* [B][ring_k][max_path] */
-    uint8_t *ring_act;   /* [B][ring_k][max_path] action taken at each level, 15 at the path's leaf */
+    int32_t *ring_node;  /* [B][ring_k][ring_levels]: the first ring_levels levels of a path (deeper levels are walked one by one) */
+    uint8_t *ring_act;   /* [B][ring_k][ring_levels] action taken at each level, 15 at the path's leaf */
     int32_t *ring_len;   /* [B][ring_k] */
     /* per tree, [B]: 0 = ordinary iterations; 1 / 2 = first / second step of a planted root's own iteration (| 16: that
      * expansion found a solved child, reported as RC_MCTS_SOLVED when the second step has completed the tree) */
@@ -367,6 +373,18 @@ typedef struct rc_mcts {
      * RUNNING, `expanded` stays 0, its iteration count does not advance) and tries again in the next one: the host maps ahead
      * of the trees' growth, the kernels never touch a row that is not there. */
     const int32_t *mapped_rows;
+    /* ---- descent paths of any length (the reference walks until it meets a leaf, agents.py:575-595) ----
+     * rc_mcts_select keeps the first lds_levels levels of the path it works on in LDS; deeper levels are read and written in
+     * path_node / path_act in place, and chained by node through path_next (same blocked layout; only entries of levels >=
+     * lds_levels are used).  Results do not depend on lds_levels (tests run 8 and 64 against the reference's traces). */
+    uint32_t path_block_log2; /* log2 of the levels per path block (12 in production) */
+    uint32_t lds_levels;      /* 1 .. 4096 */
+    uint32_t ring_levels;     /* levels per ring line, 1 .. 4096 (the line tag holds 12 bits of level) */
+    uint32_t *path_next;      /* scratch owned by the kernels */
+    /* Optional (NULL = max_path for every tree): [B] levels of tree t's path blocks that have memory behind them (a multiple of
+     * the block size).  A descent that reaches it is SUSPENDED (pending, as at a level budget) and resumes in the next call;
+     * the host maps the next block in between.  Only a descent that reaches max_path itself ends the tree (PATH_OVERFLOW). */
+    const int32_t *path_rows;
 } rc_mcts_t;
 
 /* sizeof(rc_mcts_t) as the library was compiled: a binding that mirrors the struct (ctypes, cgo, JNI) checks its own

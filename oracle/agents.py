@@ -16,14 +16,14 @@ Pinned by tests/golden/agents_golden.npz: traces (node count, action queue, neig
 counts, values, A* G/parents) recorded from the imported reference agents driven by a small
 deterministic network (tests/golden/make_golden_agents.py).
 
-Three places define behaviour where the reference raises / hangs / is unbounded (all unreachable in the golden traces):
+Two places define behaviour where the reference raises / hangs (both unreachable in the golden traces):
   * MCTS: a leaf whose 12 children are all known already -> reference raises ValueError on
     `v.max()` of an empty array (agents.py:559); here the best child value falls back to the max
     over the existing neighbours' V.
   * A*: empty open list -> reference would spin forever; here the search stops and returns False.
-  * MCTS: `max_path` (optional) bounds the number of nodes on a PUCT descent path; a descent that reaches it before
-    a leaf ends the search as unsolved with the actions taken so far as the queue (the reference's descent is
-    unbounded; the device kernels stage the path in LDS and stop at 4 096 nodes, RC_MCTS_PATH_OVERFLOW).
+A PUCT descent is as long as it gets, exactly as in the reference (agents.py:575-595): the oracle has no path bound.  It
+only RECORDS the longest descent of a search (`deepest_path`, nodes on the path) so that tests can tell which trees a
+caller-chosen bound of the product's path store (MCTS(max_path=...), a resource limit, not a search parameter) would end.
 """
 import heapq
 from collections import deque
@@ -148,9 +148,9 @@ class MCTS:
         self.L = np.concatenate([self.L, np.zeros((n, N_ACT))])
 
     # ---- search loop (agents.py:461-494) ---------------------------------------------------------
-    def search(self, state: np.ndarray, max_states: int, max_iterations: int = None, max_path: int = None) -> bool:
+    def search(self, state: np.ndarray, max_states: int, max_iterations: int = None) -> bool:
         self._reset()
-        self.max_path, self.path_overflow = max_path, False
+        self.deepest_path = 1
         self.indices[state.tobytes()] = 1
         self.states[1] = state
         if cube.is_solved(state):
@@ -169,8 +169,7 @@ class MCTS:
                     self._shorten_action_queue(solved_idx)
                 return True
             path, actions = self._find_leaf()
-            if self.path_overflow:
-                break
+            self.deepest_path = max(self.deepest_path, len(path))
         self.action_queue = deque(actions)   # best guess when the budget runs out (agents.py:492)
         return False
 
@@ -228,9 +227,6 @@ class MCTS:
         cur = 1
         path, actions = [cur], []
         while not self.leaves[cur]:
-            if getattr(self, "max_path", None) and len(path) >= self.max_path:
-                self.path_overflow = True
-                break
             sqrt_n = np.sqrt(self.N[cur].sum())
             u = self.c * self.P[cur] * sqrt_n / (1 + self.N[cur])
             q = self.W[cur] - self.L[cur]

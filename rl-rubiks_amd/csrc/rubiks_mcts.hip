@@ -25,7 +25,17 @@ constexpr int kA = kActions;   // 12
 // the pending descent path -- path_node / path_act -- from which the descents here take their counts and from which
 // MCTSForest.tree_arrays() reports it.
 constexpr int kRow = RC_MCTS_NODE_WORDS, kRowRec = kRow / 4;
-constexpr int kMaxPath = 4096;  // longest PUCT descent the kernels stage in LDS (20 KiB per workgroup in select)
+constexpr int kMaxPath = 4096;  // levels of a PUCT descent the select kernel stages in LDS (28 KiB per workgroup); deeper levels stay in HBM
+// Level k of tree t in the blocked path arrays (path_node / path_act / path_next / short_act, see rc_mcts_t): block 0 is the dense
+// [B][block] array, so for a shallow tree this is t * block + k.
+__device__ __forceinline__ size_t path_at(const rc_mcts_t &m, u32 t, int k) {
+    const u32 lg = m.path_block_log2;
+    return ((((size_t)((u32)k >> lg)) * m.n_trees + t) << lg) + ((u32)k & ((1u << lg) - 1u));
+}
+// Levels of tree t's path arrays that have memory behind them.
+__device__ __forceinline__ int path_limit(const rc_mcts_t &m, u32 t) {
+    return m.path_rows ? min(m.path_rows[t], (int)m.max_path) : (int)m.max_path;
+}
 
 // Walk record of a node (16 B, rc_mcts_t::rec): what a PUCT descent does at the node while no virtual loss
 // other than its own arrival edge is pending there.
@@ -97,7 +107,7 @@ __global__ __launch_bounds__(kBlock) void k_mcts_plant(rc_mcts_t m, const int *_
     m.iterations[t] = 0;
     m.path_len[t] = 1;
     m.pending[t] = 0;
-    m.path_node[(size_t)t * m.max_path] = 1;
+    m.path_node[path_at(m, t, 0)] = 1;
     m.expanded[t] = 0;
     m.new_mask[t] = 0;
     m.phase[t] = kPhaseRootA;
@@ -242,7 +252,7 @@ __global__ __launch_bounds__(kWave) void k_mcts_expand(rc_mcts_t m, u32 max_stat
         return;
     }
     const int plen = m.path_len[t];
-    expand_leaf_wave(m, t, slot, lane, lut, max_states, ph == kPhaseRootA, m.path_node[(size_t)t * m.max_path + plen - 1]);
+    expand_leaf_wave(m, t, slot, lane, lut, max_states, ph == kPhaseRootA, m.path_node[path_at(m, t, plen - 1)]);
 }
 
 // ---- backup: P/V of the new children, W/N/L along the path (agents.py:555-571) ------------------
@@ -333,14 +343,17 @@ __device__ __forceinline__ bool backup_phase_done(const rc_mcts_t &m, u32 t, u32
 // (node, action) pair that occurs twice on the path only once; a mark bit reproduces that for any path length: first
 // every path edge is marked, then whoever finds the mark replaces it by old + 1.  Two threads that hold the same pair
 // write the same values, whichever of them runs first, so no ordering is needed inside a pass.
-__device__ __forceinline__ void backup_path(const rc_mcts_t &m, u32 tid, size_t base, const int *pnode, const u8 *pact, int plen,
-                                            float best, int nt = kBlock) {
+__device__ __forceinline__ void backup_path(const rc_mcts_t &m, u32 t, u32 tid, size_t base, int plen, float best, int nt = kBlock) {
     const int edges = plen - 1;
     constexpr int kMark = 1 << 30;
-    for (int i = tid; i < edges; i += nt) m.N[(base + pnode[i]) * kRow + pact[i]] |= kMark;
+    for (int i = tid; i < edges; i += nt) {
+        const size_t pi = path_at(m, t, i);
+        m.N[(base + m.path_node[pi]) * kRow + m.path_act[pi]] |= kMark;
+    }
     __syncthreads();
     for (int i = tid; i < edges; i += nt) {
-        const size_t e = (base + pnode[i]) * kRow + pact[i];
+        const size_t pi = path_at(m, t, i);
+        const size_t e = (base + m.path_node[pi]) * kRow + m.path_act[pi];
         const int nv = m.N[e];
         if (nv & kMark) m.N[e] = (nv & ~kMark) + 1;            // agents.py:568
         m.W[e] = fmaxf(m.W[e], best);                           // agents.py:562
@@ -358,16 +371,15 @@ __global__ __launch_bounds__(kBlock) void k_mcts_backup(rc_mcts_t m, const void 
     if (!m.expanded[t]) return;
     const size_t base = (size_t)t * (m.capacity + 1);
     const int plen = m.path_len[t];
-    const int *pnode = m.path_node + (size_t)t * m.max_path;
-    const u8 *pact = m.path_act + (size_t)t * m.max_path;
     const int phase = m.phase[t];
     if (tid < kWave) {
-        const float best = backup_children<HEAD>(m, t, slot, tid, base, pnode[plen - 1], phase & kPhaseMask, probs_or_head, values, ld, head_bf16);
+        const float best = backup_children<HEAD>(m, t, slot, tid, base, m.path_node[path_at(m, t, plen - 1)], phase & kPhaseMask, probs_or_head,
+                                                 values, ld, head_bf16);
         if (tid == 0) s_best = best;
     }
     __syncthreads();
     if (backup_phase_done(m, t, tid, phase)) return;
-    backup_path(m, tid, base, pnode, pact, plen, s_best);
+    backup_path(m, t, tid, base, plen, s_best);
 }
 
 // ---- select: PUCT descent with virtual loss (agents.py:575-595) ---------------------------------
@@ -621,16 +633,43 @@ __global__ __launch_bounds__(NT) void k_mcts_select(rc_mcts_t m, double c, u32 l
     const unsigned long long t_begin = wall_clock64();
     const u32 seq = (u32)m.iterations[t] & 0xFFFFu;   // number of the path this call builds (its expansion count)
     const size_t base = (size_t)t * (m.capacity + 1);
-    int *pnode = m.path_node + (size_t)t * m.max_path;
-    u8 *pact = m.path_act + (size_t)t * m.max_path;
     uint4 *rec = reinterpret_cast<uint4 *>(m.rec) + base * kRowRec;   // record of node n: rec[n * kRowRec]
     const int plen_old = m.path_len[t];
     const int phase = m.phase[t];
+    // The path this call works on: levels below W in LDS (s_node / s_act, chained by node through s_head / s_next), deeper levels
+    // where they lie in HBM (path_node / path_act, chained through path_next).  The reference's descent has no length limit
+    // (agents.py:575-595); a tree that deep is rare, so its deep levels cost a memory round trip where the others cost an LDS read.
+    const int W = (int)m.lds_levels;
+    auto P = [&](int k) { return path_at(m, t, k); };
+    auto node_at = [&](int k) -> int { return k < W ? s_node[k] : m.path_node[P(k)]; };
+    auto act_at = [&](int k) -> u32 { return k < W ? (u32)s_act[k] : (u32)m.path_act[P(k)]; };
+    auto next_at = [&](int k) -> int {
+        if (k < W) {
+            const u32 nx = s_next[k];
+            return nx == 0xFFFFu ? -1 : (int)nx;
+        }
+        return (int)m.path_next[P(k)];
+    };
+    auto put_node = [&](int k, int node) { if (k < W) s_node[k] = node; else m.path_node[P(k)] = node; };
+    auto put_act = [&](int k, u32 a) { if (k < W) s_act[k] = (u8)a; else m.path_act[P(k)] = (u8)a; };
+    auto put_next = [&](int k, int nx) { if (k < W) s_next[k] = (u16)nx; else m.path_next[P(k)] = (u32)nx; };   // (u16)-1 = 0xFFFF = none
+    // All levels lo .. hi - 1 enter the chains of their nodes: first the LDS levels, then the deep ones, so that the 16-bit links
+    // of the LDS levels only ever name LDS levels (or levels a line round appends right behind them).
+    auto chain_levels = [&](int lo, int hi) {
+        for (int k = lo + (int)tid; k < min(hi, W); k += NT) s_next[k] = (u16)atomicExch(&s_head[sel_hash(s_node[k])], k);
+        if (hi > W) {
+            __syncthreads();
+            for (int k = max(lo, W) + (int)tid; k < hi; k += NT) {
+                const size_t pk = P(k);
+                m.path_next[pk] = (u32)atomicExch(&s_head[sel_hash(m.path_node[pk])], k);
+            }
+        }
+    };
     if (MODE == 0 && (phase & kPhaseMask) != kPhaseNormal) return;   // a root's first descent follows its backup in ROOT_B
     if (MODE > 0 && backup) {
         if (tid < kWave) {
-            const float best = backup_children<MODE == 2>(m, t, slot, tid, base, pnode[plen_old - 1], phase & kPhaseMask, probs_or_head, values,
-                                                           ld, head_bf16);
+            const float best = backup_children<MODE == 2>(m, t, slot, tid, base, m.path_node[P(plen_old - 1)], phase & kPhaseMask, probs_or_head,
+                                                           values, ld, head_bf16);
             if (tid == 0) s_best = best;
         }
         if ((phase & kPhaseMask) != kPhaseNormal) {   // uniform over the workgroup
@@ -642,7 +681,7 @@ __global__ __launch_bounds__(NT) void k_mcts_select(rc_mcts_t m, double c, u32 l
         }
         if (!running) {   // the expansion ended the tree (a solved child): its backup is all that is left to do
             __syncthreads();
-            backup_path(m, tid, base, pnode, pact, plen_old, s_best, NT);
+            backup_path(m, t, tid, base, plen_old, s_best, NT);
             return;
         }
     } else if (MODE > 0 && (phase & kPhaseMask) != kPhaseNormal) {
@@ -658,7 +697,7 @@ __global__ __launch_bounds__(NT) void k_mcts_select(rc_mcts_t m, double c, u32 l
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
         const int k = (int)tid + i * NT;
-        const u32 *rp = reinterpret_cast<const u32 *>(m.N) + (base + (size_t)(k < plen_old ? pnode[k] : 0)) * kRow;
+        const u32 *rp = reinterpret_cast<const u32 *>(m.N) + (base + (size_t)(k < plen_old ? m.path_node[P(k)] : 0)) * kRow;
         pf[2 * i] = rp[0];
         pf[2 * i + 1] = rp[kRow / 2];
     }
@@ -667,50 +706,55 @@ __global__ __launch_bounds__(NT) void k_mcts_select(rc_mcts_t m, double c, u32 l
     const u32 rla = ract ? rl : 0;
     const int resume = m.pending[t];   // uniform over the workgroup: a suspended descent continues at its last node
     for (int i = tid; i < kSelHash; i += NT) s_head[i] = -1;
-    for (int k = tid; k < plen_old; k += NT) {
-        s_node[k] = pnode[k];
-        s_act[k] = (k < nlev) ? pact[k] : (u8)0;
+    for (int k = tid; k < min(plen_old, W); k += NT) {
+        const size_t pk = P(k);
+        s_node[k] = m.path_node[pk];
+        s_act[k] = (k < nlev) ? m.path_act[pk] : (u8)0;
     }
     if (tid == 0) s_first = nlev;
     __syncthreads();
-    for (int k = tid; k < nlev; k += NT) s_next[k] = (u16)atomicExch(&s_head[sel_hash(s_node[k])], k);
+    chain_levels(0, nlev);
     __syncthreads();
     if (!resume) {
         // Pass A: one lane per level, float32 with the acceptance rule of lane_pick.  Levels it cannot settle (near
         // ties, NaNs, loss counts beyond 5 bits) are flagged for pass B.
+        // The flags (bitmaps and lists in LDS) hold kMaxPath levels: a deeper path is re-validated kMaxPath levels at a time,
+        // window after window (a level's decision depends on the levels ABOVE it only through the premise that they kept
+        // their actions, and a node's rows are written by its FIRST level, which lies in this window or an earlier one).
+        const float c32v = (float)c;
+        const float best_up = MODE > 0 ? s_best : 0.f;
+      for (int wb = 0; wb <= nlev; wb += kMaxPath) {
+        const int wend = min(nlev, wb + kMaxPath - 1);   // last level of the window
         for (int i = tid; i < kMaxPath / 32; i += NT) s_unc[i] = s_late[i] = 0;
         if (tid == 0) s_nlate = s_nunc = 0;
         __syncthreads();
-        const float c32v = (float)c;
-        const float best_up = MODE > 0 ? s_best : 0.f;
         // late = false: every level (MODE 0), or the FIRST level of every node (MODE > 0), which also applies the backup
         //               to the node's rows and writes them back;
         // late = true : (MODE > 0) the later levels of nodes the path visits more than once, after a barrier: they must
         //               read the rows as the first level left them.
         auto decide = [&](int k, bool late) {
-            const int node = s_node[k];
-            const int arr = k > 0 ? (int)(s_act[k - 1] ^ 1) : -1;   // own arrival edge
+            const int node = node_at(k);
+            const int arr = k > 0 ? (int)(act_at(k - 1) ^ 1u) : -1;   // own arrival edge
             u64 cnt5 = 0;
             bool dup = false, ovf = false;
             u32 taken = 0;      // MODE > 0: actions the path takes at this node, over all its levels
             int first_lvl = k;  // ... and the first of those levels
-            for (int j = s_head[sel_hash(node)]; j >= 0;) {
-                if (s_node[j] == node) {
-                    taken |= 1u << s_act[j];
+            for (int j = s_head[sel_hash(node)]; j >= 0; j = next_at(j)) {
+                if (node_at(j) == node) {
+                    taken |= 1u << act_at(j);
                     first_lvl = min(first_lvl, j);
                     if (j < k) {
                         dup = true;
-                        cnt5_add(cnt5, ovf, (u32)s_act[j]);
-                        if (j > 0) cnt5_add(cnt5, ovf, (u32)(s_act[j - 1] ^ 1));
+                        cnt5_add(cnt5, ovf, act_at(j));
+                        if (j > 0) cnt5_add(cnt5, ovf, act_at(j - 1) ^ 1u);
                     }
                 }
-                const u32 nx = s_next[j];
-                j = nx == 0xFFFFu ? -1 : (int)nx;
             }
+            const int kw = k - wb;   // the level's place in the window's flags
             if (MODE > 0 && backup && !late && k != first_lvl) {
                 const int pos = atomicAdd(&s_nlate, 1);
-                if (pos < kLateCap) s_latelist[pos] = (u16)k;
-                else atomicOr(&s_late[k >> 5], 1u << (k & 31));
+                if (pos < kLateCap) s_latelist[pos] = (u16)kw;
+                else atomicOr(&s_late[kw >> 5], 1u << (kw & 31));
                 return;
             }
             const size_t r = (base + node) * kRow;
@@ -737,50 +781,55 @@ __global__ __launch_bounds__(NT) void k_mcts_select(rc_mcts_t m, double c, u32 l
             if (dup) d = lane_pick(e, cnt5, c2);
             if (c0 && c1 && c2 && !ovf) {
                 const u32 nb0 = (u32)m.nbr[r + b0], nb1 = (u32)m.nbr[r + b1];
-                rec[(size_t)node * kRowRec] = make_uint4(nb0, nb1, (u32)b0 | ((u32)b1 << 8),   // the old path is line seq - 1
-                                       line_tag((seq - 1) & 0xFFFFu, k, k < nlev ? (u32)s_act[k] : kNoAct));
-                if (k < nlev && d != (int)s_act[k]) atomicMin(&s_first, k);
+                const u32 a_k = k < nlev ? act_at(k) : kNoAct;
+                // the old path is line seq - 1 (its first ring_levels levels: the tag has 12 bits of level; deeper levels keep the
+                // tag they have, which then names some older line -- a tag only ever proposes candidates)
+                const u32 tagw = k < (int)m.ring_levels ? line_tag((seq - 1) & 0xFFFFu, k, a_k) : reinterpret_cast<const u32 *>(rec + (size_t)node * kRowRec)[3];
+                rec[(size_t)node * kRowRec] = make_uint4(nb0, nb1, (u32)b0 | ((u32)b1 << 8), tagw);
+                if (k < nlev && d != (int)a_k) atomicMin(&s_first, k);
             } else {
                 const int pos = atomicAdd(&s_nunc, 1);
-                if (pos < kUncCap) s_unclist[pos] = (u16)k;   // (the list is written up to its size; pass B reads it only while nunc <= unc_cap)
-                atomicOr(&s_unc[k >> 5], 1u << (k & 31));
+                if (pos < kUncCap) s_unclist[pos] = (u16)kw;   // (the list is written up to its size; pass B reads it only while nunc <= unc_cap)
+                atomicOr(&s_unc[kw >> 5], 1u << (kw & 31));
             }
         };
-        for (int k = tid; k <= nlev; k += NT) decide(k, false);
+        for (int k = wb + (int)tid; k <= wend; k += NT) decide(k, false);
         if (MODE > 0 && backup) {
             __syncthreads();
             const int nlate = s_nlate;
-            for (int i = tid; i < min(nlate, kLateCap); i += NT) decide((int)s_latelist[i], true);
+            for (int i = tid; i < min(nlate, kLateCap); i += NT) decide(wb + (int)s_latelist[i], true);
             if (nlate > kLateCap)   // the overflow, by the bitmap: each group of 32 lanes takes a word of flags
-                for (int k0 = 32 * (int)(tid >> 5); k0 <= nlev; k0 += 32 * (NT / 32))
-                    if ((s_late[k0 >> 5] >> (tid & 31)) & 1u) decide(k0 + (int)(tid & 31), true);
+                for (int k0 = 32 * (int)(tid >> 5); wb + k0 <= wend; k0 += 32 * (NT / 32))
+                    if ((s_late[k0 >> 5] >> (tid & 31)) & 1u) decide(wb + k0 + (int)(tid & 31), true);
         }
         __syncthreads();
         // Pass B: the flagged levels in float64, NumPy's evaluation order, one 16-lane row per level.
         const int nunc = s_nunc;
         const bool by_list = nunc <= (int)unc_cap;   // else: scan the bitmap, kStep = NT / 16 levels per step (one 16-lane row each)
         constexpr int kStep = NT / 16;                // 16 / 32 / 64: a quarter of a flag word, one word, two words
-        for (int i0 = 0; i0 < (by_list ? nunc : nlev + 1); i0 += kStep) {
+        for (int i0 = 0; i0 < (by_list ? nunc : wend - wb + 1); i0 += kStep) {
             if (!by_list) {                           // skip steps without a flagged level (uniform over the workgroup)
                 const u32 w0 = s_unc[i0 >> 5];
                 const u32 any = kStep == 16 ? ((w0 >> (i0 & 31)) & 0xFFFFu) : kStep == 32 ? w0 : (w0 | s_unc[(i0 >> 5) + 1]);
                 if (any == 0) continue;
             }
             const int i = i0 + (int)row;
-            const int k = by_list ? (i < nunc ? (int)s_unclist[i] : nlev + 1) : i;
-            const bool live = k <= nlev && ((s_unc[k >> 5] >> (k & 31)) & 1u);
-            const int node = live ? s_node[k] : 0;
-            u32 cnt = (live && k > 0 && (u32)(s_act[k - 1] ^ 1) == rl) ? 1u : 0u;   // own arrival edge
+            const int kw = by_list ? (i < nunc ? (int)s_unclist[i] : kMaxPath) : i;   // place in the window (kMaxPath = none)
+            const int k = wb + kw;
+            const bool live = kw < kMaxPath && k <= wend && ((s_unc[kw >> 5] >> (kw & 31)) & 1u);
+            const int node = live ? node_at(k) : 0;
+            const u32 arr_k = (live && k > 0) ? (act_at(k - 1) ^ 1u) : 255u;
+            const u32 act_k = (live && k < nlev) ? act_at(k) : kNoAct;
+            u32 cnt = arr_k == rl ? 1u : 0u;   // own arrival edge
             bool dup = false;
             int j = live ? s_head[sel_hash(node)] : -1;
             while (j >= 0) {
-                if (j < k && s_node[j] == node) {
+                if (j < k && node_at(j) == node) {
                     dup = true;
-                    cnt += (u32)s_act[j] == rl;
-                    if (j > 0) cnt += (u32)(s_act[j - 1] ^ 1) == rl;
+                    cnt += act_at(j) == rl;
+                    if (j > 0) cnt += (act_at(j - 1) ^ 1u) == rl;
                 }
-                const u32 nx = s_next[j];
-                j = nx == 0xFFFFu ? -1 : (int)nx;
+                j = next_at(j);
             }
             const size_t r = (base + node) * kRow + rla;
             const int n_a = m.N[r], nb = m.nbr[r];
@@ -794,24 +843,25 @@ __global__ __launch_bounds__(NT) void k_mcts_select(rc_mcts_t m, double c, u32 l
             const int b1 = row16_argmax_first(s1, idx);
             const double sx = ract ? ud + ((double)w_f - 100.0 * (double)cnt) : -INFINITY;
             const int bx = row16_argmax_first(sx, idx);
-            const int d = dup ? bx : (live && k > 0 && (int)(s_act[live && k > 0 ? k - 1 : 0] ^ 1) == b0) ? b1 : b0;
+            const int d = dup ? bx : (int)arr_k == b0 ? b1 : b0;
             const u32 lane0 = (tid & 63u) & ~15u;
             const int nb0 = __builtin_amdgcn_ds_bpermute((int)((lane0 + (u32)b0) << 2), nb);
             const int nb1 = __builtin_amdgcn_ds_bpermute((int)((lane0 + (u32)b1) << 2), nb);
             if (live && rl == 0) {
-                rec[(size_t)node * kRowRec] = make_uint4((u32)nb0, (u32)nb1, (u32)b0 | ((u32)b1 << 8),
-                                       line_tag((seq - 1) & 0xFFFFu, k, k < nlev ? (u32)s_act[k] : kNoAct));
-                if (k < nlev && d != (int)s_act[k]) atomicMin(&s_first, k);
+                const u32 tagw = k < (int)m.ring_levels ? line_tag((seq - 1) & 0xFFFFu, k, act_k) : reinterpret_cast<const u32 *>(rec + (size_t)node * kRowRec)[3];
+                rec[(size_t)node * kRowRec] = make_uint4((u32)nb0, (u32)nb1, (u32)b0 | ((u32)b1 << 8), tagw);
+                if (k < nlev && d != (int)act_k) atomicMin(&s_first, k);
             }
         }
         __syncthreads();
+      }
         if (((pf[0] ^ pf[1] ^ pf[2] ^ pf[3]) + (pf[4] ^ pf[5] ^ pf[6] ^ pf[7])) == 0x5EED1234u && nlev < 0) s_first = 0;   // never true: keeps the requests above alive
         const int first = s_first;
         // (the kept prefix's virtual losses, agents.py:589-591, are implied by the path: see the note on L at the top)
         if (first < nlev) {   // from here on the chains hold the kept levels only; the walk appends its own
             for (int i = tid; i < kSelHash; i += NT) s_head[i] = -1;
             __syncthreads();
-            for (int k = tid; k < first; k += NT) s_next[k] = (u16)atomicExch(&s_head[sel_hash(s_node[k])], k);
+            chain_levels(0, first);
         }
     }
     __syncthreads();   // also: the records written above are visible to wave 0 from here on
@@ -849,14 +899,12 @@ __global__ __launch_bounds__(NT) void k_mcts_select(rc_mcts_t m, double c, u32 l
         u32 d_i = (arr_i ^ 1u) == rb0 ? rb1 : rb0;
         u64 cnt5 = 0;
         bool again = false, unsure = false;
-        for (int j = in_line ? s_head[sel_hash(node_i)] : -1; j >= 0;) {   // earlier visits in the chains (levels <= kb)
-            if (s_node[j] == node_i) {
+        for (int j = in_line ? s_head[sel_hash(node_i)] : -1; j >= 0; j = next_at(j)) {   // earlier visits in the chains (levels <= kb)
+            if (node_at(j) == node_i) {
                 again = true;
-                cnt5_add(cnt5, unsure, (u32)s_act[j]);
-                if (j > 0) cnt5_add(cnt5, unsure, (u32)(s_act[j - 1] ^ 1));
+                cnt5_add(cnt5, unsure, act_at(j));
+                if (j > 0) cnt5_add(cnt5, unsure, act_at(j - 1) ^ 1u);
             }
-            const u32 nx = s_next[j];
-            j = nx == 0xFFFFu ? -1 : (int)nx;
         }
         const u32 hb = ((u32)node_i * 0x9E3779B1u) >> 25;
         if (in_line) {
@@ -903,9 +951,9 @@ __global__ __launch_bounds__(NT) void k_mcts_select(rc_mcts_t m, double c, u32 l
         }
         if (gl < total) {   // the leading run of levels that follow the line is appended
             const int kk = kb + 1 + gl;
-            s_node[kk] = node_i;
-            s_act[kk] = (u8)act_i;
-            s_next[kk] = (u16)atomicExch(&s_head[sel_hash(node_i)], kk);
+            put_node(kk, node_i);
+            put_act(kk, act_i);
+            put_next(kk, atomicExch(&s_head[sel_hash(node_i)], kk));
         }
         return total;
     };
@@ -931,9 +979,10 @@ __global__ __launch_bounds__(NT) void k_mcts_select(rc_mcts_t m, double c, u32 l
     const u32 la = act ? lane : 0;
     const int start = s_first;
     const TreeBufs tb = tree_bufs(m, base);
-    const int max_path = (int)m.max_path;
-    int cur = __builtin_amdgcn_readfirstlane(s_node[start]), plen = start + 1;
-    int prev_act = start > 0 ? __builtin_amdgcn_readfirstlane((int)s_act[start - 1]) : -1;   // action that led to `cur`
+    const int max_path = path_limit(m, t);                    // levels the path arrays can take right now
+    const int ring_levels = (int)m.ring_levels;
+    int cur = __builtin_amdgcn_readfirstlane(node_at(start)), plen = start + 1;
+    int prev_act = start > 0 ? __builtin_amdgcn_readfirstlane((int)act_at(start - 1)) : -1;   // action that led to `cur`
     u32 walked = 0;
     int stop = 0;
     const float c32 = (float)c;
@@ -945,17 +994,15 @@ __global__ __launch_bounds__(NT) void k_mcts_select(rc_mcts_t m, double c, u32 l
         // The revisit test of this level needs the path only, so it runs while the node's record (requested a level ago) is
         // still in flight; a revisited node needs its rows for a full evaluation, and they are requested here, next to the
         // record instead of after it: loops through transpositions cost one memory round trip per level, not two.
-        s_node[k] = cur;   // every lane stores the same value: no exec-mask detour
+        put_node(k, cur);   // every lane stores the same value: no exec-mask detour
         u32 cnt = (prev_act >= 0 && (u32)(prev_act ^ 1) == lane) ? 1u : 0u;   // own arrival: L[cur, rev(a_prev)] += nu (agents.py:591)
         bool visited = false;
-        for (int j = head; j >= 0;) {   // earlier visits of `cur` in this descent: departure edge a_j, arrival edge rev(a_{j-1})
-            if (s_node[j] == cur) {
+        for (int j = head; j >= 0; j = next_at(j)) {   // earlier visits of `cur` in this descent: departure edge a_j, arrival edge rev(a_{j-1})
+            if (node_at(j) == cur) {
                 visited = true;
-                cnt += (u32)s_act[j] == lane;
-                if (j > 0) cnt += (u32)(s_act[j - 1] ^ 1) == lane;
+                cnt += act_at(j) == lane;
+                if (j > 0) cnt += (act_at(j - 1) ^ 1u) == lane;
             }
-            const u32 nx = s_next[j];
-            j = nx == 0xFFFFu ? -1 : (int)nx;
         }
         NodeRows rows_cur = {0, 0, 0.f, 0.f};
         if (visited) rows_cur = load_rows(tb, cur, la);   // wave-uniform
@@ -979,9 +1026,9 @@ __global__ __launch_bounds__(NT) void k_mcts_select(rc_mcts_t m, double c, u32 l
             next = __builtin_amdgcn_readlane(r.nb, arg);
             ++revisits;
         }
-        s_next[k] = (u16)head;   // LDS operations of one wave are ordered: later levels see this entry
+        put_next(k, head);   // the memory operations of one wave are ordered: later levels see this entry
         s_head[h] = k;
-        s_act[k] = (u8)arg;
+        put_act(k, (u32)arg);
         // Line following.  If this node lay on one of the tree's last ring_k descent paths and left it by the same
         // action, the levels that followed it there are the likely continuation: up to 64 of them are checked at
         // once, one lane per level, under the premise that the levels above in the segment follow the line too.  A
@@ -997,7 +1044,7 @@ __global__ __launch_bounds__(NT) void k_mcts_select(rc_mcts_t m, double c, u32 l
         int room = max_path - plen - 1;
         if (level_budget) room = min(room, (int)level_budget - (int)walked);
         if (!visited && tseq != 0 && age >= 1 && age <= ring_k && (tag & 15u) == (u32)arg && room > 0) {
-            const size_t line = ((size_t)t * ring_k + (tseq & (ring_k - 1))) * (size_t)max_path;
+            const size_t line = ((size_t)t * ring_k + (tseq & (ring_k - 1))) * (size_t)ring_levels;
             const int llen = m.ring_len[(size_t)t * ring_k + (tseq & (ring_k - 1))];
             int lpos = (int)((tag >> 4) & 0xFFFu) + 1;   // line position that lane 0 checks
             int kb = k;                                   // lane i checks level kb + 1 + i
@@ -1057,14 +1104,12 @@ __global__ __launch_bounds__(NT) void k_mcts_select(rc_mcts_t m, double c, u32 l
                 // earlier visits of the lane's node: in the chains (levels <= kb) ...
                 u64 cnt5 = 0;
                 bool again = false, unsure = false;
-                for (int j = in_line ? s_head[sel_hash(node_i)] : -1; j >= 0;) {
-                    if (s_node[j] == node_i) {
+                for (int j = in_line ? s_head[sel_hash(node_i)] : -1; j >= 0; j = next_at(j)) {
+                    if (node_at(j) == node_i) {
                         again = true;
-                        cnt5_add(cnt5, unsure, (u32)s_act[j]);
-                        if (j > 0) cnt5_add(cnt5, unsure, (u32)(s_act[j - 1] ^ 1));
+                        cnt5_add(cnt5, unsure, act_at(j));
+                        if (j > 0) cnt5_add(cnt5, unsure, act_at(j - 1) ^ 1u);
                     }
-                    const u32 nx = s_next[j];
-                    j = nx == 0xFFFFu ? -1 : (int)nx;
                 }
                 // ... and among the lanes above (they follow the line by premise: departure act_j, arrival rev(arr_j)): the lanes
                 // of the segment are chained by node bucket in LDS, and every lane walks its bucket's (short) list.
@@ -1100,9 +1145,9 @@ __global__ __launch_bounds__(NT) void k_mcts_select(rc_mcts_t m, double c, u32 l
                 revisits += __popcll(__ballot(again) & ((q < kWave ? (1ull << q) : 0ull) - 1ull));
                 if ((int)lane < q) {
                     const int kk = kb + 1 + (int)lane;
-                    s_node[kk] = node_i;
-                    s_act[kk] = (u8)act_i;
-                    s_next[kk] = (u16)atomicExch(&s_head[sel_hash(node_i)], kk);
+                    put_node(kk, node_i);
+                    put_act(kk, act_i);
+                    put_next(kk, atomicExch(&s_head[sel_hash(node_i)], kk));
                 }
                 total += q;
                 if (q > 0) {
@@ -1158,24 +1203,30 @@ __global__ __launch_bounds__(NT) void k_mcts_select(rc_mcts_t m, double c, u32 l
         if (lane == 0) s_mb[MB_CMD] = 0;
         __syncthreads();   // command: the helpers leave
     }
-    if (stop == 2 && lane == 0) m.status[t] = RC_MCTS_PATH_OVERFLOW;
-    const int suspended = stop == 3;   // out of budget at a non-leaf: resume here next call
-    // the walked levels go to memory (the path carries their virtual losses, agents.py:589-591)
-    for (int k = start + (int)lane; k < plen; k += kWave) {
-        if (k > start) pnode[k] = s_node[k];
-        if (k < plen - 1) pact[k] = (u8)s_act[k];
+    // The path store is full.  If that is the memory behind this tree's path blocks (path_rows), the descent is suspended like one
+    // that ran out of its level budget: the host maps the next block, a later call resumes.  Only the end of the store itself ends
+    // the tree (the reference has no such limit, agents.py:575-595: max_path is the caller's resource bound).
+    if (stop == 2 && max_path >= (int)m.max_path && lane == 0) m.status[t] = RC_MCTS_PATH_OVERFLOW;
+    const int suspended = stop == 3 || (stop == 2 && max_path < (int)m.max_path);   // resume here next call
+    // the walked levels go to memory (the path carries their virtual losses, agents.py:589-591); the deep ones are there already
+    for (int k = start + (int)lane; k < min(plen, W); k += kWave) {
+        const size_t pk = P(k);
+        if (k > start) m.path_node[pk] = s_node[k];
+        if (k < plen - 1) m.path_act[pk] = (u8)s_act[k];
     }
-    // the whole path becomes line `seq` of the ring, and every node on it is tagged with its place there
+    // the path's first ring_levels levels become line `seq` of the ring, and every node on them is tagged with its place there
     if (seq != 0) {
         const size_t slot = (size_t)t * ring_k + (seq & (ring_k - 1));
         u32 *rec_w = reinterpret_cast<u32 *>(m.rec) + base * kRow + 3;
-        for (int k = (int)lane; k < plen; k += kWave) {
-            const u32 a = k < plen - 1 ? (u32)s_act[k] : kNoAct;
-            m.ring_node[slot * max_path + k] = s_node[k];
-            m.ring_act[slot * max_path + k] = (u8)a;
-            rec_w[(size_t)s_node[k] * kRow] = line_tag(seq, k, a);
+        const int llen = min(plen, ring_levels);
+        for (int k = (int)lane; k < llen; k += kWave) {
+            const u32 a = k < plen - 1 ? act_at(k) : kNoAct;
+            const int nk = node_at(k);
+            m.ring_node[slot * ring_levels + k] = nk;
+            m.ring_act[slot * ring_levels + k] = (u8)a;
+            rec_w[(size_t)nk * kRow] = line_tag(seq, k, a);
         }
-        if (lane == 0) m.ring_len[slot] = plen;
+        if (lane == 0) m.ring_len[slot] = llen;
     }
     if (lane == 0) {
         if (m.select_stats) {
@@ -1317,13 +1368,16 @@ __global__ __launch_bounds__(kBlock) void k_mcts_shorten(rc_mcts_t m) {
     }
     __syncthreads();
     if (tid == 0 && s_done) {   // walk the parent pointers back to the root, then reverse
-        u8 *out = m.short_act + (size_t)t * m.max_path;
+        // (the shortest path is never longer than the tree's last descent path + its solving move, whose levels have memory)
+        u8 *out = m.short_act;
+        const int cap = path_limit(m, t);
         int len = 0;
-        for (int v = solved; v != 1 && len < (int)m.max_path; v = claim[2 * v + 1] >> 4) out[len++] = (u8)(claim[2 * v + 1] & 15);
+        for (int v = solved; v != 1 && len < cap; v = claim[2 * v + 1] >> 4) out[path_at(m, t, len++)] = (u8)(claim[2 * v + 1] & 15);
         for (int i = 0; i < len / 2; ++i) {
-            const u8 x = out[i];
-            out[i] = out[len - 1 - i];
-            out[len - 1 - i] = x;
+            const size_t pa = path_at(m, t, i), pb = path_at(m, t, len - 1 - i);
+            const u8 x = out[pa];
+            out[pa] = out[pb];
+            out[pb] = x;
         }
         m.short_len[t] = len;
     }
@@ -1387,7 +1441,11 @@ static int check_mcts(const rc_mcts_t *m, bool results_only_ok = false) {
                    m->pending && m->path_act && m->child_soa && m->child_idx && m->new_mask && m->expanded && m->rec && m->ring_node && m->ring_act &&
                    m->ring_len && m->phase,
                RC_ERR_NULL);
-    RC_REQUIRE(m->n_trees > 0 && m->capacity >= 13 && m->max_path >= 2 && m->max_path <= (uint32_t)kMaxPath, RC_ERR_RANGE);
+    RC_REQUIRE(m->n_trees > 0 && m->capacity >= 13 && m->max_path >= 2 && m->max_path < (1u << 30), RC_ERR_RANGE);
+    // the blocked path arrays: whole blocks; the first lds_levels levels of a path are worked on in LDS, the first ring_levels kept as lines
+    RC_REQUIRE(m->path_block_log2 >= 1 && m->path_block_log2 <= 24 && (m->max_path & ((1u << m->path_block_log2) - 1u)) == 0, RC_ERR_RANGE);
+    RC_REQUIRE(m->lds_levels >= 1 && m->lds_levels <= (uint32_t)kMaxPath && m->ring_levels >= 1 && m->ring_levels <= (uint32_t)kMaxPath, RC_ERR_RANGE);
+    RC_REQUIRE(results_only_ok || m->path_next != nullptr, RC_ERR_NULL);
     // the kernels address a tree's node records through 32-bit buffer resources: (capacity + 1) * 256 bytes must stay below 2^32
     RC_REQUIRE(m->capacity + 1 < (1u << 24), RC_ERR_RANGE);   // a tree's node records are addressed by 32-bit byte offsets (tree_bufs)
     RC_REQUIRE(m->active == nullptr || (m->n_active >= 1 && m->n_active <= m->n_trees), RC_ERR_RANGE);

@@ -102,6 +102,11 @@ class QueueTable:
     def put(self, g: int, other: "QueueTable", i: int):
         self._rows[g], self._lens[g] = other._rows[i], other._lens[i]
 
+    def set_row(self, g: int, acts: np.ndarray):
+        """Game g's queue from an array of its own (a queue longer than the rows of the shared array)."""
+        arr = np.ascontiguousarray(acts, dtype=np.uint8).reshape(1, -1)
+        self._rows[g], self._lens[g] = (arr, 0), arr.shape[1]
+
     def lengths(self) -> np.ndarray:
         return self._lens
 
@@ -151,6 +156,13 @@ class BatchResult:
     @property
     def states_per_sec(self) -> float:
         return float(self.nodes.sum()) / max(self.seconds, 1e-12)
+
+    @property
+    def path_overflow_trees(self) -> int:
+        """Trees that ended because a descent filled the path store (status PATH_OVERFLOW).  The reference has no such limit
+        (agents.py:575-595): with the default store (MCTS(max_path=None)) this is HBM / address space running out and is 0 in
+        every run on record; a caller who bounds the store (max_path=...) reads here what that bound cost."""
+        return int((np.asarray(self.status) == md.PATH_OVERFLOW).sum())
 
     def select(self, mask: np.ndarray) -> "BatchResult":
         idx = np.flatnonzero(mask)
@@ -255,13 +267,15 @@ class _Harvest:
         results, where they lie; games[i] is the game of trees[i].  trees_host: the same list on the host (a forest whose rows
         are mapped on demand gives the BFS scratch of exactly these trees its memory)."""
         self.games, self.graph = games, agent.search_graph
+        # (the first block of the blocked path arrays: a queue longer than that -- rare -- is fetched by `result`)
         src = {"status": forest.status, "nodes": forest.n_nodes, "iterations": forest.iterations,
-               "plen": forest.path_len, "sol": forest.solved_action, "pact": forest.path_act}
+               "plen": forest.path_len, "sol": forest.solved_action, "pact": forest.path_act[0]}
         if self.graph:
             forest.complete_graphs(trees)       # _complete_graph of all solved trees in one launch
             forest.shorten_launch(trees, trees_host)   # ... and their BFS shortening in another
-            src["slen"], src["sact"] = forest.short_len, forest.short_act
+            src["slen"], src["sact"] = forest.short_len, forest.short_act[0]
         self.host, self.n = {}, (forest.B if n is None else n) if trees is None else int(trees.numel())
+        self.tree_ids = np.arange(self.n) if trees is None else np.asarray(trees_host, dtype=np.int64)
         pick = None if trees is None else trees.long()
         # the list is read by kernels queued on THIS (side) stream; it was allocated under another one, whose allocator would hand
         # the block out again the moment the caller drops it: it lives as long as this harvest, and the allocator is told as well
@@ -284,17 +298,31 @@ class _Harvest:
         h = {k: v.numpy()[:self.n] for k, v in self.host.items()}
         status, plen = h["status"].astype(np.int64), h["plen"].astype(np.int64)
         acts = h["pact"].copy()
+        width = acts.shape[1]                             # one path block
         lens = plen - 1                                   # the actions taken: the best guess of an unsolved tree (agents.py:492)
         won = np.flatnonzero(status == md.SOLVED)
-        acts[won, plen[won] - 1] = h["sol"][won]          # agents.py:483
+        fits = won[plen[won] <= width]
+        acts[fits, plen[fits] - 1] = h["sol"][fits]       # agents.py:483
         lens[won] = plen[won]
+        shortened = np.zeros(len(status), dtype=bool)
         if self.graph and len(won):
             short = won[h["slen"][won] >= 0]
             acts[short] = h["sact"][short]
             lens[short] = h["slen"][short]
+            shortened[short] = True
         lens[status == md.ROOT_SOLVED] = 0
         solved = (status == md.SOLVED) | (status == md.ROOT_SOLVED)
-        out = BatchResult(solved, np.where(solved, lens, -1), h["nodes"].astype(np.int64), QueueTable(acts, lens), 0.0,
+        queues = QueueTable(acts, lens)
+        for i in np.flatnonzero(lens > width):            # a queue that goes beyond the first path block: read where it lies
+            t = int(self.tree_ids[i])
+            if shortened[i]:
+                q = self.forest.read_path("short_act", t, lens[i])
+            else:
+                q = self.forest.read_path("path_act", t, plen[i] - 1)
+                if status[i] == md.SOLVED:
+                    q = np.append(q, np.uint8(h["sol"][i]))
+            queues.set_row(int(i), q)
+        out = BatchResult(solved, np.where(solved, lens, -1), h["nodes"].astype(np.int64), queues, 0.0,
                           h["iterations"].astype(np.int64), status)
         for name, t in self.host.items():
             self._pinned[(t.shape[0], tuple(t.shape[1:]), t.dtype)].append(t)
@@ -310,7 +338,7 @@ class MCTS(DeepAgent):
     refill_level_budget = 0    # new levels per descent and iteration while scrambles wait for a slot (0 = no limit)
 
     def __init__(self, net, c: float, search_graph: bool, net_dtype=F32_SPLIT, use_graph: bool = True,
-                 max_path: int = 4096, sync_every: int = 16, level_budget="auto", deterministic: bool = False):
+                 max_path: int = None, sync_every: int = 16, level_budget="auto", deterministic: bool = False):
         """
         deterministic: bit-reproducible searches.  The default engines pick a layer plan by row count (whole-K tiles, K cut into
         2..32 chunks), so a state's network outputs carry rounding that depends on how many states share its launch, and a near-tie
@@ -318,10 +346,12 @@ class MCTS(DeepAgent):
         deterministic=True the split engine runs ONE plan for every row count (`SplitF32Net(deterministic=True)`): a game searched
         alone, in a batch, on fewer `slots` or in a narrowed forest builds the same tree, bit for bit (tests/test_full_size_gpu.py).
         It costs throughput at both ends of the row-count range: see DESIGN.md section 3.3 for the measured figures.
-        max_path: longest PUCT descent a tree may make (the reference has no limit; a tree that would exceed it
-        ends unsolved with status PATH_OVERFLOW).  With the ADI-trained net, 39 of 1 024 depth-20 trees needed
-        more than 1 024 levels and none more than 2 048 (longest solution found: 804 moves); 4 096 is the
-        maximum the select kernel stages in LDS.
+        max_path: None (default) = PUCT descents of any length, as in the reference (agents.py:575-595): the select kernel works
+        on a path's first 4 096 levels in LDS and on deeper ones where they lie in HBM, and the path arrays get memory block by
+        block for the trees that go that deep (`MCTSForest.ensure_path`).  A number bounds the path store instead (a resource
+        bound the reference does not have: a tree whose descent fills it ends unsolved with status PATH_OVERFLOW, counted in
+        `BatchResult.path_overflow_trees`).  With the ADI-trained net, 39 of 1 024 depth-20 trees needed more than 1 024
+        levels and none more than 2 048 (longest solution found: 804 moves).
         level_budget: how many NEW tree levels a PUCT descent may walk per lock-step iteration before it is
         suspended until the next one (0 = unlimited).  Every tree still performs exactly the reference's
         sequence of iterations; a budget only stops the deepest descent of the batch from pacing all trees.
@@ -573,9 +603,22 @@ class MCTSRun:
             if len(idx_np) == 0:
                 self.stats["harvests"] += 1
                 return
+        deep = forest.paths_seen[idx_np] > forest.path_block   # a last path beyond the first block: not into the (one-block) grave
+        if deep.any():
+            sub = forest.subset(idx_np[deep], results_only=True)
+            ev = torch.cuda.Event()
+            ev.record()
+            with torch.cuda.stream(self.side):
+                self.side.wait_event(ev)
+                self.harvests.append(_Harvest(agent, sub, games[deep]))
+            idx_np, games = idx_np[~deep], games[~deep]
+            if len(idx_np) == 0:
+                self.stats["harvests"] += 1
+                return
         if len(idx_np) < self.GRAVE // 2:
             if self.grave is None:
-                self.grave = md.MCTSForest(self.GRAVE, forest.C, forest.max_path, forest.device, _results_only=True, vmm=False)
+                self.grave = md.MCTSForest(self.GRAVE, forest.C, forest.path_block, forest.device, _results_only=True, vmm=False,
+                                           path_block=forest.path_block, lds_levels=forest.lds_levels, ring_levels=forest.ring_levels)
                 self.grave_games = np.zeros(self.GRAVE, dtype=np.int64)
             if self.grave_fill + len(idx_np) > self.GRAVE:
                 self._flush_grave()
@@ -622,6 +665,7 @@ class MCTSRun:
                 # round and one more can reach (forests mapped on demand; otherwise only the counts are noted)
                 queued = self.it - it_then
                 forest.grow(st_host[1].numpy(), queued + 2 * agent.sync_every)
+                forest.grow_paths(st_host[2].numpy())      # ... and the next path block for the trees whose descents near the end of theirs
                 forest._steps_covered = 2 * agent.sync_every
                 self.stats["mapped_gb"] = round(forest.bytes_allocated() / 1e9, 2)
             self._act_on(qi, f_snap, st_host[0])
@@ -689,6 +733,7 @@ class MCTSRun:
         torch.cuda.synchronize()
         seconds = agent.tt.tock()
         forest.grow(forest.n_nodes.cpu().numpy(), 0)     # the final node counts (what result extraction reads of a tree)
+        forest.grow_paths(forest.path_len.cpu().numpy())  # ... and path lengths
         left = np.flatnonzero(owner >= 0)
         if len(left) == forest.B:
             self._snapshot(left)

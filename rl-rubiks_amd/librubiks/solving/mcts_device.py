@@ -37,7 +37,9 @@ class _McStruct(Structure):   # mirrors rc_mcts_t (include/rubiks_hip.h)
                [(name, c_void_p) for name in ("child_idx", "new_mask", "expanded", "select_stats", "bfs", "short_act",
                                               "short_len", "rec")] + \
                [("ring_k", c_uint32)] + [(name, c_void_p) for name in ("ring_node", "ring_act", "ring_len", "phase", "active")] + \
-               [("n_active", c_uint32), ("unc_list_cap", c_uint32), ("mapped_rows", c_void_p)]
+               [("n_active", c_uint32), ("unc_list_cap", c_uint32), ("mapped_rows", c_void_p)] + \
+               [("path_block_log2", c_uint32), ("lds_levels", c_uint32), ("ring_levels", c_uint32), ("path_next", c_void_p),
+                ("path_rows", c_void_p)]
 
 
 _hip.register({
@@ -68,11 +70,22 @@ def unpack_keys(keys: np.ndarray) -> np.ndarray:
 
 
 _PER_NODE = ("keys", "node", "V", "leaf")
-_PER_TREE = ("n_nodes", "status", "solved_idx", "solved_action", "iterations", "path_len", "pending", "path_node", "path_act",
-             "ring_node", "ring_act", "ring_len", "phase")
+_PER_TREE = ("n_nodes", "status", "solved_idx", "solved_action", "iterations", "path_len", "pending", "ring_node", "ring_act", "ring_len",
+             "phase")
+_PATH_ARRAYS = {"path_node": torch.int32, "path_act": torch.uint8, "path_next": torch.int32, "short_act": torch.uint8}
 _RESULT_NODE = ("keys", "nbr", "leaf")          # what rc_mcts_complete_graph / rc_mcts_shorten read of a tree (65 B per node)
-_RESULT_TREE = ("n_nodes", "status", "solved_idx", "solved_action", "iterations", "path_len", "pending", "path_act", "phase")
+_RESULT_TREE = ("n_nodes", "status", "solved_idx", "solved_action", "iterations", "path_len", "pending", "phase")
 RING_K = 32   # descent paths kept per tree for line following (rc_mcts_t::ring_k)
+# The descent path of a tree has no length limit in the reference (agents.py:575-595).  The path arrays are blocked
+# (rc_mcts_t: [blocks][B][PATH_BLOCK]); block 0 always has memory, deeper blocks are address space that gets memory for the
+# trees that go that deep (`MCTSForest.ensure_path`).  MAX_PATH_LEVELS is the address space a tree's path can grow into.
+# RUBIKS_PATH_BLOCK / RUBIKS_LDS_LEVELS / RUBIKS_RING_LEVELS shrink the block, the levels rc_mcts_select works on in LDS and the
+# levels kept per ring line: tests drive the deep-path code with the reference's recorded (shallow) trees that way; results
+# do not depend on any of them.
+PATH_BLOCK = int(os.environ.get("RUBIKS_PATH_BLOCK", "4096"))
+LDS_LEVELS = int(os.environ.get("RUBIKS_LDS_LEVELS", "4096"))
+RING_LEVELS = int(os.environ.get("RUBIKS_RING_LEVELS", "4096"))
+MAX_PATH_LEVELS = 1 << 20
 ROWS = 11    # network rows per tree and iteration (rc_mcts_t::rows_per_tree)
 MIN_RUNG = 32     # smallest launch size a running forest is narrowed to (32 trees = 352 network rows = one GEMM row tile)
 NODE_WORDS = 64   # 32-bit words per node record (RC_MCTS_NODE_WORDS): line 0 = N | W | walk record, line 1 = P | nbr
@@ -152,8 +165,13 @@ class MCTSForest:
         first = cls.GROW_ROWS * (2 if n_trees <= cls.PREGROW_TREES else 1)
         return n_trees * (capacity + 1) * NODE_WORDS * 4 >= cls.VMM_MIN_BYTES and capacity + 1 >= 2 * first
 
-    def __init__(self, n_trees: int, capacity: int, max_path: int = 4096, device=None, _results_only: bool = False, vmm: bool = None):
-        """vmm: per-node arrays as reserved address ranges with memory mapped behind the rows in use (`grow`); None = by size."""
+    def __init__(self, n_trees: int, capacity: int, max_path: int = None, device=None, _results_only: bool = False, vmm: bool = None,
+                 path_block: int = None, lds_levels: int = None, ring_levels: int = None):
+        """vmm: per-node arrays as reserved address ranges with memory mapped behind the rows in use (`grow`); None = by size.
+        max_path: None (the default) = descents of any length, as in the reference (agents.py:575-595): the path arrays reserve
+        address space for MAX_PATH_LEVELS levels per tree and get memory a block at a time for the trees that go that deep
+        (`ensure_path`).  A number = a fixed path store of that many levels (rounded up to whole blocks), allocated up front; a
+        descent that fills it ends its tree with status PATH_OVERFLOW.  path_block / lds_levels / ring_levels: see PATH_BLOCK."""
         self.lib = _hip.lib()
         if self.lib.rc_mcts_struct_bytes() != ctypes.sizeof(_McStruct):
             raise _hip.RubiksHipError(f"rc_mcts_t is {self.lib.rc_mcts_struct_bytes()} bytes in librubiks_hip.so but {ctypes.sizeof(_McStruct)} "
@@ -161,7 +179,21 @@ class MCTSForest:
         dev = device or torch.device("cuda", torch.cuda.current_device())
         B, C = int(n_trees), int(capacity)
         self.C_asked = C            # C below may be rounded up to whole chunks per tree
-        assert B > 0 and 13 <= C <= MAX_CAPACITY and 2 <= max_path <= 4096, f"capacity {C}: 13 .. {MAX_CAPACITY} (32-bit byte offsets inside a tree's node records)"
+        assert B > 0 and 13 <= C <= MAX_CAPACITY, f"capacity {C}: 13 .. {MAX_CAPACITY} (32-bit byte offsets inside a tree's node records)"
+        pow2 = lambda x: 1 << max(1, int(np.ceil(np.log2(max(2, int(x))))))   # noqa: E731
+        pb = int(path_block or PATH_BLOCK)
+        assert pb == pow2(pb) and 2 <= pb <= 1 << 24, "path blocks are powers of two"
+        self.path_vmm = max_path is None and self.VMM_MIN_BYTES is not None
+        if max_path is None:   # address space for a 64 GB path_node array at most, whatever the number of trees
+            levels = max(pb, min(MAX_PATH_LEVELS, (16 << 30) // B) // pb * pb) if self.path_vmm else pb
+        else:
+            assert max_path >= 2
+            pb = min(pb, pow2(max_path))
+            levels = (int(max_path) + pb - 1) // pb * pb
+        self.path_block, self.path_blocks = pb, levels // pb
+        self.lds_levels = max(1, min(4096, int(lds_levels or LDS_LEVELS)))
+        self.ring_levels = max(1, min(4096, levels, int(ring_levels or RING_LEVELS)))
+        max_path = levels
         if vmm is None:
             vmm = self.on_demand_pays(B, C)
         self.vmm = bool(vmm)
@@ -183,8 +215,8 @@ class MCTSForest:
             "hash": ((B, self.hash_size), torch.int32),
             "n_nodes": ((B,), torch.int32), "status": ((B,), torch.int32), "solved_idx": ((B,), torch.int32),
             "solved_action": ((B,), torch.int32), "iterations": ((B,), torch.int32), "path_len": ((B,), torch.int32),
-            "pending": ((B,), torch.int32), "path_node": ((B, max_path), torch.int32), "path_act": ((B, max_path), torch.uint8),
-            "ring_node": ((B, RING_K, max_path), torch.int32), "ring_act": ((B, RING_K, max_path), torch.uint8),
+            "pending": ((B,), torch.int32),
+            "ring_node": ((B, RING_K, self.ring_levels), torch.int32), "ring_act": ((B, RING_K, self.ring_levels), torch.uint8),
             "ring_len": ((B, RING_K), torch.int32), "phase": ((B,), torch.int32),
         }
         self._ranges = {}     # name -> (VmmArray, bytes per row) of the arrays mapped on demand
@@ -225,6 +257,7 @@ class MCTSForest:
             else:
                 t = z(shape, dt)
             setattr(self, name, t)
+        self._make_path_store(z)
         # the reference's per-action node arrays (agents.py:421-427) are strided views of the 256-byte node records: one or two
         # adjacent cache lines per node for the kernels, the same [rows, 12] tensors for everything that inspects a tree
         for name, (lo, hi, dt) in _NODE_FIELDS.items():
@@ -252,16 +285,17 @@ class MCTSForest:
         s.node_words = N_ACT if _results_only else NODE_WORDS
         s.ring_k = RING_K
         for name in ("keys", "nbr", "P", "W", "N", "V", "leaf", "rec", "hash", "n_nodes", "status", "solved_idx",
-                     "solved_action", "iterations", "path_len", "pending", "path_node", "path_act", "child_idx", "new_mask",
-                     "expanded", "ring_node", "ring_act", "ring_len", "phase"):
+                     "solved_action", "iterations", "path_len", "pending", "path_node", "path_act", "path_next", "short_act", "child_idx",
+                     "new_mask", "expanded", "ring_node", "ring_act", "ring_len", "phase"):
             setattr(s, name, getattr(self, name).data_ptr())
+        s.path_block_log2, s.lds_levels, s.ring_levels = int(np.log2(self.path_block)), self.lds_levels, self.ring_levels
+        s.path_rows = self.path_rows.data_ptr() if self.path_rows is not None else None
         s.child_soa, s.child_stride = self.children.soa.data_ptr(), self.children.stride
         self.select_stats = z((B, 8), torch.int32)   # diagnostics: where each descent became sequential, its length, ticks
         s.select_stats = self.select_stats.data_ptr()
         self.bfs = None   # BFS scratch of rc_mcts_shorten: allocated on first use (graph search only)
-        self.short_act = z((B, max_path), torch.uint8)
         self.short_len = z((B,), torch.int32)
-        s.short_act, s.short_len = self.short_act.data_ptr(), self.short_len.data_ptr()
+        s.short_len = self.short_len.data_ptr()
         # The trees the iteration kernels work on (rc_mcts_t::active): position i of the list = workgroup i = network rows
         # 11 i .. 11 i + 10.  Finished trees are dropped from a running batch by writing a shorter list (`set_active`); no tree
         # moves in memory.  The buffer's address is baked into the captured graphs, its content and the launch size G are not.
@@ -285,6 +319,82 @@ class MCTSForest:
         if rows * NODE_WORDS * 4 < cls.BIG_CHUNKS_FROM or bpr < 16:
             return 2 << 20
         return (4 << 20) if bpr >= NODE_WORDS * 4 else (8 << 20)
+
+    # ---- the descent paths ------------------------------------------------------------------------------
+    def _make_path_store(self, z):
+        """path_node / path_act / path_next / short_act as [blocks][B][block] arrays (rc_mcts_t).  Unbounded paths: reserved address
+        ranges, block 0 of every tree with memory from the start; a fixed store: ordinary allocations.  A results-only forest keeps
+        the two arrays result extraction reads."""
+        B, pb, nb = self.B, self.path_block, self.path_blocks
+        names = [n for n in _PATH_ARRAYS if not (self.results_only and n in ("path_node", "path_next"))]
+        self._path_ranges = {}
+        if self.path_vmm:
+            try:
+                for name in names:
+                    esz = torch.empty(0, dtype=_PATH_ARRAYS[name]).element_size()
+                    arr = VmmArray.take(nb * B * pb * esz, self.device)
+                    self._path_ranges[name] = (arr, esz)
+                    arr.ensure(0, B * pb * esz)
+            except _hip.RubiksHipError as e:
+                import warnings
+                warnings.warn(f"MCTSForest: no address space for descent paths of any length ({e}); paths are limited to {pb} levels", RuntimeWarning)
+                for arr, _ in self._path_ranges.values():
+                    arr.close()
+                self._path_ranges, self.path_vmm, self.path_blocks, self.max_path, nb = {}, False, 1, pb, 1
+                self.ring_levels = min(self.ring_levels, pb)
+        for name, dt in _PATH_ARRAYS.items():
+            if name not in names:
+                t = z((1, 1, pb), dt)
+            elif self.path_vmm:
+                t = self._path_ranges[name][0].tensor(dt, (nb, B, pb))
+            else:
+                t = z((nb, B, pb), dt)
+            setattr(self, name, t)
+        # levels of tree t's path arrays with memory behind them (a whole number of blocks)
+        self.path_rows_host = np.full(B, pb if self.path_vmm else self.max_path, dtype=np.int32)
+        self.path_rows = torch.full((B,), pb, dtype=torch.int32, device=self.device) if self.path_vmm else None
+        self.paths_seen = np.zeros(B, dtype=np.int64)   # path lengths as of the host's last look (`grow_paths`)
+
+    def ensure_path(self, trees: np.ndarray, levels: np.ndarray) -> int:
+        """Memory behind levels 0 .. levels[i] - 1 of tree trees[i]'s path arrays (whole blocks; never less than the tree has);
+        the kernels learn of it in stream order.  Returns the bytes newly mapped.  No-op for a fixed path store."""
+        if not self.path_vmm:
+            return 0
+        pb, B = self.path_block, self.B
+        trees = np.asarray(trees, dtype=np.int64).reshape(-1)
+        want = np.minimum(self.max_path, (np.asarray(levels, dtype=np.int64).reshape(-1) + pb - 1) // pb * pb)
+        more = want > self.path_rows_host[trees]
+        if not more.any():
+            return 0
+        new = 0
+        for t, w in zip(trees[more], want[more]):
+            for b in range(int(self.path_rows_host[t]) // pb, int(w) // pb):
+                for arr, esz in self._path_ranges.values():
+                    off = (b * B + int(t)) * pb * esz
+                    new += arr.ensure(off, off + pb * esz)
+            self.path_rows_host[t] = w
+        self.path_rows.copy_(torch.from_numpy(self.path_rows_host.copy()).pin_memory(), non_blocking=True)
+        return new
+
+    def grow_paths(self, path_len: np.ndarray):
+        """The host's look at the path lengths ([B], as of some point of the stream): a tree whose descents have come within a
+        quarter block of the end of its path blocks gets the next one -- or as many as one and a half times its path needs (deep
+        trees get deeper: growth steps should be few).  A descent that gets there first is suspended by the kernel
+        (rc_mcts_t::path_rows) and resumes once the block is there: exact either way."""
+        self.paths_seen = np.asarray(path_len, dtype=np.int64).copy()
+        if not self.path_vmm:
+            return
+        near = np.flatnonzero((self.paths_seen + self.path_block // 4 >= self.path_rows_host) & (self.path_rows_host < self.max_path))
+        if len(near):
+            self.ensure_path(near, np.maximum(self.path_rows_host[near] + self.path_block, self.paths_seen[near] + self.paths_seen[near] // 2))
+
+    def read_path(self, name: str, t: int, n: int) -> np.ndarray:
+        """The first n entries of tree t in the blocked path array `name` ("path_node", "path_act", "short_act"), on the host."""
+        arr, pb = getattr(self, name), self.path_block
+        n = int(n)
+        assert n <= int(self.path_rows_host[t]), "levels without memory behind them"
+        parts = [arr[b, t, :min(pb, n - b * pb)] for b in range((n + pb - 1) // pb)]
+        return (torch.cat(parts) if parts else arr[0, t, :0]).cpu().numpy()
 
     # ---- memory behind the rows (forests mapped on demand) ---------------------------------------------
     def ensure_rows(self, trees: np.ndarray, rows: np.ndarray) -> int:
@@ -326,7 +436,8 @@ class MCTSForest:
         """Direct steppers (tests, tools) have no MCTSRun looking after the mapping: a synchronising look, 256 iterations ahead."""
         self.grow(self.n_nodes.cpu().numpy(), 256)
         self.ensure_rows(np.arange(self.B), np.full(self.B, self._first_rows()))
-        self._steps_covered = 256
+        self.grow_paths(self.path_len.cpu().numpy())
+        self._steps_covered = min(256, max(1, self.path_block // 16)) if self.path_vmm else 256
 
     def ensure_bfs(self, trees: np.ndarray = None):
         """rc_mcts_shorten's scratch ([rows][2] int32) behind the rows of `trees` (all if None) as counted by `nodes_seen`."""
@@ -351,22 +462,22 @@ class MCTSForest:
         graph is being captured on this thread (a forest may be garbage-collected at any point, and a synchronisation would break
         the capture): the ranges then wait in `_deferred`.  Agents close the forests they drop themselves (`MCTS._forest_for`);
         `__del__` is the safety net."""
-        ranges = getattr(self, "_ranges", None)
-        if not getattr(self, "vmm", False) or ranges is None:
+        ranges, pranges = getattr(self, "_ranges", None) or {}, getattr(self, "_path_ranges", None) or {}
+        if not ranges and not pranges:
             return
         self._graphs, self._graph_pool = {}, None
-        for name in list(ranges) + list(_NODE_FIELDS):
+        for name in list(ranges) + (list(_NODE_FIELDS) if ranges else []) + list(pranges):
             if hasattr(self, name):
                 delattr(self, name)
-        self.bfs = None
-        arrays = [arr for arr, _ in ranges.values()]
+        arrays = [arr for arr, _ in ranges.values()] + [arr for arr, _ in pranges.values()]
         if getattr(self, "_ranges_bfs", None) is not None:
+            self.bfs = None
             arrays.append(self._ranges_bfs)
-        self._ranges, self._ranges_bfs = None, None
+        self._ranges, self._ranges_bfs, self._path_ranges = None, None, None
         if torch.cuda.is_current_stream_capturing():
             MCTSForest._deferred.extend(arrays)
             return
-        torch.cuda.synchronize()
+        torch.cuda.synchronize(self.device)
         arrays, MCTSForest._deferred = MCTSForest._deferred + arrays, []
         mark = VmmArray.next_park_mark()      # this forest's arrays stay together; older parked memory beyond the cap goes first
         for arr in arrays:
@@ -391,8 +502,11 @@ class MCTSForest:
         """
         keep = np.asarray(keep, dtype=np.int64)
         # an ordinary allocation (the caching allocator hands the block of the previous harvest out again): forests that come and
-        # go with every harvest are not worth reserving, mapping and unmapping address ranges for
-        sub = MCTSForest(len(keep), self.C, self.max_path, self.device, _results_only=results_only, vmm=False)
+        # go with every harvest are not worth reserving, mapping and unmapping address ranges for.  Its path store is a fixed one
+        # that holds the deepest of the (finished) trees' last paths.
+        levels = max(self.path_block, self.ring_levels, int(self.paths_seen[keep].max()) + 1) if self.path_vmm else self.max_path
+        sub = MCTSForest(len(keep), self.C, levels, self.device, _results_only=results_only, vmm=False, path_block=self.path_block,
+                         lds_levels=self.lds_levels, ring_levels=self.ring_levels)
         sub.level_budget, sub._one_launch = self.level_budget, self._one_launch
         sub.set_net(self.engine, self.engine.dtype if hasattr(self.engine, "dtype") else torch.bfloat16)
         sub.adopt(0, self, keep)
@@ -404,7 +518,10 @@ class MCTSForest:
         extraction reads), rows 0 .. n_nodes only."""
         trees = np.asarray(trees, dtype=np.int64)
         k = len(trees)
-        assert other.C == self.C and other.max_path == self.max_path and pos + k <= self.B and not other.results_only
+        assert other.C == self.C and other.path_block == self.path_block and (self.results_only or other.ring_levels == self.ring_levels)
+        assert pos + k <= self.B and not other.results_only
+        plen = other.paths_seen[trees]          # the trees are finished: their last paths, as the host has seen them
+        assert int(plen.max(initial=0)) <= self.max_path, "the destination's path store is too small for these trees"
         n = other.nodes_seen[trees]
         self.ensure_rows(np.arange(pos, pos + k), n + 2)
         self.nodes_seen[pos:pos + k] = n
@@ -414,6 +531,15 @@ class MCTSForest:
         pick = idx.long()
         for name in (_RESULT_TREE if self.results_only else _PER_TREE):
             getattr(self, name)[pos:pos + k] = getattr(other, name)[pick]
+        for name in (("path_act",) if self.results_only else ("path_node", "path_act")):   # block by block, for the trees that reach it
+            src, dst = getattr(other, name), getattr(self, name)
+            dst[0, pos:pos + k] = src[0, pick]
+            for b in range(1, self.path_blocks):
+                deep = np.flatnonzero(plen > b * self.path_block)
+                if len(deep) == 0:
+                    break
+                dst[b, torch.from_numpy(pos + deep).to(self.device)] = src[b, pick[torch.from_numpy(deep).to(self.device)]]
+        self.paths_seen[pos:pos + k] = plen
 
     def bury(self, pos: int, other: "MCTSForest", trees: np.ndarray):
         """`adopt` into a results-only forest (the trees leave `other` for good)."""
@@ -424,8 +550,11 @@ class MCTSForest:
         """HBM behind the forest's search state: mapped bytes of the arrays mapped on demand + the ordinary allocations."""
         plain = [t for name, t in (("keys", self.keys), ("node", getattr(self, "node", None)), ("V", self.V), ("leaf", self.leaf))
                  if t is not None and name not in (self._ranges or {})]
-        plain += [self.hash, self.path_node, self.path_act, self.ring_node, self.ring_act, self.ring_len]
-        return sum(t.numel() * t.element_size() for t in plain) + sum(arr.mapped_bytes for arr, _ in (self._ranges or {}).values())
+        plain += [self.hash, self.ring_node, self.ring_act, self.ring_len]
+        if not self.path_vmm:
+            plain += [self.path_node, self.path_act, self.path_next, self.short_act]
+        return sum(t.numel() * t.element_size() for t in plain) + sum(arr.mapped_bytes for arr, _ in (self._ranges or {}).values()) + \
+            sum(arr.mapped_bytes for arr, _ in (self._path_ranges or {}).values())
 
     def bytes_mapped(self) -> int:
         """HBM currently behind the arrays mapped on demand."""
@@ -605,7 +734,7 @@ class MCTSForest:
         """One lock-step iteration of every running tree: expand -> network -> backup + select (one kernel).
         A freshly planted tree spends its first two steps on its root (evaluation + expansion, then backup + first descent)."""
         assert not self.results_only
-        if self.vmm:
+        if self.vmm or self.path_vmm:
             if self._steps_covered <= 0:
                 self._grow_now()
             self._steps_covered -= 1
@@ -675,8 +804,8 @@ class MCTSForest:
             return L
         plen = int(self.path_len[t].item())
         if plen > 1:
-            nodes = self.path_node[t, :plen].cpu().numpy().astype(np.int64)
-            acts = self.path_act[t, :plen - 1].cpu().numpy().astype(np.int64)
+            nodes = self.read_path("path_node", t, plen).astype(np.int64)
+            acts = self.read_path("path_act", t, plen - 1).astype(np.int64)
             np.add.at(L, (nodes[:-1], acts), 100.0)
             np.add.at(L, (nodes[1:], acts ^ 1), 100.0)
         return L
@@ -700,16 +829,17 @@ class MCTSForest:
         _hip.check(self.lib.rc_mcts_shorten(ctypes.byref(s), _hip.stream_ptr()), "rc_mcts_shorten")
 
     def shorten_queues(self):
-        """shorten_launch + the two result arrays on the host."""
+        """shorten_launch + the two result arrays on the host (the queues' first path_block moves)."""
         self.shorten_launch()
-        return self.short_len.cpu().numpy(), self.short_act.cpu().numpy()
+        return self.short_len.cpu().numpy(), self.short_act[0].cpu().numpy()
 
     def status_snapshot(self):
-        """(event, pinned int32[2, B]): per-tree status (row 0) and node count (row 1) as of the work queued so far, readable once
-        the event has passed."""
-        host = torch.empty((2, self.B), dtype=torch.int32, pin_memory=True)
+        """(event, pinned int32[3, B]): per-tree status (row 0), node count (row 1) and path length (row 2) as of the work queued so
+        far, readable once the event has passed."""
+        host = torch.empty((3, self.B), dtype=torch.int32, pin_memory=True)
         host[0].copy_(self.status, non_blocking=True)
         host[1].copy_(self.n_nodes, non_blocking=True)
+        host[2].copy_(self.path_len, non_blocking=True)
         ev = torch.cuda.Event()
         ev.record()
         return ev, host
@@ -719,5 +849,5 @@ class MCTSForest:
         return self.nbr[lo:lo + n + 1].cpu().numpy().astype(np.int64)
 
     def paths(self):
-        """(path_len[B], path_act[B,max_path]) on the host."""
-        return self.path_len.cpu().numpy(), self.path_act.cpu().numpy()
+        """(path_len[B], path_act[B, path_block]) on the host: the paths' first block (`read_path` for a deeper one)."""
+        return self.path_len.cpu().numpy(), self.path_act[0].cpu().numpy()

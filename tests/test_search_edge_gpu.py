@@ -7,7 +7,9 @@ production bf16 path.
    librubiks/solving/agents.py:548-559): best value = max V over the existing neighbours.  Unreachable in small
    natural searches (the cube graph has no short cycles besides a a' and commuting faces), so the situation is
    planted into BOTH trees: the unseen children of the current leaf are appended as leaf nodes.
-2. A PUCT descent longer than max_path: tree ends unsolved, RC_MCTS_PATH_OVERFLOW (reference: unbounded loop).
+2. A caller-bounded path store (MCTS(max_path=...), a resource bound the reference does not have): exactly the trees whose
+   reference search makes a descent that does not fit end with RC_MCTS_PATH_OVERFLOW, every other tree is the reference's.
+   (The default store has no bound: tests/test_deep_paths_gpu.py.)
 3. A* whose open list runs dry (reference: spins in agents.py:236-239): ends unsolved, RC_ASTAR_OPEN_EMPTY.
 4. Searches bounded by time only cap every tree at DEFAULT_NODE_CAP nodes (reference: grows without bound,
    agents.py:450-459).
@@ -92,7 +94,7 @@ def test_leaf_with_all_children_known(net_gpu):
             path.append(int(ref.neighbors[path[-1], a]))
         refs.append(ref)
         paths.append((path, actions))
-        assert forest.path_node[t, :len(path)].cpu().tolist() == path   # same descent on the device
+        assert forest.read_path("path_node", t, len(path)).tolist() == path   # same descent on the device
     # plant the unseen children of every tree's current leaf into both trees, as leaf nodes
     planted = 0
     for t, (ref, (path, actions)) in enumerate(zip(refs, paths)):
@@ -138,33 +140,36 @@ def test_leaf_with_all_children_known(net_gpu):
                 path, actions = ref._find_leaf()
             paths[t] = (path, actions)
             _compare(forest.tree_arrays(t), ref, len(ref))
-            assert forest.path_node[t, :len(path)].cpu().tolist() == path
+            assert forest.read_path("path_node", t, len(path)).tolist() == path
 
 
 @pytest.mark.parametrize("use_graph", [False, True])
 def test_path_overflow(net_gpu, use_graph):
+    """A bounded path store of 8 levels.  The oracle has no bound (it is the reference's unbounded descent): it only records its
+    deepest descent, which says which trees the bound ends -- a descent that stands on a non-leaf with 8 nodes on its path."""
     from librubiks.solving import mcts_device as md
     from librubiks.solving.agents import MCTS
     np.random.seed(4)
     states = np.array([oc.scramble(20, True)[0] for _ in range(48)])
-    max_path, cap = 7, 1500
+    max_path, cap = 8, 1500
     agent = MCTS(net_gpu, c=0.2, search_graph=True, net_dtype=torch.float32, max_path=max_path, use_graph=use_graph)
     res = agent.search_batch(states, None, cap, compact=False)
+    assert agent.forest.max_path == max_path and not agent.forest.path_vmm
     onet = oa.TorchNet(net_gpu, device="cuda")
     overflowed = 0
     for t, s in enumerate(states):
         ref = oa.MCTS(onet, c=0.2, search_graph=True)
-        ok = ref.search(s, cap, max_path=max_path)
-        assert bool(res.solved[t]) == ok and res.nodes[t] == len(ref), f"tree {t}"
-        assert list(res.queues[t]) == list(ref.action_queue), f"tree {t}"
-        assert (res.status[t] == md.PATH_OVERFLOW) == ref.path_overflow, f"tree {t}"
-        assert res.iterations[t] == ref.iterations
-        overflowed += ref.path_overflow
-        if ref.path_overflow:
-            assert len(ref.action_queue) == max_path - 1 and not ok
-            if overflowed <= 4:
-                _compare(agent.forest.tree_arrays(t), ref, len(ref))
-    assert overflowed >= 8
+        ok = ref.search(s, cap)
+        too_deep = ref.deepest_path > max_path
+        assert (res.status[t] == md.PATH_OVERFLOW) == too_deep, f"tree {t}"
+        if too_deep:
+            assert not res.solved[t] and len(res.queues[t]) == max_path - 1 and res.nodes[t] <= len(ref)
+            overflowed += 1
+        else:                      # the bound was never met: the reference's tree, node for node
+            assert bool(res.solved[t]) == ok and res.nodes[t] == len(ref), f"tree {t}"
+            assert list(res.queues[t]) == list(ref.action_queue), f"tree {t}"
+            assert res.iterations[t] == ref.iterations
+    assert overflowed >= 8 and res.path_overflow_trees == overflowed
 
 
 def test_astar_open_list_runs_dry(net_gpu):
