@@ -659,6 +659,11 @@ class MCTSRun:
         ev.synchronize()
         t2 = perf_counter()
         self.stats["host_wait_s"] += t2 - t1   # time the host had to spare: it waited for the GPU, not the other way round
+        if f_snap is forest and int(st_host[3, 0]) != 0:
+            # The split engine left half range: from then on its outputs are inf / NaN, and a PUCT descent over NaN scores need
+            # never meet a leaf (nor does the reference's on such numbers).  The search stops here; `finish` repeats it in fp32.
+            self.done = True
+            return
         try:
             if f_snap is forest:
                 # the host's look at the node counts: rows for everything the iterations queued since that snapshot, the next

@@ -834,12 +834,16 @@ class MCTSForest:
         return self.short_len.cpu().numpy(), self.short_act[0].cpu().numpy()
 
     def status_snapshot(self):
-        """(event, pinned int32[3, B]): per-tree status (row 0), node count (row 1) and path length (row 2) as of the work queued so
-        far, readable once the event has passed."""
-        host = torch.empty((3, self.B), dtype=torch.int32, pin_memory=True)
+        """(event, pinned int32[4, B]): per-tree status (row 0), node count (row 1) and path length (row 2) as of the work queued so
+        far, readable once the event has passed; [3, 0] != 0: the split engine has written an activation beyond half range (the
+        network outputs since then are not numbers: the search is to be repeated in fp32, see DeepAgent._overflowed)."""
+        host = torch.zeros((4, self.B), dtype=torch.int32, pin_memory=True)
         host[0].copy_(self.status, non_blocking=True)
         host[1].copy_(self.n_nodes, non_blocking=True)
         host[2].copy_(self.path_len, non_blocking=True)
+        flag = getattr(self.engine, "range_flag", None)
+        if flag is not None:
+            host[3, :1].copy_(flag.reshape(-1)[:1], non_blocking=True)
         ev = torch.cuda.Event()
         ev.record()
         return ev, host
