@@ -279,6 +279,8 @@ int rc_adi_targets(const float *values, const uint8_t *child_solved, const uint8
 #define RC_MCTS_PATH_OVERFLOW 3 /* a PUCT descent reached max_path levels: the path store is exhausted (the reference has no limit,
                                  * agents.py:575-595; max_path is a resource bound the caller chooses, not a search parameter) */
 #define RC_MCTS_ROOT_SOLVED 4   /* the scramble itself is solved (agents.py:468) */
+#define RC_MCTS_CORRUPT 5       /* rc_mcts_complete_graph / rc_mcts_shorten met an index that does not name a node of the tree (1 .. n_nodes)
+                                 * in its hash table or neighbour rows: the rows are not this tree's data.  The tree is left as it is. */
 
 typedef struct rc_mcts {
     uint32_t n_trees;    /* B */

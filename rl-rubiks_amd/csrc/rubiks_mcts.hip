@@ -1276,9 +1276,12 @@ __global__ __launch_bounds__(kBlock) void k_mcts_complete_graph(rc_mcts_t m) {
         const uint4 ck = make_uint4(kw[0], kw[1], kw[2], kw[3]);
         u32 h = key_hash(ck) & mask;
         int found = 0;
-        for (;;) {
+        for (u32 probes = 0;; ++probes) {
             const int s = tab[h];
             if (s == 0) break;
+            // A hash slot names a node of this tree.  Anything else is not this tree's data (a copy that went through a stale
+            // translation, a harvest of the wrong rows): the tree is marked and left alone instead of being indexed with it.
+            if ((u32)s > n || probes > mask) { m.status[t] = RC_MCTS_CORRUPT; return; }
             if (key_eq(keys[s], ck)) { found = s; break; }
             h = (h + 1) & mask;
         }
@@ -1293,7 +1296,7 @@ __global__ __launch_bounds__(kBlock) void k_mcts_complete_graph(rc_mcts_t m) {
 // (atomicMin), and the next frontier is the claimed nodes in scan-index order (block-wide ordered compaction).
 __global__ __launch_bounds__(kBlock) void k_mcts_shorten(rc_mcts_t m) {
     __shared__ int s_scan[kBlock];
-    __shared__ int s_base, s_done;
+    __shared__ int s_base, s_done, s_bad;
     const u32 tid = threadIdx.x;
     const int ti = tree_of(m, blockIdx.x);
     if (ti < 0) return;
@@ -1304,6 +1307,13 @@ __global__ __launch_bounds__(kBlock) void k_mcts_shorten(rc_mcts_t m) {
     if (solved == 1) return;   // agents.py:614: the queue is kept
     const size_t base = (size_t)t * (m.capacity + 1);
     const int n = m.n_nodes[t];
+    // Every index this kernel follows is read from memory (neighbour rows, parent links).  One that does not name a node of this
+    // tree (1 .. n) means the rows are not this tree's data: the tree is marked RC_MCTS_CORRUPT and left alone -- a diagnosable
+    // error on the host instead of a wild access.
+    if (n < 1 || (u32)n > m.capacity || solved < 1 || solved > n) {
+        if (tid == 0) m.status[t] = RC_MCTS_CORRUPT;
+        return;
+    }
     const u32 rw = m.node_words;   // 64 in a search forest, 12 in a results-only one
     const int *nbr = m.nbr + base * rw;
     int *claim = m.bfs + base * 2;            // [node][0]
@@ -1315,6 +1325,7 @@ __global__ __launch_bounds__(kBlock) void k_mcts_shorten(rc_mcts_t m) {
     if (tid == 0) {
         frontier_a[0] = 1;
         s_done = 0;
+        s_bad = 0;
     }
     __syncthreads();
     if (tid == 0) claim[2 * 1 + 1] = -1;   // the root is visited and has no parent
@@ -1326,6 +1337,7 @@ __global__ __launch_bounds__(kBlock) void k_mcts_shorten(rc_mcts_t m) {
         // phase 1: every unvisited neighbour is claimed by the smallest scan index that reaches it
         for (int idx = tid; idx < work; idx += kBlock) {
             const int c = nbr[(size_t)cur[idx / kA] * rw + idx % kA];
+            if ((u32)c > (u32)n) { s_bad = 1; continue; }
             if (c != 0 && claim[2 * c + 1] == 0) atomicMin(&claim[2 * c], idx);
         }
         // the claims are no-return atomics executed at L2: drain them before the barrier, and read them back
@@ -1335,6 +1347,7 @@ __global__ __launch_bounds__(kBlock) void k_mcts_shorten(rc_mcts_t m) {
         // phase 2: winners enter the next frontier in scan order
         if (tid == 0) s_base = 0;
         __syncthreads();
+        if (s_bad) break;   // uniform: written before the barrier above
         for (int idx0 = 0; idx0 < work; idx0 += kBlock) {
             const int idx = idx0 + (int)tid;
             int c = 0, win = 0, p = 0;
@@ -1367,7 +1380,8 @@ __global__ __launch_bounds__(kBlock) void k_mcts_shorten(rc_mcts_t m) {
         int *tmp = cur; cur = nxt; nxt = tmp;
     }
     __syncthreads();
-    if (tid == 0 && s_done) {   // walk the parent pointers back to the root, then reverse
+    if (tid == 0 && s_bad) m.status[t] = RC_MCTS_CORRUPT;
+    if (tid == 0 && s_done && !s_bad) {   // walk the parent pointers back to the root, then reverse
         // (the shortest path is never longer than the tree's last descent path + its solving move, whose levels have memory)
         u8 *out = m.short_act;
         const int cap = path_limit(m, t);

@@ -17,7 +17,7 @@ from time import perf_counter
 import numpy as np
 import torch
 
-from librubiks import gpu, no_grad
+from librubiks import _hip, gpu, no_grad
 from librubiks.cube.device import DeviceCubes
 from librubiks.model import F32_SPLIT, F32_SPLIT_DET, Model, net_fingerprint
 from librubiks.solving import astar_device as ad
@@ -25,7 +25,19 @@ from librubiks.solving import bfs_device as bd
 from librubiks.solving import mcts_device as md
 from librubiks.utils import TickTock
 
-DEFAULT_NODE_CAP = 1 << 18   # per-tree node capacity when a search is bounded by time only
+DEFAULT_NODE_CAP = 1 << 18   # per-problem node capacity of an A* search bounded by time only (its arrays are allocated up front)
+TIME_ONLY_HASH_BYTES = 32 << 30   # MCTS bounded by time only: what the trees' hash tables (the one per-node array that must exist up front) may take
+
+
+def time_only_capacity(n_trees: int) -> int:
+    """Node capacity per tree of an MCTS search bounded by wall time only.  The reference's arrays double for as long as the time
+    limit lets the tree grow (agents.py:450-459): there is no node limit.  Here a tree's node rows are address space that gets
+    memory as the tree grows (`MCTSForest.grow`), so the capacity is what the kernels can address -- 2^24 - 2 nodes per tree -- or,
+    in large batches, what 32 GB of hash tables (8 bytes per node, cleared when a tree is planted) allow; what really ends such a
+    search is its time limit or the HBM behind the rows running out (the trees then stop growing and the time limit ends it)."""
+    if md.MCTSForest.VMM_MIN_BYTES is None:     # node rows allocated up front (RUBIKS_VMM_MIN_GB=never): the old fixed capacity
+        return DEFAULT_NODE_CAP
+    return int(max(DEFAULT_NODE_CAP, min(md.MAX_CAPACITY, TIME_ONLY_HASH_BYTES // (8 * max(1, int(n_trees))) - 1)))
 bd_MAX_STATES = 1 << 26      # BFS bounded by time only: node slots for 2^26 states (~4 GB)
 
 
@@ -297,6 +309,12 @@ class _Harvest:
         self.event.synchronize()
         h = {k: v.numpy()[:self.n] for k, v in self.host.items()}
         status, plen = h["status"].astype(np.int64), h["plen"].astype(np.int64)
+        bad = np.flatnonzero(status == md.CORRUPT)
+        if len(bad):   # graph completion / BFS shortening met indices that name no node of the tree: not the tree's rows (never seen since the
+            # node store flushes translations; a loud error with the addresses instead of the GPU fault a wild index would be)
+            t = int(self.tree_ids[bad[0]])
+            raise _hip.RubiksHipError(f"MCTS result extraction: {len(bad)} tree(s) hold rows that are not theirs (first: tree {t}, game "
+                                      f"{int(self.games[bad[0]])}, {int(h['nodes'][bad[0]])} nodes): {self.forest.describe_rows(t)}")
         acts = h["pact"].copy()
         width = acts.shape[1]                             # one path block
         lens = plen - 1                                   # the actions taken: the best guess of an unsolved tree (agents.py:492)
@@ -404,7 +422,7 @@ class MCTS(DeepAgent):
         itself starts at full speed: allocates the forest (HBM, zero-filled), builds the inference engine and captures the HIP
         graph of every launch size the forest will be narrowed to (~0.1 s per size for the split engine: the allocations of
         its activations).  Optional: a search on an unprepared agent does the same work on the way."""
-        cap_states = int(max_states) if max_states and max_states < int(1e10) else DEFAULT_NODE_CAP
+        cap_states = int(max_states) if max_states and max_states < int(1e10) else time_only_capacity(n_trees)
         forest = self._forest_for(int(n_trees), max(cap_states, 16))
         if self.use_graph:
             forest.capture_all(self.c, cap_states)
@@ -432,6 +450,8 @@ class MCTS(DeepAgent):
         steps = None if max_iterations is None else max_iterations + 1
         while not run.done and (steps is None or run.it < steps):
             run.round(None if steps is None else steps - run.it)
+        if max_iterations is not None:
+            run.catch_up(max_iterations)
         return run.finish()
 
     @no_grad
@@ -496,9 +516,9 @@ class MCTSRun:
     def __init__(self, agent: "MCTS", roots: DeviceCubes, time_limit: float, max_states: int, compact: bool, slots, one_launch: bool = True):
         self.agent, self.roots, self.time_limit, self.compact = agent, roots, time_limit, compact
         self.max_states, self.slots, self.one_launch = max_states, slots, one_launch
-        self.cap_states = int(max_states) if max_states < int(1e10) else DEFAULT_NODE_CAP
         self.n_games = roots.n
         S = self.S = self.n_games if slots is None else max(1, min(int(slots), self.n_games))
+        self.cap_states = int(max_states) if max_states < int(1e10) else time_only_capacity(S)
         forest = self.forest = agent._forest_for(S, max(self.cap_states, 16))
         agent.tt.tick()
         forest.set_active(None)
@@ -669,8 +689,18 @@ class MCTSRun:
                 # the host's look at the node counts: rows for everything the iterations queued since that snapshot, the next
                 # round and one more can reach (forests mapped on demand; otherwise only the counts are noted)
                 queued = self.it - it_then
-                forest.grow(st_host[1].numpy(), queued + 2 * agent.sync_every)
-                forest.grow_paths(st_host[2].numpy())      # ... and the next path block for the trees whose descents near the end of theirs
+                try:
+                    forest.grow(st_host[1].numpy(), queued + 2 * agent.sync_every)
+                    forest.grow_paths(st_host[2].numpy())      # ... and the next path block for the trees whose descents near the end of theirs
+                except _hip.RubiksHipError as e:
+                    # HBM has run out behind the node rows / path blocks.  The trees that need more sit out behind the kernels'
+                    # guards (exact: nothing is half-written); a search with a time limit ends there, others are stopped here.
+                    if not getattr(self, "_hbm_warned", False):
+                        warnings.warn(f"MCTS: no more HBM behind the trees' node rows ({e}); the trees that need more stop growing", RuntimeWarning)
+                        self._hbm_warned = True
+                    if self.time_limit >= 1e10:
+                        self.done = True
+                        return
                 forest._steps_covered = 2 * agent.sync_every
                 self.stats["mapped_gb"] = round(forest.bytes_allocated() / 1e9, 2)
             self._act_on(qi, f_snap, st_host[0])
@@ -717,6 +747,29 @@ class MCTSRun:
             self.stats["compactions"] += 1
             if sum(len(r) for r in self.resting) >= self.GRAVE:
                 self._flush_resting()
+
+    def catch_up(self, iterations: int):
+        """A search bounded by a number of iterations (lock-step batches, three-phase form) must leave every running tree after
+        exactly that many expansions and the descent that follows the last one (agents.py:476-490).  A tree sits an iteration out
+        when its next node rows or path block have no memory yet (the kernels' guards); such trees -- rare: the host maps ahead --
+        are stepped on their own here until they are where the others are."""
+        forest = self.forest
+        listed, stepped = forest._listed, False
+        for _ in range(4 * iterations + 64):
+            torch.cuda.synchronize()
+            it, st, pend = (x.cpu().numpy() for x in (forest.iterations, forest.status, forest.pending))
+            lag = np.flatnonzero((self.owner >= 0) & (st == md.RUNNING) & ((it < iterations) | (pend != 0)))
+            if len(lag) == 0:
+                break
+            forest.grow(forest.n_nodes.cpu().numpy(), 2)
+            forest.grow_paths(forest.path_len.cpu().numpy())
+            forest._steps_covered = 2
+            forest.set_active(lag)
+            forest.step(self.agent.c, self.cap_states, self.agent.use_graph)
+            self.it += 1
+            stepped = True
+        if stepped:
+            forest.set_active(None if listed is None else listed[listed >= 0])
 
     def nodes_now(self) -> int:
         """Nodes in the trees currently in the forest plus those of the trees already harvested (synchronises)."""

@@ -23,7 +23,7 @@ from librubiks._vmm import VmmArray, zeros_or_trim
 from librubiks.cube.device import DeviceCubes
 from librubiks.model import make_inference_net, net_fingerprint
 
-RUNNING, SOLVED, EXHAUSTED, PATH_OVERFLOW, ROOT_SOLVED = 0, 1, 2, 3, 4
+RUNNING, SOLVED, EXHAUSTED, PATH_OVERFLOW, ROOT_SOLVED, CORRUPT = 0, 1, 2, 3, 4, 5
 N_ACT = 12
 
 
@@ -847,6 +847,21 @@ class MCTSForest:
         ev = torch.cuda.Event()
         ev.record()
         return ev, host
+
+    def describe_rows(self, t: int) -> str:
+        """Where tree t's rows lie and what the node store says those addresses are (for the error raised when result extraction
+        finds rows that are not the tree's data: RC_MCTS_CORRUPT)."""
+        from librubiks import _vmm
+        out = []
+        for name, t_ in (("keys", self.keys), ("nbr", self.nbr), ("hash", self.hash)):
+            per_tree = (self.hash_size * 4) if name == "hash" else (self.C + 1) * (16 if name == "keys" else self.struct.node_words * 4)
+            addr = int(getattr(self.struct, name)) + int(t) * per_tree
+            try:
+                kind, base, off = _vmm.classify(addr)
+            except Exception as e:   # noqa: BLE001 -- diagnosis must not hide the error it explains
+                kind, base, off = f"? ({e})", 0, 0
+            out.append(f"{name} @0x{addr:x}: {kind}" + (f" (range 0x{base:x} + {off})" if base else ""))
+        return "; ".join(out)
 
     def neighbors_of(self, t: int, n: int) -> np.ndarray:
         lo = t * (self.C + 1)

@@ -171,3 +171,34 @@ def test_descents_deeper_than_the_lds_window_at_production_sizes(knobs):
         assert not trees_a[t]["leaves"][nodes[:-1]].any()
         # the unsolved tree's queue is its last descent (agents.py:492), all of it
         assert list(res_a.queues[t]) == list(acts)
+
+
+def test_a_search_bounded_by_time_alone_grows_past_the_old_node_cap(net_gpu):
+    """The reference doubles its node arrays for as long as the time limit lets a tree grow (agents.py:450-459).  A search with a
+    time limit only gets the capacity the kernels can address (node rows are address space with memory behind the rows in use),
+    not the 2^18 nodes of earlier rounds: one tree, a few seconds, more than 2^18 nodes -- and still a consistent tree."""
+    from librubiks.solving import agents as ag
+    from librubiks.solving import mcts_device as md
+    assert ag.time_only_capacity(1) == md.MAX_CAPACITY and ag.time_only_capacity(1024) >= 4 * (1 << 18)
+    np.random.seed(5)
+    state = oc.scramble(30, True)[0]
+    agent = ag.MCTS(net_gpu, c=0.6, search_graph=False, net_dtype=torch.float32)
+    agent.prepare(1, None)
+    solved = agent.search(state, time_limit=8.0)
+    f = agent._last_forest
+    assert f.C >= md.MAX_CAPACITY - 8192 and f.vmm
+    n = len(agent)
+    if solved:
+        pytest.skip("the stand-in net solved this scramble before the tree reached 2^18 nodes")
+    assert n > (1 << 18), n
+    assert f.bytes_mapped() < 2 * n * 300 + (64 << 20)        # memory follows the tree, not the capacity
+    tree = agent._host_tree()
+    nb = tree["neighbors"][:n + 1]
+    i, a = np.nonzero(nb[1:])
+    i = i + 1
+    assert (nb[i, a] <= n).all() and np.array_equal(nb[nb[i, a], a ^ 1], i)          # links both ways (agents.py:533-535)
+    pick = np.random.RandomState(0).choice(len(i), 4096, replace=False)
+    kids = oc.multi_rotate(tree["states"][i[pick]], *oc.indices_to_actions(a[pick]))
+    assert np.array_equal(kids, tree["states"][nb[i[pick], a[pick]]])                 # ... between the right states
+    assert len(np.unique(tree["states"][1:n + 1], axis=0)) == n                        # every state once (agents.py:517-529)
+    assert (tree["leaves"][1:n + 1] == (nb[1:] == 0).any(axis=1)).all()

@@ -11,8 +11,9 @@ production bf16 path.
    reference search makes a descent that does not fit end with RC_MCTS_PATH_OVERFLOW, every other tree is the reference's.
    (The default store has no bound: tests/test_deep_paths_gpu.py.)
 3. A* whose open list runs dry (reference: spins in agents.py:236-239): ends unsolved, RC_ASTAR_OPEN_EMPTY.
-4. Searches bounded by time only cap every tree at DEFAULT_NODE_CAP nodes (reference: grows without bound,
-   agents.py:450-459).
+4. Searches bounded by time only: the trees' capacity is what the kernels can address / what the hash tables' budget allows
+   (`agents.time_only_capacity`; the reference's arrays double without bound, agents.py:450-459).  A tree that does reach its
+   capacity ends EXHAUSTED exactly like one that reaches max_states (growth past the old 2^18 cap: tests/test_deep_paths_gpu.py).
 5. Production dtype: the trees the bf16 engine builds (packed 11 rows, fused input layer / head / backup, graph
    replay, line following) equal node-for-node what the oracle builds from the SAME network outputs, replayed
    through a table-lookup net recorded from the device trees.
@@ -216,7 +217,7 @@ def test_time_limit_only_caps_the_tree(net_gpu, monkeypatch):
     from librubiks.solving import mcts_device as md
     np.random.seed(6)
     states = np.array([oc.scramble(20, True)[0] for _ in range(12)])
-    monkeypatch.setattr(pa, "DEFAULT_NODE_CAP", 700)
+    monkeypatch.setattr(pa, "time_only_capacity", lambda n_trees: 700)   # as if the hash-table budget allowed 700 nodes per tree
     agent = pa.MCTS(net_gpu, c=0.6, search_graph=True, net_dtype=torch.float32)
     res = agent.search_batch(states, time_limit=120.0)
     assert res.seconds < 60
@@ -227,20 +228,6 @@ def test_time_limit_only_caps_the_tree(net_gpu, monkeypatch):
         assert bool(res.solved[t]) == ok and res.nodes[t] == len(ref) and list(res.queues[t]) == list(ref.action_queue)
         if not ok:
             assert res.status[t] == md.EXHAUSTED and res.nodes[t] + 12 > 700
-
-
-def test_time_limit_only_real_cap(net_gpu):
-    """One tree at the real cap of 2^18 nodes: it stops there instead of growing without bound."""
-    from librubiks.solving import agents as pa
-    from librubiks.solving import mcts_device as md
-    assert pa.DEFAULT_NODE_CAP == 1 << 18
-    np.random.seed(2)
-    state = oc.scramble(30, True)[0]
-    agent = pa.MCTS(net_gpu, c=0.6, search_graph=False, net_dtype=torch.float32)
-    res = agent.search_batch(state[None], time_limit=300.0)
-    if not res.solved[0]:
-        assert res.status[0] == md.EXHAUSTED and (1 << 18) - 12 < res.nodes[0] <= 1 << 18
-    assert res.seconds < 120
 
 
 class _TableNet:
@@ -426,3 +413,33 @@ def test_production_trees_through_refill_narrowing_and_results_forest_equal_orac
         solved += ok
         unsolved += not ok
     assert solved >= 40 and unsolved >= 1      # both outcomes occur (the cap stops the hardest scrambles)
+
+
+@pytest.mark.parametrize("what", ["neighbour", "hash"])
+def test_rows_that_are_not_the_trees_data_raise_instead_of_faulting(what, net_gpu, agents_golden):
+    """rc_mcts_complete_graph / rc_mcts_shorten follow indices they read from memory (hash slots, neighbour rows).  An index that
+    names no node of the tree -- rows that are not the tree's data, the round-4 fault class -- marks the tree RC_MCTS_CORRUPT and
+    result extraction raises with the rows' addresses, instead of the kernel indexing with it."""
+    from librubiks import _hip
+    from librubiks.solving import mcts_device as md
+    from librubiks.solving.agents import MCTS
+    cases = ["d4_s17_c20_graph", "d5_s1_c20_graph", "d7_s25_c20_graph"]          # recorded by the reference: all solved at c = 20
+    states = np.array([agents_golden[f"mcts_{c}_state"] for c in cases])
+    agent = MCTS(net_gpu, c=20.0, search_graph=True, net_dtype=torch.float32)
+    run = agent.start_batch(states, None, 2500, compact=False)
+    while not run.done:
+        run.round()
+    torch.cuda.synchronize()
+    f = run.forest
+    assert (f.status.cpu().numpy() == md.SOLVED).all()
+    t = 1
+    if what == "neighbour":
+        f.nbr[t * (f.C + 1) + 1, 3] = 0x7FFFFF00      # the root's neighbour through action 3: far outside the tree
+    else:
+        filled = torch.nonzero(f.hash[t])[:, 0]
+        f.hash[t, filled] = 0x7FFFFF00                # every occupied slot names a node that does not exist
+    with pytest.raises(_hip.RubiksHipError, match="not theirs") as err:
+        run.finish()
+    assert "nbr @0x" in str(err.value) and "tree 1" in str(err.value)
+    torch.cuda.synchronize()                          # the process is alive and the GPU answers
+    assert int(f.status[t].item()) == md.CORRUPT and int(f.status[0].item()) == md.SOLVED
