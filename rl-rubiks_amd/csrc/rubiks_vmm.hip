@@ -18,6 +18,8 @@
 // RUBIKS_VMM_LOG names ("stderr" = the process's stderr), flushed line by line so that the record survives the abort that follows a
 // GPU memory access fault; rc_vmm_classify / tools/vmm_classify.py say what a faulting address was at that moment (memory behind
 // it / a reserved row without memory / a released range / never ours).
+#include <unistd.h>
+
 #include <cinttypes>
 #include <cstdarg>
 #include <cstdio>
@@ -67,6 +69,7 @@ std::mutex g_mu;
 std::unordered_map<void *, Range> g_ranges;
 std::multimap<std::pair<int, size_t>, Idle> g_idle;      // (device, raw bytes) -> idle reservations
 size_t g_retired_bytes = 0;                               // address space on the idle lists
+size_t g_quarantined_bytes = 0;                           // address space of ranges whose unmap / flush failed: never reused, never freed
 constexpr size_t kRetireBudget = 32ull << 40;             // of the 128 TiB a process has: beyond it released ranges are freed
 constexpr size_t kMinChunk = 2u << 20;
 constexpr int kEvents = 512;
@@ -82,7 +85,16 @@ void record(char op, const void *base, size_t a, size_t b, int rc) {   // g_mu h
     if (!g_log_checked) {
         g_log_checked = true;
         const char *path = std::getenv("RUBIKS_VMM_LOG");
-        if (path && *path) g_log = std::strcmp(path, "stderr") == 0 ? stderr : std::fopen(path, "a");
+        if (path && *path) {
+            // one file per process ("<path>.<pid>", RANK in front when a launcher set it): the ranks of one job and the child processes of
+            // a test run inherit the variable, and their address spaces have nothing to do with each other
+            std::string name = path;
+            if (std::strcmp(path, "stderr") != 0) {
+                if (const char *rank = getenv("RANK")) name += std::string(".rank") + rank;
+                name += "." + std::to_string((long)getpid());
+            }
+            g_log = std::strcmp(path, "stderr") == 0 ? stderr : std::fopen(name.c_str(), "a");
+        }
         if (g_log) std::fprintf(g_log, "# rubiks vmm log: seq op base a b rc  (A raw_bytes 0 | R/U bytes chunk uses | M offset covered | X mapped raw | I/F raw uses | E offset bytes)\n");
     }
     if (g_log) {
@@ -113,15 +125,18 @@ int failed(hipError_t e, const void *base = nullptr, size_t a = 0, size_t b = 0)
 // block).  An ordinary hipMalloc + hipFree after the unmaps cures it (0 wrong rounds with it, in every run of the probe): hipFree's
 // own unmapping is announced to the GPU, and that announcement covers everything.  rc_vmm_release does that before a range goes to
 // the idle list, so by the time an address is mapped a second time no translation of its first life is left.
-void forget_translations() {
+// Returns false when the flush could not be done (no memory for the block, a failing runtime call): the caller must then never
+// hand the addresses out again.
+bool forget_translations() {
     void *blk = nullptr;
     if (hipMalloc(&blk, 2u << 20) != hipSuccess) {
         (void)hipGetLastError();
-        return;
+        return false;
     }
-    (void)hipMemset(blk, 0, 2u << 20);
-    (void)hipDeviceSynchronize();
-    (void)hipFree(blk);
+    bool ok = hipMemset(blk, 0, 2u << 20) == hipSuccess;
+    ok = (hipDeviceSynchronize() == hipSuccess) && ok;
+    ok = (hipFree(blk) == hipSuccess) && ok;
+    return ok;
 }
 
 hipMemAllocationProp device_prop(int device) {
@@ -287,14 +302,23 @@ int rc_vmm_release(void *base) {
         if (hipError_t err = hipMemRelease(r.handles[c]); err != hipSuccess && rc == RC_OK) rc = failed(err, base, c * r.chunk, r.chunk);
     }
     record('X', base, r.mapped_bytes, r.raw_bytes, rc);
+    bool clean = rc == RC_OK;   // an unmap that failed leaves chunks mapped: such addresses are never handed out again
     if (r.mapped_bytes) {   // chunks are only ever unmapped here: a range without memory now never had any.  On the range's device, whichever is current
         int current = r.device;
         (void)hipGetDevice(&current);
         if (current != r.device) (void)hipSetDevice(r.device);
-        forget_translations();
+        if (!forget_translations()) {
+            clean = false;
+            record('E', base, 0, r.raw_bytes, RC_ERR_HIP_BASE);   // the flush failed: stale translations may remain
+        }
         if (current != r.device) (void)hipSetDevice(current);
     }
-    if (g_retired_bytes + r.raw_bytes <= kRetireBudget) {
+    if (!clean) {
+        // Neither on the idle list (a later mapping there could be read through a translation of this life) nor freed (the runtime
+        // would hand the same addresses to the next reservation): the reservation is kept, unused, for the life of the process.
+        g_quarantined_bytes += r.raw_bytes;
+        record('Q', r.raw, r.raw_bytes, r.uses, rc);
+    } else if (g_retired_bytes + r.raw_bytes <= kRetireBudget) {
         g_idle.insert({{r.device, r.raw_bytes}, Idle{r.raw, r.raw_bytes, r.device, r.uses}});
         g_retired_bytes += r.raw_bytes;
         record('I', r.raw, r.raw_bytes, r.uses, RC_OK);

@@ -4,6 +4,10 @@ What was a device address to the node store when the process died?
     RUBIKS_VMM_LOG=/path/vmm.log python bench.py ...            # every reserve / map / release, flushed line by line
     python tools/vmm_classify.py /path/vmm.log 0x7e224488d000   # e.g. the address of "Memory access fault by GPU node-2 ... on address"
 
+Every process writes its own file, /path/vmm.log[.rank<R>].<pid> (ranks of one job and child processes inherit the variable; their
+address spaces have nothing to do with each other).  Give the file itself, or the prefix when only one process wrote, or the prefix
+and --pid <pid>.
+
 Replays the event file of rl-rubiks_amd/csrc/rubiks_vmm.hip (the same bookkeeping as rc_vmm_classify inside a live process) and
 prints `<address> <kind> ...`:
     mapped    inside a live range, memory behind the chunk           -> the fault is not the node store's mapping
@@ -38,7 +42,7 @@ def replay(path):
         elif op == "X":
             r = live.pop(base)
             history.append((seq, op, r["raw"], r["raw_bytes"]))
-        elif op == "I":
+        elif op in "IQ":        # Q: a range whose unmap / flush failed -- kept out of circulation for good, nothing is ever mapped there again
             idle[base] = (a, b)
         elif op == "F":
             history.append((seq, op, base, a))
@@ -62,10 +66,24 @@ def classify(addr, live, idle, history):
 
 
 if __name__ == "__main__":
-    if len(sys.argv) < 3:
+    import glob
+    import os
+    args = sys.argv[1:]
+    pid = None
+    if "--pid" in args:
+        i = args.index("--pid")
+        pid = args[i + 1]
+        del args[i:i + 2]
+    if len(args) < 2:
         sys.exit(__doc__)
-    state = replay(sys.argv[1])
-    for text in sys.argv[2:]:
+    path = args[0]
+    if not os.path.isfile(path):
+        found = sorted(f for f in glob.glob(path + ".*") if pid is None or f.endswith("." + pid))
+        if len(found) != 1:
+            sys.exit(f"{path}: {len(found)} event files match ({', '.join(found) or 'none'}); name one, or give --pid")
+        path = found[0]
+    state = replay(path)
+    for text in args[1:]:
         addr = int(text, 16) if text.lower().startswith("0x") else int(text)
         kind, where = classify(addr, *state)
         print(f"0x{addr:x} {kind} -- {where}")
