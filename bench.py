@@ -56,10 +56,10 @@ MFMA_F32_PEAK_TFLOPS = 157.3
 # `traffic` of roofline_env is NOT measured inside this run: it is the stored figure of separate rocprofv3 --pmc passes
 # (FETCH_SIZE / WRITE_SIZE, gfx950 corrections applied by tools/rocprof_summary.py traffic) of the same launches at 2^24 states
 _PROFILES = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles")
-# the most recent measurement on the env kernels as they are (round 4 re-measured them; they have not changed since round 2)
-PMC_FILE = next((f for f in ("r4k_env_pmc_traffic.json", "r2_env_pmc_traffic.json", "r1b_env_pmc_traffic.json") if os.path.exists(os.path.join(_PROFILES, f))),
-                "r4k_env_pmc_traffic.json")
-GEMM_PMC_FILE = "r4_split_gemm_traffic.json"   # the hidden-layer kernel that runs today (k_split_gemm<2, 4, 11, 4, 2, 0>), re-measured in round 4
+# the most recent measurement of the kernels as they are in this tree (re-taken every round the kernels change: tools/r6_pmc_pass.sh)
+PMC_FILE = next((f for f in ("r6_env_pmc_traffic.json", "r4k_env_pmc_traffic.json") if os.path.exists(os.path.join(_PROFILES, f))), "r6_env_pmc_traffic.json")
+GEMM_PMC_FILE = next((f for f in ("r6_split_gemm_traffic.json", "r4_split_gemm_traffic.json") if os.path.exists(os.path.join(_PROFILES, f))),
+                     "r6_split_gemm_traffic.json")   # the hidden-layer kernel that runs today (k_split_gemm<2, 4, 11, 4, 2, 0>)
 PMC_SOURCE = f"stored PMC figure: profiles/{PMC_FILE} (separate rocprofv3 --pmc passes of these launches, not this run)"
 
 
@@ -433,6 +433,9 @@ def replay_solutions(roots_np, res, what):
     return {"games_reported_solved": int(len(idx)), "solutions_replayed_to_solved": ok}
 
 
+SPREAD_WINDOWS = 5
+
+
 def run_leg(name, model, pool_roots, config_roots, args, world, coll_device, trees, cap, window_only=False, full_warm=True):
     """
     One network precision: steady-state window of K steps on the continuously refilled pool, the whole pool to
@@ -501,6 +504,23 @@ def run_leg(name, model, pool_roots, config_roots, args, world, coll_device, tre
     mean_path = float(plen[(status == 0) & (run.owner >= 0)].mean()) if running_in_window else 0.0
     refills_in_window = run.stats["refills"] - refills0
     flushes_in_window = run.stats.get("flushes", 0) - flushes0
+    # Five more windows of K steps right behind the timed one (same bracket): how far one K-step window of this run is from the next,
+    # so that a change of a few per cent between two runs can be told from the window's own scatter (value_spread: median, min, max).
+    more = torch.zeros((SPREAD_WINDOWS, 2), dtype=torch.float64)
+    for w in range(SPREAD_WINDOWS):
+        if run.done:
+            break
+        n_before = run.nodes_now()
+        barrier()
+        tw = time.perf_counter()
+        left = args.steps
+        while left > 0 and not run.done:
+            before = run.it
+            run.round(left)
+            left -= run.it - before
+        barrier()
+        more[w, 0] = time.perf_counter() - tw
+        more[w, 1] = run.nodes_now() - n_before
     pool = None
     if not window_only:
         while not run.done:
@@ -511,7 +531,7 @@ def run_leg(name, model, pool_roots, config_roots, args, world, coll_device, tre
         pool_check = replay_solutions(pool_roots.numpy(), res, f"{name} pool run")
         pool = {"games": int(run.n_games), "slots": trees, "nodes": int(res.nodes.sum()), "seconds": round(pool_seconds, 3), **pool_check,
                 "nodes_per_sec": round(float(res.nodes.sum()) / pool_seconds, 1), "solve_rate": float(res.solved.mean()),
-                "iterations": int(run.it), **{k: (round(v, 4) if isinstance(v, float) else v) for k, v in run.stats.items() if k != "iterations"}}
+                "path_overflow_trees": res.path_overflow_trees, "iterations": int(run.it), **{k: (round(v, 4) if isinstance(v, float) else v) for k, v in run.stats.items() if k != "iterations"}}
     del run
     # ---- the first `trees` scrambles as one batch, to completion (BASELINE configs[1]) ------------------------
     rtc = local = None
@@ -527,6 +547,7 @@ def run_leg(name, model, pool_roots, config_roots, args, world, coll_device, tre
         rtc_seconds = time.perf_counter() - t1
         local = {"nodes": full.nodes, "solved": full.solved, "lengths": full.lengths}
         rtc = {"seconds": rtc_seconds, "nodes": int(full.nodes.sum()), "iterations": int(full.iterations.max()),
+               "path_overflow_trees": full.path_overflow_trees,
                "launch_sizes": int(agent.refill_stats.get("compactions", 0)) + 1,
                "check": replay_solutions(config_roots.numpy(), full, f"{name} run to completion")}
     forest_gb = {"hbm_behind_the_forest_gb": round(agent.forest.bytes_allocated() / 1e9, 2), "mapped_on_demand": bool(agent.forest.vmm),
@@ -535,6 +556,15 @@ def run_leg(name, model, pool_roots, config_roots, args, world, coll_device, tre
                           float(pool["nodes"]) if pool else 0.0, float(pool["seconds"]) if pool else 0.0],
                          dtype=torch.float64, device=coll_device)
     rank_values = [round(nodes / seconds, 1)]           # every rank's own window: its nodes / its seconds
+    more = more.to(coll_device)
+    if world > 1:       # a window of the job: all ranks' nodes / the slowest rank's seconds
+        sec, nod = more[:, 0].clone(), more[:, 1].clone()
+        dist.all_reduce(sec, op=dist.ReduceOp.MAX)
+        dist.all_reduce(nod, op=dist.ReduceOp.SUM)
+        more = torch.stack([sec, nod], 1)
+    windows = sorted(float(n / t) for t, n in more.cpu().tolist() if t > 0 and n > 0)
+    spread = {"windows": len(windows), "median": round(windows[len(windows) // 2], 1), "min": round(windows[0], 1), "max": round(windows[-1], 1),
+              "note": f"{len(windows)} further windows of K steps right behind the timed one"} if windows else None
     if world > 1:
         every = [torch.zeros_like(stats) for _ in range(world)]
         dist.all_gather(every, stats)
@@ -550,7 +580,7 @@ def run_leg(name, model, pool_roots, config_roots, args, world, coll_device, tre
            "nodes_in_window": nodes, "steps_timed": steps_done, "prep_iterations_untimed": prep_iters, "result_flushes_in_window": flushes_in_window,
            "refills_in_window": refills_in_window, "running_trees_rank0": running_in_window,
            "mean_descent_depth_rank0": round(mean_path, 1), "max_states_per_tree": cap,
-           "prepare_seconds_rank0": round(prepare_seconds, 3), "forest_rank0": forest_gb, "rank_values": rank_values}
+           "prepare_seconds_rank0": round(prepare_seconds, 3), "forest_rank0": forest_gb, "rank_values": rank_values, "value_spread": spread}
     if pool:
         out["pool_run"] = dict(pool, nodes=pool_nodes, seconds=round(pool_s, 3), nodes_per_sec=round(pool_nodes / pool_s, 1),
                                games=int(pool["games"]) * world,
@@ -567,6 +597,7 @@ def run_leg(name, model, pool_roots, config_roots, args, world, coll_device, tre
             "ci95": float(1.959963984540054 * np.sqrt(p * (1 - p) / total)),
             "mean_solution_length": float(np.mean(g["lengths"][g["solved"].astype(bool)])) if np.any(g["solved"]) else None,
             "lock_step_iterations_rank0": rtc["iterations"], "launch_sizes_rank0": rtc["launch_sizes"],
+            "path_overflow_trees_rank0": rtc["path_overflow_trees"],
             **{k + "_rank0": v for k, v in rtc["check"].items()},
             "seconds_incl_prepare_rank0": round(rtc["seconds"] + prepare_seconds, 3),
             "warm_up": "forest allocated and HIP graphs of every launch size captured before (MCTS.prepare), then "
@@ -952,7 +983,12 @@ def step_rooflines(engine, agent, roots, args, name):
                               (f"first hidden layer of the split engine via hipBLASLt: f16 GEMMs [{rows} x {W1[1]}] x [{W1[1]} x {W1[0]}] (hi.hi) and "
                                f"[{rows} x {2 * W1[1]}] x [{2 * W1[1]} x {W1[0]}] (hi.lo + lo.hi), fp32 out"),
                     "bound": "mfma", "achieved": round(executed / t / 1e12, 1), "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s",
-                    "frac": round(executed / t / 1e12 / MFMA_BF16_PEAK_TFLOPS, 4), "traffic": gemm_traffic, "traffic_source": gemm_traffic_src,
+                    "frac": round(executed / t / 1e12 / MFMA_BF16_PEAK_TFLOPS, 4),
+                    # `frac` prices the f16 flops the kernel EXECUTES (three products per fp32-equivalent product); SURVEY 8(d)'s algorithmic
+                    # figure for the layer (2 x 4096 x 2048 flops per row = 189 GFLOP per launch) against the same peak is algorithmic_frac
+                    "algorithmic_frac": round(f32_equiv / t / 1e12 / MFMA_BF16_PEAK_TFLOPS, 4), "algorithmic_flops_per_launch": f32_equiv,
+                    "traffic": gemm_traffic, "traffic_source": gemm_traffic_src,
+                    "traffic_source_short": f"stored: profiles/{GEMM_PMC_FILE} (separate --pmc FETCH_SIZE / WRITE_SIZE passes, not this run)" if gemm_traffic else None,
                     "flops_per_launch": executed,
                     "ms_per_launch": phases["gemm_hidden1"], "fp32_equivalent_tflops": round(f32_equiv / t / 1e12, 1),
                     "fp32_mfma_peak_tflops": MFMA_F32_PEAK_TFLOPS,
@@ -1041,7 +1077,7 @@ def draw_scrambles(n_config, n_pool, depth, slice_rank, slice_world):
     return config_roots, pool_roots
 
 
-def scale_efficiency(world, value, workload_key, ref_path, write=True, gpu=""):
+def scale_efficiency(world, value, workload_key, ref_path, write=True, gpu="", ref_value=None):
     """
     The scaling curve without post-processing: a one-GPU run leaves {value, workload} in `ref_path`; an N-GPU run of the SAME
     workload on the same checkout returns value / (N x that value).  (efficiency, note); efficiency is None for one GPU, when
@@ -1055,6 +1091,8 @@ def scale_efficiency(world, value, workload_key, ref_path, write=True, gpu=""):
             except OSError:
                 pass
         return None, "one GPU: this run IS the reference of the curve"
+    if ref_value:   # handed in (--scale-ref-value / RUBIKS_SCALE_REF): no file of an earlier run is needed
+        return round(value / (world * ref_value), 4), f"value / ({world} x {ref_value}), the one-GPU value given with --scale-ref-value / RUBIKS_SCALE_REF"
     name = os.path.basename(ref_path)
     if not os.path.exists(ref_path):
         return None, f"no one-GPU record of this workload ({name}) next to bench.py: run --gpus 1 first on this checkout"
@@ -1086,6 +1124,9 @@ def launch_ranks(n, argv, script=os.path.abspath(__file__)):
     for r in range(n):
         env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
                    MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        # RCCL shares device buffers between the ranks of a node through IPC handles; the hosts of this pool only support the dmabuf
+        # form (with the legacy mode hipIpcGetMemHandle fails with "invalid argument" and the first collective with it).  The image
+        # exports the variable already; a rank started from an environment that lost it gets it back (tests/test_bench_line.py).
         env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         procs.append(subprocess.Popen([sys.executable, script, *argv], env=env,
                                       stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL, text=True))
@@ -1132,8 +1173,14 @@ def main():
                     help="network engines to measure; the FIRST one is the headline `value`: f32s = fp32 accuracy on the f16 matrix "
                          "cores (SplitF32Net), f32 = fp32 MFMA GEMMs (the reference's arithmetic as is), bf16 = the fast engine; "
                          "`:window` = timed window only (no pool tail, no run to completion)")
-    ap.add_argument("--extra-legs", default="astar,config5,adi",
-                    help="astar = BASELINE configs[2] (4 096 depth-20 A* problems per GPU); config5 = one GPU's share of configs[4] "
+    ap.add_argument("--scale-ref-value", type=float, default=float(os.environ.get("RUBIKS_SCALE_REF", 0)) or None,
+                    help="the one-GPU `value` of this workload (or RUBIKS_SCALE_REF): `efficiency` of an N-GPU run = value / (N x it).  Without "
+                         "it the record a --gpus 1 run of the same checkout left next to bench.py is used, else efficiency is null -- the "
+                         "line always carries value_per_gpu (= value / N), which is all a driver needs to compute the curve itself")
+    ap.add_argument("--extra-legs", default="auto",
+                    help="auto = astar,config5,adi on one GPU; config5 alone under --gpus N > 1 (the curve needs the MCTS window, the run to "
+                         "completion and the config-5 share: A* and ADI at two precisions on every rank add a minute of wall time and "
+                         "nothing to it).  astar = BASELINE configs[2] (4 096 depth-20 A* problems per GPU); config5 = one GPU's share of configs[4] "
                          "(8 192 concurrent depth-24 trees); adi = configs[3] (data generation of a 16 384-state ADI rollout); none = "
                          "none of them.  Each runs at f32s, then bf16")
     ap.add_argument("--adi-states", type=int, default=16384, help="states per ADI rollout of the `adi` leg (BASELINE configs[3]: 16 384 = 512 games x 32 moves)")
@@ -1175,6 +1222,8 @@ def main():
     legs = [x.split(":")[0] for x in args.legs.split(",") if x]
     leg_window_only = {x.split(":")[0]: x.endswith(":window") for x in args.legs.split(",") if x}
     assert legs and all(x in LEG_DTYPE for x in legs)
+    if args.extra_legs == "auto":
+        args.extra_legs = "astar,config5,adi" if args.gpus == 1 else "config5"
     extra = [] if args.extra_legs in ("", "none") else [x for x in args.extra_legs.split(",") if x]
     assert all(x in ("astar", "config5", "adi") for x in extra)
 
@@ -1288,6 +1337,8 @@ def main():
         # solutions walked through cube.multi_rotate / multi_is_solved outside the timed regions (rank 0's games; a mismatch aborts the run)
         "run_to_completion_solutions_replayed": rtc_of(head).get("solutions_replayed_to_solved_rank0"),
         "pool_solutions_replayed": (head.get("pool_run") or {}).get("solutions_replayed_to_solved"),
+        # trees ended by a full path store: 0 -- the default store has no bound (descents of any length, as in the reference)
+        "path_overflow_trees": (rtc_of(head).get("path_overflow_trees_rank0") or 0) + ((head.get("pool_run") or {}).get("path_overflow_trees") or 0),
     }
     for name in legs[1:]:
         summary[f"{name}_value"] = results[name]["value"]
@@ -1320,13 +1371,14 @@ def main():
     workload_key = {"trees": args.trees, "depth": args.depth, "max_states": args.solve_max_states, "leg": legs[0], "pool_factor": args.pool_factor,
                     "steps": args.steps, "warmup": args.warmup}
     efficiency, efficiency_note = scale_efficiency(world, head["value"], workload_key, os.path.join(ROOT, SCALE_REF), write=not args.as_rank,
-                                                   gpu=torch.cuda.get_device_name(device_index))
+                                                   gpu=torch.cuda.get_device_name(device_index), ref_value=args.scale_ref_value)
     weights_short = os.path.relpath(args.weights, ROOT) if os.path.isdir(args.weights) else "random-init"
     result = {
         "metric": "MCTS node expansions/sec, depth-20 scrambles", "value": head["value"],
         "unit": "node expansions/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": head["ms_per_step"], "higher_is_better": True, "scaling": "weak", "scaling_measured": world > 1,
-        "rank_values": head.get("rank_values"), "efficiency": efficiency, "efficiency_note": efficiency_note,
+        "rank_values": head.get("rank_values"), "value_per_gpu": round(head["value"] / world, 1), "value_spread": head.get("value_spread"),
+        "efficiency": efficiency, "efficiency_note": efficiency_note,
         "vs_baseline": None, "dtype": head["dtype"], "data": "synthetic",
         "config": {"workload": f"{args.trees} concurrent depth-{args.depth} MCTS trees per GPU (c=0.6, graph search, max_states "
                                f"{args.solve_max_states}), slots refilled from a pool of {args.pool_factor} x {args.trees} scrambles "
@@ -1413,16 +1465,19 @@ def compact_line(full, detail_name="bench_detail.json"):
     """
     cfg = full["config"]
     line = {k: full[k] for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
-                                 "scaling_measured", "rank_values", "efficiency", "vs_baseline", "data") if k in full}
+                                 "scaling_measured", "rank_values", "value_per_gpu", "value_spread", "efficiency", "vs_baseline", "data") if k in full}
+    if isinstance(line.get("value_spread"), dict):
+        line["value_spread"] = {k: v for k, v in line["value_spread"].items() if k != "note"}
     line["dtype"] = _short(full["dtype"], 96)
     line["config"] = {"workload": _short(cfg.get("workload_short") or cfg["workload"], STR_LIMIT), "trees_per_gpu": cfg.get("trees_per_gpu"),
                       "max_states": cfg.get("max_states"), "scramble_depth": cfg.get("scramble_depth"), "parallelism": cfg.get("parallelism"),
                       "timed_region": _short(cfg.get("timed_region_short") or cfg.get("timed_region", ""), STR_LIMIT),
                       "results": dict(cfg.get("results") or {})}
     roof = full.get("roofline") or {}
-    keep = ("kernel", "bound", "achieved", "peak", "unit", "frac", "traffic", "algorithmic_bytes", "flops_per_launch", "ms_per_launch", "ms",
-            "fp32_equivalent_tflops")
-    line["roofline"] = {k: (_short(roof.get("kernel_short") or roof[k], STR_LIMIT) if k == "kernel" else roof[k]) for k in keep if k in roof}
+    keep = ("kernel", "bound", "achieved", "peak", "unit", "frac", "algorithmic_frac", "traffic", "traffic_source", "algorithmic_bytes", "flops_per_launch",
+            "algorithmic_flops_per_launch", "ms_per_launch", "ms", "fp32_equivalent_tflops")
+    line["roofline"] = {k: (_short(roof.get("kernel_short") or roof[k], STR_LIMIT) if k == "kernel" else
+                            _short(roof.get("traffic_source_short") or roof[k] or "", STR_LIMIT) if k == "traffic_source" else roof[k]) for k in keep if k in roof}
     for sub in ("env_multi_rotate_2p24", "astar_dominant_kernel", "adi_dominant_kernel", "adi_env"):
         if sub in roof:
             line["roofline"][sub] = {k: (_short(roof[sub].get("kernel_short") or v, STR_LIMIT) if isinstance(v, str) else v)

@@ -22,6 +22,7 @@
 // and the activations its B operand, so a lane's four accumulator registers are four ADJACENT output columns of one row:
 // the epilogue stores 8 bytes of hi halves and 8 bytes of lo halves per fragment.
 #include <atomic>
+#include <type_traits>
 
 #include "rubiks_common.h"
 #include "rubiks_netmath.h"
@@ -35,6 +36,12 @@ constexpr int kOutHalves = 0, kOutF32 = 1, kBf16 = 2, kPartials = 3;   // operan
 typedef __attribute__((address_space(3))) void lds_void;
 typedef const __attribute__((address_space(1))) void glb_void;
 
+// Diagnostic builds only (tools/build_ab_lib.sh WORK <name> -DRUBIKS_GEMM_ABLATE=n; WRONG RESULTS, timing experiments):
+//   1 no LDS-DMA after the first stage (what memory costs)   2 no barrier / vmcnt wait after the first step (what synchronisation costs)
+//   3 both                                                    4 no fragment reads after the first step (what LDS reads cost)
+#ifndef RUBIKS_GEMM_ABLATE
+#define RUBIKS_GEMM_ABLATE 0
+#endif
 constexpr int kGemmRowBytes = 128;   // one K-step: 64 halves per row
 constexpr int kPiecesPerRow = 2;   // LDS-DMA pieces a wave issues behind the MFMAs of one 16-row fragment
 
@@ -54,6 +61,23 @@ struct GemmArgs {
     u32 P;                       // products of the f16 kinds: 3 = the split layer (a hi | lo, w lo | hi | hi), 1 = a [M][K] x w [N][K] as they are
 };
 constexpr float kHalfMax = 65504.0f;
+
+// The rows of a tile's two operands as buffer resources (wave-uniform, in scalar registers): an LDS-DMA piece is then one
+// buffer_load ... lds with a loop-invariant VGPR offset and a scalar K offset.
+struct StageBufs {
+    __amdgpu_buffer_rsrc_t a, w;
+};
+__device__ __forceinline__ StageBufs stage_bufs(const void *a, const void *w) {
+    StageBufs b;
+    b.a = __builtin_amdgcn_make_buffer_rsrc((void *)a, 0, 0x7FFFFFFF, 0x00020000);   // raw buffer, offsets checked against 2 GB
+    b.w = __builtin_amdgcn_make_buffer_rsrc((void *)w, 0, 0x7FFFFFFF, 0x00020000);
+    return b;
+}
+
+// (a plain function: used directly inside the kernel template, the builtin silently drops the template's host-side instantiation)
+__device__ __forceinline__ void lds_dma16(__amdgpu_buffer_rsrc_t r, lds_void *dst, u32 voffset, u32 soffset) {
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(r, dst, 16, voffset, soffset, 0, 0);
+}
 
 template <int WM, int WN, int MR, int NR> struct GemmTile {
     static constexpr int BM = WM * MR * 16, BN = WN * NR * 16, WAVES = WM * WN, THREADS = WAVES * 64;
@@ -91,27 +115,31 @@ __global__ __launch_bounds__(WM *WN * 64) void k_split_gemm(GemmArgs g) {
     const u32 K = g.K, lda = (one ? 1 : 2) * K * 2, ldw = (one ? 1 : 3) * K * 2;   // bytes
     const u32 last_row = (u32)(g.M - 1 - row0);            // rows past M re-read the last row; their outputs are not stored
 
-    u32 src_off[T::PPW];
+    // A wave's LDS-DMA pieces (8 rows x 128 bytes each): its activation pieces first (PA of them: piece p = i WAVES + wave of the
+    // tile's BM / 8), then its weight pieces.  Each is ONE buffer_load ... lds: the tile's rows as a buffer resource (scalar
+    // registers), the lane's place in it a loop-invariant VGPR, the K-step a scalar offset -- no vector address arithmetic per piece
+    // (a 64-bit vector add in front of every piece held the wave's issue next to the MFMAs: profiles/r6_gemm_ablation.txt).
+    constexpr int PA = (T::BM / 8 + T::WAVES - 1) / T::WAVES, PW = (T::BN / 8 + T::WAVES - 1) / T::WAVES;
+    static_assert(PA + PW == T::PPW || PA + PW == T::PPW + 1, "piece bookkeeping");
+    u32 src_off[PA + PW];
 #pragma unroll
-    for (int i = 0; i < T::PPW; ++i) {
-        const u32 p = i * T::WAVES + wave, R = p * 8 + (lane >> 3), chunk = (lane & 7) ^ ((R >> 1) & 7);
-        if (p < (u32)(T::BM / 8)) src_off[i] = min(R, last_row) * lda + chunk * 16;
-        else src_off[i] = (R - T::BM) * ldw + chunk * 16;
+    for (int i = 0; i < PA + PW; ++i) {
+        const u32 p = (i < PA ? i : i - PA) * T::WAVES + wave, R = p * 8 + (lane >> 3), chunk = (lane & 7) ^ ((R >> 1) & 7);
+        src_off[i] = i < PA ? min(R, last_row) * lda + chunk * 16 : R * ldw + chunk * 16;   // (the swizzle depends on R mod 16 only: BM is a multiple of 16)
     }
-    const unsigned char *a_tile = g.a + row0 * lda;
-    const unsigned char *w_tile = g.w + (size_t)col0 * ldw;
+    const StageBufs sb = stage_bufs(g.a + row0 * lda, g.w + (size_t)col0 * ldw);
 
-    auto stage = [&](u32 ks, u32 buf, int lo = 0, int hi = T::PPW) {   // this wave's pieces lo .. hi - 1 of stage ks
+    auto stage = [&](u32 ks, u32 buf, int lo = 0, int hi = 64) {   // this wave's pieces lo .. hi - 1 of stage ks
         const u32 kk = ks * 64, a_col = (one || kk < 2 * K) ? kk : kk - 2 * K;
-        const unsigned char *ab = a_tile + a_col * 2, *wb = w_tile + kk * 2;
         unsigned char *dst = lds + buf * T::STAGE;
 #pragma unroll
-        for (int i = 0; i < T::PPW; ++i) {
+        for (int i = 0; i < PA + PW; ++i) {
             if (i < lo || i >= hi) continue;
-            const u32 p = i * T::WAVES + wave;
-            if (p < (u32)T::PIECES) {
-                const unsigned char *src = (p < (u32)(T::BM / 8) ? ab : wb) + src_off[i];
-                __builtin_amdgcn_global_load_lds((glb_void *)src, (lds_void *)(dst + p * 1024), 16, 0, 0);
+            const u32 p = (i < PA ? i : i - PA) * T::WAVES + wave;
+            if (i < PA) {
+                if (p < (u32)(T::BM / 8)) lds_dma16(sb.a, (lds_void *)(dst + p * 1024), src_off[i], a_col * 2);
+            } else if (p < (u32)(T::BN / 8)) {
+                lds_dma16(sb.w, (lds_void *)(dst + T::A_BYTES + p * 1024), src_off[i], kk * 2);
             }
         }
     };
@@ -135,38 +163,51 @@ __global__ __launch_bounds__(WM *WN * 64) void k_split_gemm(GemmArgs g) {
     const u32 nk_all = (one ? 1 : 3) * K / 64, scale_step = one ? 0xFFFFFFFFu : 2 * K / 64;
     const u32 ks0 = KIND == kPartials ? half * (nk_all / g.S) : 0u, nk = KIND == kPartials ? ks0 + nk_all / g.S : nk_all;
     stage(ks0, 0);
-    for (u32 ks = ks0; ks < nk; ++ks) {
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
-        const bool more = ks + 1 < nk;
-        if (ks == scale_step) {
-#pragma unroll
-            for (int m = 0; m < MR; ++m)
-#pragma unroll
-                for (int n = 0; n < NR; ++n) acc[m][n] *= (1.0f / kSplitScale);
+    // two loops over the K-steps with the scaling of the correction products between them (one loop with the scaling behind a
+    // test costs the 512-register tiles their register allocation: the accumulators live in AGPRs, the scaling needs them in VGPRs)
+    const u32 ks_mid = scale_step > ks0 && scale_step < nk ? scale_step : nk;
+    auto k_step = [&](u32 ks) {
+        if (!(RUBIKS_GEMM_ABLATE & 2) || ks == ks0) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
         }
+        const bool more = (RUBIKS_GEMM_ABLATE & 1) ? false : ks + 1 < nk;
         const unsigned char *s = lds + ((ks - ks0) & 1) * T::STAGE;
         f16x8 wf[NR][2];
 #pragma unroll
         for (int n = 0; n < NR; ++n)
 #pragma unroll
             for (int kh = 0; kh < 2; ++kh) wf[n][kh] = *reinterpret_cast<const f16x8 *>(s + w_off[kh] + n * 16 * kGemmRowBytes);
+        // the activation fragments of row m + 1 are requested BEFORE the MFMAs of row m (two registers sets, alternating): a wave's
+        // matrix instructions then wait for LDS once per K-step, not once per row
+        f16x8 xf[2][2];
+#pragma unroll
+        for (int kh = 0; kh < 2; ++kh) xf[0][kh] = *reinterpret_cast<const f16x8 *>(s + x_off[kh]);
 #pragma unroll
         for (int m = 0; m < MR; ++m) {
-            f16x8 xf[2];
+            if (m + 1 < MR) {
 #pragma unroll
-            for (int kh = 0; kh < 2; ++kh) xf[kh] = *reinterpret_cast<const f16x8 *>(s + x_off[kh] + m * 16 * kGemmRowBytes);
+                for (int kh = 0; kh < 2; ++kh) xf[(m + 1) & 1][kh] = *reinterpret_cast<const f16x8 *>(s + x_off[kh] + (m + 1) * 16 * kGemmRowBytes);
+            }
 #pragma unroll
             for (int kh = 0; kh < 2; ++kh)
 #pragma unroll
                 for (int n = 0; n < NR; ++n)
-                    acc[m][n] = KIND == kBf16 ? __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, wf[n][kh]), __builtin_bit_cast(bf16x8, xf[kh]), acc[m][n], 0, 0, 0)
-                                              : __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[n][kh], xf[kh], acc[m][n], 0, 0, 0);
+                    acc[m][n] = KIND == kBf16 ? __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, wf[n][kh]), __builtin_bit_cast(bf16x8, xf[m & 1][kh]), acc[m][n], 0, 0, 0)
+                                              : __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[n][kh], xf[m & 1][kh], acc[m][n], 0, 0, 0);
             // the next stage, two LDS-DMA pieces behind each of the first rows' MFMAs: issued in the shadow of the matrix cores
             // (and of the SIMD's other wave) instead of all at once behind the barrier, early enough to land before the next one
-            if (more && kPiecesPerRow * m < T::PPW) stage(ks + 1, (ks + 1 - ks0) & 1, kPiecesPerRow * m, kPiecesPerRow * (m + 1));
+            if (more && kPiecesPerRow * m < PA + PW) stage(ks + 1, (ks + 1 - ks0) & 1, kPiecesPerRow * m, kPiecesPerRow * (m + 1));
         }
+    };
+    for (u32 ks = ks0; ks < ks_mid; ++ks) k_step(ks);
+    if (ks_mid < nk) {   // (scaling in front of a chunk's first step would scale zeros: left out)
+#pragma unroll
+        for (int m = 0; m < MR; ++m)
+#pragma unroll
+            for (int n = 0; n < NR; ++n) acc[m][n] *= (1.0f / kSplitScale);
     }
+    for (u32 ks = ks_mid; ks < nk; ++ks) k_step(ks);
 
     // epilogue: lane holds columns cbase + 16 n + 4 fq + {0..3} of row rbase + 16 m + fr
     const u32 cbase = col0 + wc * NR * 16 + 4 * fq;
@@ -301,15 +342,23 @@ extern "C" int rc_split_layer_f16(const rc_split_layer_t *L, rc_stream_t stream)
         if (L->tile == 3) return launch_split_gemm<2, 4, 11, 2, RC_ACT_NONE, kPartials>(g, s);   // 352 x 128 tiles: small batches
         return launch_split_gemm<2, 4, 11, 4, RC_ACT_NONE, kPartials>(g, s);
     }
-    RC_REQUIRE(L->bias != nullptr && L->k_splits <= 1 && L->tile >= 0 && L->tile <= 3, RC_ERR_RANGE);
+    RC_REQUIRE(L->bias != nullptr && L->k_splits <= 1 && L->tile >= 0 && L->tile <= 6, RC_ERR_RANGE);
     g.out = L->out_hi_lo ? (void *)L->out_hi_lo : (void *)L->out_f32;
     const bool split = L->out_hi_lo != nullptr;
     int tile = L->tile;
     // tile 0: choose -- the 352 x 256 tile when it fills the chip, else 352 x 128, else 176 x 128
     const size_t row_tiles = ceil_div(L->n_rows, (size_t)352);
     if (tile == 0) tile = (L->n_out % 256 == 0 && row_tiles * (L->n_out / 256) >= 192) ? 1 : (row_tiles * (L->n_out / 128) >= 192) ? 3 : 2;
-    RC_REQUIRE(tile != 1 || L->n_out % 256 == 0, RC_ERR_RANGE);
+    RC_REQUIRE((tile != 1 && tile < 4) || L->n_out % 256 == 0, RC_ERR_RANGE);
     const int activation = L->activation;
+    if (tile == 6)   // 256 x 256 by four waves, 128 x 128 per wave: the accumulators are exactly the 256 AGPRs
+        return split ? dispatch_split_gemm<2, 2, 8, 8, kOutHalves>(g, activation, s) : dispatch_split_gemm<2, 2, 8, 8, kOutF32>(g, activation, s);
+    // 352 x 256 by FOUR waves, one per SIMD, accumulators in the upper half of the 512-register file: 176 x 128 per wave (tile 4:
+    // 152 KB of fragment reads per K-step instead of 240 KB) or 352 x 64 per wave (tile 5).  Same K order: bit-identical outputs.
+    if (tile == 4)
+        return split ? dispatch_split_gemm<2, 2, 11, 8, kOutHalves>(g, activation, s) : dispatch_split_gemm<2, 2, 11, 8, kOutF32>(g, activation, s);
+    if (tile == 5)
+        return split ? dispatch_split_gemm<1, 4, 22, 4, kOutHalves>(g, activation, s) : dispatch_split_gemm<1, 4, 22, 4, kOutF32>(g, activation, s);
     if (tile == 1)   // 352 x 256
         return split ? dispatch_split_gemm<2, 4, 11, 4, kOutHalves>(g, activation, s) : dispatch_split_gemm<2, 4, 11, 4, kOutF32>(g, activation, s);
     if (tile == 3)   // 352 x 128
@@ -341,13 +390,14 @@ extern "C" int rc_gemm_layer_bf16(const rc_split_layer_t *L, rc_stream_t stream)
     if (int rc = layer_args(L, g)) return rc;
     if (L->n_rows == 0) return RC_OK;
     RC_REQUIRE(L->bias && L->out_bf16 && !L->out_hi_lo && !L->out_f32 && !L->out_partials, RC_ERR_NULL);
-    RC_REQUIRE(L->tile == 0 || L->tile == 1 || L->tile == 3, RC_ERR_RANGE);
+    RC_REQUIRE(L->tile == 0 || L->tile == 1 || L->tile == 3 || L->tile == 4, RC_ERR_RANGE);
     g.out = (void *)L->out_bf16;
     int tile = L->tile;
     const size_t row_tiles = ceil_div(L->n_rows, (size_t)352);
     if (tile == 0) tile = (L->n_out % 256 == 0 && row_tiles * (L->n_out / 256) >= 192) ? 1 : 3;
-    RC_REQUIRE(tile != 1 || L->n_out % 256 == 0, RC_ERR_RANGE);
+    RC_REQUIRE((tile != 1 && tile != 4) || L->n_out % 256 == 0, RC_ERR_RANGE);
     hipStream_t s = (hipStream_t)stream;
+    if (tile == 4) return dispatch_split_gemm<2, 2, 11, 8, kBf16>(g, L->activation, s);
     if (tile == 1) return dispatch_split_gemm<2, 4, 11, 4, kBf16>(g, L->activation, s);
     return dispatch_split_gemm<2, 4, 11, 2, kBf16>(g, L->activation, s);
 }

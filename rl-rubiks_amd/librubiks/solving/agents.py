@@ -161,9 +161,14 @@ class QueueTable:
 class BatchResult:
     """Per-scramble outcome of a batched search (shapes (B,)); `queues[t]` is tree t's action queue."""
 
-    def __init__(self, solved, lengths, nodes, queues, seconds, iterations, status):
+    def __init__(self, solved, lengths, nodes, queues, seconds, iterations, status, game_seconds=None):
         self.solved, self.lengths, self.nodes, self.queues = solved, lengths, nodes, queues
         self.seconds, self.iterations, self.status = seconds, iterations, status
+        # Per-game wall interval (float64 [B]) where the agent keeps one: from the moment the game's search starts (its tree is
+        # planted / its problem enters the batch) to the moment the host sees it finished -- what the reference's Evaluator times
+        # around agent.search (evaluation.py:45-52).  Games of one batch share the GPU, so these intervals OVERLAP: their sum is not
+        # the batch's wall time (`seconds`).  None: the agent does not record them.
+        self.game_seconds = game_seconds
 
     @property
     def states_per_sec(self) -> float:
@@ -185,7 +190,8 @@ class BatchResult:
         else:
             queues = [self.queues[i] for i in idx]
         return BatchResult(self.solved[idx], self.lengths[idx], self.nodes[idx], queues,
-                           self.seconds, self.iterations[idx], self.status[idx])
+                           self.seconds, self.iterations[idx], self.status[idx],
+                           None if self.game_seconds is None else self.game_seconds[idx])
 
     @staticmethod
     def merge(n: int, parts, seconds: float) -> "BatchResult":
@@ -238,17 +244,19 @@ class BFS(Agent):
         states = states.numpy() if isinstance(states, DeviceCubes) else np.asarray(states)
         B = len(states)
         solved, lengths, nodes = np.zeros(B, dtype=bool), np.full(B, -1, dtype=np.int64), np.zeros(B, dtype=np.int64)
-        queues, levels = [], np.zeros(B, dtype=np.int64)
+        queues, levels, each = [], np.zeros(B, dtype=np.int64), np.zeros(B)
         tt = TickTock()
         tt.tick()
         for g in range(B):
+            t0 = tt.tock()
             solved[g] = self.search(states[g], time_limit, max_states)
+            each[g] = tt.tock() - t0
             queues.append(self.action_queue)
             nodes[g], levels[g] = len(self), self._dev.levels
             if solved[g]:
                 lengths[g] = len(self.action_queue)
         status = np.where(solved, np.where(nodes == 0, 4, 1), 2)
-        return BatchResult(solved, lengths, nodes, queues, tt.tock(), levels, status)
+        return BatchResult(solved, lengths, nodes, queues, tt.tock(), levels, status, each)
 
     def __str__(self):
         return "Breadth-first search"
@@ -527,6 +535,8 @@ class MCTSRun:
         # iterations that may be queued before the host has looked at the node counts: what a planted tree's first rows cover
         # (16 384 rows: its first ~1 360 iterations), so that a long `sync_every` cannot make trees sit out behind the kernel's guard
         forest._steps_covered = min(2 * agent.sync_every, max(1, (forest._first_rows() - 14) // 12))
+        self.t_start = np.zeros(self.n_games)               # per game: seconds on the agent's clock when its tree was planted ...
+        self.t_end = np.full(self.n_games, np.nan)          # ... and when the host first saw it finished (NaN: still running)
         self.owner = np.arange(S)          # game index of every slot; -1 once its result has been taken and nobody moved in
         self.stale_until = np.full(S, -1)  # snapshots up to this index predate the tree that now lives in the slot
         self.next_game = S
@@ -718,6 +728,10 @@ class MCTSRun:
         fresh = self.stale_until < qi
         running = live & ((status == md.RUNNING) | ~fresh)      # a slot refilled after the snapshot runs by definition
         done = np.flatnonzero(live & fresh & (status != md.RUNNING))
+        if len(done):                                           # the host has just seen these games finished (first sighting counts)
+            g = owner[done]
+            first = np.isnan(self.t_end[g])
+            self.t_end[g[first]] = agent.tt.tock()
         n_run = int(running.sum())
         out_of_time = agent.tt.tock() >= self.time_limit
         waiting = self.next_game < self.n_games
@@ -732,6 +746,7 @@ class MCTSRun:
             forest.plant(idx, self.roots, self.next_game, self.plant_states, slots_host=done[:k])   # the waiting scrambles move in: roots evaluated by the next two iterations
             owner[done] = -1
             owner[done[:k]] = np.arange(self.next_game, self.next_game + k)
+            self.t_start[self.next_game:self.next_game + k] = agent.tt.tock()
             self.stale_until[done[:k]] = self.q - 1     # every snapshot queued so far predates the adoption
             self.next_game += k
             self.stats["refills"] += 1
@@ -806,6 +821,8 @@ class MCTSRun:
         result = BatchResult.merge(self.n_games, self.parts, seconds)
         if self.next_game < self.n_games:   # games that never got a slot before the time limit: unsolved, nothing explored
             result.status[self.next_game:] = md.EXHAUSTED
+            self.t_start[self.next_game:] = seconds
+        result.game_seconds = np.where(np.isnan(self.t_end), seconds, self.t_end) - self.t_start   # (still running at the end: until the end)
         self.done = True
         if agent._overflowed(forest.engine):   # the split engine could not represent an activation: the same search in fp32
             again = MCTSRun(agent, self.roots, self.time_limit, self.max_states, self.compact, self.slots, self.one_launch)
@@ -866,10 +883,14 @@ class AStar(DeepAgent):
         self.tt.tick()
         batch.reset(roots)
         it = 0
+        t_end = np.full(roots.n, np.nan)
         while max_iterations is None or it < max_iterations:
             batch.iteration(self.lambda_, cap_states)
             it += 1
-            if not batch.any_running() or self.tt.tock() >= time_limit:
+            running = (batch.status == ad.RUNNING).cpu().numpy()      # (the loop synchronises here anyway: any_running)
+            now = self.tt.tock()
+            t_end[np.isnan(t_end) & ~running] = now                   # first sighting of a finished problem
+            if not running.any() or now >= time_limit:
                 break
         torch.cuda.synchronize()
         if self._overflowed(batch.engine):   # the split engine could not represent an activation: the same search in fp32
@@ -896,7 +917,8 @@ class AStar(DeepAgent):
         self._explored_states = int(nodes[0])
         self.action_queue = queues[0]
         self._arrays = None
-        return BatchResult(solved, lengths, nodes, queues, seconds, batch.iterations.cpu().numpy(), status)
+        return BatchResult(solved, lengths, nodes, queues, seconds, batch.iterations.cpu().numpy(), status,
+                           np.where(np.isnan(t_end), seconds, t_end))
 
     def search(self, state: np.ndarray, time_limit: float = None, max_states: int = None) -> bool:
         return bool(self.search_batch(np.asarray(state)[None], time_limit, max_states).solved[0])

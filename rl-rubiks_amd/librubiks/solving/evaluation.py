@@ -9,8 +9,13 @@ at once through `agent.search_batch` (one tree / one A* problem per scramble on 
 scrambles are the reference's own (same np.random stream, `cube.scramble(depth, True)` per game), so
 `res` / `states` are comparable game by game with a reference run on the same seed for agents that
 do not draw random numbers themselves (MCTS, AStar).  `max_time` bounds every game's wall time as in
-the reference, but the games of a depth run concurrently.  `times[d, g]` is the batch wall time
-divided by the number of games (a throughput-equivalent per-game time).
+the reference, but the games of a depth run concurrently.
+
+`times[d, g]` is the reference's quantity (evaluation.py:45-52): game g's own wall interval, from the moment its search starts
+(its tree is planted, its problem enters the batch) to the moment the host sees it finished (`BatchResult.game_seconds`), and
+"states per sec" is the mean over games of states / time as in evaluation.py:120-124.  Because the games of a batch share the
+GPU these intervals overlap -- their sum is not the wall time of the evaluation; the throughput figure (all states of a depth /
+the batch's wall seconds) is kept beside it as `states_per_sec_batch` in `log_this_depth`'s summary and in `batch_seconds`.
 """
 import inspect
 import json
@@ -50,6 +55,7 @@ class Evaluator:
     def eval(self, agent):
         """(res, states, times), each (len(scrambling_depths), n_games); res = solution length or -1."""
         res, states, times = [], [], []
+        self.batch_seconds = []     # wall seconds of each depth's batch (the pooled form: one entry for everything)
         if self.slots and hasattr(agent, "search_batch") and "slots" in inspect.signature(agent.search_batch).parameters:
             return self._eval_pooled(agent)
         for d in self.scrambling_depths:
@@ -59,14 +65,15 @@ class Evaluator:
                 self.tt.profile(f"Evaluation of {agent}. Depth {'100 - 999' if self._isdeep() else d}")
                 if _world_size() > 1:   # one process per GPU: each searches its slice of the games, results are all-gathered
                     got = sharded_search_batch(agent, cubes.numpy(), self.max_time, self.max_states, device=cubes.soa.device)
-                    lengths, nodes = got["lengths"], got["nodes"]
+                    lengths, nodes, each = got["lengths"], got["nodes"], got["seconds"]
                 else:
                     out = agent.search_batch(cubes, self.max_time, self.max_states)
-                    lengths, nodes = out.lengths, out.nodes
+                    lengths, nodes, each = out.lengths, out.nodes, getattr(out, "game_seconds", None)
                 dt = self.tt.end_profile()
                 res.append(lengths)
                 states.append(nodes)
-                times.append(np.full(self.n_games, dt / self.n_games))
+                times.append(np.asarray(each, dtype=float) if each is not None else np.full(self.n_games, dt / self.n_games))
+                self.batch_seconds.append(dt)
             else:   # agents without a batched search: the reference's game-by-game loop
                 r, s, t = [], [], []
                 for _ in range(self.n_games):
@@ -80,7 +87,7 @@ class Evaluator:
                 res.append(r), states.append(s), times.append(t)
         res, states, times = np.array(res, dtype=np.int64), np.array(states, dtype=np.int64), np.array(times, dtype=float)
         for i, d in enumerate(self.scrambling_depths):
-            self.log_this_depth(res[i], states[i], times[i], d)
+            self.log_this_depth(res[i], states[i], times[i], d, self.batch_seconds[i] if i < len(self.batch_seconds) else None)
         return res, states, times
 
     def _eval_pooled(self, agent):
@@ -96,13 +103,17 @@ class Evaluator:
         out = agent.search_batch(pool, self.max_time * D if self.max_time else None, self.max_states, slots=self.slots)
         dt = self.tt.end_profile()
         res, states = out.lengths.reshape(D, G).astype(np.int64), out.nodes.reshape(D, G).astype(np.int64)
-        times = np.full((D, G), dt / (D * G))
+        each = getattr(out, "game_seconds", None)
+        times = np.asarray(each, dtype=float).reshape(D, G) if each is not None else np.full((D, G), dt / (D * G))
+        self.batch_seconds = [dt]
         for i, d in enumerate(self.scrambling_depths):
             self.log_this_depth(res[i], states[i], times[i], d)
         return res, states, times
 
-    def log_this_depth(self, res, states, times, depth) -> dict:
-        """Summary statistics of one depth (evaluation.py:96-125); logged and returned."""
+    def log_this_depth(self, res, states, times, depth, batch_seconds=None) -> dict:
+        """Summary statistics of one depth (evaluation.py:96-125); logged and returned.  batch_seconds: wall time of the depth's
+        batch -> `states_per_sec_batch`, the throughput of the GPU (the reference's figure, the mean of per-game states / time,
+        is `states_per_sec`)."""
         won = res[res != -1]
         share = len(won) / len(res)
         ok = times != 0
@@ -113,6 +124,7 @@ class Evaluator:
             "median_turns": float(np.median(won)) if won.size else None,
             "states_per_game": float(states.mean()), "states_per_sec": float(sps.mean()) if sps.size else 0.0,
             "time_per_game": float(times.mean()),
+            "states_per_sec_batch": float(states.sum() / batch_seconds) if batch_seconds else None,
         }
         self.log(f"Scrambling depth {depth if depth else 'deep'}\n"
                  f"\tShare completed: {share * 100:.2f} % {bernoulli_error(share, len(res), 0.05, stringify=True)} (approx. 95 % CI)\n"

@@ -61,7 +61,8 @@ def sharded_search_batch(agent, states: np.ndarray, time_limit=None, max_states=
     """
     One batched search over `states` ((n, 20) int8, the SAME array on every rank) with the games split over the
     ranks of the default process group: rank r runs agent.search_batch on its contiguous slice, then the per-game
-    vectors are all-gathered.  Returns {"solved", "lengths", "nodes"} for all n games, in game order, on every rank.
+    vectors are all-gathered.  Returns {"solved", "lengths", "nodes", "seconds"} for all n games, in game order, on every rank
+    ("seconds": every game's own wall interval on its rank, `BatchResult.game_seconds`).
     With a single process this is agent.search_batch on everything.
     """
     states = np.asarray(states)
@@ -70,9 +71,12 @@ def sharded_search_batch(agent, states: np.ndarray, time_limit=None, max_states=
     lo, hi = shard_range(len(states), rank, world)
     if hi > lo:
         out = agent.search_batch(states[lo:hi], time_limit, max_states, **kwargs)
-        local = {"solved": np.asarray(out.solved), "lengths": np.asarray(out.lengths), "nodes": np.asarray(out.nodes)}
+        each = getattr(out, "game_seconds", None)
+        local = {"solved": np.asarray(out.solved), "lengths": np.asarray(out.lengths), "nodes": np.asarray(out.nodes),
+                 "seconds": np.asarray(each, dtype=np.float64) if each is not None else np.full(hi - lo, out.seconds / max(1, hi - lo))}
     else:   # more ranks than games
-        local = {"solved": np.zeros(0, dtype=bool), "lengths": np.zeros(0, dtype=np.int64), "nodes": np.zeros(0, dtype=np.int64)}
+        local = {"solved": np.zeros(0, dtype=bool), "lengths": np.zeros(0, dtype=np.int64), "nodes": np.zeros(0, dtype=np.int64),
+                 "seconds": np.zeros(0)}
     return gather_results(local, len(states), device=device)
 
 

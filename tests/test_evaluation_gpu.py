@@ -40,8 +40,16 @@ def test_evaluator_matches_sequential_protocol(standin_net, tmp_path):
         assert np.array_equal(res, ref_res)
         assert np.array_equal(states, ref_states)
         assert (res[0] == 1).all()   # depth-1 scrambles are always solved in one move
-        summary = ev.log_this_depth(res[0], states[0], times[0], 1)
+        summary = ev.log_this_depth(res[0], states[0], times[0], 1, ev.batch_seconds[0])
         assert summary["share_completed"] == 1.0 and summary["ci95"] == 0.0 and summary["mean_turns"] == 1.0
+        # times[d, g] is game g's own wall interval (the reference times each agent.search, evaluation.py:45-52): positive, never
+        # longer than its batch, and "states per sec" is the mean of the per-game ratios (evaluation.py:120-124)
+        assert (times > 0).all() and all((times[i] <= ev.batch_seconds[i] * 1.001).all() for i in range(5))
+        assert np.isclose(summary["states_per_sec"], (states[0] / times[0]).mean())
+        assert np.isclose(summary["states_per_sec_batch"], states[0].sum() / ev.batch_seconds[0])
+        deep = 4                                                 # depth 5: solved games end before the exhausted ones of their batch
+        if (res[deep] != -1).any() and (res[deep] == -1).any():
+            assert times[deep][res[deep] != -1].min() < times[deep][res[deep] == -1].max()
         paths = ev.save(str(tmp_path), "agent", res, states, times)
         assert np.array_equal(np.load(paths[0]), res) and np.load(paths[2]).shape == (5, n_games)
 
@@ -79,6 +87,10 @@ def test_mcts_continuous_batching_equals_plain_batches(standin_net):
         assert np.array_equal(pooled.lengths, plain.lengths)
         assert np.array_equal(pooled.nodes, plain.nodes)
         assert [list(q) for q in pooled.queues] == [list(q) for q in plain.queues]
+        # per-game wall intervals: a game that had to wait for a slot starts later than the batch, none lasts longer than the batch
+        assert pooled.game_seconds.shape == (150,) and (pooled.game_seconds > 0).all() and (pooled.game_seconds <= pooled.seconds * 1.001).all()
+        assert pooled.game_seconds[slots:].mean() < pooled.seconds                    # (they did not all run from the start to the end)
+    assert (plain.game_seconds > 0).all() and plain.game_seconds.max() <= plain.seconds * 1.001
     assert 0 < plain.solved.sum() and not plain.solved[60:].all()   # both outcomes occur
 
 

@@ -34,6 +34,19 @@ gemm_pmc)
   rocprofv3 --kernel-trace --stats -d /tmp/prof_gs_$tag -o g -- python3 $R/tools/split_gemm_fused_probe.py --rows 11264 --shapes 4096x2048 --reps 8 >> $O/${tag}_split_gemm_pmc.log 2>&1
   python3 $R/tools/rocprof_summary.py kernels "$(find /tmp/prof_gs_$tag -name '*.db' | head -1)" $O/${tag}_split_gemm_kernel_stats.csv 6
   tail -3 $O/${tag}_split_gemm_pmc.log >> $O/${tag}_split_gemm_pmc.txt ;;
+gemm_lds)
+  # LDS / matrix-pipe counters of the hidden-layer kernel at 196 608 rows, this build and (RUBIKS_HIP_LIB_B) a diagnostic build of it
+  for v in tree ${RUBIKS_HIP_LIB_B:+b}; do
+    if [ $v = b ]; then export RUBIKS_HIP_LIB=$RUBIKS_HIP_LIB_B; fi
+    rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_LDS SQ_LDS_IDX_ACTIVE SQ_LDS_BANK_CONFLICT SQ_ACTIVE_INST_LDS --output-format csv -d /tmp/prof_gl_${tag}_$v -- python3 $R/tools/gemm_tile_ab.py --tiles 1 --rows 196608 --reps 4 > $O/${tag}_gemm_lds_$v.log 2>&1
+    echo "== build: ${RUBIKS_HIP_LIB:-tree}"; python3 $R/tools/rocprof_summary.py pmc "$(find /tmp/prof_gl_${tag}_$v -name '*counter_collection.csv' | head -1)" k_split_gemm
+  done > $O/${tag}_gemm_lds_pmc.txt ;;
+gemm_traffic)
+  # HBM bytes per launch of the hidden-layer kernel at the step's 11 264 rows: FETCH_SIZE and WRITE_SIZE in separate passes
+  rocprofv3 --pmc FETCH_SIZE --output-format csv -d /tmp/prof_gf_$tag -- python3 $R/tools/gemm_tile_ab.py --tiles 1 --rows 11264 --reps 8 > $O/${tag}_gemm_fetch.log 2>&1
+  rocprofv3 --pmc WRITE_SIZE --output-format csv -d /tmp/prof_gw_$tag -- python3 $R/tools/gemm_tile_ab.py --tiles 1 --rows 11264 --reps 8 > $O/${tag}_gemm_write.log 2>&1
+  { echo "FETCH_SIZE pass"; python3 $R/tools/rocprof_summary.py pmc "$(find /tmp/prof_gf_$tag -name '*counter_collection.csv' | head -1)" k_split_gemm
+    echo "WRITE_SIZE pass"; python3 $R/tools/rocprof_summary.py pmc "$(find /tmp/prof_gw_$tag -name '*counter_collection.csv' | head -1)" k_split_gemm; } > $O/${tag}_gemm_traffic.txt ;;
 env_stats)
   rocprofv3 --kernel-trace --stats -d /tmp/prof_es_$tag -o env -- python3 $R/tools/env_bench.py 24 > $O/${tag}_env_bench.log 2>&1
   python3 $R/tools/rocprof_summary.py kernels "$(find /tmp/prof_es_$tag -name '*.db' | head -1)" $O/${tag}_env_kernel_stats.csv 12 ;;
