@@ -94,6 +94,7 @@ class VmmArray:
     # (RUBIKS_VMM_PARK_GB; torch's allocator cannot see or reclaim parked memory, `trim` gives all of it back)
     PARK_CAP_BYTES = int(float(os.environ.get("RUBIKS_VMM_PARK_GB", "64")) * 2 ** 30)
     _park_clock = 0
+    before_trim = []   # callables run at the start of `trim` (owners that hold arrays outside the parking lot hand them in first)
 
     @classmethod
     def take(cls, nbytes: int, device, chunk: int = CHUNK) -> "VmmArray":
@@ -205,6 +206,8 @@ class VmmArray:
         """Releases every parked array (memory back to the device, address range to its class's idle list); returns how many.
         Call it before a large torch allocation in a process that has searched with node stores mapped on demand: torch's
         caching allocator cannot see or reclaim parked memory."""
+        for hook in cls.before_trim:
+            hook()
         n = 0
         for arrs in cls._parked.values():
             while arrs:

@@ -510,6 +510,28 @@ class SplitF32Net:
         self._model, self._fallback = model, None
         self._zeros = {layer[1].shape[0]: torch.zeros(layer[1].shape[0], dtype=torch.float32, device=self.device)
                        for layer in self.layers + self.value_layers if layer[0] == "hid"}
+        if self.deterministic:
+            self._check_deterministic()
+
+    def _check_deterministic(self):
+        """Deterministic mode promises ONE summation order per output, whatever the batch: every layer must run on a kernel whose
+        order does not depend on the row count.  Checked here, when the engine is built -- not in the middle of a search or of a
+        graph capture -- and there is no silent way out: a network that does not fit raises, and `fallback()` (library GEMMs, which
+        choose their kernels by batch shape) is refused."""
+        for layers in (self.layers, self.value_layers):
+            H = layers[0][5].shape[0]
+            if not self.fused_input or H % 64 or len(layers) < 3:
+                raise SplitRangeError(f"deterministic mode: the input layer ({H} wide, {len(layers)} layers) does not run on the fused one-hot MFMA kernel "
+                                      "(width % 64 == 0, at least one hidden layer behind it); the library GEMM it would fall back to chooses its "
+                                      "kernel by batch shape")
+            for i, layer in enumerate(layers):
+                if layer[0] == "hid":
+                    self._layer_plan(352, layers, i)          # raises SplitRangeError for a shape the K-cut kernel does not take
+            last = layers[-1]
+            w = layers[-2][1].shape[0]
+            if not (self.fused_head and last[0] == "f32" and last[1].shape[0] <= 16 and w in (512, 1024)):
+                raise SplitRangeError(f"deterministic mode: the output layer ({w} -> {last[1].shape[0]}) does not run on rc_head_split_f32 (512 or 1 024 wide, "
+                                      "at most 16 outputs); torch.addmm would choose its kernel by batch shape")
 
     def overflowed(self) -> bool:
         """True if an activation left half range since the last call (reads and clears the device flag: synchronises)."""
@@ -519,7 +541,11 @@ class SplitF32Net:
         return hit
 
     def fallback(self) -> "InferenceNet":
-        """The same network on the fp32 MFMA GEMM chain (1/16 of the f16 rate, no range limit)."""
+        """The same network on the fp32 MFMA GEMM chain (1/16 of the f16 rate, no range limit).  Not in deterministic mode: the
+        library GEMMs choose their kernels by batch shape, so the promise would be broken without anybody noticing."""
+        if self.deterministic:
+            raise SplitRangeError("deterministic mode: an activation left IEEE half's range and the fp32 GEMM chain that would take over is not "
+                                  "bit-reproducible across batch shapes; search these weights with deterministic=False")
         if self._fallback is None:
             self._fallback = InferenceNet(self._model, dtype=torch.float32, device=self.device)
         return self._fallback
@@ -724,13 +750,25 @@ class SplitF32Net:
         return a
 
     # ---- InferenceNet's interface --------------------------------------------------------------------------------
+    @staticmethod
+    def _cubes_from_oh(oh: torch.Tensor):
+        """The states a one-hot batch encodes (cube.py:265-277 backwards), as device cubes: deterministic mode runs the input layer
+        on the fused kernel for this entry point as well (the library GEMM on the one-hot matrix chooses its kernel by batch shape)."""
+        from librubiks.cube.device import DeviceCubes
+        codes = oh.reshape(oh.shape[0], 20, 24).argmax(2).to(torch.int8)
+        return DeviceCubes.from_aos(codes.contiguous())
+
     @torch.no_grad()
     def __call__(self, oh: torch.Tensor):
+        if self.deterministic:
+            return self.forward_cubes(self._cubes_from_oh(oh))
         out = self._forward(self._input_from_oh(oh), self.layers)
         return out[:, :N_ACTIONS], out[:, N_ACTIONS]
 
     @torch.no_grad()
     def value(self, oh: torch.Tensor) -> torch.Tensor:
+        if self.deterministic:
+            return self.value_cubes(self._cubes_from_oh(oh))
         return self._forward(self._input_from_oh(oh), self.value_layers).reshape(-1)
 
     @torch.no_grad()
@@ -814,6 +852,8 @@ def make_inference_net(net, dtype=torch.bfloat16):
             try:
                 return SplitF32Net(net, deterministic=dtype == F32_SPLIT_DET)
             except SplitRangeError as e:   # the reference's fp32 forward has no such limit: run these weights on the fp32 GEMM chain
+                if dtype == F32_SPLIT_DET:     # ... but not under a promise of bit-reproducibility, which that chain does not keep
+                    raise
                 warnings.warn(f"SplitF32Net: {e}; using the fp32 GEMM chain for this network", RuntimeWarning)
                 return InferenceNet(net, dtype=torch.float32)
         return InferenceNet(net, dtype=dtype)

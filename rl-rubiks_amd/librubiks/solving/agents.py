@@ -86,9 +86,10 @@ class DeepAgent(Agent):
         caller repeats the search, which `_search_net` then runs in fp32.  Synchronises (call where results are collected)."""
         if not (hasattr(engine, "overflowed") and engine.overflowed()):
             return False
+        fallback = engine.fallback()    # (deterministic mode: raises -- the fp32 chain is not bit-reproducible across batch shapes)
         warnings.warn("SplitF32Net: a hidden activation left IEEE half's range (|x| > 65504) during this search; it is repeated "
                       "on the fp32 GEMM chain, and so are later searches with these weights", RuntimeWarning)
-        self._fp32_for = (net_fingerprint(self.net, self.net_dtype), engine.fallback())
+        self._fp32_for = (net_fingerprint(self.net, self.net_dtype), fallback)
         return True
 
     @classmethod
@@ -416,6 +417,17 @@ class MCTS(DeepAgent):
         if f is None or f.B != n_trees or f.C < capacity or f.C_asked > 4 * capacity:
             self.forest = None
             if f is not None:
+                # what still points into the forest that is about to hand its memory on: game 0's tree is read out now (the
+                # reference's inspectable attributes keep working), the pointers are dropped
+                if self._tree_src is not None and self._tree_src[0] is f:
+                    if self._tree is None:
+                        try:
+                            self._host_tree()
+                        except Exception:   # noqa: BLE001 -- a forest whose search never finished has no tree to show
+                            pass
+                    self._tree_src = None
+                if self._last_forest is f:
+                    self._last_forest = None
                 f.close()             # node store mapped on demand: parked for the next forest of that shape (not left to __del__)
                 del f
             torch.cuda.empty_cache()

@@ -42,6 +42,8 @@ class _McStruct(Structure):   # mirrors rc_mcts_t (include/rubiks_hip.h)
                 ("path_rows", c_void_p)]
 
 
+VmmArray.before_trim.append(lambda: MCTSForest.drain_deferred())   # (defined below; resolved when called)
+
 _hip.register({
     "rc_mcts_struct_bytes": [],
     "rc_mcts_plant": [POINTER(_McStruct), c_void_p, c_uint32, c_void_p, c_size_t, c_size_t, c_void_p],
@@ -173,6 +175,7 @@ class MCTSForest:
         (`ensure_path`).  A number = a fixed path store of that many levels (rounded up to whole blocks), allocated up front; a
         descent that fills it ends its tree with status PATH_OVERFLOW.  path_block / lds_levels / ring_levels: see PATH_BLOCK."""
         self.lib = _hip.lib()
+        MCTSForest.drain_deferred()
         if self.lib.rc_mcts_struct_bytes() != ctypes.sizeof(_McStruct):
             raise _hip.RubiksHipError(f"rc_mcts_t is {self.lib.rc_mcts_struct_bytes()} bytes in librubiks_hip.so but {ctypes.sizeof(_McStruct)} "
                                       "here: rebuild the library (make -C rl-rubiks_amd)")
@@ -455,6 +458,18 @@ class MCTSForest:
                 self._ranges_bfs.ensure(base * 8, (base + int(self.nodes_seen[t]) + 2) * 8)
 
     _deferred = []   # ranges of forests collected while a HIP graph was being captured: parked by the next close() outside a capture
+
+    @classmethod
+    def drain_deferred(cls):
+        """Parks the arrays of forests that were collected during a graph capture (they could not synchronise then).  Called where a
+        forest is built and before parked memory is given back (`VmmArray.trim`), so that such memory never stays out of the books."""
+        if not cls._deferred or not torch.cuda.is_available() or torch.cuda.is_current_stream_capturing():
+            return
+        torch.cuda.synchronize()
+        arrays, cls._deferred = cls._deferred, []
+        mark = VmmArray.next_park_mark()
+        for arr in arrays:
+            arr.park(protect_from=mark)
 
     def close(self):
         """Hands the node store on (forests mapped on demand; others free theirs with their tensors): the arrays are parked for the

@@ -73,7 +73,7 @@ def sharded_search_batch(agent, states: np.ndarray, time_limit=None, max_states=
         out = agent.search_batch(states[lo:hi], time_limit, max_states, **kwargs)
         each = getattr(out, "game_seconds", None)
         local = {"solved": np.asarray(out.solved), "lengths": np.asarray(out.lengths), "nodes": np.asarray(out.nodes),
-                 "seconds": np.asarray(each, dtype=np.float64) if each is not None else np.full(hi - lo, out.seconds / max(1, hi - lo))}
+                 "seconds": np.asarray(each, dtype=np.float64) if each is not None else np.full(hi - lo, float(getattr(out, "seconds", 0.0)) / max(1, hi - lo))}
     else:   # more ranks than games
         local = {"solved": np.zeros(0, dtype=bool), "lengths": np.zeros(0, dtype=np.int64), "nodes": np.zeros(0, dtype=np.int64),
                  "seconds": np.zeros(0)}

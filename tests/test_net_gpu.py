@@ -852,3 +852,34 @@ def test_deterministic_split_engine_gives_a_state_the_same_outputs_in_every_laun
     pd, vd = eng.forward_cubes(DeviceCubes.from_numpy(states[:4096]))
     err = lambda a, b: float((a.double() - b).abs().max())   # noqa: E731
     assert max(err(pd, p64), err(vd, v64.reshape(-1))) <= 1.25 * max(err(p32, p64), err(v32.reshape(-1), v64.reshape(-1))) + 1e-7
+
+
+def test_deterministic_mode_has_no_silent_way_out():
+    """deterministic=True is a promise (one summation order per output, whatever the batch).  It is checked when the engine is BUILT:
+    a network with a layer that would fall to a library GEMM raises there -- not in the middle of a search or of a graph capture --,
+    the one-hot entry points run the fused input kernel too, and the fp32 fallback behind a half-range overflow is refused."""
+    from librubiks.cube import DeviceCubes
+    from librubiks.model import F32_SPLIT_DET, Model, ModelConfig, SplitF32Net, SplitRangeError, make_inference_net
+    torch.manual_seed(0)
+    ok = Model.create(ModelConfig()).eval()
+    eng = SplitF32Net(ok, deterministic=True)
+    np.random.seed(3)
+    from librubiks import cube
+    cubes, _, _ = cube.scramble_batch(640, 20, True)
+    p, v = eng.forward_cubes(cubes)
+    oh = cubes.as_oh(torch.float32)
+    p2, v2 = eng(oh)                                  # the one-hot API: decoded, then the same kernels
+    assert torch.equal(p, p2) and torch.equal(v, v2) and torch.equal(eng.value(oh[:17]), eng.value_cubes(DeviceCubes.from_numpy(cubes.numpy()[:17])))
+    with pytest.raises(SplitRangeError, match="deterministic"):
+        eng.fallback()
+    # a hidden width the K-cut kernel does not take (n_out % 128 != 0): refused at construction
+
+    class Odd(SplitF32Net):                           # the first hidden layer cut to 2 000 outputs
+        def _split(self, layers, ref_opts):
+            out = super()._split(layers, ref_opts)
+            kind, Wh, B2, b, code, alpha, W3 = out[1]
+            out[1] = (kind, Wh[:2000].contiguous(), B2[:2000].contiguous(), b[:2000].contiguous(), code, alpha, W3[:2000].contiguous())
+            return out
+    with pytest.raises(SplitRangeError, match="deterministic"):
+        Odd(ok, deterministic=True)
+    assert isinstance(make_inference_net(ok, F32_SPLIT_DET), SplitF32Net)

@@ -188,6 +188,58 @@ def groups(argv):
         print(name, json.dumps(one_form(g)), flush=True)
 
 
+def rtc_groups(argv):
+    """BASELINE configs[1] (1 024 depth-20 scrambles as ONE batch, to completion) as G independent groups of 1 024 / G trees, each on a
+    HIP stream of its own with rounds alternating: in the tail of the run (tens of trees left) a step is one tree kernel (~92 us on a
+    few CUs) behind one network pass (~84 us of short kernels) -- two groups can run the one beside the other."""
+    name, G, reps = (argv[0] if argv else "f32s"), int(argv[1]) if len(argv) > 1 else 2, int(argv[2]) if len(argv) > 2 else 2
+    CAP, N = 175000, 1024
+    np.random.seed(0)
+    cubes, _, _ = cube.scramble_batch(N, 20, True)
+    states = cubes.numpy()
+    model = Model.load(WEIGHTS).eval()
+
+    def one_form(g):
+        agents = [MCTS(model, c=0.6, search_graph=True, net_dtype=DT[name]) for _ in range(g)]
+        streams = [torch.cuda.Stream() for _ in range(g)] if g > 1 else [torch.cuda.current_stream()]
+        for a, st in zip(agents, streams):
+            with torch.cuda.stream(st):
+                a.prepare(N // g, CAP)
+            torch.cuda.synchronize()
+        secs = []
+        for rep in range(reps + 1):      # the first pass warms up (library heuristics, clocks)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            runs = []
+            for i, (a, st) in enumerate(zip(agents, streams)):
+                with torch.cuda.stream(st):
+                    runs.append(a.start_batch(states[i::g], None, CAP))
+            while any(not r.done for r in runs):
+                for r, st in zip(runs, streams):
+                    if not r.done:
+                        with torch.cuda.stream(st):
+                            r.round()
+            res = []
+            for r, st in zip(runs, streams):
+                with torch.cuda.stream(st):
+                    res.append(r.finish())
+            torch.cuda.synchronize()
+            if rep:
+                secs.append(time.perf_counter() - t0)
+        nodes = sum(int(x.nodes.sum()) for x in res)
+        out = {"groups": g, "seconds": [round(x, 3) for x in secs], "nodes_per_sec_best": round(nodes / min(secs)), "nodes": nodes,
+               "solved": float(np.mean(np.concatenate([x.solved for x in res]))), "iterations": [int(x.iterations.max()) for x in res]}
+        for a in agents:
+            if a.forest is not None:
+                a.forest.close()
+        del agents, runs
+        torch.cuda.empty_cache()
+        return out
+
+    for g in (1, G, 1, G):
+        print(name, json.dumps(one_form(g)), flush=True)
+
+
 def ab(argv):
     attr, vals = argv[0], [float(v) if "." in v else int(v) for v in argv[1:3]]
     CAP = 175000
@@ -222,4 +274,4 @@ def ab(argv):
 
 
 if __name__ == "__main__":
-    {"solve": solve, "window": window, "rtc": rtc, "ab": ab, "groups": groups}[sys.argv[1]](sys.argv[2:])
+    {"solve": solve, "window": window, "rtc": rtc, "ab": ab, "groups": groups, "rtc_groups": rtc_groups}[sys.argv[1]](sys.argv[2:])
