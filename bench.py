@@ -779,7 +779,7 @@ def adi_leg(name, model, args, world, coll_device):
         return res
     # ---- the same steps between HIP events (rank 0's view), and the dominant kernel alone -------------------------------------
     lib, eng = _hip.lib(), tr._adi_engine(model)
-    names = ["sequence_scrambler (host RNG + moves to the device + rc_sequence_states)", "expand12", "is_solved (substates + states)",
+    names = ["sequence_scrambler (host RNG + moves to the device + rc_sequence_states)", "expand12 + is_solved (substates + states), one launch", "flag views",
              "value_net", "rc_adi_targets", "as_oh(states, f32)"]
     acc = np.zeros(len(names))
     reps = 5
@@ -788,10 +788,9 @@ def adi_leg(name, model, args, world, coll_device):
         ev[0].record()
         states = pcube.sequence_scrambler_device(games, depth, with_solved=True)
         ev[1].record()
-        kids = states.expand12()
+        kids, state_solved, kid_solved = states.expand12_flags()   # ONE launch: children + both solved tests (as Train.ADI_traindata does)
         ev[2].record()
-        kid_solved = kids.is_solved().view(torch.uint8)
-        state_solved = states.is_solved().view(torch.uint8)
+        kid_solved, state_solved = kid_solved.view(torch.uint8), state_solved.view(torch.uint8)
         ev[3].record()
         values = eng.value_cubes(kids)
         ev[4].record()
@@ -806,9 +805,9 @@ def adi_leg(name, model, args, world, coll_device):
         acc += [ev[i].elapsed_time(ev[i + 1]) for i in range(len(names))]
     res["phases_ms"] = {k: round(float(v) / reps, 4) for k, v in zip(names, acc)}
     rows = 12 * n
-    env_bytes = 260 * n + 21 * (12 * n) + 21 * n + 1940 * n      # expand12 + is_solved (flags) on substates and states + one-hot f32
-    env_ms = res["phases_ms"]["expand12"] + res["phases_ms"]["is_solved (substates + states)"] + res["phases_ms"]["as_oh(states, f32)"]
-    res["roofline_env"] = {"kernel": f"expand12 ({n} parents) + is_solved ({13 * n} states) + as_oh f32 ({n} states): the rollout's environment kernels",
+    env_bytes = 260 * n + 13 * n + 1940 * n      # expand12 with the 13 solved flags per parent written by the same launch + one-hot f32
+    env_ms = res["phases_ms"]["expand12 + is_solved (substates + states), one launch"] + res["phases_ms"]["as_oh(states, f32)"]
+    res["roofline_env"] = {"kernel": f"expand12 + solved flags of {13 * n} states in one launch ({n} parents) + as_oh f32 ({n} states): the rollout's environment kernels",
                            "bound": "hbm", "algorithmic_bytes": int(env_bytes), "ms": round(env_ms, 4), "achieved": round(env_bytes / (env_ms * 1e-3) / 1e9, 1),
                            "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": round(env_bytes / (env_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4), "traffic": None,
                            "note": "a rollout's arrays are a few MB: these launches are bound by launch latency, not by HBM (roofline_env of the main line has the kernels at 2^14 .. 2^26 states)"}

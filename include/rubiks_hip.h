@@ -91,6 +91,13 @@ int rc_multi_rotate(const int8_t *in_soa, const uint8_t *actions, int8_t *out_so
  * stride_c >= round_up(12 n_parents, 16).  Algorithmic HBM bytes: 260 per parent. */
 int rc_expand12(const int8_t *parents_soa, int8_t *children_soa, size_t n_parents, size_t stride_p,
                 size_t stride_c, rc_stream_t stream);
+/* rc_expand12 that also answers multi_is_solved (cube.py:85-89) for the parents and for every child in the same launch -- the
+ * three calls one data-generation step of an ADI rollout makes (train.py:285-296).  The flags come from the staged parents
+ * (child k of p is solved iff p is the solved cube turned by rev(k)); no child is read back.
+ *   parent_solved: uint8[round_up(n_parents, 16)]   child_solved: uint8[12 round_up(n_parents, 16)]   (1 = solved; 16-byte aligned;
+ *   entries behind n_parents / 12 n_parents are padding).  Algorithmic HBM bytes: 273 per parent. */
+int rc_expand12_flags(const int8_t *parents_soa, int8_t *children_soa, size_t n_parents, size_t stride_p, size_t stride_c,
+                      uint8_t *parent_solved, uint8_t *child_solved, rc_stream_t stream);
 
 /* Solved test.  Replaces multi_is_solved (librubiks/cube/cube.py:85-89).  Any of the three
  * outputs may be NULL:

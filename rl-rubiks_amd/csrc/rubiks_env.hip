@@ -100,10 +100,32 @@ __global__ __launch_bounds__(kBlock) void k_multi_rotate(const typename DW<W>::T
 // a single 4-byte read of the action-minor table lut4[kind][code][4m..4m+3].  Stores are 16 B per
 // lane, fully coalesced.
 // =================================================================================================
-template <int BLOCK, bool NT = false>
+__device__ __forceinline__ u32 zero_bytes_to_flags(u32 x) {
+    // byte -> 1 if the byte of x is zero else 0 (exact for all byte values)
+    const u32 nz = (((x & 0x7f7f7f7fu) + 0x7f7f7f7fu) | x) & 0x80808080u;
+    return (nz >> 7) ^ 0x01010101u;
+}
+
+// The twelve states one move from solved: child k of a parent is the solved cube iff the parent is kNearSolved[k] = the solved cube
+// turned by rev(k) = k ^ 1 (cube.py:194-200).  Such a parent agrees with the solved cube on exactly 12 of its 20 cubies.
+struct NearSolved {
+    uint8_t code[kActions][kPlanes];
+};
+constexpr NearSolved make_near_solved() {
+    NearSolved t{};
+    for (int k = 0; k < kActions; ++k)
+        for (int j = 0; j < kPlanes; ++j) t.code[k][j] = kTables.lut[k ^ 1][j >= kCorners ? 1 : 0][(int)kTables.solved[j]];
+    return t;
+}
+static __constant__ NearSolved c_near_solved = make_near_solved();
+
+// FLAGS: the launch also answers multi_is_solved for the parents and for all their children (one data-generation step of an ADI
+// rollout asks for both, train.py:285-296): from the parents it has staged anyway, without reading a child.
+template <int BLOCK, bool NT = false, bool FLAGS = false>
 __global__ __launch_bounds__(BLOCK) void k_expand12(const u32 *__restrict__ par, uint4 *__restrict__ child,
                                                     size_t n_parents, size_t n_par_dw, size_t n_chunks,
-                                                    size_t sp_dw, size_t sc_vec) {
+                                                    size_t sp_dw, size_t sc_vec, u32 *__restrict__ parent_flags = nullptr,
+                                                    uint4 *__restrict__ child_flags = nullptr) {
     constexpr int PB = 4 * BLOCK;   // parents per tile
     __shared__ u32 s_lut4[sizeof(kTables.lut4) / 4];
     __shared__ u32 s_stage[kPlanes * BLOCK];
@@ -131,6 +153,27 @@ __global__ __launch_bounds__(BLOCK) void k_expand12(const u32 *__restrict__ par,
 #pragma unroll
         for (int j = 0; j < kPlanes; ++j) s_stage[j * BLOCK + tid] = (dw0 < n_par_dw) ? ld4<NT>(&par[(size_t)j * sp_dw + dw0]) : 0u;
         __syncthreads();
+        if (FLAGS && dw0 < n_par_dw) {   // this lane's four parents: how many cubies sit solved (byte-wise count), then the rare full compare
+            u32 cnt = 0;
+#pragma unroll
+            for (int j = 0; j < kPlanes; ++j)
+                cnt += zero_bytes_to_flags((s_stage[j * BLOCK + tid] & 0x1f1f1f1fu) ^ ((u32)(u8)kTables.solved[j] * 0x01010101u));
+            parent_flags[dw0] = zero_bytes_to_flags(cnt ^ 0x14141414u);                  // 20 of 20
+            u32 cf[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};                           // 48 flag bytes: children 12 p .. 12 p + 11 of the four parents
+            const u32 twelve = zero_bytes_to_flags(cnt ^ 0x0c0c0c0cu);                   // candidates: exactly 12 cubies solved
+            if (twelve) {
+                for (int b = 0; b < 4; ++b) {
+                    if (!((twelve >> (8 * b)) & 1u)) continue;
+                    for (int k = 0; k < kActions; ++k) {
+                        bool same = true;
+                        for (int j = 0; j < kPlanes; ++j) same &= (stage[(j * BLOCK + tid) * 4 + b] & 31u) == c_near_solved.code[k][j];
+                        if (same) cf[(12 * b + k) >> 2] |= 1u << (8 * ((12 * b + k) & 3));
+                    }
+                }
+            }
+#pragma unroll
+            for (int i = 0; i < 3; ++i) st16<NT>(&child_flags[3 * dw0 + i], make_uint4(cf[4 * i], cf[4 * i + 1], cf[4 * i + 2], cf[4 * i + 3]));
+        }
         const size_t q0 = tile * (3 * BLOCK);     // first child chunk of this tile
 #pragma unroll
         for (int j = 0; j < kPlanes; ++j) {
@@ -154,11 +197,6 @@ __global__ __launch_bounds__(BLOCK) void k_expand12(const u32 *__restrict__ par,
 // is_solved: all 20 planes equal the solved code                       (librubiks/cube/cube.py:85-89)
 // Lane owns 16 cubes (one 16-byte load per plane); the solved codes are compile-time immediates.
 // =================================================================================================
-__device__ __forceinline__ u32 zero_bytes_to_flags(u32 x) {
-    // byte -> 1 if the byte of x is zero else 0 (exact for all byte values)
-    const u32 nz = (((x & 0x7f7f7f7fu) + 0x7f7f7f7fu) | x) & 0x80808080u;
-    return (nz >> 7) ^ 0x01010101u;
-}
 __device__ __forceinline__ u32 flags_to_bits(u32 f) { return ((f * 0x01020408u) >> 24) & 0xfu; }
 
 template <bool NT>
@@ -488,6 +526,32 @@ int rc_expand12(const int8_t *parents_soa, int8_t *children_soa, size_t n_parent
         hipLaunchKernelGGL(k_expand12<BLOCK>, dim3((unsigned)(tiles < 8192 ? tiles : 8192)), dim3(BLOCK), 0, s,
                            (const u32 *)parents_soa, (uint4 *)children_soa, n_parents, n_par_dw, n_chunks, stride_p / 4,
                            stride_c / 16);
+    }
+    return launch_status();
+}
+
+int rc_expand12_flags(const int8_t *parents_soa, int8_t *children_soa, size_t n_parents, size_t stride_p, size_t stride_c,
+                      uint8_t *parent_solved, uint8_t *child_solved, rc_stream_t stream) {
+    if (n_parents == 0) return RC_OK;
+    RC_CHECK_SOA(parents_soa, n_parents, stride_p);
+    RC_CHECK_SOA(children_soa, n_parents * kActions, stride_c);
+    RC_REQUIRE(parent_solved != nullptr && child_solved != nullptr, RC_ERR_NULL);
+    RC_REQUIRE(aligned16(parent_solved) && aligned16(child_solved), RC_ERR_ALIGN);
+    hipStream_t s = (hipStream_t)stream;
+    const size_t n_par_dw = round_up(n_parents, 16) / 4;
+    const size_t n_chunks = ceil_div(n_parents * kActions, 16);
+    if (n_parents >= ((size_t)1 << 18)) {
+        constexpr int BLOCK = 256;
+        const size_t tiles = ceil_div(n_parents, 4 * BLOCK);
+        hipLaunchKernelGGL((k_expand12<BLOCK, false, true>), dim3((unsigned)(tiles < 4096 ? tiles : 4096)), dim3(BLOCK), 0, s,
+                           (const u32 *)parents_soa, (uint4 *)children_soa, n_parents, n_par_dw, n_chunks, stride_p / 4,
+                           stride_c / 16, (u32 *)parent_solved, (uint4 *)child_solved);
+    } else {
+        constexpr int BLOCK = 64;
+        const size_t tiles = ceil_div(n_parents, 4 * BLOCK);
+        hipLaunchKernelGGL((k_expand12<BLOCK, false, true>), dim3((unsigned)(tiles < 8192 ? tiles : 8192)), dim3(BLOCK), 0, s,
+                           (const u32 *)parents_soa, (uint4 *)children_soa, n_parents, n_par_dw, n_chunks, stride_p / 4,
+                           stride_c / 16, (u32 *)parent_solved, (uint4 *)child_solved);
     }
     return launch_status();
 }

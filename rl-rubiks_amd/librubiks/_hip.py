@@ -31,6 +31,7 @@ SIGNATURES = {
     "rc_as_oh_aos_f32": [P, P, SZ, P],
     "rc_multi_rotate": [P, P, P, SZ, SZ, SZ, P],
     "rc_expand12": [P, P, SZ, SZ, SZ, P],
+    "rc_expand12_flags": [P, P, SZ, SZ, SZ, P, P, P],
     "rc_is_solved": [P, P, P, P, SZ, SZ, P],
     "rc_as_oh_f32": [P, P, SZ, SZ, P],
     "rc_as_oh_bf16": [P, P, SZ, SZ, P],

@@ -99,6 +99,19 @@ class DeviceCubes:
                                    _hip.stream_ptr()), "rc_expand12")
         return out
 
+    def expand12_flags(self, out: "DeviceCubes" = None):
+        """(children, parents solved bool[n], children solved bool[12 n]) in ONE launch: `expand12()`, `is_solved()` and
+        `expand12().is_solved()` as a data-generation step of an ADI rollout asks for them (reference train.py:285-296)."""
+        lib = _hip.lib()
+        out = out or DeviceCubes.empty(12 * self.n, self.soa.device)
+        assert out.n == 12 * self.n
+        pad = (self.n + 15) // 16 * 16
+        pflags = torch.empty(pad, dtype=torch.uint8, device=self.soa.device)
+        cflags = torch.empty(12 * pad, dtype=torch.uint8, device=self.soa.device)
+        _hip.check(lib.rc_expand12_flags(self.soa.data_ptr(), out.soa.data_ptr(), self.n, self.stride, out.stride, pflags.data_ptr(),
+                                         cflags.data_ptr(), _hip.stream_ptr()), "rc_expand12_flags")
+        return out, pflags[:self.n].view(torch.bool), cflags[:12 * self.n].view(torch.bool)
+
     def is_solved(self) -> torch.Tensor:
         """bool[n] device tensor."""
         lib = _hip.lib()

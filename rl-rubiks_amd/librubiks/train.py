@@ -202,9 +202,8 @@ class Train:
         G, D = self.rollout_games, self.rollout_depth
         states = cube.sequence_scrambler_device(G, D, with_solved=self.reward_method == "lapanfix")
         n = states.n
-        kids = states.expand12()
-        kid_solved = kids.is_solved().view(torch.uint8)
-        state_solved = states.is_solved().view(torch.uint8)
+        kids, state_solved, kid_solved = states.expand12_flags()      # one launch: the children and both solved tests (train.py:285-296)
+        kid_solved, state_solved = kid_solved.view(torch.uint8), state_solved.view(torch.uint8)
         values = torch.empty(12 * n, dtype=torch.float32, device=states.soa.device)
         engine = self._adi_engine(net)
         for lo in range(0, 12 * n, self.adi_chunk):   # chunked like the reference's adi_ff_batches (train.py:301-310)

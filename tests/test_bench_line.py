@@ -176,3 +176,40 @@ def test_scale_efficiency_from_the_one_gpu_record(tmp_path):
     assert bench.scale_efficiency(1, 1.0e7, key, ref, write=False)[0] is None and json.load(open(ref))["value"] == 1.25e7   # --as-rank runs leave no record
     open(ref, "w").write("{not json")
     assert bench.scale_efficiency(4, 1.0, key, ref)[0] is None
+    # a one-GPU value handed in (--scale-ref-value / RUBIKS_SCALE_REF) needs no record next to the script at all
+    assert bench.scale_efficiency(8, 9.6e7, key, str(tmp_path / "absent.json"), ref_value=1.25e7)[0] == 0.96
+
+
+def test_launched_ranks_get_the_ipc_mode_rccl_needs_on_this_pool(monkeypatch, tmp_path):
+    """`bench.py --gpus N` without a launcher starts its ranks itself.  RCCL shares device buffers between the ranks of a node through
+    IPC handles and the hosts of this pool only support the dmabuf form (HSA_ENABLE_IPC_MODE_LEGACY=0; with the legacy mode
+    hipIpcGetMemHandle fails and so does the first collective): a rank started from an environment that lost the variable gets it
+    back, one that sets it keeps its own value."""
+    import subprocess
+    import sys
+    seen = []
+
+    class FakeProc:
+        returncode = 0
+
+        def __init__(self, argv, env=None, stdout=None, text=None):
+            seen.append(env)
+            import io
+            self.stdout = io.StringIO('{"ok": 1}\n') if stdout is not None and stdout != subprocess.DEVNULL else None
+
+        def poll(self):
+            return 0
+
+        def wait(self, timeout=None):
+            return 0
+
+        def terminate(self):
+            pass
+
+    monkeypatch.setattr(subprocess, "Popen", FakeProc)
+    monkeypatch.delenv("HSA_ENABLE_IPC_MODE_LEGACY", raising=False)
+    assert bench.launch_ranks(2, ["--gpus", "2"]) == 0
+    assert [e["HSA_ENABLE_IPC_MODE_LEGACY"] for e in seen] == ["0", "0"] and [e["RANK"] for e in seen] == ["0", "1"]
+    seen.clear()
+    monkeypatch.setenv("HSA_ENABLE_IPC_MODE_LEGACY", "1")
+    assert bench.launch_ranks(2, ["--gpus", "2"]) == 0 and [e["HSA_ENABLE_IPC_MODE_LEGACY"] for e in seen] == ["1", "1"]

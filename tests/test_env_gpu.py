@@ -117,6 +117,23 @@ def test_expand12_vs_oracle(n):
     assert np.array_equal(kids.numpy(), oc.expand12(s))
 
 
+@pytest.mark.parametrize("n", [1, 5, 64, 85, 257, 1000, 3001, (1 << 18) + 3])
+def test_expand12_flags_is_the_three_calls_in_one(n):
+    """rc_expand12_flags = expand12 + is_solved(parents) + is_solved(children) in one launch (a data-generation step of an ADI rollout,
+    train.py:285-296): the same children, and the oracle's flags -- with solved parents, parents one move from solved (whose child
+    through the reverse move is solved) and ordinary ones in the batch."""
+    from librubiks.cube import DeviceCubes
+    s = reachable(n, 14, seed=300 + n)
+    near = oc.expand12(oc.get_solved()[None])                    # the twelve states one move from solved
+    for i in range(0, n, 7):
+        s[i] = near[(i // 7) % 12] if i % 3 else oc.get_solved()
+    kids, ps, ks = DeviceCubes.from_numpy(s).expand12_flags()
+    want = oc.expand12(s)
+    assert np.array_equal(kids.numpy(), want)
+    assert np.array_equal(ps.cpu().numpy(), oc.multi_is_solved(s)) and np.array_equal(ks.cpu().numpy(), oc.multi_is_solved(want))
+    assert ks.cpu().numpy().sum() >= min(n, 1) - 1 and ps.dtype == torch.bool
+
+
 def test_expand12_property_full_size():
     """2^22 parents -> 50 M children: undoing action k on child 12p+k gives parent p back."""
     from librubiks.cube import DeviceCubes

@@ -137,7 +137,7 @@ def test_bench_two_ranks_aggregate_their_shares():
     import socket
     common = ["--steps", "6", "--warmup", "2", "--trees", "48", "--pool-factor", "2", "--legs", "bf16", "--solve-max-states",
               "1500", "--phase-reps", "0", "--no-cpu-baseline", "--no-env-roofline", "--prep-cap", "40", "--astar-problems", "24",
-              "--config5-trees", "32", "--config5-max-states", "800"]
+              "--config5-trees", "32", "--config5-max-states", "800", "--extra-legs", "astar,config5"]   # (N > 1 defaults to config5 alone)
     with socket.socket() as s:
         s.bind(("127.0.0.1", 0))
         port = s.getsockname()[1]
@@ -162,6 +162,7 @@ def test_bench_two_ranks_aggregate_their_shares():
     assert len(line["rank_values"]) == 2 and all(v > 0 for v in line["rank_values"]) and line["value"] <= sum(line["rank_values"]) * 1.001
     assert two["preflight"]["backend"] == "gloo" and two["preflight"]["collectives"].endswith("ok") and two["preflight"]["free_hbm_gb"] > 90
     assert "efficiency" in line and (line["efficiency"] is None or 0 < line["efficiency"] < 2) and shares[0]["efficiency"] is None
+    assert line["value_per_gpu"] == round(line["value"] / 2, 1) and line["value_spread"]["min"] <= line["value_spread"]["median"] <= line["value_spread"]["max"]
     assert max(len(v) for v in (line["config"]["workload"], line["config"]["timed_region"], line["roofline"].get("kernel", ""))) <= 120
     # the self-launched run searched the same games to the same trees
     ap = two_plain["legs"]["bf16"]
