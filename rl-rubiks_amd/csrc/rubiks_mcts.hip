@@ -10,6 +10,8 @@
 #include <limits.h>
 #include <stdlib.h>
 
+#include <type_traits>
+
 #include "rubiks_common.h"
 
 namespace rubiks {
@@ -639,25 +641,30 @@ __global__ __launch_bounds__(NT) void k_mcts_select(rc_mcts_t m, double c, u32 l
     // The path this call works on: levels below W in LDS (s_node / s_act, chained by node through s_head / s_next), deeper levels
     // where they lie in HBM (path_node / path_act, chained through path_next).  The reference's descent has no length limit
     // (agents.py:575-595); a tree that deep is rare, so its deep levels cost a memory round trip where the others cost an LDS read.
-    const int W = (int)m.lds_levels;
+    // The body below exists twice: DEEP = false for a path that lies in LDS whole (every level access is the plain LDS access of
+    // rounds 1-5: a test per access costs the sequential walk ~20 %, profiles/r6_select_deep_ab.txt) -- its walk stops at the
+    // window's end and the descent is suspended there for one iteration --, DEEP = true for a path that is, or has become, deeper.
+    auto body = [&](auto deep_c) __attribute__((always_inline)) {
+    constexpr bool DEEP = decltype(deep_c)::value;
+    const int W = DEEP ? (int)m.lds_levels : kMaxPath;
     auto P = [&](int k) { return path_at(m, t, k); };
-    auto node_at = [&](int k) -> int { return k < W ? s_node[k] : m.path_node[P(k)]; };
-    auto act_at = [&](int k) -> u32 { return k < W ? (u32)s_act[k] : (u32)m.path_act[P(k)]; };
+    auto node_at = [&](int k) -> int { return (!DEEP || k < W) ? s_node[k] : m.path_node[P(k)]; };
+    auto act_at = [&](int k) -> u32 { return (!DEEP || k < W) ? (u32)s_act[k] : (u32)m.path_act[P(k)]; };
     auto next_at = [&](int k) -> int {
-        if (k < W) {
+        if (!DEEP || k < W) {
             const u32 nx = s_next[k];
             return nx == 0xFFFFu ? -1 : (int)nx;
         }
         return (int)m.path_next[P(k)];
     };
-    auto put_node = [&](int k, int node) { if (k < W) s_node[k] = node; else m.path_node[P(k)] = node; };
-    auto put_act = [&](int k, u32 a) { if (k < W) s_act[k] = (u8)a; else m.path_act[P(k)] = (u8)a; };
-    auto put_next = [&](int k, int nx) { if (k < W) s_next[k] = (u16)nx; else m.path_next[P(k)] = (u32)nx; };   // (u16)-1 = 0xFFFF = none
+    auto put_node = [&](int k, int node) { if (!DEEP || k < W) s_node[k] = node; else m.path_node[P(k)] = node; };
+    auto put_act = [&](int k, u32 a) { if (!DEEP || k < W) s_act[k] = (u8)a; else m.path_act[P(k)] = (u8)a; };
+    auto put_next = [&](int k, int nx) { if (!DEEP || k < W) s_next[k] = (u16)nx; else m.path_next[P(k)] = (u32)nx; };   // (u16)-1 = 0xFFFF = none
     // All levels lo .. hi - 1 enter the chains of their nodes: first the LDS levels, then the deep ones, so that the 16-bit links
     // of the LDS levels only ever name LDS levels (or levels a line round appends right behind them).
     auto chain_levels = [&](int lo, int hi) {
         for (int k = lo + (int)tid; k < min(hi, W); k += NT) s_next[k] = (u16)atomicExch(&s_head[sel_hash(s_node[k])], k);
-        if (hi > W) {
+        if (DEEP && hi > W) {
             __syncthreads();
             for (int k = max(lo, W) + (int)tid; k < hi; k += NT) {
                 const size_t pk = P(k);
@@ -979,7 +986,7 @@ __global__ __launch_bounds__(NT) void k_mcts_select(rc_mcts_t m, double c, u32 l
     const u32 la = act ? lane : 0;
     const int start = s_first;
     const TreeBufs tb = tree_bufs(m, base);
-    const int max_path = path_limit(m, t);                    // levels the path arrays can take right now
+    const int max_path = DEEP ? path_limit(m, t) : min(path_limit(m, t), kMaxPath);   // levels the path can take right now (shallow body: the LDS window)
     const int ring_levels = (int)m.ring_levels;
     int cur = __builtin_amdgcn_readfirstlane(node_at(start)), plen = start + 1;
     int prev_act = start > 0 ? __builtin_amdgcn_readfirstlane((int)act_at(start - 1)) : -1;   // action that led to `cur`
@@ -1246,6 +1253,9 @@ __global__ __launch_bounds__(NT) void k_mcts_select(rc_mcts_t m, double c, u32 l
     }
     if (FUSE && stop == 1)   // the descent stands on a leaf: its expansion, the first act of the next iteration (agents.py:477)
         expand_leaf_wave(m, t, slot, lane, reinterpret_cast<const u8 *>(s_lut), max_states, false, cur);
+    };
+    if ((int)m.lds_levels < kMaxPath || plen_old >= kMaxPath) body(std::true_type{});
+    else body(std::false_type{});
 }
 
 // ---- _complete_graph (agents.py:597-611): one workgroup per solved tree, one thread per (leaf, action) ----
@@ -1400,7 +1410,9 @@ __global__ __launch_bounds__(kBlock) void k_mcts_shorten(rc_mcts_t m) {
 // ---- finished trees leave a forest: rows 0 .. n_nodes of what the destination keeps, and the tree's hash table ---------
 // grid (trees, parts): the parts of a tree's workgroups stride over its rows.  FULL: into a search forest (records + V),
 // else into a results-only forest (neighbour rows as a plain [rows][12] array).
-template <bool FULL>
+// HASH: the tree's hash table travels as it is (source and destination have the same capacity); otherwise the destination's table --
+// of its own size -- is rebuilt from the copied keys by k_mcts_rehash.
+template <bool FULL, bool HASH>
 __global__ __launch_bounds__(kBlock) void k_mcts_copy_trees(rc_mcts_t src, rc_mcts_t dst, const int *__restrict__ src_trees, u32 dst_first) {
     const u32 ts = (u32)src_trees[blockIdx.x], td = dst_first + blockIdx.x;
     const size_t sb = (size_t)ts * (src.capacity + 1), db = (size_t)td * (dst.capacity + 1);
@@ -1422,9 +1434,29 @@ __global__ __launch_bounds__(kBlock) void k_mcts_copy_trees(rc_mcts_t src, rc_mc
         uint4 *dnbr = reinterpret_cast<uint4 *>(dst.nbr);
         for (u32 i = tid; i < rows * 3u; i += nt) dnbr[(db + i / 3u) * 3u + i % 3u] = snbr[(sb + i / 3u) * (kRow / 4) + i % 3u];
     }
-    const uint4 *shash = reinterpret_cast<const uint4 *>(src.hash + (size_t)ts * src.hash_size);
-    uint4 *dhash = reinterpret_cast<uint4 *>(dst.hash + (size_t)td * dst.hash_size);
-    for (u32 i = tid; i < src.hash_size / 4; i += nt) dhash[i] = shash[i];
+    if (HASH) {
+        const uint4 *shash = reinterpret_cast<const uint4 *>(src.hash + (size_t)ts * src.hash_size);
+        uint4 *dhash = reinterpret_cast<uint4 *>(dst.hash + (size_t)td * dst.hash_size);
+        for (u32 i = tid; i < src.hash_size / 4; i += nt) dhash[i] = shash[i];
+    }
+}
+
+// The hash table of trees dst_first .. of a forest, rebuilt from their keys (nodes 1 .. n_nodes, which the caller has just copied in from a
+// forest of another capacity): cleared, then every key claims the first free slot from its home (the order does not matter to a lookup).
+// One workgroup per tree.
+__global__ __launch_bounds__(kBlock) void k_mcts_rehash(rc_mcts_t m, const rc_mcts_t src, const int *__restrict__ src_trees, u32 dst_first) {
+    const u32 t = dst_first + blockIdx.x;
+    const int n = src.n_nodes[src_trees[blockIdx.x]];   // (the destination's per-tree words are copied by the host afterwards)
+    int *tab = m.hash + (size_t)t * m.hash_size;
+    uint4 *tab4 = reinterpret_cast<uint4 *>(tab);
+    for (u32 i = threadIdx.x; i < m.hash_size / 4; i += kBlock) tab4[i] = make_uint4(0, 0, 0, 0);
+    __syncthreads();
+    const uint4 *keys = reinterpret_cast<const uint4 *>(m.keys) + (size_t)t * (m.capacity + 1);
+    const u32 mask = m.hash_size - 1;
+    for (int i = 1 + (int)threadIdx.x; i <= n; i += kBlock) {
+        u32 h = key_hash(keys[i]) & mask;
+        while (atomicCAS(&tab[h], 0, i) != 0) h = (h + 1) & mask;
+    }
 }
 
 }  // namespace rubiks
@@ -1554,13 +1586,21 @@ int rc_mcts_copy_trees(const rc_mcts_t *src, const rc_mcts_t *dst, const int32_t
     if (n == 0) return RC_OK;
     RC_REQUIRE(src_trees != nullptr, RC_ERR_NULL);
     RC_REQUIRE(n <= src->n_trees && dst_first <= dst->n_trees && n <= dst->n_trees - dst_first, RC_ERR_RANGE);
-    RC_REQUIRE(src->capacity == dst->capacity && src->hash_size == dst->hash_size && (src->hash_size & 3u) == 0, RC_ERR_RANGE);
+    // the destination may be a forest of another (smaller) capacity -- the caller has made sure the trees fit its rows (n_nodes <= capacity):
+    // the hash tables then differ in size and the destination's are rebuilt from the keys
+    RC_REQUIRE((src->hash_size & 3u) == 0 && (dst->hash_size & 3u) == 0, RC_ERR_RANGE);
     RC_REQUIRE(src->keys != dst->keys, RC_ERR_RANGE);
+    const bool same = src->capacity == dst->capacity && src->hash_size == dst->hash_size;
     const unsigned parts = n >= 256 ? 2 : n >= 32 ? 8 : 32;
-    if (dst->node_words == (uint32_t)kRow)
-        hipLaunchKernelGGL(k_mcts_copy_trees<true>, dim3(n, parts), dim3(kBlock), 0, (hipStream_t)stream, *src, *dst, (const int *)src_trees, dst_first);
-    else
-        hipLaunchKernelGGL(k_mcts_copy_trees<false>, dim3(n, parts), dim3(kBlock), 0, (hipStream_t)stream, *src, *dst, (const int *)src_trees, dst_first);
+    const bool full = dst->node_words == (uint32_t)kRow;
+#define RC_COPY(FULL_, HASH_) \
+    hipLaunchKernelGGL((k_mcts_copy_trees<FULL_, HASH_>), dim3(n, parts), dim3(kBlock), 0, (hipStream_t)stream, *src, *dst, (const int *)src_trees, dst_first)
+    if (full && same) RC_COPY(true, true);
+    else if (full) RC_COPY(true, false);
+    else if (same) RC_COPY(false, true);
+    else RC_COPY(false, false);
+#undef RC_COPY
+    if (!same) hipLaunchKernelGGL(k_mcts_rehash, dim3(n), dim3(kBlock), 0, (hipStream_t)stream, *dst, *src, (const int *)src_trees, dst_first);
     return launch_status();
 }
 

@@ -645,7 +645,8 @@ class MCTSRun:
             if len(idx_np) == 0:
                 self.stats["harvests"] += 1
                 return
-        deep = forest.paths_seen[idx_np] > forest.path_block   # a last path beyond the first block: not into the (one-block) grave
+        # a last path beyond the first block, or (searches bounded by time alone) more nodes than the grave's rows: a results forest of its own
+        deep = (forest.paths_seen[idx_np] > forest.path_block) | (forest.nodes_seen[idx_np] + 13 > min(forest.C, forest.COPY_CAPACITY_MAX))
         if deep.any():
             sub = forest.subset(idx_np[deep], results_only=True)
             ev = torch.cuda.Event()
@@ -659,7 +660,7 @@ class MCTSRun:
                 return
         if len(idx_np) < self.GRAVE // 2:
             if self.grave is None:
-                self.grave = md.MCTSForest(self.GRAVE, forest.C, forest.path_block, forest.device, _results_only=True, vmm=False,
+                self.grave = md.MCTSForest(self.GRAVE, min(forest.C, forest.COPY_CAPACITY_MAX), forest.path_block, forest.device, _results_only=True, vmm=False,
                                            path_block=forest.path_block, lds_levels=forest.lds_levels, ring_levels=forest.ring_levels)
                 self.grave_games = np.zeros(self.GRAVE, dtype=np.int64)
             if self.grave_fill + len(idx_np) > self.GRAVE:
@@ -711,6 +712,7 @@ class MCTSRun:
                 # the host's look at the node counts: rows for everything the iterations queued since that snapshot, the next
                 # round and one more can reach (forests mapped on demand; otherwise only the counts are noted)
                 queued = self.it - it_then
+                forest.paths_seen = st_host[2].numpy().astype(np.int64)   # (what `_harvest` sizes its copies by, whatever happens below)
                 try:
                     forest.grow(st_host[1].numpy(), queued + 2 * agent.sync_every)
                     forest.grow_paths(st_host[2].numpy())      # ... and the next path block for the trees whose descents near the end of theirs

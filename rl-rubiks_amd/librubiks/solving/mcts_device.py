@@ -520,12 +520,23 @@ class MCTSForest:
         # go with every harvest are not worth reserving, mapping and unmapping address ranges for.  Its path store is a fixed one
         # that holds the deepest of the (finished) trees' last paths.
         levels = max(self.path_block, self.ring_levels, int(self.paths_seen[keep].max()) + 1) if self.path_vmm else self.max_path
-        sub = MCTSForest(len(keep), self.C, levels, self.device, _results_only=results_only, vmm=False, path_block=self.path_block,
-                         lds_levels=self.lds_levels, ring_levels=self.ring_levels)
+        sub = MCTSForest(len(keep), self.copy_capacity(self.nodes_seen[keep]), levels, self.device, _results_only=results_only, vmm=False,
+                         path_block=self.path_block, lds_levels=self.lds_levels, ring_levels=self.ring_levels)
         sub.level_budget, sub._one_launch = self.level_budget, self._one_launch
         sub.set_net(self.engine, self.engine.dtype if hasattr(self.engine, "dtype") else torch.bfloat16)
         sub.adopt(0, self, keep)
         return sub
+
+    COPY_CAPACITY_MAX = (1 << 18) + 8192   # forests up to this capacity are copied into forests of the same capacity (hash tables travel as they are)
+
+    def copy_capacity(self, nodes: np.ndarray) -> int:
+        """Capacity of a forest that takes copies of (finished) trees of this one with `nodes` nodes: this forest's own, unless that is
+        the address-space-sized capacity of a search bounded by time alone -- an up-front copy of that would be gigabytes per tree --
+        then what the trees need (a power of two; the copy rebuilds their hash tables, rc_mcts_copy_trees)."""
+        if self.C <= self.COPY_CAPACITY_MAX:
+            return self.C
+        need = int(np.max(nodes, initial=0)) + 14
+        return int(min(self.C, max(1 << 14, 1 << int(np.ceil(np.log2(need))))))
 
     def adopt(self, pos: int, other: "MCTSForest", trees: np.ndarray):
         """Copies the (finished) trees `trees` of `other` into this forest's slots pos .. pos + len(trees) - 1: what this kind
@@ -533,7 +544,8 @@ class MCTSForest:
         extraction reads), rows 0 .. n_nodes only."""
         trees = np.asarray(trees, dtype=np.int64)
         k = len(trees)
-        assert other.C == self.C and other.path_block == self.path_block and (self.results_only or other.ring_levels == self.ring_levels)
+        assert other.path_block == self.path_block and (self.results_only or other.ring_levels == self.ring_levels)
+        assert other.C == self.C or int(other.nodes_seen[np.asarray(trees, dtype=np.int64)].max(initial=0)) + 13 <= self.C, "the trees do not fit this forest's rows"
         assert pos + k <= self.B and not other.results_only
         plen = other.paths_seen[trees]          # the trees are finished: their last paths, as the host has seen them
         assert int(plen.max(initial=0)) <= self.max_path, "the destination's path store is too small for these trees"

@@ -202,3 +202,35 @@ def test_a_search_bounded_by_time_alone_grows_past_the_old_node_cap(net_gpu):
     assert np.array_equal(kids, tree["states"][nb[i[pick], a[pick]]])                 # ... between the right states
     assert len(np.unique(tree["states"][1:n + 1], axis=0)) == n                        # every state once (agents.py:517-529)
     assert (tree["leaves"][1:n + 1] == (nb[1:] == 0).any(axis=1)).all()
+
+
+def test_time_only_search_with_continuous_batching_copies_trees_into_small_forests(net_gpu):
+    """A pool of games bounded by time alone, on fewer slots than games: the forest's capacity is address-space sized (2^24 - 2 rows
+    per tree), so finished trees are copied into results forests of the capacity they NEED (hash tables rebuilt from the keys,
+    rc_mcts_copy_trees) -- not into gigabyte copies of the big one.  Shallow scrambles that the stand-in net solves: every game is the
+    oracle's search, the inspectable tree of game 0 included."""
+    from librubiks.solving import mcts_device as md
+    from librubiks.solving.agents import MCTS
+    np.random.seed(31)
+    onet = oa.TorchNet(net_gpu, device="cuda")
+    states = []
+    while len(states) < 40:                      # scrambles the stand-in net does solve (a search bounded by time alone ends no other way)
+        cand = oc.scramble(1 + len(states) % 4, True)[0]
+        if oa.MCTS(onet, c=20.0, search_graph=True).search(cand, 3000):
+            states.append(cand)
+    states = np.array(states)
+    agent = MCTS(net_gpu, c=20.0, search_graph=True, net_dtype=torch.float32, sync_every=4)
+    free0 = torch.cuda.mem_get_info()[0]
+    res = agent.search_batch(states, time_limit=60.0, slots=8)
+    assert agent.forest.C > 1 << 20 and agent.forest.vmm                      # the searching forest: capacity by address space
+    assert free0 - torch.cuda.mem_get_info()[0] < 24 << 30                    # ... and nothing near 8 x 4.5 GB of rows, or a 256 x 1 GB grave
+    assert res.solved.all() and res.seconds < 50
+    for t, s in enumerate(states):
+        ref = oa.MCTS(onet, c=20.0, search_graph=True)
+        assert ref.search(s, 100000)
+        assert res.nodes[t] == len(ref) and list(res.queues[t]) == list(ref.action_queue), f"game {t}"
+    tree = agent._host_tree()                                                  # game 0, read from the small forest it was copied into
+    ref0 = oa.MCTS(onet, c=20.0, search_graph=True)
+    ref0.search(states[0], 100000)
+    assert tree["n"] == len(ref0) and np.array_equal(tree["neighbors"][:tree["n"] + 1], ref0.neighbors[:len(ref0) + 1])
+    assert agent._tree_src[0].C <= 1 << 14
