@@ -25,7 +25,15 @@ from librubiks.solving import bfs_device as bd
 from librubiks.solving import mcts_device as md
 from librubiks.utils import TickTock
 
-DEFAULT_NODE_CAP = 1 << 18   # per-problem node capacity of an A* search bounded by time only (its arrays are allocated up front)
+DEFAULT_NODE_CAP = 1 << 18   # least per-tree / per-problem node capacity of a search bounded by time only
+ASTAR_TIME_ONLY_BYTES = 32 << 30   # A* bounded by time only: what its per-node arrays (57 bytes per node, allocated up front) may take
+
+
+def astar_time_only_capacity(n_problems: int) -> int:
+    """Node capacity per problem of an A* search bounded by wall time only (the reference's arrays double without bound,
+    agents.py:396-404): 2^18 nodes at least, 2^26 at most, and in between what 32 GB of node arrays allow for the batch --
+    one problem gets 2^26 nodes (3.8 GB), 4 096 problems keep 2^18 each."""
+    return int(max(DEFAULT_NODE_CAP, min(1 << 26, ASTAR_TIME_ONLY_BYTES // (57 * max(1, int(n_problems))))))
 TIME_ONLY_HASH_BYTES = 32 << 30   # MCTS bounded by time only: what the trees' hash tables (the one per-node array that must exist up front) may take
 
 
@@ -892,7 +900,7 @@ class AStar(DeepAgent):
                      max_iterations: int = None) -> BatchResult:
         time_limit, max_states = self.reset(time_limit, max_states)
         roots = states if isinstance(states, DeviceCubes) else DeviceCubes.from_numpy(np.asarray(states))
-        cap_states = int(max_states) if max_states < int(1e10) else DEFAULT_NODE_CAP
+        cap_states = int(max_states) if max_states < int(1e10) else astar_time_only_capacity(roots.n)
         batch = self._batch_for(roots.n, max(cap_states, 12 * self.expansions + 1))
         self.tt.tick()
         batch.reset(roots)

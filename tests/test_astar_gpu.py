@@ -152,3 +152,28 @@ def test_deterministic_astar_does_not_depend_on_the_batch():
     assert list(one.action_queue) == list(big.queues[200])
     with pytest.raises(ValueError):
         AStar(net, lambda_=0.2, expansions=50, net_dtype=torch.bfloat16, deterministic=True)
+
+
+def test_a_search_bounded_by_time_alone_is_not_capped_at_2_to_the_18(net_gpu):
+    """The reference's A* arrays double for as long as the time limit lets the search run (agents.py:396-404).  Here a search with a
+    time limit only gets what 32 GB of node arrays allow for its batch (`agents.astar_time_only_capacity`): one problem 2^26 nodes,
+    and it does grow past the 2^18 nodes of earlier rounds -- with parents that still lead back to the start state."""
+    from librubiks.solving import agents as ag
+    assert ag.astar_time_only_capacity(1) == 1 << 26 and ag.astar_time_only_capacity(4096) == 1 << 18
+    np.random.seed(9)
+    state = oc.scramble(40, True)[0]
+    agent = ag.AStar(net_gpu, lambda_=0.2, expansions=400, net_dtype=torch.float32)
+    solved = agent.search(state, time_limit=6.0)
+    assert agent.batch.C == 1 << 26
+    if solved:
+        pytest.skip("the stand-in net solved this scramble before the search reached 2^18 nodes")
+    n = len(agent)
+    assert n > (1 << 18), n
+    h = agent._host()
+    par, act, states = h["parents"], h["parent_actions"], h["states"]
+    pick = np.random.RandomState(0).randint(2, n + 1, 2000)
+    assert np.array_equal(oc.multi_rotate(states[par[pick]], *oc.indices_to_actions(act[pick])), states[pick])   # child = parent turned by its action
+    i, steps = n, 0
+    while i != 1 and steps <= n:
+        i, steps = int(par[i]), steps + 1
+    assert i == 1 and len(np.unique(states[1:n + 1], axis=0)) == n

@@ -157,3 +157,42 @@ def test_vmm_classify_replays_an_event_log(tmp_path):
     state = vc.replay(str(log))
     assert vc.classify(0x7100_0000_0000 + 3 * MB, *state)[0] == "mapped" and vc.classify(0x7100_0000_0000, *state)[0] == "unmapped"
     assert vc.classify(0x7100_0000_0000 + 12 * MB, *state)[0] == "slack"
+
+
+def test_capacities_of_searches_bounded_by_time_alone():
+    """A search with a time limit only has no node limit in the reference (its arrays double, agents.py:396-404,450-459).  The host
+    logic that stands in for "unbounded": MCTS gets what the kernels can address (node rows are address space) or what 32 GB of hash
+    tables allow for the batch; A* what 32 GB of its (up-front) node arrays allow; never less than the 2^18 nodes of earlier rounds."""
+    from librubiks.solving import agents as ag
+    from librubiks.solving import mcts_device as md
+    assert ag.time_only_capacity(1) == md.MAX_CAPACITY == (1 << 24) - 2
+    assert ag.time_only_capacity(1024) == (32 << 30) // (8 * 1024) - 1 and ag.time_only_capacity(10 ** 6) == 1 << 18
+    assert [ag.astar_time_only_capacity(b) for b in (1, 8, 4096, 10 ** 6)] == [1 << 26, 1 << 26, 1 << 18, 1 << 18]
+    assert ag.astar_time_only_capacity(64) == (32 << 30) // (57 * 64)
+
+
+def test_queue_table_takes_rows_longer_than_the_shared_array():
+    """A queue that goes beyond the first path block (descents of any length) is set from an array of its own (`QueueTable.set_row`)."""
+    import numpy as np
+    from librubiks.solving.agents import QueueTable
+    table = QueueTable(np.zeros((2, 4), dtype=np.uint8), np.array([4, 2]))
+    long = (np.arange(5000) % 12).astype(np.uint8)
+    table.set_row(1, long)
+    assert len(table[1]) == 5000 and list(table[1])[:13] == list(range(12)) + [0] and table.lengths()[1] == 5000
+    padded, lens = table.padded()
+    assert padded.shape == (2, 5000) and list(lens) == [4, 5000] and (padded[0, 4:] == 255).all() and np.array_equal(padded[1], long)
+
+
+def test_blocked_path_index_is_dense_in_block_zero():
+    """rc_mcts_t's path arrays are [block][tree][2^lg levels]: level k of tree t at ((k >> lg) B + t) << lg | (k & (2^lg - 1)).  Block 0 is
+    the dense [B][block] array of rounds 1-5; a tensor shaped (blocks, B, block) indexes the same element (what `MCTSForest.read_path` relies on)."""
+    import numpy as np
+    B, lg, blocks = 5, 4, 3
+    flat = np.arange(blocks * B << lg)
+    view = flat.reshape(blocks, B, 1 << lg)
+    for t in range(B):
+        for k in range(blocks << lg):
+            idx = (((k >> lg) * B + t) << lg) | (k & ((1 << lg) - 1))
+            assert view[k >> lg, t, k & ((1 << lg) - 1)] == idx
+            if k < (1 << lg):
+                assert idx == t * (1 << lg) + k
