@@ -234,3 +234,26 @@ def test_time_only_search_with_continuous_batching_copies_trees_into_small_fores
     ref0.search(states[0], 100000)
     assert tree["n"] == len(ref0) and np.array_equal(tree["neighbors"][:tree["n"] + 1], ref0.neighbors[:len(ref0) + 1])
     assert agent._tree_src[0].C <= 1 << 14
+
+
+def test_large_forest_form_of_the_deep_kernel(net_gpu, knobs):
+    """Forests of more than 512 trees run the tree kernel with 256 threads per tree and ONE wave checking a line (smaller ones: 512 / 1 024
+    threads, four waves): the same deep-path body in its other launch shape.  640 trees with 8 levels in LDS and 16-level path blocks, every
+    fifth tree against the oracle's single-tree run."""
+    from librubiks.solving.agents import MCTS
+    knobs(8, 16, 32)
+    np.random.seed(17)
+    states = np.array([oc.scramble(2 + i % 19, True)[0] for i in range(640)])
+    max_states = 420
+    agent = MCTS(net_gpu, c=0.6, search_graph=True, net_dtype=torch.float32, sync_every=4)
+    res = agent.search_batch(states, None, max_states, compact=False)        # the forest keeps its 640-tree launch shape to the end
+    assert res.path_overflow_trees == 0 and int(agent._last_forest.path_rows_host.max()) > 16
+    onet = oa.TorchNet(net_gpu, device="cuda")
+    deepest = 0
+    for t in range(0, 640, 5):
+        ref = oa.MCTS(onet, c=0.6, search_graph=True)
+        ok = ref.search(states[t], max_states)
+        deepest = max(deepest, ref.deepest_path)
+        assert bool(res.solved[t]) == ok and res.nodes[t] == len(ref) and res.iterations[t] == ref.iterations, f"tree {t}"
+        assert list(res.queues[t]) == list(ref.action_queue), f"tree {t}"
+    assert deepest > 16
