@@ -38,7 +38,7 @@ typedef const __attribute__((address_space(1))) void glb_void;
 
 // Diagnostic builds only (tools/build_ab_lib.sh WORK <name> -DRUBIKS_GEMM_ABLATE=n; WRONG RESULTS, timing experiments):
 //   1 no LDS-DMA after the first stage (what memory costs)   2 no barrier / vmcnt wait after the first step (what synchronisation costs)
-//   3 both                                                    4 no fragment reads after the first step (what LDS reads cost)
+//   3 both                                                    4 no fragment reads after the first step (what LDS reads cost); 5, 7: combined
 #ifndef RUBIKS_GEMM_ABLATE
 #define RUBIKS_GEMM_ABLATE 0
 #endif
@@ -119,12 +119,12 @@ __global__ __launch_bounds__(WM *WN * 64) void k_split_gemm(GemmArgs g) {
     // tile's BM / 8), then its weight pieces.  Each is ONE buffer_load ... lds: the tile's rows as a buffer resource (scalar
     // registers), the lane's place in it a loop-invariant VGPR, the K-step a scalar offset -- no vector address arithmetic per piece
     // (a 64-bit vector add in front of every piece held the wave's issue next to the MFMAs: profiles/r6_gemm_ablation.txt).
-    constexpr int PA = (T::BM / 8 + T::WAVES - 1) / T::WAVES, PW = (T::BN / 8 + T::WAVES - 1) / T::WAVES;
-    static_assert(PA + PW == T::PPW || PA + PW == T::PPW + 1, "piece bookkeeping");
+    constexpr int DW = T::WAVES;   // waves that issue LDS-DMA: all of them (one wave per SIMD issuing everything: 7.9 -> 9.2 ms, profiles/r6_gemm_ablation.txt)
+    constexpr int PA = (T::BM / 8 + DW - 1) / DW, PW = (T::BN / 8 + DW - 1) / DW;
     u32 src_off[PA + PW];
 #pragma unroll
     for (int i = 0; i < PA + PW; ++i) {
-        const u32 p = (i < PA ? i : i - PA) * T::WAVES + wave, R = p * 8 + (lane >> 3), chunk = (lane & 7) ^ ((R >> 1) & 7);
+        const u32 p = (i < PA ? i : i - PA) * DW + wave, R = p * 8 + (lane >> 3), chunk = (lane & 7) ^ ((R >> 1) & 7);
         src_off[i] = i < PA ? min(R, last_row) * lda + chunk * 16 : R * ldw + chunk * 16;   // (the swizzle depends on R mod 16 only: BM is a multiple of 16)
     }
     const StageBufs sb = stage_bufs(g.a + row0 * lda, g.w + (size_t)col0 * ldw);
@@ -135,7 +135,8 @@ __global__ __launch_bounds__(WM *WN * 64) void k_split_gemm(GemmArgs g) {
 #pragma unroll
         for (int i = 0; i < PA + PW; ++i) {
             if (i < lo || i >= hi) continue;
-            const u32 p = (i < PA ? i : i - PA) * T::WAVES + wave;
+            const u32 p = (i < PA ? i : i - PA) * DW + wave;
+            if (wave >= (u32)DW) continue;
             if (i < PA) {
                 if (p < (u32)(T::BM / 8)) lds_dma16(sb.a, (lds_void *)(dst + p * 1024), src_off[i], a_col * 2);
             } else if (p < (u32)(T::BN / 8)) {
@@ -166,6 +167,9 @@ __global__ __launch_bounds__(WM *WN * 64) void k_split_gemm(GemmArgs g) {
     // two loops over the K-steps with the scaling of the correction products between them (one loop with the scaling behind a
     // test costs the 512-register tiles their register allocation: the accumulators live in AGPRs, the scaling needs them in VGPRs)
     const u32 ks_mid = scale_step > ks0 && scale_step < nk ? scale_step : nk;
+#if RUBIKS_GEMM_ABLATE & 4
+    f16x8 wf_keep[NR][2], xf_keep[2][2];   // (diagnostic build: fragments read in the first step only)
+#endif
     auto k_step = [&](u32 ks) {
         if (!(RUBIKS_GEMM_ABLATE & 2) || ks == ks0) {
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -173,19 +177,32 @@ __global__ __launch_bounds__(WM *WN * 64) void k_split_gemm(GemmArgs g) {
         }
         const bool more = (RUBIKS_GEMM_ABLATE & 1) ? false : ks + 1 < nk;
         const unsigned char *s = lds + ((ks - ks0) & 1) * T::STAGE;
+#if RUBIKS_GEMM_ABLATE & 4
+        f16x8 (&wf)[NR][2] = wf_keep;
+        f16x8 (&xf)[2][2] = xf_keep;
+        const bool rd = ks == ks0;
+#else
         f16x8 wf[NR][2];
+        constexpr bool rd = true;
+#endif
+        if (rd) {
 #pragma unroll
         for (int n = 0; n < NR; ++n)
 #pragma unroll
             for (int kh = 0; kh < 2; ++kh) wf[n][kh] = *reinterpret_cast<const f16x8 *>(s + w_off[kh] + n * 16 * kGemmRowBytes);
+        }
         // the activation fragments of row m + 1 are requested BEFORE the MFMAs of row m (two registers sets, alternating): a wave's
         // matrix instructions then wait for LDS once per K-step, not once per row
+#if !(RUBIKS_GEMM_ABLATE & 4)
         f16x8 xf[2][2];
+#endif
+        if (rd) {
 #pragma unroll
         for (int kh = 0; kh < 2; ++kh) xf[0][kh] = *reinterpret_cast<const f16x8 *>(s + x_off[kh]);
+        }
 #pragma unroll
         for (int m = 0; m < MR; ++m) {
-            if (m + 1 < MR) {
+            if (rd && m + 1 < MR) {
 #pragma unroll
                 for (int kh = 0; kh < 2; ++kh) xf[(m + 1) & 1][kh] = *reinterpret_cast<const f16x8 *>(s + x_off[kh] + (m + 1) * 16 * kGemmRowBytes);
             }
