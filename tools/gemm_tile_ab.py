@@ -83,8 +83,10 @@ def main():
                 first = y.clone()
             else:
                 same = bool(torch.equal(first, y))
+            v = y.view(torch.int32).to(torch.int64).reshape(-1)
+            checksum = int((v * (torch.arange(v.numel(), device=dev, dtype=torch.int64) % 8191 + 1)).sum().item()) & ((1 << 62) - 1)   # equal across builds <=> same bits
             rec = {"rows": M, "tile": tile, "ms": round(ms, 4), "tflops_f16": round(flops / ms / 1e9, 1), "frac": round(flops / ms / 1e9 / PEAK, 4),
-                   "bit_identical_to_first_tile": same}
+                   "bit_identical_to_first_tile": same, "checksum": checksum}
             print(json.dumps(rec), flush=True)
             out["runs"].append(rec)
         del first
