@@ -32,7 +32,6 @@ namespace rubiks {
 typedef __attribute__((ext_vector_type(8))) _Float16 f16x8;
 typedef __attribute__((ext_vector_type(4))) float f32x4;
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
-typedef __attribute__((ext_vector_type(4))) unsigned int u32x4_t;
 constexpr int kOutHalves = 0, kOutF32 = 1, kBf16 = 2, kPartials = 3;   // operand / output kinds of the layer kernels
 typedef __attribute__((address_space(3))) void lds_void;
 typedef const __attribute__((address_space(1))) void glb_void;
@@ -43,9 +42,7 @@ typedef const __attribute__((address_space(1))) void glb_void;
 #ifndef RUBIKS_GEMM_ABLATE
 #define RUBIKS_GEMM_ABLATE 0
 #endif
-#ifndef RUBIKS_GEMM_PINGPONG
-#define RUBIKS_GEMM_PINGPONG 1   // 0: the 8-wave tiles run the lock-step K loop of rounds 2-5 (same-box A/B builds)
-#endif
+
 constexpr int kGemmRowBytes = 128;   // one K-step: 64 halves per row
 constexpr int kPiecesPerRow = 2;   // LDS-DMA pieces a wave issues behind the MFMAs of one 16-row fragment
 
@@ -151,12 +148,12 @@ __global__ __launch_bounds__(WM *WN * 64) void k_split_gemm(GemmArgs g) {
 
     // fragment addresses inside a stage: row (lane & 15) of a 16-row block, chunk ((lane >> 4) + 4 kh) ^ swizzle(row)
     const u32 fr = lane & 15, fq = lane >> 4, swz = fr >> 1;
-    u32 x_off[2], w_off_frag[2];
+    u32 x_off[2], w_off[2];
 #pragma unroll
     for (int kh = 0; kh < 2; ++kh) {
         const u32 c = ((fq + 4 * kh) ^ swz) * 16;
         x_off[kh] = (wr * MR * 16 + fr) * kGemmRowBytes + c;
-        w_off_frag[kh] = T::A_BYTES + (wc * NR * 16 + fr) * kGemmRowBytes + c;
+        w_off[kh] = T::A_BYTES + (wc * NR * 16 + fr) * kGemmRowBytes + c;
     }
 
     f32x4 acc[MR][NR];
@@ -168,88 +165,6 @@ __global__ __launch_bounds__(WM *WN * 64) void k_split_gemm(GemmArgs g) {
     const u32 nk_all = (one ? 1 : 3) * K / 64, scale_step = one ? 0xFFFFFFFFu : 2 * K / 64;
     const u32 ks0 = KIND == kPartials ? half * (nk_all / g.S) : 0u, nk = KIND == kPartials ? ks0 + nk_all / g.S : nk_all;
     stage(ks0, 0);
-#if RUBIKS_GEMM_PINGPONG
-    // ---- eight waves, two per SIMD: the two take TURNS (profiles/r6_gemm_ablation.txt, 5. and 6.) --------------------------------
-    // LDS-DMA is the bound of the lock-step loop: the CU moves ~19 bytes per cycle through it (76 pieces of 1 KB per K-step ~ 4 000
-    // cycles, whoever issues them and whenever), more than the 2 816 cycles of the K-step's MFMAs.  Here a K-step is two half-steps:
-    // in the first, group 0 (waves 0-3, one per SIMD, the tile's upper rows) runs its MFMAs on stage k while group 1 (waves 4-7, the
-    // lower rows) stages for stage k + 1; in the second they swap.  A staging wave's fragment registers are free, so half of what it
-    // stages goes the other way round -- global_load into those registers, ds_write_b128 at the end of the phase (the weight rows:
-    // needed by everybody right behind the next barrier) -- and only the OTHER group's activation rows, which have a whole half-step
-    // more to land, go through LDS-DMA: 22 pieces per half-step instead of 38.  One barrier per half-step; a wave waits for its
-    // LDS-DMA pieces at the end of its matrix phase (issued a half-step ago).  Every wave accumulates exactly as before: bit-identical.
-    if constexpr (T::WAVES == 8 && WM == 2) {
-        constexpr int NA = T::BM / 16, NW = T::BN / 8;     // pieces (8 rows x 128 bytes) of one group's activation rows, and of the weight rows
-        static_assert(NW % 8 == 0, "the weight rows are staged half by each group, a whole number of pieces per wave");
-        constexpr int NAQ = (NA + 3) / 4, NWQ = NW / 8;   // per wave and staging phase: LDS-DMA pieces (at most), register-staged pieces
-        const u32 grp = wave >> 2, wj = wave & 3;
-        u32 a_off[NAQ], a_dst[NAQ], w_off[NWQ], w_dst[NWQ];
-        bool a_ok[NAQ];
-#pragma unroll
-        for (int i = 0; i < NAQ; ++i) {   // the OTHER group's activation rows
-            const u32 q = (u32)i * 4 + wj, piece = (grp == 1 ? 0u : (u32)NA) + q;
-            const u32 R = piece * 8 + (lane >> 3), chunk = (lane & 7) ^ ((R >> 1) & 7);
-            a_ok[i] = q < (u32)NA;
-            a_off[i] = min(R, last_row) * lda + chunk * 16;
-            a_dst[i] = piece * 1024;
-        }
-#pragma unroll
-        for (int i = 0; i < NWQ; ++i) {   // this group's half of the weight rows
-            const u32 piece = grp * (NW / 2) + (u32)i * 4 + wj, R = piece * 8 + (lane >> 3), chunk = (lane & 7) ^ ((R >> 1) & 7);
-            w_off[i] = R * ldw + chunk * 16;
-            w_dst[i] = (u32)T::A_BYTES + piece * 1024 + lane * 16;
-        }
-        const u32 S = nk - ks0;
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
-        for (u32 hs = 0; hs < 2 * S; ++hs) {
-            const u32 sidx = hs >> 1, ks = ks0 + sidx;
-            if ((hs & 1) == grp) {   // the matrix phase: stage ks, alone on the SIMD's matrix pipe
-                if (ks == scale_step && ks != ks0) {
-#pragma unroll
-                    for (int m = 0; m < MR; ++m)
-#pragma unroll
-                        for (int n = 0; n < NR; ++n) acc[m][n] *= (1.0f / kSplitScale);
-                }
-                const unsigned char *s = lds + (sidx & 1) * T::STAGE;
-                f16x8 wf[NR][2], xf[2][2];
-#pragma unroll
-                for (int n = 0; n < NR; ++n)
-#pragma unroll
-                    for (int kh = 0; kh < 2; ++kh) wf[n][kh] = *reinterpret_cast<const f16x8 *>(s + w_off_frag[kh] + n * 16 * kGemmRowBytes);
-#pragma unroll
-                for (int kh = 0; kh < 2; ++kh) xf[0][kh] = *reinterpret_cast<const f16x8 *>(s + x_off[kh]);
-#pragma unroll
-                for (int m = 0; m < MR; ++m) {
-                    if (m + 1 < MR) {
-#pragma unroll
-                        for (int kh = 0; kh < 2; ++kh) xf[(m + 1) & 1][kh] = *reinterpret_cast<const f16x8 *>(s + x_off[kh] + (m + 1) * 16 * kGemmRowBytes);
-                    }
-#pragma unroll
-                    for (int kh = 0; kh < 2; ++kh)
-#pragma unroll
-                        for (int n = 0; n < NR; ++n)
-                            acc[m][n] = KIND == kBf16 ? __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, wf[n][kh]), __builtin_bit_cast(bf16x8, xf[m & 1][kh]), acc[m][n], 0, 0, 0)
-                                                      : __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[n][kh], xf[m & 1][kh], acc[m][n], 0, 0, 0);
-                }
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the LDS-DMA pieces this wave issued a half-step ago are in LDS before anybody is let at them
-            } else if (sidx + 1 < S) {   // the staging phase: this group's share of stage ks + 1, into the buffer both groups have left
-                const u32 kk = (ks + 1) * 64, a_col = (one || kk < 2 * K) ? kk : kk - 2 * K;
-                unsigned char *dst = lds + ((sidx + 1) & 1) * T::STAGE;
-                u32x4_t wv[NWQ];
-#pragma unroll
-                for (int i = 0; i < NWQ; ++i) wv[i] = __builtin_amdgcn_raw_buffer_load_b128(sb.w, w_off[i], kk * 2, 0);   // first: they are waited for first
-#pragma unroll
-                for (int i = 0; i < NAQ; ++i)
-                    if (a_ok[i]) lds_dma16(sb.a, (lds_void *)(dst + a_dst[i]), a_off[i], a_col * 2);
-                asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NA / 4) : "memory");   // in order: the register loads are back, the LDS-DMA pieces behind them may still fly
-#pragma unroll
-                for (int i = 0; i < NWQ; ++i) *reinterpret_cast<u32x4_t *>(dst + w_dst[i]) = wv[i];
-            }
-            __syncthreads();
-        }
-    } else
-#endif
     {
     // two loops over the K-steps with the scaling of the correction products between them (one loop with the scaling behind a
     // test costs the 512-register tiles their register allocation: the accumulators live in AGPRs, the scaling needs them in VGPRs)
@@ -276,7 +191,7 @@ __global__ __launch_bounds__(WM *WN * 64) void k_split_gemm(GemmArgs g) {
 #pragma unroll
         for (int n = 0; n < NR; ++n)
 #pragma unroll
-            for (int kh = 0; kh < 2; ++kh) wf[n][kh] = *reinterpret_cast<const f16x8 *>(s + w_off_frag[kh] + n * 16 * kGemmRowBytes);
+            for (int kh = 0; kh < 2; ++kh) wf[n][kh] = *reinterpret_cast<const f16x8 *>(s + w_off[kh] + n * 16 * kGemmRowBytes);
         }
         // the activation fragments of row m + 1 are requested BEFORE the MFMAs of row m (two registers sets, alternating): a wave's
         // matrix instructions then wait for LDS once per K-step, not once per row
