@@ -43,6 +43,7 @@ typedef const __attribute__((address_space(1))) void glb_void;
 #define RUBIKS_GEMM_ABLATE 0
 #endif
 
+
 constexpr int kGemmRowBytes = 128;   // one K-step: 64 halves per row
 constexpr int kPiecesPerRow = 2;   // LDS-DMA pieces a wave issues behind the MFMAs of one 16-row fragment
 
@@ -179,6 +180,7 @@ __global__ __launch_bounds__(WM *WN * 64) void k_split_gemm(GemmArgs g) {
         }
         const bool more = (RUBIKS_GEMM_ABLATE & 1) ? false : ks + 1 < nk;
         const unsigned char *s = lds + ((ks - ks0) & 1) * T::STAGE;
+
 #if RUBIKS_GEMM_ABLATE & 4
         f16x8 (&wf)[NR][2] = wf_keep;
         f16x8 (&xf)[2][2] = xf_keep;
