@@ -51,7 +51,9 @@ def main():
         ev.save(args.out, str(agent), res, states, times)
         per_depth = [ev.log_this_depth(res[i], states[i], times[i], d) for i, d in enumerate(depths)]
         summary[name] = {"agent": str(agent), "seconds": dt, "states": int(states.sum()), "states_per_sec": float(states.sum() / dt),
-                         "per_depth": [{k: p[k] for k in ("depth", "share_completed", "ci95", "mean_turns", "states_per_game")} for p in per_depth]}
+                         "per_depth": [{k: p[k] for k in ("depth", "share_completed", "ci95", "mean_turns", "states_per_game", "time_per_game", "states_per_sec")} for p in per_depth],
+                         "note": "time_per_game / states_per_sec per depth are the reference's quantities (each game's own wall interval; the games of a batch "
+                                 "overlap on the GPU), `states_per_sec` at this level is the throughput of the evaluation (all states / wall seconds)"}
         print(name, json.dumps(summary[name]), flush=True)
         del agent
         torch.cuda.empty_cache()
