@@ -105,7 +105,10 @@ def run_leg(name, model, pool_roots, config_roots, args, world, coll_device, tre
     # so that a change of a few per cent between two runs can be told from the window's own scatter (value_spread: median, min, max).
     more = torch.zeros((SPREAD_WINDOWS, 2), dtype=torch.float64)
     for w in range(SPREAD_WINDOWS):
-        if run.done:
+        over = torch.tensor([1.0 if run.done else 0.0], dtype=torch.float64, device=coll_device)
+        if world > 1:      # every rank runs the same number of windows (each ends in a collective): stop together when any pool has run dry
+            dist.all_reduce(over, op=dist.ReduceOp.MAX)
+        if float(over.item()):
             break
         n_before = run.nodes_now()
         barrier()
