@@ -38,7 +38,7 @@ typedef const __attribute__((address_space(1))) void glb_void;
 
 // Diagnostic builds only (tools/build_ab_lib.sh WORK <name> -DRUBIKS_GEMM_ABLATE=n; WRONG RESULTS, timing experiments):
 //   1 no LDS-DMA after the first stage (what memory costs)   2 no barrier / vmcnt wait after the first step (what synchronisation costs)
-//   3 both                                                    4 no fragment reads after the first step (what LDS reads cost); 5, 7: combined
+//   3 both       (the builds with the fragment reads removed as well, -DRUBIKS_GEMM_ABLATE=4 / 5 / 7 of profiles/r6_gemm_ablation.txt: commit 0190886)
 #ifndef RUBIKS_GEMM_ABLATE
 #define RUBIKS_GEMM_ABLATE 0
 #endif
@@ -170,9 +170,6 @@ __global__ __launch_bounds__(WM *WN * 64) void k_split_gemm(GemmArgs g) {
     // two loops over the K-steps with the scaling of the correction products between them (one loop with the scaling behind a
     // test costs the 512-register tiles their register allocation: the accumulators live in AGPRs, the scaling needs them in VGPRs)
     const u32 ks_mid = scale_step > ks0 && scale_step < nk ? scale_step : nk;
-#if RUBIKS_GEMM_ABLATE & 4
-    f16x8 wf_keep[NR][2], xf_keep[2][2];   // (diagnostic build: fragments read in the first step only)
-#endif
     auto k_step = [&](u32 ks) {
         if (!(RUBIKS_GEMM_ABLATE & 2) || ks == ks0) {
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -181,32 +178,19 @@ __global__ __launch_bounds__(WM *WN * 64) void k_split_gemm(GemmArgs g) {
         const bool more = (RUBIKS_GEMM_ABLATE & 1) ? false : ks + 1 < nk;
         const unsigned char *s = lds + ((ks - ks0) & 1) * T::STAGE;
 
-#if RUBIKS_GEMM_ABLATE & 4
-        f16x8 (&wf)[NR][2] = wf_keep;
-        f16x8 (&xf)[2][2] = xf_keep;
-        const bool rd = ks == ks0;
-#else
         f16x8 wf[NR][2];
-        constexpr bool rd = true;
-#endif
-        if (rd) {
 #pragma unroll
         for (int n = 0; n < NR; ++n)
 #pragma unroll
             for (int kh = 0; kh < 2; ++kh) wf[n][kh] = *reinterpret_cast<const f16x8 *>(s + w_off[kh] + n * 16 * kGemmRowBytes);
-        }
         // the activation fragments of row m + 1 are requested BEFORE the MFMAs of row m (two registers sets, alternating): a wave's
         // matrix instructions then wait for LDS once per K-step, not once per row
-#if !(RUBIKS_GEMM_ABLATE & 4)
         f16x8 xf[2][2];
-#endif
-        if (rd) {
 #pragma unroll
         for (int kh = 0; kh < 2; ++kh) xf[0][kh] = *reinterpret_cast<const f16x8 *>(s + x_off[kh]);
-        }
 #pragma unroll
         for (int m = 0; m < MR; ++m) {
-            if (rd && m + 1 < MR) {
+            if (m + 1 < MR) {
 #pragma unroll
                 for (int kh = 0; kh < 2; ++kh) xf[(m + 1) & 1][kh] = *reinterpret_cast<const f16x8 *>(s + x_off[kh] + (m + 1) * 16 * kGemmRowBytes);
             }
