@@ -1014,7 +1014,7 @@ class _StepAgent(Agent):
         solved = cubes.is_solved().clone()
         root_solved = solved.clone()
         running = ~solved
-        history = []
+        history, stamps = [], []     # stamps[i]: seconds on the agent's clock when step i had been queued and the loop's test had waited for step i - 1
         steps = torch.zeros(B, dtype=torch.int64, device=solved.device)
         while len(history) < cap and bool(running.any()) and self.tt.tock() < time_limit:
             actions = self._actions(cubes, running)
@@ -1025,6 +1025,7 @@ class _StepAgent(Agent):
             now = cubes.is_solved()
             solved |= now & running
             running &= ~now
+            stamps.append(self.tt.tock())
         torch.cuda.synchronize()
         seconds = self.tt.tock()
         hist = torch.stack(history, 1).cpu().numpy() if history else np.zeros((B, 0), dtype=np.uint8)
@@ -1034,7 +1035,11 @@ class _StepAgent(Agent):
         self._explored_states = int(steps[0])
         self.action_queue = queues[0]
         status = np.where(root_solved.cpu().numpy(), 4, np.where(solved_h, 1, 2))
-        return BatchResult(solved_h, lengths, steps.astype(np.int64), queues, seconds, steps, status)
+        # a game's wall interval: from the start of the batch to the host's first look after its last move (`running.any()` synchronises
+        # every step, so the look behind step i sees it done); games that ran to the end: the batch's seconds
+        after = np.array(stamps[1:] + [seconds]) if stamps else np.zeros(0)
+        each = np.where(steps > 0, after[np.maximum(steps, 1) - 1] if len(after) else seconds, stamps[0] if stamps else seconds)
+        return BatchResult(solved_h, lengths, steps.astype(np.int64), queues, seconds, steps, status, np.asarray(each, dtype=np.float64))
 
     def search(self, state: np.ndarray, time_limit: float = None, max_states: int = None) -> bool:
         return bool(self.search_batch(np.asarray(state)[None], time_limit, max_states).solved[0])

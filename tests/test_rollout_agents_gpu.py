@@ -19,6 +19,11 @@ def test_value_search_reference_traces(standin_net):
     assert res.solved.all()
     for q, ref in zip(res.queues, g["value_queues"]):
         assert list(q) == list(ref[ref >= 0])
+    # per-game wall intervals (what the Evaluator reports as `times`): a game with fewer moves is seen finished no later than one with more
+    lens = np.array([len(q) for q in res.queues])
+    assert res.game_seconds.shape == lens.shape and (res.game_seconds > 0).all() and res.game_seconds.max() <= res.seconds
+    order = np.argsort(lens, kind="stable")
+    assert (np.diff(res.game_seconds[order]) >= 0).all()
     assert agent.search(g["value_states"][3], None, 64) and list(agent.action_queue) == list(res.queues[3])
     assert str(agent) == "Greedy value"
 
