@@ -163,7 +163,7 @@ def test_a_search_bounded_by_time_alone_is_not_capped_at_2_to_the_18(net_gpu):
     np.random.seed(9)
     state = oc.scramble(40, True)[0]
     agent = ag.AStar(net_gpu, lambda_=0.2, expansions=400, net_dtype=torch.float32)
-    solved = agent.search(state, time_limit=6.0)
+    solved = agent.search(state, time_limit=2.5)            # (~1.2 M nodes in 1.5 s on an MI355X)
     assert agent.batch.C == 1 << 26
     if solved:
         pytest.skip("the stand-in net solved this scramble before the search reached 2^18 nodes")

@@ -176,7 +176,7 @@ def test_descents_deeper_than_the_lds_window_at_production_sizes(knobs):
 def test_a_search_bounded_by_time_alone_grows_past_the_old_node_cap(net_gpu):
     """The reference doubles its node arrays for as long as the time limit lets a tree grow (agents.py:450-459).  A search with a
     time limit only gets the capacity the kernels can address (node rows are address space with memory behind the rows in use),
-    not the 2^18 nodes of earlier rounds: one tree, a few seconds, more than 2^18 nodes -- and still a consistent tree."""
+    not the 2^18 nodes of earlier rounds: one tree, six seconds, more than 2^18 nodes -- and still a consistent tree."""
     from librubiks.solving import agents as ag
     from librubiks.solving import mcts_device as md
     assert ag.time_only_capacity(1) == md.MAX_CAPACITY and ag.time_only_capacity(1024) >= 4 * (1 << 18)
@@ -184,7 +184,7 @@ def test_a_search_bounded_by_time_alone_grows_past_the_old_node_cap(net_gpu):
     state = oc.scramble(30, True)[0]
     agent = ag.MCTS(net_gpu, c=0.6, search_graph=False, net_dtype=torch.float32)
     agent.prepare(1, None)
-    solved = agent.search(state, time_limit=8.0)
+    solved = agent.search(state, time_limit=6.0)            # (one tree: ~280 k nodes in 2 s, ~700 k in 6 s on an MI355X)
     f = agent._last_forest
     assert f.C >= md.MAX_CAPACITY - 8192 and f.vmm
     n = len(agent)
