@@ -135,6 +135,20 @@ def growth_plan(have: np.ndarray, seen: np.ndarray, steps_ahead: int, max_rows: 
     return trees, np.minimum(max_rows, np.maximum(need[trees], grown))
 
 
+def path_growth_plan(have: np.ndarray, seen: np.ndarray, block: int, max_path: int):
+    """
+    Which trees get more path blocks, and up to which level (host logic of the on-demand path store, `MCTSForest.grow_paths`).
+    have[t]: levels of tree t's path arrays with memory behind them (whole blocks); seen[t]: its path length at the host's last look.
+    A tree whose descents have come within a quarter block of the end of its blocks gets the next block -- or as many as one and a half
+    times its path needs (deep trees get deeper: growth steps should be few) --, never beyond max_path.  Returns (tree indices, levels).
+    """
+    have = np.asarray(have, dtype=np.int64)
+    seen = np.asarray(seen, dtype=np.int64)
+    near = np.flatnonzero((seen + block // 4 >= have) & (have < max_path))
+    want = np.maximum(have[near] + block, seen[near] + seen[near] // 2)
+    return near, np.minimum(max_path, (want + block - 1) // block * block)
+
+
 class MCTSForest:
     # node records of at least this many bytes: the per-node arrays are mapped on demand (None: never).  RUBIKS_VMM_MIN_GB
     # overrides it for a process (0 = every forest, "never" = none): A/B runs and diagnosis.
@@ -387,9 +401,9 @@ class MCTSForest:
         self.paths_seen = np.asarray(path_len, dtype=np.int64).copy()
         if not self.path_vmm:
             return
-        near = np.flatnonzero((self.paths_seen + self.path_block // 4 >= self.path_rows_host) & (self.path_rows_host < self.max_path))
+        near, levels = path_growth_plan(self.path_rows_host, self.paths_seen, self.path_block, self.max_path)
         if len(near):
-            self.ensure_path(near, np.maximum(self.path_rows_host[near] + self.path_block, self.paths_seen[near] + self.paths_seen[near] // 2))
+            self.ensure_path(near, levels)
 
     def read_path(self, name: str, t: int, n: int) -> np.ndarray:
         """The first n entries of tree t in the blocked path array `name` ("path_node", "path_act", "short_act"), on the host."""

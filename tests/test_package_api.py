@@ -196,3 +196,19 @@ def test_blocked_path_index_is_dense_in_block_zero():
             assert view[k >> lg, t, k & ((1 << lg) - 1)] == idx
             if k < (1 << lg):
                 assert idx == t * (1 << lg) + k
+
+
+def test_path_growth_plan():
+    """Host logic of the on-demand path store: which trees get their next path blocks, and how many."""
+    import numpy as np
+    from librubiks.solving.mcts_device import path_growth_plan
+    have = np.array([4096, 4096, 4096, 8192, 1 << 20])
+    seen = np.array([100, 3071, 3072, 8000, (1 << 20) - 1])
+    trees, levels = path_growth_plan(have, seen, 4096, 1 << 20)
+    assert list(trees) == [2, 3] and list(levels) == [8192, 12288]         # within a quarter block of the end; the full store gets nothing
+    trees, levels = path_growth_plan([16], [40000], 16, 1 << 20)           # far behind a deep tree: one and a half times its path, in whole blocks
+    assert list(trees) == [0] and levels[0] == 60000 and levels[0] % 16 == 0
+    trees, levels = path_growth_plan([1 << 20], [1 << 20], 4096, 1 << 20)  # the address space itself is the end
+    assert len(trees) == 0
+    trees, levels = path_growth_plan([4096], [5000], 4096, 8192)
+    assert list(levels) == [8192]
