@@ -11,6 +11,7 @@ semantics; the network runs through an engine of librubiks.model chosen by `net_
 accuracy, the reference's precision, on the f16 matrix cores), torch.bfloat16 (the fast engine) or torch.float32.
 """
 import warnings
+import weakref
 from collections import deque
 from time import perf_counter
 
@@ -436,7 +437,12 @@ class MCTS(DeepAgent):
                     self._tree_src = None
                 if self._last_forest is f:
                     self._last_forest = None
-                f.close()             # node store mapped on demand: parked for the next forest of that shape (not left to __del__)
+                run = getattr(f, "_run", None)
+                run = run() if run is not None else None
+                if run is None or run.done:
+                    f.close()         # node store mapped on demand: parked for the next forest of that shape (not left to __del__)
+                # (a run started with `start_batch` and not finished still steps this forest: it keeps it -- and its memory -- until it
+                # is finished or dropped; the forest is then collected like any object, `MCTSForest.__del__`)
                 del f
             torch.cuda.empty_cache()
             f = self.forest = md.MCTSForest(n_trees, capacity, self.max_path)
@@ -548,6 +554,7 @@ class MCTSRun:
         S = self.S = self.n_games if slots is None else max(1, min(int(slots), self.n_games))
         self.cap_states = int(max_states) if max_states < int(1e10) else time_only_capacity(S)
         forest = self.forest = agent._forest_for(S, max(self.cap_states, 16))
+        forest._run = weakref.ref(self)     # who steps this forest: an agent does not hand its memory on under a run that is not done
         agent.tt.tick()
         forest.set_active(None)
         self.plant_states = self.cap_states if one_launch else None   # one-launch iterations: roots expanded by the plant itself

@@ -338,3 +338,27 @@ def test_one_launch_entry_points_check_their_arguments(net_gpu):
     s.n_active = 65
     assert lib.rc_mcts_complete_graph(ctypes.byref(s), None) == -4                                                # list longer than the forest
     torch.cuda.synchronize()
+
+
+def test_a_second_batch_does_not_take_the_forest_from_a_run_that_is_not_done(net_gpu):
+    """`start_batch` hands out a run that steps the agent's forest.  Starting another batch of another shape on the same agent before the
+    first is finished must not hand the first forest's memory on under it: the first run still ends with the oracle's trees."""
+    from librubiks.solving.agents import MCTS
+    np.random.seed(12)
+    states = np.array([oc.scramble(3 + i % 6, True)[0] for i in range(24)])
+    agent = MCTS(net_gpu, c=0.6, search_graph=True, net_dtype=torch.float32, sync_every=4)
+    first = agent.start_batch(states, None, 500, compact=False)
+    for _ in range(3):
+        first.round()
+    forest = first.forest
+    other = agent.search_batch(states[:5], None, 300)             # another shape: the agent builds a new forest ...
+    assert agent.forest is not forest and hasattr(forest, "keys")  # ... and the first one still has its arrays
+    while not first.done:
+        first.round()
+    res = first.finish()
+    onet = oa.TorchNet(net_gpu, device="cuda")
+    for t in range(0, 24, 4):
+        ref = oa.MCTS(onet, c=0.6, search_graph=True)
+        ok = ref.search(states[t], 500)
+        assert bool(res.solved[t]) == ok and res.nodes[t] == len(ref) and list(res.queues[t]) == list(ref.action_queue), f"tree {t}"
+    assert len(other.nodes) == 5
