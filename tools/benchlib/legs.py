@@ -407,10 +407,27 @@ def adi_leg(name, model, args, world, coll_device):
     rows = 12 * n
     env_bytes = 260 * n + 13 * n + 1940 * n      # expand12 with the 13 solved flags per parent written by the same launch + one-hot f32
     env_ms = res["phases_ms"]["expand12 + is_solved (substates + states), one launch"] + res["phases_ms"]["as_oh(states, f32)"]
+    # the same two launches as a captured HIP graph, replayed: what the kernels take on the device, without the host's launch path
+    # (eager calls from Python cost ~10 us each before the GPU sees them: for 36 MB of traffic that IS the time measured above)
+    g_states = pcube.sequence_scrambler_device(games, depth, with_solved=True)
+    g_kids = pcube.DeviceCubes.empty(12 * n, g_states.soa.device)
+    g_oh = torch.empty((n, 480), dtype=torch.float32, device=g_states.soa.device)
+    g_states.expand12_flags(out=g_kids)
+    g_states.as_oh(torch.float32, out=g_oh)
+    torch.cuda.synchronize()
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph):
+        g_states.expand12_flags(out=g_kids)
+        g_states.as_oh(torch.float32, out=g_oh)
+    env_graph_ms = event_ms(graph.replay, 20)[0]
+    res["phases_ms"]["environment step as a replayed HIP graph (expand12 + flags, as_oh)"] = round(env_graph_ms, 4)
+    eager_ms, env_ms = env_ms, env_graph_ms
     res["roofline_env"] = {"kernel": f"expand12 + solved flags of {13 * n} states in one launch ({n} parents) + as_oh f32 ({n} states): the rollout's environment kernels",
+                           "ms_eager_from_python": round(eager_ms, 4),
                            "bound": "hbm", "algorithmic_bytes": int(env_bytes), "ms": round(env_ms, 4), "achieved": round(env_bytes / (env_ms * 1e-3) / 1e9, 1),
                            "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": round(env_bytes / (env_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4), "traffic": None,
-                           "note": "a rollout's arrays are a few MB: these launches are bound by launch latency, not by HBM (roofline_env of the main line has the kernels at 2^14 .. 2^26 states)"}
+                           "note": "the two launches replayed as one HIP graph (device time); called eagerly from Python they take ms_eager_from_python, the host's launch path. "
+                                   "A rollout's arrays are a few MB: far from the HBM roof either way (roofline_env of the main line has the kernels at 2^14 .. 2^26 states)"}
     if isinstance(eng, SplitF32Net):
         a = eng._first_from_cubes(kids, eng.value_layers, 0, rows)
         _, Wh, B2, b, code, alpha, W3 = eng.value_layers[1]
