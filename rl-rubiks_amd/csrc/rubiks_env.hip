@@ -146,14 +146,19 @@ __global__ __launch_bounds__(BLOCK) void k_expand12(const u32 *__restrict__ par,
             moff[r][i] = (d - 3u * poff[r][i]) * 4u;
         }
 
+    // gridDim.y workgroups share a tile by child PLANES (few parents, e.g. an ADI rollout's 16 384: 64 tiles alone leave three quarters
+    // of the chip idle): workgroup y emits planes j0 .. j1 - 1; the flags, which need all 20 planes of a parent, come from y = 0.
+    const int ppg = kPlanes / (int)gridDim.y, j0 = (int)blockIdx.y * ppg, j1 = j0 + ppg;
+    const bool flags_here = FLAGS && blockIdx.y == 0;
     const size_t n_tiles = ceil_div(n_parents, (size_t)PB);
     for (size_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
         const size_t dw0 = tile * BLOCK + tid;   // this lane's parent dword within a plane
         __syncthreads();                          // previous tile's readers are done (and lut4 staged)
 #pragma unroll
-        for (int j = 0; j < kPlanes; ++j) s_stage[j * BLOCK + tid] = (dw0 < n_par_dw) ? ld4<NT>(&par[(size_t)j * sp_dw + dw0]) : 0u;
+        for (int j = 0; j < kPlanes; ++j)
+            if (flags_here || (j >= j0 && j < j1)) s_stage[j * BLOCK + tid] = (dw0 < n_par_dw) ? ld4<NT>(&par[(size_t)j * sp_dw + dw0]) : 0u;
         __syncthreads();
-        if (FLAGS && dw0 < n_par_dw) {   // this lane's four parents: how many cubies sit solved (byte-wise count), then the rare full compare
+        if (flags_here && dw0 < n_par_dw) {   // this lane's four parents: how many cubies sit solved (byte-wise count), then the rare full compare
             u32 cnt = 0;
 #pragma unroll
             for (int j = 0; j < kPlanes; ++j)
@@ -177,6 +182,7 @@ __global__ __launch_bounds__(BLOCK) void k_expand12(const u32 *__restrict__ par,
         const size_t q0 = tile * (3 * BLOCK);     // first child chunk of this tile
 #pragma unroll
         for (int j = 0; j < kPlanes; ++j) {
+            if (j < j0 || j >= j1) continue;
             const u32 kbase = (j >= kCorners) ? kCodePad * kActions : 0;
 #pragma unroll
             for (int r = 0; r < 3; ++r) {
@@ -523,7 +529,8 @@ int rc_expand12(const int8_t *parents_soa, int8_t *children_soa, size_t n_parent
     } else {
         constexpr int BLOCK = 64;
         const size_t tiles = ceil_div(n_parents, 4 * BLOCK);
-        hipLaunchKernelGGL(k_expand12<BLOCK>, dim3((unsigned)(tiles < 8192 ? tiles : 8192)), dim3(BLOCK), 0, s,
+        const unsigned split = tiles <= 128 ? 4u : tiles <= 512 ? 2u : 1u;
+        hipLaunchKernelGGL(k_expand12<BLOCK>, dim3((unsigned)(tiles < 8192 ? tiles : 8192), split), dim3(BLOCK), 0, s,
                            (const u32 *)parents_soa, (uint4 *)children_soa, n_parents, n_par_dw, n_chunks, stride_p / 4,
                            stride_c / 16);
     }
@@ -549,7 +556,8 @@ int rc_expand12_flags(const int8_t *parents_soa, int8_t *children_soa, size_t n_
     } else {
         constexpr int BLOCK = 64;
         const size_t tiles = ceil_div(n_parents, 4 * BLOCK);
-        hipLaunchKernelGGL((k_expand12<BLOCK, false, true>), dim3((unsigned)(tiles < 8192 ? tiles : 8192)), dim3(BLOCK), 0, s,
+        const unsigned split = tiles <= 128 ? 4u : tiles <= 512 ? 2u : 1u;   // planes shared by 4 / 2 workgroups while the tiles alone do not fill the chip
+        hipLaunchKernelGGL((k_expand12<BLOCK, false, true>), dim3((unsigned)(tiles < 8192 ? tiles : 8192), split), dim3(BLOCK), 0, s,
                            (const u32 *)parents_soa, (uint4 *)children_soa, n_parents, n_par_dw, n_chunks, stride_p / 4,
                            stride_c / 16, (u32 *)parent_solved, (uint4 *)child_solved);
     }
