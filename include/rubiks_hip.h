@@ -215,7 +215,7 @@ int rc_split_gemm_f16(const uint16_t *a_hi_lo, const uint16_t *w_lo_hi_hi, const
  * not finite) -- the f16x3 split cannot carry it; librubiks.model.SplitF32Net then falls back to the fp32 GEMM chain.
  * Exactly one output.  rc_split_layer_f16: out_hi_lo | out_f32 | out_partials; with out_partials the K loop (3 k / 64 steps) is
  * cut into k_splits chunks (a divisor of 3 k / 64 leaving >= 2 steps per chunk, 2 .. 32; tile 0 / 1: 352 x 256 tiles, n_out % 256
- * == 0; tile 3: 352 x 128 tiles for small batches, n_out % 128 == 0), one workgroup per tile and chunk storing raw
+ * == 0; tile 3: 352 x 128 tiles for small batches, n_out % 128 == 0; tile 7: 352 x 64), one workgroup per tile and chunk storing raw
  * accumulators out_partials[k_splits][n_rows][n_out] (no bias / residual / activation): the first rc_split_layer_corr_chunks(k,
  * k_splits) of them hold correction products only and still carry the factor 2^11, the others are in units of y
  * (rc_split_reduce_f16 finishes the layer).  rc_gemm_layer_bf16: a, w, residual, out_bf16 in bf16, one product. */

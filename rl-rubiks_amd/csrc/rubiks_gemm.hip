@@ -340,12 +340,13 @@ extern "C" int rc_split_layer_f16(const rc_split_layer_t *L, rc_stream_t stream)
     RC_REQUIRE(outs == 1 && L->out_bf16 == nullptr, RC_ERR_NULL);
     if (L->out_partials) {   // K cut into k_splits chunks, raw accumulators: no epilogue inputs
         const u32 S = (u32)L->k_splits, nk_all = g.P * g.K / 64;
-        RC_REQUIRE(L->k_splits >= 2 && L->k_splits <= 32 && nk_all % S == 0 && nk_all / S >= 2 && (L->tile == 0 || L->tile == 1 || L->tile == 3) &&
-                       L->n_out % (L->tile == 3 ? 128 : 256) == 0, RC_ERR_RANGE);
+        RC_REQUIRE(L->k_splits >= 2 && L->k_splits <= 32 && nk_all % S == 0 && nk_all / S >= 2 && (L->tile == 0 || L->tile == 1 || L->tile == 3 || L->tile == 7) &&
+                       L->n_out % (L->tile == 3 ? 128 : L->tile == 7 ? 64 : 256) == 0, RC_ERR_RANGE);
         g.out = (void *)L->out_partials;
         g.S = S;
         g.bias = nullptr;
         if (L->tile == 3) return launch_split_gemm<2, 4, 11, 2, RC_ACT_NONE, kPartials>(g, s);   // 352 x 128 tiles: small batches
+        if (L->tile == 7) return launch_split_gemm<2, 4, 11, 1, RC_ACT_NONE, kPartials>(g, s);   // 352 x 64: fewer, deeper chunks for one row tile
         return launch_split_gemm<2, 4, 11, 4, RC_ACT_NONE, kPartials>(g, s);
     }
     RC_REQUIRE(L->bias != nullptr && L->k_splits <= 1 && L->tile >= 0 && L->tile <= 6, RC_ERR_RANGE);

@@ -4,6 +4,8 @@
 // activation / reduce passes of the split engine and the ADI target kernel.
 #include <atomic>
 
+#include <type_traits>
+
 #include "rubiks_common.h"
 #include "rubiks_netmath.h"
 
@@ -444,14 +446,30 @@ __global__ __launch_bounds__(kBlock) void k_split_reduce(const float4 *__restric
     for (size_t idx = (size_t)blockIdx.x * kBlock + threadIdx.x; idx < n_rows * chunks; idx += (size_t)gridDim.x * kBlock) {
         const size_t r = idx / chunks, ch = idx - r * chunks;
         float y[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-        for (int p = 0; p < n_partials; ++p) {
-            if (p == n_corr) {
+        // up to eight partials' loads in flight before the first add (a loop of load-then-add pays one memory latency per partial: 32
+        // partials of a 352-row layer took 13 us, latency-bound).  The adds keep the order p = 0, 1, ...; the factor 2^-11 that the sum
+        // of the first n_corr partials takes is a multiplication by 2^-11 or by 1.0 (exact), so a group is one straight block of code.
+        auto group = [&](auto width, int p0) {
+            constexpr int G = decltype(width)::value;
+            float4 a0[G], a1[G];
 #pragma unroll
-                for (int e = 0; e < 8; ++e) y[e] *= (1.0f / kSplitScale);
+            for (int u = 0; u < G; ++u) {
+                const size_t at = (size_t)(p0 + u) * pstride4 + idx * 2;
+                a0[u] = partials[at], a1[u] = partials[at + 1];
             }
-            const float4 a0 = partials[p * pstride4 + idx * 2], a1 = partials[p * pstride4 + idx * 2 + 1];
-            y[0] += a0.x, y[1] += a0.y, y[2] += a0.z, y[3] += a0.w, y[4] += a1.x, y[5] += a1.y, y[6] += a1.z, y[7] += a1.w;
-        }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int u = 0; u < G; ++u) {
+                const float f = p0 + u == n_corr ? 1.0f / kSplitScale : 1.0f;
+                y[0] = y[0] * f + a0[u].x, y[1] = y[1] * f + a0[u].y, y[2] = y[2] * f + a0[u].z, y[3] = y[3] * f + a0[u].w;
+                y[4] = y[4] * f + a1[u].x, y[5] = y[5] * f + a1[u].y, y[6] = y[6] * f + a1[u].z, y[7] = y[7] * f + a1[u].w;
+            }
+        };
+        int p = 0;
+        for (; p + 8 <= n_partials; p += 8) group(std::integral_constant<int, 8>{}, p);
+        if (p + 4 <= n_partials) group(std::integral_constant<int, 4>{}, p), p += 4;
+        if (p + 2 <= n_partials) group(std::integral_constant<int, 2>{}, p), p += 2;
+        if (p < n_partials) group(std::integral_constant<int, 1>{}, p);
         if (n_corr >= n_partials) {
 #pragma unroll
             for (int e = 0; e < 8; ++e) y[e] *= (1.0f / kSplitScale);

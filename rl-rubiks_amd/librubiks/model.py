@@ -602,8 +602,8 @@ class SplitF32Net:
     def _k_split(rows: int, n_out: int, k: int):
         """(tile, chunks) of rc_split_layer_f16 with out_partials for a layer too small to fill the chip with whole-K tiles: the K loop
         (3 k / 64 steps) cut into as many chunks as bring the launch to at most one workgroup per CU, 352 x 128 tiles (tile 3) for
-        few rows or shallow layers, 352 x 256 (tile 1) otherwise.  None when no cut applies.  Measured against the two library GEMMs in
-        profiles/r3_skinny_split_probe.txt (the library runs one 64 x 64 tile per workgroup over the whole K: latency-bound)."""
+        few rows or shallow layers (352 x 64, tile 7, where that would leave chunks of under six steps), 352 x 256 (tile 1) otherwise.
+        None when no cut applies.  Measured against the two library GEMMs in profiles/r3_skinny_split_probe.txt (the library runs one 64 x 64 tile per workgroup over the whole K: latency-bound)."""
         if k % 64:
             return None
         steps, best = 3 * k // 64, None
@@ -616,7 +616,18 @@ class SplitF32Net:
                 key = (base * chunks, cols if rows * k >= 2048 * 4096 else -cols)   # wide tiles pay once A is large: deep layers, many rows
                 if best is None or key > best[0]:
                     best = (key, (tile, chunks))
-        return None if best is None or best[0][0] < 128 else best[1]
+        if best is None or best[0][0] < 128:
+            return None
+        tile, chunks = best[1]
+        if tile == 3 and steps // chunks < 6 and n_out % 64 == 0:
+            # chunks of fewer than six K-steps are mostly pipeline fill: 352 x 64 tiles (tile 7) reach one workgroup per CU with half
+            # the chunks -- chunks twice as deep, half the partials (2048 -> 1024 at 352 rows: 23.2 against 27.5 us with the reduce,
+            # profiles/r6_kcut_tile7.txt; with twelve or more steps per chunk the narrow tile's activation re-reads cost more than that)
+            base = -(-rows // 352) * (n_out // 64)
+            c7 = max((c for c in range(2, 33) if steps % c == 0 and base * c <= 256), default=0)
+            if c7 and steps // c7 >= 6 and base * c7 >= 128:
+                return (7, c7)
+        return best[1]
 
     @staticmethod
     def _fused_tile(rows: int, n_out: int, k: int) -> int:

@@ -703,8 +703,7 @@ class MCTSRun:
         if max_steps is not None:
             n_steps = min(n_steps, max_steps)
         t0 = perf_counter()
-        for _ in range(n_steps):
-            forest.step(agent.c, self.cap_states, agent.use_graph)
+        forest.steps(n_steps, agent.c, self.cap_states, agent.use_graph)
         self.it += n_steps
         self.stats["iterations"] = self.it
         self.snapshots.append((self.q, forest, *forest.status_snapshot(), self.it))

@@ -798,6 +798,42 @@ class MCTSForest:
             return
         g.replay()
 
+    GRAPH_STEPS = max(1, int(os.environ.get("RUBIKS_GRAPH_STEPS", "4")))   # iterations per replayed graph in `steps` (1: one graph launch per iteration)
+
+    def _graph_of_steps(self, c: float, max_states: int):
+        """The HIP graph of GRAPH_STEPS consecutive iterations at the current launch size (captured on first use, once the
+        one-iteration graph of that size exists: its eager run has settled the library's kernel choices and the allocator)."""
+        key = (self.G, float(c), int(max_states), int(self.level_budget), self._one_launch)
+        if key not in self._graphs:
+            return None
+        g = self._graphs.get(key + (self.GRAPH_STEPS,))
+        if g is None:
+            torch.cuda.synchronize()
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g, pool=self._graph_pool):
+                for _ in range(self.GRAPH_STEPS):
+                    self._iteration(c, max_states)
+            self._graphs[key + (self.GRAPH_STEPS,)] = g
+        return g
+
+    def steps(self, n: int, c: float, max_states: int, use_graph: bool = True):
+        """n lock-step iterations.  Between two graph launches the queue idles ~9 us (the kernels inside a graph follow each other
+        without a gap: profiles/r6_step_timelines_f32s.txt), 5 % of a 32-tree step -- so the iterations go out GRAPH_STEPS to a graph
+        launch, the remainder one by one.  The host looks at the trees between calls, never between the iterations of a call."""
+        U = self.GRAPH_STEPS
+        while n > 0:
+            g = self._graph_of_steps(c, max_states) if (use_graph and U > 1 and n >= U) else None
+            if g is None:
+                self.step(c, max_states, use_graph)
+                n -= 1
+                continue
+            if self.vmm or self.path_vmm:
+                if self._steps_covered < U:
+                    self._grow_now()
+                self._steps_covered -= U
+            g.replay()
+            n -= U
+
     def capture_all(self, c: float, max_states: int):
         """Captures the iteration's HIP graph for every launch size of the ladder (`rungs`) ahead of time, on an idle forest (every
         tree marked finished: the tree kernels return at once, the network runs on whatever the row buffers hold).  One-off set-up
@@ -811,6 +847,8 @@ class MCTSForest:
             self.set_active(np.arange(G))
             if (self.G, float(c), int(max_states), int(self.level_budget), self._one_launch) not in self._graphs:
                 self.step(c, max_states, use_graph=True)
+            if self.GRAPH_STEPS > 1:
+                self._graph_of_steps(c, max_states)
         self.set_active(None)
         torch.cuda.synchronize()
 

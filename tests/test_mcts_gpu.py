@@ -129,6 +129,31 @@ def test_max_iterations_and_budget(net_gpu):
     assert not res.solved.any() and (res.lengths == -1).all()
 
 
+@pytest.mark.parametrize("graph_steps", [1, 3, 4])
+def test_iterations_per_graph_launch_do_not_change_a_search(net_gpu, graph_steps, monkeypatch):
+    """`MCTSForest.steps` sends the iterations of a round out several to a graph launch (GRAPH_STEPS, the remainder one by one): a
+    packaging of the same launches.  With 1, 3 and 4 iterations per graph, rounds of 7 (never a multiple) and an iteration bound that
+    ends a round early, every tree is the reference's: node count, iterations, solution, and the arrays of two trees."""
+    from librubiks.solving import mcts_device as md
+    from librubiks.solving.agents import MCTS
+    monkeypatch.setattr(md.MCTSForest, "GRAPH_STEPS", graph_steps)
+    np.random.seed(21)
+    states = np.array([oc.scramble(int(d), True)[0] for d in np.random.randint(3, 9, size=24)])
+    agent = MCTS(net_gpu, c=0.6, search_graph=True, net_dtype=torch.float32, sync_every=7)
+    res = agent.search_batch(states, None, 600)
+    assert graph_steps == 1 or any(len(k) == 6 and k[5] == graph_steps for k in agent.forest._graphs)   # the multi-iteration graph was used
+    onet = oa.TorchNet(net_gpu, device="cuda")
+    for t in range(0, 24, 5):
+        ref = oa.MCTS(onet, c=0.6, search_graph=True)
+        assert ref.search(states[t], 600) == bool(res.solved[t])
+        assert res.nodes[t] == len(ref) and res.iterations[t] == ref.iterations and list(res.queues[t]) == list(ref.action_queue), t
+    bounded = agent.search_batch(states, None, 600, max_iterations=9)
+    for t in (1, 13):
+        ref = oa.MCTS(onet, c=0.6, search_graph=True)
+        ref.search(states[t], 600, max_iterations=9)
+        assert bounded.nodes[t] == len(ref) and bounded.iterations[t] == ref.iterations, t
+
+
 def test_structural_invariants_real_net():
     """tests/test_agents.py:38-94 of the reference, on fc_small with the bf16 inference engine."""
     from librubiks import cube

@@ -597,9 +597,11 @@ def test_layer_request_k_splits_and_reduce_match_the_whole_kernel():
     z = (xh.double() + xl.double() / 2048) @ (wh.double() + wl.double() / 2048).t() + b.cpu().double() + (sh.double() + sl.double() / 2048)
     ref = torch.where(z > 0, z, torch.expm1(z)) * ps.cpu().double() + pt.cpu().double()
     assert float((y_whole.cpu() - ref).abs().max()) < 2e-5 and int(flag.item()) == 0
-    for S, tile in ((2, 0), (3, 1), (4, 0), (6, 0), (4, 3), (12, 3), (18, 3)):     # tile 3: 352 x 128 tiles (small batches)
+    parts = {}
+    for S, tile in ((2, 0), (3, 1), (4, 0), (6, 0), (4, 3), (12, 3), (18, 3), (4, 7), (9, 7), (18, 7), (2, 7)):   # tile 3: 352 x 128 tiles, 7: 352 x 64
         part = torch.full((S, rows, n_out), float("nan"), device="cuda")
         _layer_call("rc_split_layer_f16", a=a, w=w3, n_rows=rows, n_out=n_out, k=k, out_partials=part, k_splits=S, tile=tile)
+        assert torch.equal(parts.setdefault(S, part), part), (S, tile)      # a chunk's partial sums do not depend on the tile's shape
         n_corr = lib.rc_split_layer_corr_chunks(k, S)
         assert n_corr == sum((p + 1) * (36 // S) <= 24 for p in range(S))
         out = torch.empty((rows, 2 * n_out), dtype=torch.float16, device="cuda")
@@ -617,7 +619,7 @@ def test_layer_request_k_splits_and_reduce_match_the_whole_kernel():
     bad(out_partials=part, k_splits=5)                                   # 36 K-steps are not divisible by 5
     bad(out_partials=part, k_splits=1)                                   # partials need at least two chunks
     bad(out_partials=part, k_splits=36)                                  # ... of at least two K-steps each
-    bad(out_partials=part, k_splits=2, tile=2)                           # partials come in 352 x 256 and 352 x 128 tiles only
+    bad(out_partials=part, k_splits=2, tile=2)                           # partials come in 352 x 256, 352 x 128 and 352 x 64 tiles only
     bad(out_partials=part, out_hi_lo=whole, k_splits=2)                  # exactly one output
     bad(bias=b, out_hi_lo=whole, post_scale=ps)                          # post_scale without post_shift
     bad(out_hi_lo=whole)                                                 # the fused epilogue needs a bias
@@ -627,6 +629,32 @@ def test_layer_request_k_splits_and_reduce_match_the_whole_kernel():
                                                kw.get("o", whole.data_ptr()), None, None, None)
     assert red() == 0 and red(o=None) == -1 and red(nc=3) == -4 and red(P=0) == -4 and red(act=7) == -4 and red(cols=n_out + 4) == -2
     assert red(stride=rows * n_out - 4) == -4
+
+
+def test_reduce_kernel_adds_the_partials_in_order_bit_for_bit():
+    """rc_split_reduce_f16 with fp32 output and no activation against the same fp32 sum in torch, in the order p = 0, 1, ... with the
+    factor 2^-11 applied once the first n_corr partials are in: equal bit for bit for every partial count the kernel's load groups
+    (8, 4, 2, 1 partials in flight) split differently, and for every place of the scaling inside a group."""
+    from librubiks import _hip
+    lib = _hip.lib()
+    g = torch.Generator().manual_seed(17)
+    rows, cols = 37, 264
+    bias = torch.randn(cols, generator=g).cuda()
+    for P in (1, 2, 3, 5, 7, 8, 9, 13, 16, 23, 32):
+        part = (torch.randn(P, rows, cols, generator=g) * 3.0).cuda()
+        for n_corr in sorted({0, 1, P // 2, P - 1, P}):
+            ref = torch.zeros(rows, cols, device="cuda")
+            for p in range(P):
+                if p == n_corr:
+                    ref = ref * (1.0 / 2048.0)
+                ref = ref + part[p]
+            if n_corr >= P:
+                ref = ref * (1.0 / 2048.0)
+            ref = ref + bias
+            out = torch.full((rows, cols), float("nan"), device="cuda")
+            _hip.check(lib.rc_split_reduce_f16(part.data_ptr(), rows * cols, P, n_corr, rows, cols, bias.data_ptr(), None, 0, 1.0, None, None,
+                                               None, out.data_ptr(), None, None), "rc_split_reduce_f16")
+            assert torch.equal(out, ref), (P, n_corr)
 
 
 def test_split_engine_small_batches_run_the_cut_kernel():
@@ -640,7 +668,8 @@ def test_split_engine_small_batches_run_the_cut_kernel():
     np.random.seed(3)
     net = Model.create(ModelConfig(architecture="fc_small")).eval().cuda()
     eng = make_inference_net(net, F32_SPLIT)
-    assert SplitF32Net._k_split(352, 2048, 4096) == (3, 16) and SplitF32Net._k_split(352, 1024, 2048) == (3, 32)
+    assert SplitF32Net._k_split(352, 2048, 4096) == (3, 16) and SplitF32Net._k_split(352, 1024, 2048) == (7, 16)
+    assert SplitF32Net._k_split(704, 1024, 2048) == (3, 16)
     assert SplitF32Net._k_split(2816, 2048, 4096) == (1, 4) and SplitF32Net._k_split(2816, 1024, 2048) == (3, 4)
     assert SplitF32Net._k_split(5632, 2048, 4096) == (1, 2) and SplitF32Net._k_split(7040, 2048, 4096) is None
     seen = set()

@@ -1,6 +1,6 @@
 """
 The K-cut hidden layers of a small forest (rc_split_layer_f16 with out_partials + rc_split_reduce_f16), one row count at a time:
-every tile that takes the shape (1 = 352 x 256, 3 = 352 x 128) with every chunk count that keeps the launch within one round of the
+every tile that takes the shape (1 = 352 x 256, 3 = 352 x 128, 7 = 352 x 64: fewer, deeper chunks) with every chunk count that keeps the launch within one round of the
 chip, timed as GEMM + reduce; the plan `SplitF32Net._k_split` picks is marked.  (Round 5 also ran it on a build with tile 5 = 176 x 128
 tiles and FOUR LDS stages, counted vmcnt waits: profiles/r5_kcut_deep_pipeline.txt.)
 
@@ -44,7 +44,7 @@ for K, N in ((4096, 2048), (2048, 1024)):
         out = torch.empty((rows, 2 * N), dtype=torch.float16, device="cuda")
         flag = torch.zeros(1, dtype=torch.int32, device="cuda")
         results, keep = [], {}
-        for tile, bm, bn in ((1, 352, 256), (3, 352, 128)) + (((5, 176, 128),) if os.environ.get("KCUT_PROBE_TILE5") else ()):
+        for tile, bm, bn in ((1, 352, 256), (3, 352, 128), (7, 352, 64)) + (((5, 176, 128),) if os.environ.get("KCUT_PROBE_TILE5") else ()):
             if N % bn:
                 continue
             base = -(-rows // bm) * (N // bn)
@@ -66,10 +66,13 @@ for K, N in ((4096, 2048), (2048, 1024)):
         best = results[0]
         mine = [r for r in results if picked and (r[2], r[3]) == tuple(picked)]
         five = min((r for r in results if r[2] == 5), default=None)
+        seven = min((r for r in results if r[2] == 7), default=None)
         line = f"{K}->{N} rows {rows:5d}: best tile {best[2]} x {best[3]:2d} chunks ({best[4]:3d} wgs) {best[0]:6.1f} us (gemm {best[1]:5.1f})"
         if mine:
             line += f" | plan in the tree: tile {mine[0][2]} x {mine[0][3]:2d} {mine[0][0]:6.1f} us (gemm {mine[0][1]:5.1f})"
         if five:
             line += f" | best tile 5: x {five[3]:2d} {five[0]:6.1f} us (gemm {five[1]:5.1f})"
+        if seven:
+            line += f" | best tile 7: x {seven[3]:2d} {seven[0]:6.1f} us (gemm {seven[1]:5.1f})"
         line += f" | tile 5 == tile 3 partials: {all(same) if same else 'n/a'}"
         print(line, flush=True)

@@ -70,10 +70,10 @@ def solve(argv):
             log.append((state["it"], self.G, int((self.status == md.RUNNING).sum().item()), round(time.perf_counter() - state["t0"], 4)))
         return r
 
-    md.MCTSForest.step = step
+    md.MCTSForest.step, graph_steps, md.MCTSForest.GRAPH_STEPS = step, md.MCTSForest.GRAPH_STEPS, 1   # (the logged run: one graph launch per iteration)
     state["t0"] = time.perf_counter()
     res, total = _timed(lambda: agent.search_batch(cubes, None, args.max_states))
-    md.MCTSForest.step = orig
+    md.MCTSForest.step, md.MCTSForest.GRAPH_STEPS = orig, graph_steps
     res2, again = _timed(lambda: agent.search_batch(cubes, None, args.max_states))
     out = {"dtype": args.dtype, "prepare_seconds": prep, "seconds_logged_run": total, "solved": float(res.solved.mean()), "nodes": int(res.nodes.sum()),
            "iterations_max": int(res.iterations.max()), "second_run_seconds": again, "second_run_nodes_per_sec": float(res2.nodes.sum()) / again,
