@@ -272,7 +272,10 @@ extern "C" int rc_first_layer_mfma_bf16(const int8_t *soa, size_t n, size_t stri
     RC_REQUIRE(H >= kMfCols && H % kMfCols == 0 && activation >= RC_ACT_NONE && activation <= RC_ACT_ELU, RC_ERR_RANGE);
     const u32 col_tiles = (u32)(H / kMfCols);
     u32 row_groups = (256 + col_tiles - 1) / col_tiles;   // one workgroup per CU (LDS), every W1 slice staged once per row group
-    u32 rows_per_block = (u32)round_up(ceil_div(n, row_groups), kMfWaves * kMfSub * kMfTile);
+    // whole passes of the eight waves per workgroup; a batch too small for that (a narrowed forest: 352 rows) is spread over more
+    // workgroups in units of ONE wave's rows instead -- fewer busy waves per CU, the same work per wave, a shorter launch
+    const size_t per_group = ceil_div(n, row_groups), pass_rows = kMfWaves * kMfSub * kMfTile;
+    u32 rows_per_block = (u32)round_up(per_group, per_group < pass_rows ? (size_t)kMfSub * kMfTile : pass_rows);
     row_groups = (u32)ceil_div(n, rows_per_block);
     const size_t lds_bytes = (size_t)kMfCols * kMfPitch + 9 * 16;
     const dim3 grid(col_tiles * row_groups), block(kMfWaves * kWave);
@@ -846,7 +849,8 @@ extern "C" int rc_first_layer_split_flag_f16(const int8_t *soa, size_t n, size_t
     const u32 col_tiles = (u32)(H / kSpCols);
     u32 row_groups = (256 + col_tiles - 1) / col_tiles;   // ~one workgroup per CU (the LDS slice allows no more)
     constexpr u32 kRowsPerPass = kMfWaves * kSpSub * kMfTile;
-    u32 rows_per_block = (u32)round_up(ceil_div(n, row_groups), kRowsPerPass);
+    const size_t per_group = ceil_div(n, row_groups);   // (small batches: units of one wave's rows, as in rc_first_layer_mfma_bf16)
+    u32 rows_per_block = (u32)round_up(per_group, per_group < kRowsPerPass ? (size_t)kSpSub * kMfTile : (size_t)kRowsPerPass);
     row_groups = (u32)ceil_div(n, rows_per_block);
     const size_t lds_bytes = (size_t)2 * kSpCols * kMfPitch + 2 * 9 * 16;
     const dim3 grid(col_tiles * row_groups), block(kMfWaves * kWave);
