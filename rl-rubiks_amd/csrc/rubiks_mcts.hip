@@ -700,9 +700,10 @@ __global__ __launch_bounds__(NT) void k_mcts_select(rc_mcts_t m, double c, u32 l
     // memory latency once per 256 levels while the shallow trees are long done.  So every thread requests the lines of ALL its
     // levels now (first 1 024 levels); the values are only consumed after the pass, the later rounds of the pass find their
     // records in L2.
-    u32 pf[8];
+    constexpr int kPf = 4;
+    u32 pf[2 * kPf];
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
+    for (int i = 0; i < kPf; ++i) {
         const int k = (int)tid + i * NT;
         const u32 *rp = reinterpret_cast<const u32 *>(m.N) + (base + (size_t)(k < plen_old ? m.path_node[P(k)] : 0)) * kRow;
         pf[2 * i] = rp[0];
@@ -711,6 +712,9 @@ __global__ __launch_bounds__(NT) void k_mcts_select(rc_mcts_t m, double c, u32 l
     const u32 row = tid >> 4, rl = tid & 15;
     const bool ract = rl < kA;
     const u32 rla = ract ? rl : 0;
+#ifdef RUBIKS_SELECT_PHASES
+    unsigned long long ph1 = 0, ph2 = 0, ph3 = 0;   // diagnostic build: ticks at the end of staging, pass A (+ late levels), pass B
+#endif
     const int resume = m.pending[t];   // uniform over the workgroup: a suspended descent continues at its last node
     for (int i = tid; i < kSelHash; i += NT) s_head[i] = -1;
     for (int k = tid; k < min(plen_old, W); k += NT) {
@@ -722,6 +726,9 @@ __global__ __launch_bounds__(NT) void k_mcts_select(rc_mcts_t m, double c, u32 l
     __syncthreads();
     chain_levels(0, nlev);
     __syncthreads();
+#ifdef RUBIKS_SELECT_PHASES
+    ph1 = wall_clock64();
+#endif
     if (!resume) {
         // Pass A: one lane per level, float32 with the acceptance rule of lane_pick.  Levels it cannot settle (near
         // ties, NaNs, loss counts beyond 5 bits) are flagged for pass B.
@@ -803,6 +810,9 @@ __global__ __launch_bounds__(NT) void k_mcts_select(rc_mcts_t m, double c, u32 l
         for (int k = wb + (int)tid; k <= wend; k += NT) decide(k, false);
         if (MODE > 0 && backup) {
             __syncthreads();
+#ifdef RUBIKS_SELECT_PHASES
+            ph3 = wall_clock64();   // (overwritten by pass B's stamp unless RUBIKS_SELECT_PHASES == 2: first levels | late levels)
+#endif
             const int nlate = s_nlate;
             for (int i = tid; i < min(nlate, kLateCap); i += NT) decide(wb + (int)s_latelist[i], true);
             if (nlate > kLateCap)   // the overflow, by the bitmap: each group of 32 lanes takes a word of flags
@@ -810,6 +820,9 @@ __global__ __launch_bounds__(NT) void k_mcts_select(rc_mcts_t m, double c, u32 l
                     if ((s_late[k0 >> 5] >> (tid & 31)) & 1u) decide(wb + k0 + (int)(tid & 31), true);
         }
         __syncthreads();
+#ifdef RUBIKS_SELECT_PHASES
+        ph2 = wall_clock64();
+#endif
         // Pass B: the flagged levels in float64, NumPy's evaluation order, one 16-lane row per level.
         const int nunc = s_nunc;
         const bool by_list = nunc <= (int)unc_cap;   // else: scan the bitmap, kStep = NT / 16 levels per step (one 16-lane row each)
@@ -861,8 +874,14 @@ __global__ __launch_bounds__(NT) void k_mcts_select(rc_mcts_t m, double c, u32 l
             }
         }
         __syncthreads();
+#ifdef RUBIKS_SELECT_PHASES
+        if (RUBIKS_SELECT_PHASES != 2) ph3 = wall_clock64();
+#endif
       }
-        if (((pf[0] ^ pf[1] ^ pf[2] ^ pf[3]) + (pf[4] ^ pf[5] ^ pf[6] ^ pf[7])) == 0x5EED1234u && nlev < 0) s_first = 0;   // never true: keeps the requests above alive
+        u32 pfx = 0;
+#pragma unroll
+        for (int i = 0; i < 2 * kPf; ++i) pfx ^= pf[i];
+        if (pfx == 0x5EED1234u && nlev < 0) s_first = 0;   // never true: keeps the requests above alive
         const int first = s_first;
         // (the kept prefix's virtual losses, agents.py:589-591, are implied by the path: see the note on L at the top)
         if (first < nlev) {   // from here on the chains hold the kept levels only; the walk appends its own
@@ -1247,6 +1266,10 @@ __global__ __launch_bounds__(NT) void k_mcts_select(rc_mcts_t m, double c, u32 l
             m.select_stats[8 * t + 5] = (unc_max << 16) | min(slow_levels, 0xFFFF);
             m.select_stats[8 * t + 6] = revisits;
             m.select_stats[8 * t + 7] = (line_rounds << 16) | min(line_levels, 0xFFFF);
+#ifdef RUBIKS_SELECT_PHASES
+            m.select_stats[8 * t + 5] = (int)(ph1 - t_begin), m.select_stats[8 * t + 6] = (int)(ph2 - ph1), m.select_stats[8 * t + 7] = (int)(ph3 - ph2);
+            if (RUBIKS_SELECT_PHASES == 2) m.select_stats[8 * t + 6] = (int)(ph3 - ph1), m.select_stats[8 * t + 7] = s_nlate;   // first levels; number of late levels
+#endif
         }
         m.path_len[t] = plen;
         m.pending[t] = suspended;   // 1 = resume at path_len - 1
