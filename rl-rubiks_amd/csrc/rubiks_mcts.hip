@@ -915,12 +915,15 @@ __global__ __launch_bounds__(NT) void k_mcts_select(rc_mcts_t m, double c, u32 l
         const u32 act_i = in_line ? (u32)m.ring_act[line + lpos + gl] : kNoAct;
         const bool has_pred = in_line && gl > 0;
         const u32 arr_i = has_pred ? (u32)m.ring_act[line + lpos + gl - 1] : arr0;
-        const int pred = has_pred ? m.ring_node[line + lpos + gl - 1] : 0;
         const u32x4 r = load_rec(tb, node_i);
         const bool inner = in_line && act_i != kNoAct;
-        const int nl_i = inner ? m.nbr[(base + node_i) * kRow + act_i] : 0;               // where the line's action leads
-        const int from = has_pred ? m.nbr[(base + pred) * kRow + (arr_i & 15u)] : want;    // where the level above leads
-        const LaneEval e = lane_prepare(c32, m, (base + node_i) * kRow);
+        // Where the line's action leads is the line's next node (a neighbour entry never changes once it is set, and the line is a path
+        // that was walked): read from the ring, not from the node's neighbour row -- a level then costs ONE line of its node's record
+        // (the walk record) instead of two, and the three rows a revisited node needs are requested only by the lanes that need them.
+        // (The last level a line keeps of a path longer than ring_levels has no successor in the ring: the neighbour row then.)
+        const int nxt = lpos + gl + 1;
+        const int nl_i = inner ? (nxt < llen ? m.ring_node[line + nxt] : m.nbr[(base + node_i) * kRow + act_i]) : 0;
+        const int from = has_pred ? node_i : want;   // where the level above leads: by the same argument the lane's own node, if the level above follows the line
         const u32 rb0 = r.z & 15u, rb1 = (r.z >> 8) & 15u;
         u32 d_i = (arr_i ^ 1u) == rb0 ? rb1 : rb0;
         u64 cnt5 = 0;
@@ -952,6 +955,7 @@ __global__ __launch_bounds__(NT) void k_mcts_select(rc_mcts_t m, double c, u32 l
         if (again) {   // the level revisits a node: its decision from its rows, in the lane
             cnt5_add(cnt5, unsure, arr_i ^ 1u);   // own arrival edge
             bool sure;
+            const LaneEval e = lane_prepare(c32, m, (base + node_i) * kRow);
             d_i = (u32)lane_pick(e, cnt5, sure);
             unsure |= !sure;
         }
@@ -1117,8 +1121,8 @@ __global__ __launch_bounds__(NT) void k_mcts_select(rc_mcts_t m, double c, u32 l
             for (; LW == 1;) {
                 const u32x4 r = load_rec(tb, node_i);
                 const bool inner = in_line && act_i != kNoAct;
-                const int nl_i = inner ? m.nbr[(base + node_i) * kRow + act_i] : 0;   // where the line's action leads
-                const LaneEval e = lane_prepare(c32, m, (base + node_i) * kRow);      // requested with the records: one round trip
+                const int nx1 = lpos + (int)lane + 1;   // where the line's action leads: the line's next node (see line_round)
+                const int nl_i = inner ? (nx1 < llen ? m.ring_node[line + nx1] : m.nbr[(base + node_i) * kRow + act_i]) : 0;
                 // the next segment of the line, in flight while this one is checked
                 const int li2 = lpos + kWave + (int)lane;
                 const bool in2 = li2 < llen && kWave + (int)lane < room;
@@ -1154,14 +1158,12 @@ __global__ __launch_bounds__(NT) void k_mcts_select(rc_mcts_t m, double c, u32 l
                         j = en.y & 0xFFu;
                     }
                 }
-                if (__ballot(inner && again)) {   // some level revisits a node: its decision from its rows, in the lane
+                if (again) {   // the level revisits a node (few lanes do): its decision from its rows, requested here, in the lane
                     cnt5_add(cnt5, unsure, arr_i ^ 1u);   // own arrival edge
                     bool sure;
-                    const u32 dx = (u32)lane_pick(e, cnt5, sure);
-                    if (again) {
-                        d_i = dx;
-                        unsure |= !sure;
-                    }
+                    const LaneEval e = lane_prepare(c32, m, (base + node_i) * kRow);
+                    d_i = (u32)lane_pick(e, cnt5, sure);
+                    unsure |= !sure;
                 }
                 const int from = __shfl_up(nl_i, 1);
                 const bool ok = inner && !(r.z & kRecLeaf) && !(again && unsure) && d_i == act_i && (lane == 0 ? want : from) == node_i;
