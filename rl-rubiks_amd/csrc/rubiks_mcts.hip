@@ -1003,6 +1003,10 @@ __global__ __launch_bounds__(NT) void k_mcts_select(rc_mcts_t m, double c, u32 l
     const unsigned long long t_walk = wall_clock64();
     const long long c_walk = clock64();
     int slow_levels = 0, revisits = 0, line_rounds = 0, line_levels = 0;
+#ifdef RUBIKS_SELECT_PHASES
+    long long cyc_lines = 0;   // shader cycles inside line segments (all their rounds)
+    int n_segments = 0, n_loop = 0;
+#endif
     const u32 ring_k = m.ring_k;
     const u32 lane = tid;
     const bool act = lane < kA;
@@ -1020,6 +1024,9 @@ __global__ __launch_bounds__(NT) void k_mcts_select(rc_mcts_t m, double c, u32 l
     u32 h = sel_hash(cur);
     int head = s_head[h];
     for (;;) {
+#ifdef RUBIKS_SELECT_PHASES
+        ++n_loop;
+#endif
         const int k = plen - 1;
         // The revisit test of this level needs the path only, so it runs while the node's record (requested a level ago) is
         // still in flight; a revisited node needs its rows for a full evaluation, and they are requested here, next to the
@@ -1082,6 +1089,9 @@ __global__ __launch_bounds__(NT) void k_mcts_select(rc_mcts_t m, double c, u32 l
             int arr0 = arg;                               // the action that leads to it
             int total = 0;
             bool have = false;
+#ifdef RUBIKS_SELECT_PHASES
+            const long long c_seg = clock64();
+#endif
             if (LW > 1) {
                 for (;;) {
                     if (lane == 0) {
@@ -1201,6 +1211,10 @@ __global__ __launch_bounds__(NT) void k_mcts_select(rc_mcts_t m, double c, u32 l
                 arr_i = arr2;
                 if (!__ballot(in_line)) break;   // line or room exhausted
             }
+#ifdef RUBIKS_SELECT_PHASES
+            cyc_lines += clock64() - c_seg;
+            ++n_segments;
+#endif
             if (total > 0) {
                 cur = want;
                 prev_act = arr0;
@@ -1231,6 +1245,9 @@ __global__ __launch_bounds__(NT) void k_mcts_select(rc_mcts_t m, double c, u32 l
         if (lane == 0) s_mb[MB_CMD] = 0;
         __syncthreads();   // command: the helpers leave
     }
+#ifdef RUBIKS_SELECT_PHASES
+    const unsigned long long ph4 = wall_clock64();   // end of the walk loop
+#endif
     // The path store is full.  If that is the memory behind this tree's path blocks (path_rows), the descent is suspended like one
     // that ran out of its level budget: the host maps the next block, a later call resumes.  Only the end of the store itself ends
     // the tree (the reference has no such limit, agents.py:575-595: max_path is the caller's resource bound).
@@ -1242,6 +1259,9 @@ __global__ __launch_bounds__(NT) void k_mcts_select(rc_mcts_t m, double c, u32 l
         if (k > start) m.path_node[pk] = s_node[k];
         if (k < plen - 1) m.path_act[pk] = (u8)s_act[k];
     }
+#ifdef RUBIKS_SELECT_PHASES
+    const unsigned long long ph5 = wall_clock64();   // walked levels written back
+#endif
     // the path's first ring_levels levels become line `seq` of the ring, and every node on them is tagged with its place there
     if (seq != 0) {
         const size_t slot = (size_t)t * ring_k + (seq & (ring_k - 1));
@@ -1271,6 +1291,10 @@ __global__ __launch_bounds__(NT) void k_mcts_select(rc_mcts_t m, double c, u32 l
 #ifdef RUBIKS_SELECT_PHASES
             m.select_stats[8 * t + 5] = (int)(ph1 - t_begin), m.select_stats[8 * t + 6] = (int)(ph2 - ph1), m.select_stats[8 * t + 7] = (int)(ph3 - ph2);
             if (RUBIKS_SELECT_PHASES == 2) m.select_stats[8 * t + 6] = (int)(ph3 - ph1), m.select_stats[8 * t + 7] = s_nlate;   // first levels; number of late levels
+            if (RUBIKS_SELECT_PHASES == 4)   // shader cycles inside line segments | segments | passes of the walk loop
+                m.select_stats[8 * t + 5] = (int)cyc_lines, m.select_stats[8 * t + 6] = n_segments, m.select_stats[8 * t + 7] = n_loop;
+            if (RUBIKS_SELECT_PHASES == 3)   // the walk: its loop | write-back of the walked levels | ring line + tags
+                m.select_stats[8 * t + 5] = (int)(ph4 - t_walk), m.select_stats[8 * t + 6] = (int)(ph5 - ph4), m.select_stats[8 * t + 7] = (int)(wall_clock64() - ph5);
 #endif
         }
         m.path_len[t] = plen;

@@ -6,7 +6,9 @@ staging + re-validation and of the sequential walk, levels walked without a walk
     python tools/select_tail_probe.py [launch size to start sampling at, default 64] [rounds, default 40]
 
 With a diagnostic build of the library (tools/build_ab_lib.sh WORK phases -DRUBIKS_SELECT_PHASES, RUBIKS_HIP_LIB=.../ab/phases.so) the
-last three slots hold the ticks of the kernel's parallel phases instead: children's backup + staging, pass A, pass B.
+last three slots hold the ticks of the kernel's parallel phases instead: children's backup + staging, pass A, pass B
+(-DRUBIKS_SELECT_PHASES=2: pass A's first levels, number of later levels; =3: walk loop, write-back, ring line; =4: shader cycles inside
+line segments, segments, passes of the walk loop -- csrc/rubiks_mcts.hip; the three 'ticks:' lines keep the labels of the first mode).
 """
 import os
 import sys
