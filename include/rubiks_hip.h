@@ -34,7 +34,7 @@
 extern "C" {
 #endif
 
-#define RC_ABI_VERSION 9
+#define RC_ABI_VERSION 10
 
 #define RC_OK 0
 #define RC_ERR_NULL (-1)      /* required pointer is NULL */
@@ -177,6 +177,13 @@ int rc_first_layer_split_f16(const int8_t *soa, size_t n, size_t stride, const u
 int rc_first_layer_split_flag_f16(const int8_t *soa, size_t n, size_t stride, const uint16_t *w_hi, const uint16_t *w_lo,
                                   const float *bias, uint16_t *out_hi_lo, size_t H, int activation, float alpha,
                                   int32_t *range_flag, rc_stream_t stream);
+/* The input layer as a sum of rows: a one-hot state times W is the sum of the 20 rows of W^T its cubies select,
+ *   out_hi_lo[r] = [hi(y), lo(y)],  y = act(bias + sum_{j < 20} w_rows[24 j + code_j(r)])          (row pitch 2 H halves)
+ * in fp32, in the order j = 0 .. 19 behind the bias (one order whatever the batch).  w_rows: float [480][H] = the nn.Linear
+ * weight transposed, H % 64 == 0.  20 additions per output instead of 960 multiply-adds: what librubiks.model.SplitF32Net
+ * runs (cube.py:265-277 + model.py:123-127,150-157); range_flag as above (may be NULL). */
+int rc_first_layer_gather_f16(const int8_t *soa, size_t n, size_t stride, const float *w_rows, const float *bias,
+                              uint16_t *out_hi_lo, size_t H, int activation, float alpha, int32_t *range_flag, rc_stream_t stream);
 int rc_split_act_f16(const float *c, const float *c_corr, float corr_scale, size_t n_rows, size_t n_cols, const float *bias,
                      int activation, float alpha, uint16_t *out_hi_lo, float *out_f32, rc_stream_t stream);
 

@@ -41,6 +41,7 @@ SIGNATURES = {
     "rc_oh_split_f16": [P, SZ, SZ, P, P],
     "rc_first_layer_split_f16": [P, SZ, SZ, P, P, P, P, SZ, I, ctypes.c_float, P],
     "rc_first_layer_split_flag_f16": [P, SZ, SZ, P, P, P, P, SZ, I, ctypes.c_float, P, P],
+    "rc_first_layer_gather_f16": [P, SZ, SZ, P, P, P, SZ, I, ctypes.c_float, P, P],
     "rc_split_act_f16": [P, P, ctypes.c_float, SZ, SZ, P, I, ctypes.c_float, P, P, P],
     "rc_split_reduce_f16": [P, SZ, I, I, SZ, SZ, P, P, I, ctypes.c_float, P, P, P, P, P, P],
     "rc_split_layer_f16": [P, P],

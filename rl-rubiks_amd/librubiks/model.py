@@ -480,7 +480,8 @@ class SplitF32Net:
         y = act(hi_x W_hi^T + 2^-11 (hi_x W_lo^T + lo_x W_hi^T) + b),
     run by the own MFMA kernel (csrc/rubiks_gemm.hip): one launch per layer with the epilogue fused where whole-K tiles fill the chip,
     else with the K loop cut into chunks + a reduce kernel (`_layer_plan`); shapes the kernel does not take fall back to two library
-    GEMMs.  The input layer is a one-hot MFMA kernel straight from the cube states.  BatchNorm is
+    GEMMs.  The input layer is the sum of the 20 rows of W^T a state's cubies select, in fp32 straight from the cube states
+    (rc_first_layer_gather_f16).  BatchNorm is
     folded in float64 as in InferenceNet, the two heads are merged, the 13-wide output layer runs in plain fp32.
     Against the float64 forward the error is BELOW that of the fp32 GEMM chain (tests/test_net_gpu.py), at ~2.5x its
     speed; it is the reference-precision engine of bench.py.  Same interface as InferenceNet.
@@ -567,7 +568,8 @@ class SplitF32Net:
             code = 0 if act is None else 1 if isinstance(act, nn.ReLU) else 2
             alpha = float(getattr(act, "alpha", 1.0))
             if i == 0:    # one-hot input: x_lo = 0, so y = oh W_hi^T + 2^-11 oh W_lo^T = [oh, oh 2^-11] [W_hi | W_lo]^T
-                out.append(("in", torch.cat([hi, lo], 1).contiguous(), b.float().contiguous(), code, alpha, hi.contiguous(), lo.contiguous()))
+                out.append(("in", torch.cat([hi, lo], 1).contiguous(), b.float().contiguous(), code, alpha, hi.contiguous(), lo.contiguous(),
+                            W.t().float().contiguous()))   # ... and W^T [480][H] in fp32: the rows rc_first_layer_gather_f16 adds up
             else:
                 out.append(("hid", hi.contiguous(), torch.cat([lo, hi], 1).contiguous(), b.float().contiguous(), code, alpha,
                             torch.cat([lo, hi, hi], 1).contiguous()))   # [W_lo | W_hi | W_hi]: the operand of rc_split_gemm_f16
@@ -673,12 +675,13 @@ class SplitF32Net:
     def _zero_bias(self, w: int) -> torch.Tensor:
         return self._zeros[w]   # made in __init__: never allocated (and filled) inside a graph capture
 
-    fused_input = True   # the input layer as one MFMA kernel from the cube states (rc_first_layer_split_f16) when shapes allow
+    fused_input = True   # the input layer as one kernel from the cube states when shapes allow ...
+    gather_input = True  # ... rc_first_layer_gather_f16 (sum of 20 fp32 rows of W^T per state); False: rc_first_layer_split_f16 (one-hot MFMA, hi / lo tables)
 
     def _first_from_cubes(self, cubes, layers, lo: int = 0, n: int = None):
         """[hi | lo] activations of the input layer straight from device cubes, or None if the fused kernel does not apply."""
         from librubiks import _hip
-        _, B, b, code, alpha, Wh, Wl = layers[0]
+        _, B, b, code, alpha, Wh, Wl, Wrows = layers[0]
         H = Wh.shape[0]
         if not self.fused_input or H % 64 or len(layers) < 3:
             return None
@@ -687,6 +690,10 @@ class SplitF32Net:
             assert lo % 16 == 0 and 0 <= lo and lo + n <= cubes.n
             cubes = _CubeWindow(cubes.soa.data_ptr() + lo, n, cubes.stride)
         out = torch.empty((cubes.n, 2 * H), dtype=torch.float16, device=self.device)
+        if self.gather_input:   # the one-hot row times W as the sum of 20 rows of W^T, in fp32 (no matrix cores: 20 additions per output)
+            _hip.check(_hip.lib().rc_first_layer_gather_f16(_soa_ptr(cubes), cubes.n, cubes.stride, Wrows.data_ptr(), b.data_ptr(), out.data_ptr(), H,
+                                                            code, alpha, self.range_flag.data_ptr(), _hip.stream_ptr()), "rc_first_layer_gather_f16")
+            return out
         _hip.check(_hip.lib().rc_first_layer_split_flag_f16(_soa_ptr(cubes), cubes.n, cubes.stride, Wh.data_ptr(), Wl.data_ptr(), b.data_ptr(),
                                                             out.data_ptr(), H, code, alpha, self.range_flag.data_ptr(), _hip.stream_ptr()),
                    "rc_first_layer_split_flag_f16")

@@ -33,7 +33,7 @@ def test_library_exports_every_declared_symbol():
     for name in declared:
         assert hasattr(lib, name), f"{name} declared in include/ but not exported"
         assert name in _hip.SIGNATURES, f"{name} has no ctypes signature in librubiks/_hip.py"
-    assert lib.rc_abi_version() == 9
+    assert lib.rc_abi_version() == 10
     assert lib.rc_error_string(-3).decode().startswith("stride")
 
 

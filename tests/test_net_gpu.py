@@ -85,6 +85,65 @@ def test_engine_paths_agree_and_track_fp32():
     assert torch.allclose(p3, p0, rtol=1e-3, atol=1e-3) and torch.allclose(v3, v0.reshape(-1), rtol=1e-3, atol=1e-3)
 
 
+@pytest.mark.parametrize("n", [1, 5, 352, 1000, 11267])
+def test_input_layer_as_a_sum_of_rows(n):
+    """
+    rc_first_layer_gather_f16: y = act(bias + sum_j W^T[24 j + code_j]) in fp32, in the order j = 0 .. 19 behind the bias, written as
+    [hi | lo] halves.  Without activation the kernel equals the same twenty fp32 additions in torch BIT FOR BIT (and so does its split
+    into halves); with ELU it stays within fp32 rounding of float64; the one-hot MFMA kernel it replaces in the split engine
+    (rc_first_layer_split_flag_f16, hi / lo tables of the same weights) agrees to the split format's 2^-22; rows past n are not written;
+    the half-range flag rises with an output beyond 65504; malformed requests are refused.
+    """
+    from librubiks import _hip
+    from librubiks.cube import DeviceCubes
+    lib = _hip.lib()
+    g = torch.Generator().manual_seed(100 + n)
+    H = 192
+    Wt = (torch.randn(480, H, generator=g) * 0.4).cuda().contiguous()        # W^T: one row per (cubie, code)
+    b = torch.randn(H, generator=g).cuda()
+    s = _states(n, seed=7 + n)
+    cubes = DeviceCubes.from_numpy(s)
+    idx = torch.from_numpy(s.astype(np.int64)).cuda() + 24 * torch.arange(20, device="cuda")      # [n, 20] rows of W^T
+    flag = torch.zeros(1, dtype=torch.int32, device="cuda")
+    out = torch.full((n + 3, 2 * H), 7.0, dtype=torch.float16, device="cuda")
+
+    def run(act, bias=b):
+        _hip.check(lib.rc_first_layer_gather_f16(cubes.soa.data_ptr(), n, cubes.stride, Wt.data_ptr(), bias.data_ptr(), out.data_ptr(), H, act, 1.0,
+                                                 flag.data_ptr(), None), "rc_first_layer_gather_f16")
+        return out[:n, :H].clone(), out[:n, H:].clone()
+    hi, lo = run(0)
+    acc = b.expand(n, H).clone()
+    for j in range(20):
+        acc = acc + Wt[idx[:, j]]                                            # the same fp32 additions, in the same order
+    ref_hi = acc.half()
+    ref_lo = ((acc - ref_hi.float()) * 2048.0).half()
+    assert torch.equal(hi, ref_hi) and torch.equal(lo, ref_lo)
+    assert bool((out[n:] == 7.0).all()) and int(flag.item()) == 0          # nothing behind row n
+    y64 = b.double() + Wt.double()[idx].sum(1)
+    hi, lo = run(2)
+    got = hi.double() + lo.double() / 2048
+    want = torch.where(y64 > 0, y64, torch.expm1(y64))
+    assert float((got - want).abs().max()) < 2e-6 * max(1.0, float(want.abs().max()))
+    # the MFMA form of the same layer: hi / lo tables of the same weights
+    W = Wt.t().contiguous()
+    Wh = W.half()
+    Wl = ((W - Wh.float()) * 2048.0).half()
+    out2 = torch.empty((n, 2 * H), dtype=torch.float16, device="cuda")
+    _hip.check(lib.rc_first_layer_split_flag_f16(cubes.soa.data_ptr(), n, cubes.stride, Wh.data_ptr(), Wl.data_ptr(), b.data_ptr(), out2.data_ptr(), H, 2, 1.0,
+                                                 flag.data_ptr(), None), "rc_first_layer_split_flag_f16")
+    assert float((out2[:, :H].double() + out2[:, H:].double() / 2048 - got).abs().max()) < 4e-6 * max(1.0, float(want.abs().max()))
+    assert int(flag.item()) == 0
+    big = b.clone()
+    big[H - 1] = 1.0e5                                                       # column H - 1 of every state leaves half's range
+    run(2, big)
+    assert int(flag.item()) == 1
+    args = (cubes.soa.data_ptr(), n, cubes.stride, Wt.data_ptr(), b.data_ptr(), out.data_ptr())
+    assert lib.rc_first_layer_gather_f16(*args, 100, 2, 1.0, None, None) == -4          # H not a multiple of 64
+    assert lib.rc_first_layer_gather_f16(*args, H, 7, 1.0, None, None) == -4            # unknown activation
+    assert lib.rc_first_layer_gather_f16(args[0], n, args[2], None, *args[4:], H, 2, 1.0, None, None) == -1   # no table
+    assert lib.rc_first_layer_gather_f16(*args, H, 1, 1.0, None, None) == 0             # ReLU, no flag
+
+
 def test_first_layer_argument_errors():
     from librubiks import _hip
     lib = _hip.lib()
