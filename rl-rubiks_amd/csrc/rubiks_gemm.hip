@@ -38,6 +38,7 @@ typedef const __attribute__((address_space(1))) void glb_void;
 
 // Diagnostic builds only (tools/build_ab_lib.sh WORK <name> -DRUBIKS_GEMM_ABLATE=n; WRONG RESULTS, timing experiments):
 //   1 no LDS-DMA after the first stage (what memory costs)   2 no barrier / vmcnt wait after the first step (what synchronisation costs)
+//   8 no epilogue (activation, split, stores)   16 the epilogue without its stores
 //   3 both       (the builds with the fragment reads removed as well, -DRUBIKS_GEMM_ABLATE=4 / 5 / 7 of profiles/r6_gemm_ablation.txt: commit 0190886)
 #ifndef RUBIKS_GEMM_ABLATE
 #define RUBIKS_GEMM_ABLATE 0
@@ -225,6 +226,8 @@ __global__ __launch_bounds__(WM *WN * 64) void k_split_gemm(GemmArgs g) {
     for (int m = 0; m < MR; ++m) {
         const size_t row = row0 + wr * MR * 16 + m * 16 + fr;
         if (row >= g.M) continue;
+        if ((RUBIKS_GEMM_ABLATE & 8) && acc[m][0][0] != 1.2345e-30f) continue;    // (8: no epilogue at all -- what the epilogue costs)
+
 #pragma unroll
         for (int n = 0; n < NR; ++n) {
             float y[4] = {acc[m][n][0] + b4[n].x, acc[m][n][1] + b4[n].y, acc[m][n][2] + b4[n].z, acc[m][n][3] + b4[n].w};
@@ -246,8 +249,10 @@ __global__ __launch_bounds__(WM *WN * 64) void k_split_gemm(GemmArgs g) {
                     }
                 }
             }
-#pragma unroll
-            for (int e = 0; e < 4; ++e) y[e] = act_value<ACT>(y[e], g.alpha);   // branch-free (rubiks_netmath.h)
+            {   // branch-free, two values per packed instruction (rubiks_netmath.h)
+                const netmath_f32x2 y01 = act_value2<ACT>(netmath_f32x2{y[0], y[1]}, g.alpha), y23 = act_value2<ACT>(netmath_f32x2{y[2], y[3]}, g.alpha);
+                y[0] = y01.x, y[1] = y01.y, y[2] = y23.x, y[3] = y23.y;
+            }
             if (KIND != kPartials && g.post_scale) {
                 const float4 ps = *reinterpret_cast<const float4 *>(g.post_scale + col), pt = *reinterpret_cast<const float4 *>(g.post_shift + col);
                 y[0] = y[0] * ps.x + pt.x, y[1] = y[1] * ps.y + pt.y, y[2] = y[2] * ps.z + pt.z, y[3] = y[3] * ps.w + pt.w;
@@ -263,8 +268,15 @@ __global__ __launch_bounds__(WM *WN * 64) void k_split_gemm(GemmArgs g) {
                 for (int e = 0; e < 4; ++e) out_of_range |= !(fabsf(y[e]) <= kHalfMax);   // hi would be +-inf (or y is NaN): the caller falls back to fp32
                 const SplitPair p01 = split_pair(y[0], y[1]), p23 = split_pair(y[2], y[3]);   // hi = half(y), lo = half((y - hi) 2^11): 5 operations per pair
                 unsigned char *orow = reinterpret_cast<unsigned char *>(g.out) + row * ((size_t)g.N * 4);
-                *reinterpret_cast<uint2 *>(orow + col * 2) = make_uint2(p01.hi, p23.hi);
-                *reinterpret_cast<uint2 *>(orow + ((size_t)g.N + col) * 2) = make_uint2(p01.lo, p23.lo);
+                if ((RUBIKS_GEMM_ABLATE & 16) && p01.hi != 0x12345678u) continue;
+                // ONE 16-byte store per lane instead of two of 8 (the epilogue's stores are bound by their issue: 15 us of the launch at
+                // 11 264 rows, profiles/r6_gemm_epilogue.txt): the lanes of fragment column groups 4 fq and 4 (fq + 1) -- 16 lanes apart,
+                // the same row -- trade halves (v_permlane16_swap: the odd 16-lane rows of the first operand against the even rows of the
+                // second), the even group then stores the hi halves of both, the odd group the lo halves of both.
+                const auto s0 = __builtin_amdgcn_permlane16_swap(p01.hi, p01.lo, false, false);
+                const auto s1 = __builtin_amdgcn_permlane16_swap(p23.hi, p23.lo, false, false);
+                const size_t at = (fq & 1u) ? (size_t)g.N + col - 4 : (size_t)col;
+                *reinterpret_cast<uint4 *>(orow + at * 2) = make_uint4(s0[0], s1[0], s0[1], s1[1]);
             } else {
                 float *orow = reinterpret_cast<float *>(g.out) + row * (size_t)g.N;
                 *reinterpret_cast<float4 *>(orow + col) = make_float4(y[0], y[1], y[2], y[3]);
