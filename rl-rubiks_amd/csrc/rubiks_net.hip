@@ -758,23 +758,31 @@ __global__ __launch_bounds__(kMfWaves * kWave) void k_first_layer_split(const u8
 // The input layer as what it is: a one-hot row times W1 is the SUM OF 20 ROWS of W1^T, one per cubie (480 = 20 x 24 codes),
 //   y = act(bias + sum_j W1^T[24 j + code_j]),   written as the two halves [hi(y) | lo(y)]
 // -- 20 fp32 additions per output instead of 960 multiply-adds on the matrix cores (k_first_layer_split: 60 k-steps of
-// mostly-zero one-hot fragments, 98 us at 11 264 rows, VALU-bound on building those fragments), in plain fp32 from the fp32
-// table (no hi / lo split of the weights: the sum is exact to fp32 rounding, in the fixed order j = 0 .. 19 behind the bias).
-// A workgroup owns 64 columns: its slice of the table, [480][64] fp32 = 120 KiB, lives in LDS; 16 lanes take one state (4
-// adjacent columns each: one ds_read_b128 per cubie, the 16 lanes of a state read the 256 bytes of a row -- all 64 banks
-// once), a wave 4 states at a time, the codes of the next 4 are requested while these are summed.
+// mostly-zero one-hot fragments, VALU-bound on building those fragments), in plain fp32 from the fp32 table (no hi / lo split of
+// the weights: the sum is exact to fp32 rounding, in the fixed order j = 0 .. 19 behind the bias -- whatever the form below).
+// A workgroup owns 64 columns: its slice of the table, [480][64] fp32 = 120 KiB, lives in LDS.  A lane takes C adjacent columns
+// of one state (C / 4 ds_read_b128 per cubie; with C = 4 the 16 lanes of a state read the 256 bytes of a row, all 64 banks once),
+// a wave 64 C / 64 states at a time; the codes of the next states are requested while these are summed.  Like every elementwise
+// part of the network the loop is bound by instruction ISSUE (profiles/r6_input_layer_ab.txt: stores, LDS reads, activation each
+// cost their share of instructions, no resource is full), so the two forms trade per-output overhead against granularity:
+//   <16 waves, C = 4>: four waves per SIMD, units of 4 states -- small batches (352 rows: 9 us);
+//   < 8 waves, C = 8>: half the code loads, address computations and stores per output -- large batches (11 264 rows: 95 us).
 // =================================================================================================
-constexpr int kGaCols = 64, kGaRows = 480, kGaWaves = 16;   // sixteen waves: four per SIMD hide what two could not (108 -> ? us at 11 264 rows)
-#ifndef RUBIKS_GATHER_ABLATE   // diagnostic builds (WRONG RESULTS): 1 no stores, 2 no LDS reads, 4 no code loads, 8 no activation / split
+constexpr int kGaCols = 64, kGaRows = 480;
+#ifndef RUBIKS_GATHER_ABLATE   // diagnostic builds (WRONG RESULTS): 1 no stores, 2 no LDS reads, 4 no code loads, 8 no activation
 #define RUBIKS_GATHER_ABLATE 0
 #endif
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 
-template <int ACT>
-__global__ __launch_bounds__(kGaWaves * kWave) void k_first_layer_gather(const u8 *__restrict__ soa, size_t n, size_t stride,
-                                                                        const float4 *__restrict__ w_rows, const float *__restrict__ bias,
-                                                                        unsigned char *__restrict__ out, u32 H, u32 rows_per_block, float alpha,
-                                                                        int *__restrict__ range_flag) {
+template <int ACT, int WAVES, int C>
+__global__ __launch_bounds__(WAVES * kWave) void k_first_layer_gather(const u8 *__restrict__ soa, size_t n, size_t stride,
+                                                                     const float4 *__restrict__ w_rows, const float *__restrict__ bias,
+                                                                     unsigned char *__restrict__ out, u32 H, u32 rows_per_block, float alpha,
+                                                                     int *__restrict__ range_flag) {
+    static_assert(C == 4 || C == 8, "4 or 8 columns per lane");
+    constexpr int R = C / 4;                  // 16-byte reads per table row and lane
+    constexpr u32 kLanes = kGaCols / C;       // lanes per state
+    constexpr u32 kStates = kWave / kLanes;   // states per wave and pass
     extern __shared__ __attribute__((aligned(256))) unsigned char lds[];   // [480][64] fp32
     const u32 tid = threadIdx.x, lane = tid & 63;
     const u32 wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -783,7 +791,7 @@ __global__ __launch_bounds__(kGaWaves * kWave) void k_first_layer_gather(const u
     if (row_lo >= n) return;
     const size_t row_hi = (row_lo + rows_per_block < n) ? row_lo + rows_per_block : n;
     {   // the slice: 480 rows x 16 chunks of 16 B = 7 680 chunks, four requests in flight per thread at a time
-        constexpr u32 kChunks = kGaRows * (kGaCols / 4), kThreads = kGaWaves * kWave, kBatch = 4;
+        constexpr u32 kChunks = kGaRows * (kGaCols / 4), kThreads = WAVES * kWave, kBatch = 4;
         for (u32 i0 = tid; i0 < kChunks; i0 += kBatch * kThreads) {
             float4 tmp[kBatch];
 #pragma unroll
@@ -798,13 +806,14 @@ __global__ __launch_bounds__(kGaWaves * kWave) void k_first_layer_gather(const u
             }
         }
     }
-    const u32 q = lane & 15, sub = lane >> 4;        // the lane's 4 columns of the tile: 4 q .. 4 q + 3; its state among the wave's four
-    const u32 col = ct * kGaCols + 4 * q;
-    const float4 b4 = *reinterpret_cast<const float4 *>(bias + col);
+    const u32 u = lane % kLanes, sub = lane / kLanes;   // the lane's columns of the tile: C u .. C u + C - 1; its state among the wave's
+    const u32 col = ct * kGaCols + C * u;
+    float4 b4[R];
+#pragma unroll
+    for (int r = 0; r < R; ++r) b4[r] = *reinterpret_cast<const float4 *>(bias + col + 4 * r);
     bool out_of_range = false;
     // The codes: plane j of state t is byte j stride + t of the SoA block -- a buffer load with the state in the vector offset and the
-    // plane in the scalar offset, no 64-bit address arithmetic per byte (20 bytes per state and lane: that arithmetic was a third of
-    // the loop).  Rows past the end are clamped (computed, not stored).
+    // plane in the scalar offset, no 64-bit address arithmetic per byte.  Rows past the end are clamped (computed, not stored).
     const __amdgpu_buffer_rsrc_t planes = __builtin_amdgcn_make_buffer_rsrc((void *)soa, 0, (int)(u32)(kPlanes * stride), 0x00020000);
     const u32 last = (u32)(n - 1), pitch = (u32)stride;
     auto codes_of = [&](size_t t, u32 (&c)[kPlanes]) {
@@ -812,57 +821,76 @@ __global__ __launch_bounds__(kGaWaves * kWave) void k_first_layer_gather(const u
 #pragma unroll
         for (int j = 0; j < kPlanes; ++j) c[j] = (RUBIKS_GATHER_ABLATE & 4) ? (tv + j) % 24u : (u32)__builtin_amdgcn_raw_buffer_load_b8(planes, tv, (u32)j * pitch, 0);
     };
-    // row (24 j + code) of the slice at byte (24 j + code) 256 + 16 q: the code shifted onto one of two bases, the cubie in the
-    // instruction's offset field (16 bits: cubies 0 .. 10 on the first base, 11 .. 19 on the second)
-    const u32 base0 = q * 16, base1 = q * 16 + 11 * 24 * (kGaCols * 4);
+    // row (24 j + code) of the slice at byte (24 j + code) 256 + 4 C u: the code shifted onto one of two bases, the cubie (and the
+    // lane's second 16 bytes) in the instruction's offset field (16 bits: cubies 0 .. 10 on the first base, 11 .. 19 on the second)
+    const u32 base0 = u * (4 * C), base1 = u * (4 * C) + 11 * 24 * (kGaCols * 4);
     __syncthreads();
-    constexpr size_t kStep = (size_t)kGaWaves * 4;   // states per pass of the workgroup
-    size_t t = row_lo + (size_t)wave * 4 + sub;
+    constexpr size_t kStep = (size_t)WAVES * kStates;   // states per pass of the workgroup
+    size_t t = row_lo + (size_t)wave * kStates + sub;
     u32 code[kPlanes], code_next[kPlanes];
     codes_of(t, code);
-    for (size_t t0 = row_lo + (size_t)wave * 4; t0 < row_hi; t0 += kStep, t += kStep) {
+    for (size_t t0 = row_lo + (size_t)wave * kStates; t0 < row_hi; t0 += kStep, t += kStep) {
         const bool more = t0 + kStep < row_hi;        // wave-uniform
-        // the rows are requested ten at a time before the first of them is added (left to itself the compiler waits for each read in
-        // turn: twenty LDS latencies per state), the next states' codes in between, the additions in the order j = 0 .. 19
-        f32x2 a01 = {b4.x, b4.y}, a23 = {b4.z, b4.w};
+        // the rows are requested a batch at a time before the first of them is added (left to itself the compiler waits for each read
+        // in turn: an LDS latency per row), the next states' codes in between, the additions in the order j = 0 .. 19
+        f32x2 acc[2 * R];
 #pragma unroll
-        for (int half = 0; half < 2; ++half) {
-            float4 v[kPlanes / 2];
+        for (int r = 0; r < R; ++r) acc[2 * r] = f32x2{b4[r].x, b4[r].y}, acc[2 * r + 1] = f32x2{b4[r].z, b4[r].w};
+        constexpr int kBatch = 10 / R;
 #pragma unroll
-            for (int i = 0; i < kPlanes / 2; ++i) {
-                const int j = half * (kPlanes / 2) + i;
+        for (int part = 0; part < kPlanes / kBatch; ++part) {
+            float4 v[kBatch][R];
+#pragma unroll
+            for (int i = 0; i < kBatch; ++i) {
+                const int j = part * kBatch + i;
                 const u32 at = (code[j] << 8) + (j < 11 ? base0 : base1);   // (codes are 0 .. 23; a byte beyond would read zeros past the slice, never fault)
-                if (RUBIKS_GATHER_ABLATE & 2) v[i] = make_float4(__uint_as_float(at), 1.f, 2.f, 3.f);
-                else v[i] = *reinterpret_cast<const float4 *>(lds + at + (j < 11 ? j : j - 11) * 24 * (kGaCols * 4));
+                const unsigned char *rowp = lds + at + (j < 11 ? j : j - 11) * 24 * (kGaCols * 4);
+#pragma unroll
+                for (int r = 0; r < R; ++r)
+                    v[i][r] = (RUBIKS_GATHER_ABLATE & 2) ? make_float4(__uint_as_float(at), 1.f, 2.f, 3.f) : *reinterpret_cast<const float4 *>(rowp + 16 * r);
             }
             __builtin_amdgcn_sched_barrier(0);
-            if (half == 0 && more) codes_of(t + kStep, code_next);
+            if (part == 0 && more) codes_of(t + kStep, code_next);
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-            for (int i = 0; i < kPlanes / 2; ++i) {
-                a01 += f32x2{v[i].x, v[i].y};
-                a23 += f32x2{v[i].z, v[i].w};
-            }
+            for (int i = 0; i < kBatch; ++i)
+#pragma unroll
+                for (int r = 0; r < R; ++r) {
+                    acc[2 * r] += f32x2{v[i][r].x, v[i][r].y};
+                    acc[2 * r + 1] += f32x2{v[i][r].z, v[i][r].w};
+                }
             __builtin_amdgcn_sched_barrier(0);
         }
-        if (!(RUBIKS_GATHER_ABLATE & 8)) a01 = act_value2<ACT>(a01, alpha), a23 = act_value2<ACT>(a23, alpha);
-        const float y[4] = {a01.x, a01.y, a23.x, a23.y};
         bool bad = false;
+        SplitPair sp[2 * R];
 #pragma unroll
-        for (int e = 0; e < 4; ++e) bad |= !(fabsf(y[e]) <= 65504.0f);
-        const SplitPair p01 = split_pair(y[0], y[1]), p23 = split_pair(y[2], y[3]);
-        // Stores are what this layer is made of (2 x 184 MB at 11 264 rows) and 8-byte stores are bound by their issue, not by
-        // bandwidth: neighbouring lanes (columns 8 i .. 8 i + 3 and 8 i + 4 .. 8 i + 7 of one state) swap halves through DPP, the
-        // even lane stores the 16 bytes of hi halves of both, the odd lane the 16 bytes of lo halves -- one 16-byte store per lane.
-        constexpr int kSwapPairs = 0xB1;   // quad_perm [1, 0, 3, 2]
-        const u32 n_hi0 = (u32)__builtin_amdgcn_mov_dpp((int)p01.hi, kSwapPairs, 0xF, 0xF, true), n_hi1 = (u32)__builtin_amdgcn_mov_dpp((int)p23.hi, kSwapPairs, 0xF, 0xF, true);
-        const u32 n_lo0 = (u32)__builtin_amdgcn_mov_dpp((int)p01.lo, kSwapPairs, 0xF, 0xF, true), n_lo1 = (u32)__builtin_amdgcn_mov_dpp((int)p23.lo, kSwapPairs, 0xF, 0xF, true);
-        if ((RUBIKS_GATHER_ABLATE & 1) ? (t < row_hi && y[0] == 1.2345e-30f) : t < row_hi) {
-            out_of_range |= bad;
-            const bool odd = lane & 1u;
-            unsigned char *orow = out + t * ((size_t)H * 4);   // row pitch 2 H halves
-            const uint4 both = odd ? make_uint4(n_lo0, n_lo1, p01.lo, p23.lo) : make_uint4(p01.hi, p23.hi, n_hi0, n_hi1);
-            *reinterpret_cast<uint4 *>(orow + (odd ? (size_t)H + col - 4 : (size_t)col) * 2) = both;
+        for (int p = 0; p < 2 * R; ++p) {
+            if (!(RUBIKS_GATHER_ABLATE & 8)) acc[p] = act_value2<ACT>(acc[p], alpha);
+            bad |= !(fabsf(acc[p].x) <= 65504.0f);
+            bad |= !(fabsf(acc[p].y) <= 65504.0f);
+            sp[p] = split_pair(acc[p].x, acc[p].y);
+        }
+        // 16-byte stores (8-byte stores are bound by their issue, not by bandwidth).  C = 8: the lane's eight hi halves, its eight lo
+        // halves.  C = 4: neighbouring lanes (columns 8 i .. 8 i + 3 and 8 i + 4 .. 8 i + 7 of one state) swap halves through DPP, the even
+        // lane stores the hi halves of both, the odd lane the lo halves of both.
+        const bool live = (RUBIKS_GATHER_ABLATE & 1) ? (t < row_hi && acc[0].x == 1.2345e-30f) : t < row_hi;
+        unsigned char *orow = out + t * ((size_t)H * 4);   // row pitch 2 H halves
+        if (C == 8) {
+            if (live) {
+                out_of_range |= bad;
+                *reinterpret_cast<uint4 *>(orow + (size_t)col * 2) = make_uint4(sp[0].hi, sp[1].hi, sp[2 * R - 2].hi, sp[2 * R - 1].hi);
+                *reinterpret_cast<uint4 *>(orow + ((size_t)H + col) * 2) = make_uint4(sp[0].lo, sp[1].lo, sp[2 * R - 2].lo, sp[2 * R - 1].lo);
+            }
+        } else {
+            constexpr int kSwapPairs = 0xB1;   // quad_perm [1, 0, 3, 2]
+            const u32 n_hi0 = (u32)__builtin_amdgcn_mov_dpp((int)sp[0].hi, kSwapPairs, 0xF, 0xF, true), n_hi1 = (u32)__builtin_amdgcn_mov_dpp((int)sp[1].hi, kSwapPairs, 0xF, 0xF, true);
+            const u32 n_lo0 = (u32)__builtin_amdgcn_mov_dpp((int)sp[0].lo, kSwapPairs, 0xF, 0xF, true), n_lo1 = (u32)__builtin_amdgcn_mov_dpp((int)sp[1].lo, kSwapPairs, 0xF, 0xF, true);
+            if (live) {
+                out_of_range |= bad;
+                const bool odd = lane & 1u;
+                const uint4 both = odd ? make_uint4(n_lo0, n_lo1, sp[0].lo, sp[1].lo) : make_uint4(sp[0].hi, sp[1].hi, n_hi0, n_hi1);
+                *reinterpret_cast<uint4 *>(orow + (odd ? (size_t)H + col - 4 : (size_t)col) * 2) = both;
+            }
         }
         if (more) {
 #pragma unroll
@@ -1004,31 +1032,41 @@ extern "C" int rc_first_layer_gather_f16(const int8_t *soa, size_t n, size_t str
     RC_REQUIRE(H >= (size_t)kGaCols && H % kGaCols == 0 && H < (1u << 24) && activation >= RC_ACT_NONE && activation <= RC_ACT_ELU, RC_ERR_RANGE);
     RC_REQUIRE(stride * kPlanes < (1ull << 32), RC_ERR_RANGE);   // the planes as ONE buffer resource: 32-bit offsets (214 M states per launch)
     const u32 col_tiles = (u32)(H / kGaCols);
-    u32 row_groups = (256 + col_tiles - 1) / col_tiles;   // ~one workgroup per CU (the LDS slice allows no more)
-    constexpr u32 kRowsPerPass = kGaWaves * 4;
-    const size_t per_group = ceil_div(n, (size_t)row_groups);   // (small batches: units of one wave's four states, more workgroups)
-    u32 rows_per_block = (u32)round_up(per_group, per_group < kRowsPerPass ? (size_t)4 : (size_t)kRowsPerPass);
-    row_groups = (u32)ceil_div(n, (size_t)rows_per_block);
     const size_t lds_bytes = (size_t)kGaRows * kGaCols * 4;
-    const dim3 grid(col_tiles * row_groups), block(kGaWaves * kWave);
     hipStream_t s = (hipStream_t)stream;
-#define RC_LAUNCH_GA(ACT)                                                                                             \
+    // small batches: sixteen waves, four columns per lane (units of 4 states); large ones: eight waves, eight columns per lane.
+    // A state's outputs are the same bits either way (the same additions in the same order).
+    const bool wide = n * col_tiles > (size_t)5000 * 64;
+    const u32 waves = wide ? 8 : 16, states = wide ? 8 : 4;
+    u32 row_groups = (256 + col_tiles - 1) / col_tiles;   // ~one workgroup per CU (the LDS slice allows no more)
+    const u32 rows_per_pass = waves * states;
+    const size_t per_group = ceil_div(n, (size_t)row_groups);   // (small batches: units of one wave's states, more workgroups)
+    const u32 rows_per_block = (u32)round_up(per_group, per_group < rows_per_pass ? (size_t)states : (size_t)rows_per_pass);
+    row_groups = (u32)ceil_div(n, (size_t)rows_per_block);
+    const dim3 grid(col_tiles * row_groups);
+#define RC_LAUNCH_GA(ACT, WAVES, C)                                                                                   \
     do {                                                                                                              \
         static std::atomic<unsigned long long> attr_set{0};                                                           \
         int dev_ = 0;                                                                                                 \
         (void)hipGetDevice(&dev_);                                                                                    \
         if (!((attr_set.load(std::memory_order_acquire) >> (dev_ & 63)) & 1ull)) {                                     \
-            hipError_t e = hipFuncSetAttribute((const void *)k_first_layer_gather<ACT>, hipFuncAttributeMaxDynamicSharedMemorySize, \
-                                               (int)lds_bytes);                                                       \
+            hipError_t e = hipFuncSetAttribute((const void *)k_first_layer_gather<ACT, WAVES, C>,                     \
+                                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);           \
             if (e != hipSuccess) return hip_rc(e);                                                                    \
             attr_set.fetch_or(1ull << (dev_ & 63), std::memory_order_release);                                        \
         }                                                                                                             \
-        hipLaunchKernelGGL((k_first_layer_gather<ACT>), grid, block, lds_bytes, s, (const u8 *)soa, n, stride, (const float4 *)w_rows, \
-                           bias, (unsigned char *)out_hi_lo, (u32)H, rows_per_block, alpha, (int *)range_flag);       \
+        hipLaunchKernelGGL((k_first_layer_gather<ACT, WAVES, C>), grid, dim3(WAVES * kWave), lds_bytes, s, (const u8 *)soa, n, stride, \
+                           (const float4 *)w_rows, bias, (unsigned char *)out_hi_lo, (u32)H, rows_per_block, alpha, (int *)range_flag); \
     } while (0)
-    if (activation == RC_ACT_ELU) RC_LAUNCH_GA(RC_ACT_ELU);
-    else if (activation == RC_ACT_RELU) RC_LAUNCH_GA(RC_ACT_RELU);
-    else RC_LAUNCH_GA(RC_ACT_NONE);
+#define RC_LAUNCH_GA_ACT(ACT)            \
+    do {                                 \
+        if (wide) RC_LAUNCH_GA(ACT, 8, 8); \
+        else RC_LAUNCH_GA(ACT, 16, 4);   \
+    } while (0)
+    if (activation == RC_ACT_ELU) RC_LAUNCH_GA_ACT(RC_ACT_ELU);
+    else if (activation == RC_ACT_RELU) RC_LAUNCH_GA_ACT(RC_ACT_RELU);
+    else RC_LAUNCH_GA_ACT(RC_ACT_NONE);
+#undef RC_LAUNCH_GA_ACT
 #undef RC_LAUNCH_GA
     return launch_status();
 }

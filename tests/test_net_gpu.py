@@ -85,14 +85,15 @@ def test_engine_paths_agree_and_track_fp32():
     assert torch.allclose(p3, p0, rtol=1e-3, atol=1e-3) and torch.allclose(v3, v0.reshape(-1), rtol=1e-3, atol=1e-3)
 
 
-@pytest.mark.parametrize("n", [1, 5, 352, 1000, 11267])
+@pytest.mark.parametrize("n", [1, 5, 352, 1000, 11267, 120003])
 def test_input_layer_as_a_sum_of_rows(n):
     """
     rc_first_layer_gather_f16: y = act(bias + sum_j W^T[24 j + code_j]) in fp32, in the order j = 0 .. 19 behind the bias, written as
     [hi | lo] halves.  Without activation the kernel equals the same twenty fp32 additions in torch BIT FOR BIT (and so does its split
     into halves); with ELU it stays within fp32 rounding of float64; the one-hot MFMA kernel it replaces in the split engine
     (rc_first_layer_split_flag_f16, hi / lo tables of the same weights) agrees to the split format's 2^-22; rows past n are not written;
-    the half-range flag rises with an output beyond 65504; malformed requests are refused.
+    the half-range flag rises with an output beyond 65504; malformed requests are refused.  The kernel has two forms by batch size (four
+    columns per lane on sixteen waves / eight on eight: the last n of the list is in the second) -- the same additions in the same order.
     """
     from librubiks import _hip
     from librubiks.cube import DeviceCubes
